@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- block-sparse matmul hot path on MI355X: effective TFLOP/s (+ GB/s, roofline, CPU baseline).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json metric: bsmm 4096x4096 bs=32 @ 20% density): one STEP = fprop + bprop + updat of
+one minibatch of N_LOCAL columns on every rank, bf16 storage / fp32 accumulate, synthetic data resident in
+HBM before the timed region.  Multi-GPU = data parallel: tables and W replicated, minibatch sharded
+(weak scaling: N_LOCAL fixed per GPU), one RCCL all-reduce of dw per step overlapped with bprop.
+Effective FLOPs per pass = 2 * blocks * bs^2 * N (nonzero blocks only; the reference's own definition,
+src/gpu_types.cc:48, src/blocksparse_matmul_op.cc:102,182).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_MFMA = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
+PEAK_HBM = 8000.0                                            # GB/s (spec)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--hidden", type=int, default=4096)
+    p.add_argument("--bsize", type=int, default=32)
+    p.add_argument("--density", type=float, default=0.2)
+    p.add_argument("--axis", type=int, default=1)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    p.add_argument("--n-local", type=int, default=8192, help="minibatch columns per GPU")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--sweep", action="store_true", help="also time 10%% and 50%% density (extra JSON fields)")
+    return p.parse_args()
+
+
+def alg_bytes_xprop(b, N, s):
+    segs = b._dev_tables["fprop"]["segments"]
+    return s * (b.C * N + b.K * N + b.blocks * b.bsize ** 2) + 4 * (4 * segs + 2 * b.blocks)
+
+
+def alg_bytes_updat(b, N, s):
+    return s * (b.C * N + b.K * N) + s * b.blocks * b.bsize ** 2 + 8 * b.blocks
+
+
+def cpu_baseline(layout, bs, axis, seconds):
+    """The oracle's batched-BLAS port (fp32) of the same three passes on the host cores, bounded sample."""
+    from oracle import bsmm_oracle as orc
+    t = orc.build_layout_luts(layout, bs)
+    N = 1024
+    rng = np.random.default_rng(0)
+    CB, KB = layout.shape
+    W = rng.normal(0, 0.01, (t["blocks"], bs, bs)).astype(np.float32)
+    X = rng.normal(0, 0.1, (N, CB * bs) if axis else (CB * bs, N)).astype(np.float32)
+    E = rng.normal(0, 0.1, (N, KB * bs) if axis else (KB * bs, N)).astype(np.float32)
+    flops_step = 3 * 2.0 * t["blocks"] * bs * bs * N
+    orc.fprop_fast(t, X, W, axis)                       # warm up BLAS threads
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        orc.fprop_fast(t, X, W, axis)
+        orc.bprop_fast(t, E, W, axis)
+        orc.updat_fast(t, X, E, axis)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 50:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count()])
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": round(flops_step * steps / el / 1e12, 4), "unit": "TFLOP/s", "cores": int(cores), "kind": "port",
+            "sample": "oracle batched-BLAS fp32 port (oracle/bsmm_oracle.py *_fast), same layout, minibatch %d, "
+                      "%d steps of fprop+bprop+updat in %.1f s" % (N, steps, el)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import _parity as P
+    from blocksparse_amd import BlocksparseMatMul, _lib
+    from blocksparse_amd.dist import DwAllReduce
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    _lib.load()
+
+    td = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    s = 4 if a.dtype == "f32" else 2
+    CB = a.hidden // a.bsize
+
+    def setup(density):
+        layout = P.random_layout(CB, CB, density, seed=1234)
+        b = BlocksparseMatMul(layout, block_size=a.bsize, feature_axis=a.axis)
+        g = torch.Generator(device="cuda").manual_seed(1 + rank)
+        w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.01).to(td)
+        x = (torch.randn(b.i_shape(a.n_local), device="cuda", generator=g) * 0.1).to(td)
+        dy = (torch.randn(b.o_shape(a.n_local), device="cuda", generator=g) * 0.1).to(td)
+        return layout, b, w, x, dy
+
+    def run(b, w, x, dy, steps, warmup, timed_events):
+        red = DwAllReduce(accumulate_fp32=False)
+        dw = torch.empty(b.w_shape, dtype=td, device="cuda")
+
+        def step(ev=None):
+            if ev: ev[0].record()
+            y = b.fprop(x, w)
+            if ev: ev[1].record()
+            b.updat(x, dy, dw=dw)
+            if ev: ev[2].record()
+            red.start(dw)                  # overlaps with bprop
+            dx = b.bprop(dy, w)
+            if ev: ev[3].record()
+            red.wait()
+            return y, dx
+
+        for _ in range(warmup):
+            step()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)] if timed_events else None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(evs[i] if evs else None)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        per = None
+        if evs:
+            per = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i in range(3)]   # ms: fprop, updat, bprop
+        return el, per
+
+    layout, b, w, x, dy = setup(a.density)
+    el, per = run(b, w, x, dy, a.steps, a.warmup, timed_events=True)
+    N = a.n_local
+    flops_pass = 2.0 * b.blocks * a.bsize ** 2 * N
+    total_flops = 3 * flops_pass * world * a.steps
+    ms_step = el / a.steps * 1e3
+    value = total_flops / el / 1e12
+    bytes_step = 2 * alg_bytes_xprop(b, N, s) + alg_bytes_updat(b, N, s)
+    f_ms, u_ms, b_ms = per
+
+    # roofline of the dominant kernel.  bprop is ONE launch of the xprop kernel (fprop = the same kernel + a
+    # small weight-transpose launch); updat is one launch of the updat kernel.  HIP events on the launch stream.
+    cand = {
+        "bsmm_xprop(bprop)": (b_ms, flops_pass, alg_bytes_xprop(b, N, s)),
+        "bsmm_updat": (u_ms, flops_pass, alg_bytes_updat(b, N, s)),
+    }
+    dom = max(cand, key=lambda k: cand[k][0])
+    d_ms, d_flops, d_bytes = cand[dom]
+    ai = d_flops / d_bytes
+    ridge = PEAK_MFMA[a.dtype] * 1e12 / (PEAK_HBM * 1e9)
+    if ai >= ridge:
+        roof = {"bound": "mfma", "achieved": round(d_flops / (d_ms * 1e-3) / 1e12, 2), "peak": PEAK_MFMA[a.dtype], "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": round(d_bytes / (d_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof["traffic"] = None
+    roof["kernel"] = dom
+    roof["kernel_ms"] = round(d_ms, 4)
+    roof["arithmetic_intensity"] = round(ai, 1)
+
+    out = {
+        "metric": "bsmm_effective_tflops_%dx%d_bs%d_d%d" % (a.hidden, a.hidden, a.bsize, round(a.density * 100)),
+        "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "bsmm fprop+bprop+updat %dx%d block_size=%d density=%.0f%% feature_axis=%d, minibatch %d per GPU, "
+                               "layout default_rng(1234)" % (a.hidden, a.hidden, a.bsize, a.density * 100, a.axis, N),
+                   "blocks": int(b.blocks), "global_minibatch": N * world,
+                   "parallelism": "dp%d (minibatch sharded, dw all-reduce over RCCL)" % world if world > 1 else "single GPU"},
+        "gbps_algorithmic": round(bytes_step / (ms_step * 1e-3) / 1e9, 1),
+        "pass_ms": {"fprop": round(f_ms, 4), "bprop": round(b_ms, 4), "updat": round(u_ms, 4)},
+        "pass_tflops": {"fprop": round(flops_pass / f_ms / 1e9, 2), "bprop": round(flops_pass / b_ms / 1e9, 2),
+                        "updat": round(flops_pass / u_ms / 1e9, 2)},
+        "roofline": roof,
+    }
+    if a.sweep:
+        sw = {}
+        for d in (0.1, 0.5):
+            _, b2, w2, x2, dy2 = setup(d)
+            el2, per2 = run(b2, w2, x2, dy2, max(3, a.steps // 2), 2, timed_events=True)
+            fp = 2.0 * b2.blocks * a.bsize ** 2 * N
+            sw["d%d" % round(d * 100)] = {"tflops": round(3 * fp * world * max(3, a.steps // 2) / el2 / 1e12, 2),
+                                          "pass_ms": [round(v, 4) for v in per2], "blocks": int(b2.blocks)}
+        out["density_sweep"] = sw
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(layout, a.bsize, a.axis, a.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

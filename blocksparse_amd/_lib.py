@@ -1,0 +1,82 @@
+"""ctypes binding of libbsmm_hip.so (the C ABI declared in include/bsmm.h).
+
+There is NO CPU fallback: if the shared library is missing this module raises, loudly, at first use.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` (or ``blocksparse_amd.build.build()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbsmm_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
+
+SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_identity_init", "bsmm_workspace_bytes",
+           "bsmm_set_kernel_variant", "bsmm_get_kernel_variant", "bsmm_error_string", "bsmm_version")
+
+
+class BsmmArgs(ctypes.Structure):
+    """Mirror of ``struct bsmm_args`` (include/bsmm.h)."""
+    _fields_ = [
+        ("lut", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_size_t),
+        ("blocks", ctypes.c_int32), ("bsize", ctypes.c_int32), ("segments", ctypes.c_int32),
+        ("locks", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
+        ("shared", ctypes.c_int32), ("pcount", ctypes.c_int32), ("axis", ctypes.c_int32),
+        ("dtype", ctypes.c_int32), ("alpha", ctypes.c_float), ("beta", ctypes.c_float),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+_lib = None
+
+
+class BsmmError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__("%s failed with code %d: %s" % (where, code, error_string(code)))
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "blocksparse_amd: %s not found -- the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` in the repo root. "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+    pargs = ctypes.POINTER(BsmmArgs)
+    lib.bsmm_fprop.argtypes = [vp, vp, vp, pargs]
+    lib.bsmm_fprop.restype = ctypes.c_int
+    lib.bsmm_bprop.argtypes = [vp, vp, vp, pargs]
+    lib.bsmm_bprop.restype = ctypes.c_int
+    lib.bsmm_updat.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), vp, pargs]
+    lib.bsmm_updat.restype = ctypes.c_int
+    lib.bsmm_identity_init.argtypes = [vp, vp, i32, i32, i32, i32, f32, i32, vp]
+    lib.bsmm_identity_init.restype = ctypes.c_int
+    lib.bsmm_workspace_bytes.argtypes = [ctypes.c_int, pargs]
+    lib.bsmm_workspace_bytes.restype = ctypes.c_size_t
+    lib.bsmm_set_kernel_variant.argtypes = [ctypes.c_int]
+    lib.bsmm_set_kernel_variant.restype = None
+    lib.bsmm_get_kernel_variant.argtypes = []
+    lib.bsmm_get_kernel_variant.restype = ctypes.c_int
+    lib.bsmm_error_string.argtypes = [ctypes.c_int]
+    lib.bsmm_error_string.restype = ctypes.c_char_p
+    lib.bsmm_version.argtypes = []
+    lib.bsmm_version.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def error_string(code):
+    return load().bsmm_error_string(int(code)).decode()
+
+
+def check(code, where):
+    if code != 0:
+        raise BsmmError(code, where)

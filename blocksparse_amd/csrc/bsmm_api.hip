@@ -1,0 +1,238 @@
+// bsmm_api.hip -- C-ABI entry points (include/bsmm.h) and kernel dispatch for gfx950.
+#include <atomic>
+#include <cstdio>
+
+#include "bsmm.h"
+#include "bsmm_updat.h"
+#include "bsmm_xprop.h"
+
+using namespace bsmm;
+
+namespace {
+
+std::atomic<int> g_variant{0};
+
+inline size_t elem_size(int dtype) { return dtype == BSMM_F32 ? 4 : 2; }
+
+int check_common(const bsmm_args* a) {
+    if (!a || !a->lut) return BSMM_ERR_ARG;
+    if (a->blocks <= 0 || a->N <= 0 || a->C <= 0 || a->K <= 0) return BSMM_ERR_ARG;
+    if (a->bsize != 8 && a->bsize != 16 && a->bsize != 32) return BSMM_ERR_UNSUPPORTED;
+    if (a->axis != 0 && a->axis != 1) return BSMM_ERR_UNSUPPORTED;
+    if (a->dtype != BSMM_F32 && a->dtype != BSMM_F16 && a->dtype != BSMM_BF16) return BSMM_ERR_UNSUPPORTED;
+    if (a->gate) return BSMM_ERR_UNSUPPORTED;
+    if (a->C % a->bsize || a->K % a->bsize) return BSMM_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(a->lut) & 15) return BSMM_ERR_ARG;
+    return BSMM_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// xprop
+// ---------------------------------------------------------------------------------------------
+template <class DT, int BS, int AXIS, bool FPROP>
+int launch_xprop_valu(const void* X, const void* W, void* Y, const bsmm_args* a, hipStream_t st) {
+    typedef typename DT::T T;
+    dim3 grid((a->N + 255) / 256, a->segments);
+    xprop_valu_kernel<DT, BS, AXIS, FPROP><<<grid, 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(W),
+                                                                 static_cast<T*>(Y), a->lut, a->N, a->C, a->K);
+    return (int)hipGetLastError();
+}
+
+template <class DT, int BS, int AXIS>
+int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    typedef typename DT::T T;
+    const int N = a->N;
+    auto go = [&](auto nsub_tag) {
+        constexpr int NSUB = decltype(nsub_tag)::value;
+        constexpr int NT = 4 * BS * NSUB;
+        XMap m;
+        m.ntiles = (N + NT - 1) / NT;
+        m.segments = a->segments;
+        m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+        if (m.P > m.segments) m.P = m.segments;
+        m.SP = (m.segments + m.P - 1) / m.P;
+        if constexpr (BS == 32)
+            xprop32_kernel<DT, AXIS, NSUB><<<m.grid(), 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
+                                                                     static_cast<T*>(Y), a->lut, m, N, a->C, a->K);
+        else
+            xprop16_kernel<DT, AXIS, NSUB><<<m.grid(), 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
+                                                                     static_cast<T*>(Y), a->lut, m, N, a->C, a->K);
+    };
+    // per-wave minibatch extent: BS*NSUB columns; use the wide tile only when it still fills the chip
+    if constexpr (BS == 32) {
+        if (N >= 2048) go(std::integral_constant<int, 2>{});
+        else           go(std::integral_constant<int, 1>{});
+    } else {
+        if (N >= 2048) go(std::integral_constant<int, 4>{});
+        else if (N >= 512) go(std::integral_constant<int, 2>{});
+        else           go(std::integral_constant<int, 1>{});
+    }
+    return (int)hipGetLastError();
+}
+
+template <class DT, int BS>
+int launch_transpose(const void* W, void* Wt, int blocks, hipStream_t st) {
+    typedef typename DT::T T;
+    transpose_blocks_kernel<DT, BS><<<blocks, 256, 0, st>>>(static_cast<const T*>(W), static_cast<T*>(Wt), blocks);
+    return (int)hipGetLastError();
+}
+
+template <class DT, int BS, int AXIS>
+int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    if (a->locks > 0) {   // several segments accumulate into the same output block: start from zero
+        hipError_t e = hipMemsetAsync(Y, 0, (size_t)a->N * a->K * elem_size(a->dtype), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
+    const bool use_valu = (BS == 8) || g_variant.load(std::memory_order_relaxed) == 1 || !vec_ok;
+    if (use_valu) {
+        return fprop ? launch_xprop_valu<DT, BS, AXIS, true>(X, W, Y, a, st)
+                     : launch_xprop_valu<DT, BS, AXIS, false>(X, W, Y, a, st);
+    }
+    if constexpr (BS != 8) {
+        const void* Wsel = W;
+        if (fprop) {
+            const size_t need = (size_t)a->blocks * BS * BS * elem_size(a->dtype);
+            if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+            int rc = launch_transpose<DT, BS>(W, a->workspace, a->blocks, st);
+            if (rc) return rc;
+            Wsel = a->workspace;
+        }
+        return launch_xprop_mfma<DT, BS, AXIS>(X, Wsel, Y, a, st);
+    }
+    return BSMM_ERR_UNSUPPORTED;
+}
+
+template <class DT>
+int xprop_dt(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
+#define BSMM_CASE(BS, AX) \
+    if (a->bsize == BS && a->axis == AX) return xprop_typed<DT, BS, AX>(fprop, X, W, Y, a);
+    BSMM_CASE(32, 0) BSMM_CASE(32, 1) BSMM_CASE(16, 0) BSMM_CASE(16, 1) BSMM_CASE(8, 0) BSMM_CASE(8, 1)
+#undef BSMM_CASE
+    return BSMM_ERR_UNSUPPORTED;
+}
+
+int xprop(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (!X || !W || !Y || a->segments <= 0) return BSMM_ERR_ARG;
+    switch (a->dtype) {
+        case BSMM_F32:  return xprop_dt<DTf32>(fprop, X, W, Y, a);
+        case BSMM_F16:  return xprop_dt<DTf16>(fprop, X, W, Y, a);
+        case BSMM_BF16: return xprop_dt<DTbf16>(fprop, X, W, Y, a);
+    }
+    return BSMM_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// updat
+// ---------------------------------------------------------------------------------------------
+template <class DT, int BS, int AXIS>
+int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a) {
+    typedef typename DT::T T;
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const int N = a->N;
+    bool vec_ok = aligned16(DW);
+    if (AXIS == 0) {
+        // 16-byte row loads need every row start aligned
+        vec_ok = vec_ok && (N % (DT::is16 ? 8 : 4) == 0);
+        for (int p = 0; p < a->pcount; ++p) vec_ok = vec_ok && aligned16(xs.p[p]) && aligned16(es.p[p]);
+    }
+    const bool use_valu = (BS == 8) || g_variant.load(std::memory_order_relaxed) == 1 || !vec_ok;
+    if (use_valu) {
+        updat_valu_kernel<DT, BS, AXIS><<<a->blocks, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C,
+                                                                   a->K, a->pcount, a->alpha, a->beta);
+    } else if constexpr (BS == 32) {
+        const int grid = 8 * ((a->blocks + 7) / 8);
+        updat32_kernel<DT, AXIS><<<grid, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K,
+                                                       a->pcount, a->alpha, a->beta);
+    } else if constexpr (BS == 16) {
+        const int grid = 8 * ((a->blocks + 7) / 8);
+        updat16_kernel<DT, AXIS><<<grid, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K,
+                                                       a->pcount, a->alpha, a->beta);
+    }
+    return (int)hipGetLastError();
+}
+
+template <class DT>
+int updat_dt(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a) {
+#define BSMM_CASE(BS, AX) \
+    if (a->bsize == BS && a->axis == AX) return updat_typed<DT, BS, AX>(xs, es, DW, a);
+    BSMM_CASE(32, 0) BSMM_CASE(32, 1) BSMM_CASE(16, 0) BSMM_CASE(16, 1) BSMM_CASE(8, 0) BSMM_CASE(8, 1)
+#undef BSMM_CASE
+    return BSMM_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsmm_fprop(const void* X, const void* W, void* Y, const bsmm_args* args) { return xprop(true, X, W, Y, args); }
+
+int bsmm_bprop(const void* DY, const void* W, void* DX, const bsmm_args* args) { return xprop(false, DY, W, DX, args); }
+
+int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (!X || !DY || !DW) return BSMM_ERR_ARG;
+    if (a->pcount < 1 || a->pcount > 8) return BSMM_ERR_ARG;
+    PtrList8 xs, es;
+    for (int p = 0; p < 8; ++p) {
+        xs.p[p] = p < a->pcount ? X[p] : nullptr;
+        es.p[p] = p < a->pcount ? DY[p] : nullptr;
+        if (p < a->pcount && (!xs.p[p] || !es.p[p])) return BSMM_ERR_ARG;
+    }
+    switch (a->dtype) {
+        case BSMM_F32:  return updat_dt<DTf32>(xs, es, DW, a);
+        case BSMM_F16:  return updat_dt<DTf16>(xs, es, DW, a);
+        case BSMM_BF16: return updat_dt<DTbf16>(xs, es, DW, a);
+    }
+    return BSMM_ERR_UNSUPPORTED;
+}
+
+int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks, int32_t bsize,
+                       float scale, int32_t dtype, void* stream) {
+    if (!W || !updat_lut || CB <= 0 || KB <= 0 || blocks <= 0 || bsize <= 0) return BSMM_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case BSMM_F32:
+            identity_init_kernel<DTf32><<<blocks, 256, 0, st>>>(static_cast<float*>(W), updat_lut, CB, KB, bsize, scale);
+            break;
+        case BSMM_F16:
+            identity_init_kernel<DTf16><<<blocks, 256, 0, st>>>(static_cast<uint16_t*>(W), updat_lut, CB, KB, bsize, scale);
+            break;
+        case BSMM_BF16:
+            identity_init_kernel<DTbf16><<<blocks, 256, 0, st>>>(static_cast<uint16_t*>(W), updat_lut, CB, KB, bsize, scale);
+            break;
+        default:
+            return BSMM_ERR_UNSUPPORTED;
+    }
+    return (int)hipGetLastError();
+}
+
+size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
+    if (!a) return 0;
+    // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)
+    if (op == BSMM_OP_FPROP && a->bsize != 8) return (size_t)a->blocks * a->bsize * a->bsize * elem_size(a->dtype);
+    return 0;
+}
+
+void bsmm_set_kernel_variant(int variant) { g_variant.store(variant == 1 ? 1 : 0); }
+int bsmm_get_kernel_variant(void) { return g_variant.load(); }
+
+const char* bsmm_error_string(int code) {
+    switch (code) {
+        case BSMM_OK: return "ok";
+        case BSMM_ERR_ARG: return "bsmm: invalid argument (null pointer, non-positive size, misaligned lut, pcount outside 1..8)";
+        case BSMM_ERR_UNSUPPORTED: return "bsmm: unsupported configuration (bsize must be 8/16/32, axis 0/1, dtype f32/f16/bf16, gate NULL)";
+        case BSMM_ERR_WORKSPACE: return "bsmm: workspace missing, misaligned or smaller than bsmm_workspace_bytes()";
+        default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "bsmm: unknown error";
+    }
+}
+
+int bsmm_version(void) { return BSMM_VERSION; }
+
+}  // extern "C"

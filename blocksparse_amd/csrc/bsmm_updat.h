@@ -1,0 +1,227 @@
+// bsmm_updat.h -- weight-gradient kernels:  DW[w] = alpha * sum_p sum_n X_p[c,:,n] (x) DY_p[k,:,n] + beta * DW[w]
+// with (c,k) = updat_lut[w].  Replaces gemm_blocksparse_{32,16,08}x64x*_updat
+// (src/blocksparse_matmul_op_gpu.cu:960-1835,2424-2892) and hgemm_blocksparse_*_{nt_dds,tn_dds}.
+//
+// One workgroup (4 waves) per nonzero block; the minibatch reduction is split over the waves (wave v
+// takes 32-wide n chunks v, v+4, ...), each wave accumulates a full bs x bs tile on the matrix cores
+// (K dimension of the MFMA = n), then the 4 partial tiles are summed through LDS.
+//   MFMA roles: A[ci][n] (M = c-in-block), B[n][ko] (N = k-in-block)  ->  D[ci][ko]
+//   axis 0: both operands are K(=n)-contiguous in memory -> 16-byte loads
+//   axis 1: both operands are K-strided (stride = feature count) -> element gathers (v1)
+#pragma once
+#include "bsmm_common.h"
+
+namespace bsmm {
+
+// block b -> weight block w so that each XCD (b % 8) walks a contiguous z-order range of blocks
+// (neighbouring blocks share X rows / DY rows -> L2 hits).  Bijective for any `blocks`.
+__device__ __forceinline__ int updat_block(int b, int blocks) {
+    const int q8 = blocks >> 3, r8 = blocks & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    const int len = q8 + (xcd < r8 ? 1 : 0);
+    if (idx >= len) return -1;
+    const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    return start + idx;
+}
+
+template <class DT, int AXIS>
+__global__ void __launch_bounds__(256)
+updat32_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
+               int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+    typedef typename DT::T T;
+    __shared__ float red[4 * 1024];
+    const int w = updat_block(blockIdx.x, blocks);
+    if (w < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int c = lut[2 * w], k = lut[2 * w + 1];
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int p = 0; p < pcount; ++p) {
+        const T* X = static_cast<const T*>(Xs.p[p]);
+        const T* E = static_cast<const T*>(Es.p[p]);
+        for (int n0 = wave * 32; n0 < N; n0 += 128) {
+            const int klim = N - n0;
+            Frag32<DT> a, b;
+            if constexpr (AXIS == 0) {
+                a.load_contig_lim(X + (size_t)(c * 32 + r) * N + n0, h, klim);
+                b.load_contig_lim(E + (size_t)(k * 32 + r) * N + n0, h, klim);
+            } else {
+                a.load_strided_lim(X + (size_t)n0 * Cf + c * 32 + r, (size_t)Cf, h, klim);
+                b.load_strided_lim(E + (size_t)n0 * Kf + k * 32 + r, (size_t)Kf, h, klim);
+            }
+            mma32<DT>(a, b, acc);
+        }
+    }
+
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[wave * 1024 + reg * 64 + lane] = acc[reg];
+    __syncthreads();
+    for (int slot = threadIdx.x; slot < 1024; slot += 256) {
+        const float sum = red[slot] + red[1024 + slot] + red[2048 + slot] + red[3072 + slot];
+        const int reg = slot >> 6, ln = slot & 63;
+        const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5), ko = ln & 31;
+        const size_t idx = (size_t)w * 1024 + ci * 32 + ko;
+        float out = alpha * sum;
+        if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+        DW[idx] = DT::from_f32(out);
+    }
+}
+
+template <class DT, int AXIS>
+__global__ void __launch_bounds__(256)
+updat16_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
+               int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+    typedef typename DT::T T;
+    constexpr int KS = Frag16<DT>::KS;   // n per MFMA slab: 32 (16-bit) / 16 (f32)
+    constexpr int KL = Frag16<DT>::KL;   // n per lane per slab: 8 / 4
+    __shared__ float red[4 * 256];
+    const int w = updat_block(blockIdx.x, blocks);
+    if (w < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int c = lut[2 * w], k = lut[2 * w + 1];
+
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < pcount; ++p) {
+        const T* X = static_cast<const T*>(Xs.p[p]);
+        const T* E = static_cast<const T*>(Es.p[p]);
+        for (int n0 = wave * KS; n0 < N; n0 += 4 * KS) {
+            const int nl = n0 + KL * q;          // this lane's first n
+            const int lim = N - nl;
+            Frag16<DT> a, b;
+            if constexpr (AXIS == 0) {
+                a.load_contig_lim(X + (size_t)(c * 16 + r) * N + nl, lim);
+                b.load_contig_lim(E + (size_t)(k * 16 + r) * N + nl, lim);
+            } else {
+                if (lim > 0) {
+                    a.load_strided_lim(X + (size_t)nl * Cf + c * 16 + r, (size_t)Cf, lim);
+                    b.load_strided_lim(E + (size_t)nl * Kf + k * 16 + r, (size_t)Kf, lim);
+                } else {
+                    a.zero();
+                    b.zero();
+                }
+            }
+            mma16<DT>(a, b, acc);
+        }
+    }
+
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[wave * 256 + reg * 64 + lane] = acc[reg];
+    __syncthreads();
+    {
+        const int slot = threadIdx.x;
+        const float sum = red[slot] + red[256 + slot] + red[512 + slot] + red[768 + slot];
+        const int reg = slot >> 6, ln = slot & 63;
+        const int ci = 4 * (ln >> 4) + reg, ko = ln & 15;
+        const size_t idx = (size_t)w * 256 + ci * 16 + ko;
+        float out = alpha * sum;
+        if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+        DW[idx] = DT::from_f32(out);
+    }
+}
+
+// VALU kernel, any bsize.  A chunk of CH minibatch columns of the X rows of block-row c and the DY rows
+// of block-row k is staged in LDS as fp32 ([feature][n], +1 pad); thread t owns output(s)
+// (ci,ko) and, when bs*bs < 256, one of 256/(bs*bs) slices of the chunk; slices are summed via LDS.
+template <class DT, int BS, int AXIS>
+__global__ void __launch_bounds__(256)
+updat_valu_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
+                  int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+    typedef typename DT::T T;
+    constexpr int CH = 64;
+    constexpr int OUTS = BS * BS;
+    constexpr int SL = (OUTS >= 256) ? 1 : 256 / OUTS;     // n-slices per chunk
+    constexpr int PER = (OUTS >= 256) ? OUTS / 256 : 1;    // outputs per thread
+    constexpr int SLN = CH / SL;                            // n per slice
+    __shared__ float xs[BS][CH + 1];
+    __shared__ float es[BS][CH + 1];
+    __shared__ float red[256];
+
+    const int w = blockIdx.x;
+    const int c = lut[2 * w], k = lut[2 * w + 1];
+    const int tid = threadIdx.x;
+    const int slice = (SL == 1) ? 0 : tid / OUTS;
+    const int obase = (SL == 1) ? tid : tid % OUTS;
+
+    float acc[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) acc[j] = 0.f;
+
+    for (int p = 0; p < pcount; ++p) {
+        const T* X = static_cast<const T*>(Xs.p[p]);
+        const T* E = static_cast<const T*>(Es.p[p]);
+        for (int n0 = 0; n0 < N; n0 += CH) {
+            __syncthreads();
+            for (int idx = tid; idx < BS * CH; idx += 256) {
+                int f, nn;
+                if (AXIS == 0) { f = idx / CH; nn = idx % CH; }     // n fastest (contiguous in memory)
+                else           { nn = idx / BS; f = idx % BS; }     // feature fastest
+                const int n = n0 + nn;
+                float xv = 0.f, ev = 0.f;
+                if (n < N) {
+                    if (AXIS == 0) {
+                        xv = DT::to_f32(X[(size_t)(c * BS + f) * N + n]);
+                        ev = DT::to_f32(E[(size_t)(k * BS + f) * N + n]);
+                    } else {
+                        xv = DT::to_f32(X[(size_t)n * Cf + c * BS + f]);
+                        ev = DT::to_f32(E[(size_t)n * Kf + k * BS + f]);
+                    }
+                }
+                xs[f][nn] = xv;
+                es[f][nn] = ev;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int o = obase + j * 256;
+                const int ci = o / BS, ko = o % BS;
+                float a = acc[j];
+#pragma unroll 8
+                for (int nn = 0; nn < SLN; ++nn) a = fmaf(xs[ci][slice * SLN + nn], es[ko][slice * SLN + nn], a);
+                acc[j] = a;
+            }
+        }
+    }
+
+    if (SL > 1) {
+        __syncthreads();
+        red[tid] = acc[0];
+        __syncthreads();
+        if (tid < OUTS) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < SL; ++j) s += red[j * OUTS + tid];
+            const size_t idx = (size_t)w * OUTS + tid;
+            float out = alpha * s;
+            if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+            DW[idx] = DT::from_f32(out);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const size_t idx = (size_t)w * OUTS + obase + j * 256;
+            float out = alpha * acc[j];
+            if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+            DW[idx] = DT::from_f32(out);
+        }
+    }
+}
+
+template <class DT>
+__global__ void __launch_bounds__(256)
+identity_init_kernel(typename DT::T* __restrict__ W, const int32_t* __restrict__ lut, int CB, int KB, int bsize, float scale) {
+    const int w = blockIdx.x;
+    const int c = lut[2 * w], k = lut[2 * w + 1];
+    const bool diag = (c % KB) == (k % CB);
+    const int n = bsize * bsize;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int i = idx / bsize, j = idx % bsize;
+        W[(size_t)w * n + idx] = DT::from_f32((diag && i == j) ? scale : 0.f);
+    }
+}
+
+}  // namespace bsmm

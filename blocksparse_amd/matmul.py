@@ -1,0 +1,370 @@
+"""``BlocksparseMatMul`` -- host-side mirror of the reference operator interface.
+
+Same constructor, attributes and call semantics as /root/reference/blocksparse/matmul.py:74-483
+(``BlocksparseMatMul``), with the TensorFlow custom ops replaced by the C ABI of libbsmm_hip.so
+(include/bsmm.h) and TF autodiff (matmul.py:485-527) replaced by a ``torch.autograd.Function``.
+PyTorch is used for device memory, streams and autograd plumbing only; all arithmetic on the path
+(fprop / bprop / updat) runs in the hand-written gfx950 kernels.  There is no CPU fallback.
+
+    bsmm = BlocksparseMatMul(layout, block_size=32, feature_axis=0)
+    w = torch.randn(bsmm.w_shape, device="cuda") * 0.01
+    y = bsmm(x, w)              # x: (C, N) for feature_axis=0, (N, C) for feature_axis=1
+    y.backward(dy)              # dx via bprop lut, dw via updat lut
+
+Differences from the reference that a user can observe:
+  * (axis, block_size) combinations: the reference admits axis 0 x {8,16,32} and axis 1 x {32,64}
+    (matmul.py:84-89); we admit {8,16,32} on both axes (north_star), not 64.
+  * By default the device walks an *unsegmented* lookup table (one segment per output block, no locks:
+    deterministic, fp32-accumulated, single rounding).  ``segmented=True`` feeds the device the
+    reference-policy tables; output blocks shared by several segments are then accumulated with atomics
+    in the storage type, like the reference's locked path.  The public attributes ``fprop_lut`` etc.
+    always hold the reference-policy tables (bit-identical to the reference builder).
+  * gating (``gate=``) is not implemented yet and raises NotImplementedError.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import lut as _lut
+
+try:  # torch is plumbing (device memory, streams, autograd); import lazily-tolerant for pure-host use
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _dtype_code(dt):
+    if dt == torch.float32:
+        return _lib.F32
+    if dt == torch.float16:
+        return _lib.F16
+    if dt == torch.bfloat16:
+        return _lib.BF16
+    raise TypeError("blocksparse_amd: unsupported dtype %s (float32, float16, bfloat16)" % dt)
+
+
+class _DeviceTables(object):
+    """int32 lookup tables resident on one device (the reference keeps them as TF variables, matmul.py:33-53)."""
+
+    def __init__(self, tables, device):
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        self.fprop = up(tables["fprop"]["lut"])
+        self.bprop = up(tables["bprop"]["lut"])
+        self.updat = up(tables["updat_lut"])
+
+
+class BlocksparseMatMul(object):
+
+    def __getstate__(self):
+        return (self.layout, self.bsize, self.axis, self.z_order, self.name, self.segmented)
+
+    def __setstate__(self, state):
+        self.__init__(*state)
+
+    def __init__(self, layout, block_size=32, feature_axis=0, z_order=True, name=None, segmented=False):
+        if feature_axis not in (0, 1) or block_size not in (8, 16, 32):
+            raise ValueError("Unsupported block size with this feature axis")
+        layout = np.asarray(layout)
+        assert len(layout.shape) == 2
+        self.axis = feature_axis
+        self.bsize = block_size
+        self.z_order = bool(z_order)
+        self.segmented = bool(segmented)
+        self.name = name if name is not None else "BlocksparseMatMul"
+
+        ref = _lut.build_tables(layout, z_order=z_order, segmented=True)      # reference-policy tables
+        self._ref_tables = ref
+        self._dev_tables = ref if segmented else _lut.build_tables(layout, z_order=z_order, segmented=False)
+
+        CB, KB = ref["CB"], ref["KB"]
+        blocks = ref["blocks"]
+        self.updat_lut = ref["updat_lut"]
+        self.updat_list = [tuple(r) for r in ref["updat_lut"].tolist()]
+        f, b = ref["fprop"], ref["bprop"]
+        self.fprop_list, self.fprop_lut, self.l2_lut = f["cols"], f["lut"], f["l2_lut"]
+        self.fprop_shared, self.l2_shared = f["shared"], f["l2_shared"]
+        self.fprop_segments, self.fprop_locks = f["segments"], f["locks"]
+        self.bprop_list, self.bprop_lut = b["cols"], b["lut"]
+        self.bprop_shared, self.bprop_segments, self.bprop_locks = b["shared"], b["segments"], b["locks"]
+
+        self.flops = blocks * block_size * block_size * 2
+        self.blocks = blocks
+        self.w_shape = (blocks, block_size, block_size)
+        self.g_shape = (blocks,)
+        self.count = 0
+        self.CB, self.KB = CB, KB
+        self.C, self.K = CB * block_size, KB * block_size
+        self.sparsity = round(float(blocks) / float(CB * KB), 3)
+        self.layout = ref["layout"]
+        self._device_cache = {}
+
+    # ---- shapes ----------------------------------------------------------------------------------
+    def i_shape(self, N):
+        return (N, self.C) if self.axis else (self.C, N)
+
+    def o_shape(self, N):
+        return (N, self.K) if self.axis else (self.K, N)
+
+    def block_coord(self, block):
+        return self.updat_list[block]
+
+    # ---- device plumbing -------------------------------------------------------------------------
+    def _tables_on(self, device):
+        key = (device.type, device.index)
+        t = self._device_cache.get(key)
+        if t is None:
+            t = _DeviceTables(self._dev_tables, device)
+            self._device_cache[key] = t
+        return t
+
+    def _check_tensor(self, t, what):
+        if torch is None:
+            raise RuntimeError("blocksparse_amd needs PyTorch-ROCm for device memory")
+        if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+            raise RuntimeError("blocksparse_amd: %s must be a tensor on a ROCm device (no CPU fallback)" % what)
+
+    def _n_of(self, x, feat):
+        if self.axis == 0:
+            if x.shape[0] != feat:
+                raise ValueError("expected %d features on axis 0, got shape %s" % (feat, tuple(x.shape)))
+            return int(x.numel() // feat)
+        if x.shape[-1] != feat:
+            raise ValueError("expected %d features on the last axis, got shape %s" % (feat, tuple(x.shape)))
+        return int(x.numel() // feat)
+
+    def _args(self, lut_t, side, N, Cin, Kout, dtype, pcount=1, alpha=1.0, beta=0.0, workspace=None):
+        a = _lib.BsmmArgs()
+        a.lut = lut_t.data_ptr()
+        a.gate = None
+        a.workspace = workspace.data_ptr() if workspace is not None else None
+        a.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+        a.blocks, a.bsize = self.blocks, self.bsize
+        if side is not None:
+            a.segments, a.locks, a.shared = side["segments"], side["locks"], side["shared"]
+        a.C, a.K, a.N = Cin, Kout, N
+        a.pcount, a.axis, a.dtype = pcount, self.axis, _dtype_code(dtype)
+        a.alpha, a.beta = alpha, beta
+        a.stream = torch.cuda.current_stream(lut_t.device).cuda_stream
+        return a
+
+    def _out_shape(self, x, feat_out):
+        shp = list(x.shape)
+        if self.axis == 0:
+            shp[0] = feat_out
+        else:
+            shp[-1] = feat_out
+        return shp
+
+    # ---- the three passes ------------------------------------------------------------------------
+    def fprop(self, x, w):
+        """Y = fprop(X, W): axis 0 Y(K,N) = Wd^T X, axis 1 Y(N,K) = X Wd (op BlocksparseMatmul)."""
+        self._check_tensor(x, "x"); self._check_tensor(w, "w")
+        if x.dtype != w.dtype:
+            raise TypeError("x and w must have the same dtype")
+        x = x.contiguous(); w = w.contiguous()
+        N = self._n_of(x, self.C)
+        lib = _lib.load()
+        tabs = self._tables_on(x.device)
+        y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
+        a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype)
+        need = lib.bsmm_workspace_bytes(_lib.OP_FPROP, ctypes.byref(a))
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device) if need else None
+        if ws is not None:
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        _lib.check(lib.bsmm_fprop(x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(a)), "bsmm_fprop")
+        return y
+
+    def bprop(self, dy, w):
+        """DX = bprop(DY, W) (op BlocksparseMatmulDX; C and K swapped as in matmul.py:506-510)."""
+        self._check_tensor(dy, "dy"); self._check_tensor(w, "w")
+        if dy.dtype != w.dtype:
+            raise TypeError("dy and w must have the same dtype")
+        dy = dy.contiguous(); w = w.contiguous()
+        N = self._n_of(dy, self.K)
+        lib = _lib.load()
+        tabs = self._tables_on(dy.device)
+        dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)
+        a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype)
+        _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
+        return dx
+
+    def updat(self, xs, dys, alpha=1.0, beta=0.0, dw=None):
+        """DW = alpha * sum_p updat(X_p, DY_p) + beta * DW  (ops BlocksparseMatmulDW / ...DWA).
+
+        ``xs``/``dys``: one tensor each or equally long lists of up to 8 tensors (the reference's Plist)."""
+        if isinstance(xs, torch.Tensor):
+            xs, dys = [xs], [dys]
+        if len(xs) != len(dys) or not 1 <= len(xs) <= 8:
+            raise ValueError("updat takes 1..8 (x, dy) pairs")
+        for t in list(xs) + list(dys):
+            self._check_tensor(t, "x/dy")
+            if t.dtype != xs[0].dtype:
+                raise TypeError("all x/dy tensors must share one dtype")
+        xs = [t.contiguous() for t in xs]
+        dys = [t.contiguous() for t in dys]
+        N = self._n_of(xs[0], self.C)
+        for x, dy in zip(xs, dys):
+            if self._n_of(x, self.C) != N or self._n_of(dy, self.K) != N:
+                raise ValueError("all pairs must share the minibatch size")
+        lib = _lib.load()
+        dev = xs[0].device
+        tabs = self._tables_on(dev)
+        if dw is None:
+            if beta != 0.0:
+                raise ValueError("beta != 0 needs dw")
+            dw = torch.empty(self.w_shape, dtype=xs[0].dtype, device=dev)
+        else:
+            self._check_tensor(dw, "dw")
+            if tuple(dw.shape) != self.w_shape or dw.dtype != xs[0].dtype or not dw.is_contiguous():
+                raise ValueError("dw must be a contiguous %s tensor of dtype %s" % (self.w_shape, xs[0].dtype))
+        a = self._args(tabs.updat, None, N, self.C, self.K, xs[0].dtype, pcount=len(xs), alpha=alpha, beta=beta)
+        arr = ctypes.c_void_p * len(xs)
+        xp = arr(*[t.data_ptr() for t in xs])
+        ep = arr(*[t.data_ptr() for t in dys])
+        _lib.check(lib.bsmm_updat(xp, ep, dw.data_ptr(), ctypes.byref(a)), "bsmm_updat")
+        return dw
+
+    # ---- operator interface (matmul.py:455-483) ---------------------------------------------------
+    def __call__(self, I, W, gate=None, gate_grad=False, dw_gated=False, name=None, bench=0):
+        if gate is not None:
+            raise NotImplementedError("per-block gating is not implemented yet")
+        self.count += 1
+        return _BsmmFunction.apply(I, W, self)
+
+    def matmul(self, I, W, gate=None, gate_grad=False, dw_gated=False, name=None, bench=0):
+        return self.__call__(I, W, gate=gate, gate_grad=gate_grad, dw_gated=dw_gated, name=name, bench=bench)
+
+    # ---- initialisers ----------------------------------------------------------------------------
+    def identity_init(self, scale=1.0):
+        """Returns ``init(shape=None, dtype=torch.float32, device="cuda") -> W`` computed on the device
+        (op BlocksparseMatmulIdentityInit, matmul.py:55-72,321-323)."""
+        def _initializer(shape=None, dtype=None, device="cuda"):
+            dtype = dtype or torch.float32
+            if shape is not None:
+                assert tuple(shape) == self.w_shape
+            dev = torch.device(device)
+            if dev.type != "cuda":
+                raise RuntimeError("blocksparse_amd: identity_init runs on a ROCm device only")
+            if dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            lib = _lib.load()
+            tabs = self._tables_on(dev)
+            W = torch.empty(self.w_shape, dtype=dtype, device=dev)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.bsmm_identity_init(W.data_ptr(), tabs.updat.data_ptr(), self.CB, self.KB, self.blocks,
+                                              self.bsize, float(scale), _dtype_code(dtype), st), "bsmm_identity_init")
+            return W
+        return _initializer
+
+    def ortho_init(self):
+        """NumPy initializer (host), same construction as matmul.py:291-319."""
+        def _initializer(shape=None, dtype=np.float32, partition_info=None):
+            W = np.empty(self.w_shape, dtype=dtype)
+            bs = self.bsize
+            if self.sparsity < 1.0:
+                for k, col in self.fprop_list:
+                    if not col:
+                        continue
+                    shp = (len(col) * bs, bs)
+                    a = np.random.normal(0.0, 1.0, shp).astype(dtype)
+                    u, _, v = np.linalg.svd(a, full_matrices=False)
+                    if u.shape != shp:
+                        u = v
+                    for i, (c, w) in enumerate(col):
+                        W[w, :, :] = u[i * bs:(i + 1) * bs, :]
+            else:
+                shp = (self.C, self.K)
+                a = np.random.normal(0.0, 1.0, shp).astype(dtype)
+                u, _, v = np.linalg.svd(a, full_matrices=False)
+                if u.shape != shp:
+                    u = v
+                for w, (c, k) in enumerate(self.updat_list):
+                    W[w, :, :] = u[c * bs:(c + 1) * bs, k * bs:(k + 1) * bs]
+            return W
+        return _initializer
+
+    def checker_init(self):
+        def _initializer(shape=None, dtype=np.float32, partition_info=None):
+            ul = self.updat_lut
+            return (((ul[:, 0] & 1) ^ (ul[:, 1] & 1)) ^ 1).astype(dtype)
+        return _initializer
+
+    # ---- NumPy reference functions shipped with the class (matmul.py:353-419) ----------------------
+    # Host-side API parity only (the reference exposes them as methods); the device path never calls them.
+    def fprop_test(self, I, W, gate=None):
+        assert gate is None
+        bs = self.bsize
+        I = np.asarray(I); W = np.asarray(W)
+        if self.axis:
+            n = I.shape[0]
+            X = I.reshape(n, self.CB, bs)
+            O = np.zeros((n, self.KB, bs))
+            for k, col in self.fprop_list:
+                if col:
+                    cs = [e[0] for e in col]; ws = [e[1] for e in col]
+                    O[:, k, :] = X[:, cs, :].reshape(n, -1) @ W[ws].reshape(-1, bs)
+            return O.reshape(n, -1)
+        n = I[0].size
+        X = I.reshape(self.CB, bs, n)
+        O = np.zeros((self.KB, bs, n))
+        for k, col in self.fprop_list:
+            if col:
+                cs = [e[0] for e in col]; ws = [e[1] for e in col]
+                O[k] = W[ws].reshape(-1, bs).T @ X[cs].reshape(-1, n)
+        return O.reshape(-1, n)
+
+    def bprop_test(self, E, W, gate=None):
+        assert gate is None
+        bs = self.bsize
+        E = np.asarray(E); W = np.asarray(W)
+        if self.axis:
+            n = E.shape[0]
+            D = E.reshape(n, self.KB, bs)
+            B = np.zeros((n, self.CB, bs))
+            for c, row in self.bprop_list:
+                if row:
+                    ks = [e[0] for e in row]; ws = [e[1] for e in row]
+                    B[:, c, :] = D[:, ks, :].reshape(n, -1) @ np.transpose(W[ws], (0, 2, 1)).reshape(-1, bs)
+            return B.reshape(n, -1)
+        n = E[0].size
+        D = E.reshape(self.KB, bs, n)
+        B = np.zeros((self.CB, bs, n))
+        for c, row in self.bprop_list:
+            if row:
+                ks = [e[0] for e in row]; ws = [e[1] for e in row]
+                B[c] = np.transpose(W[ws], (1, 0, 2)).reshape(bs, -1) @ D[ks].reshape(-1, n)
+        return B.reshape(-1, n)
+
+    def updat_test(self, I, E, gate=None, dw_gated=False):
+        assert gate is None
+        bs = self.bsize
+        I = np.asarray(I, dtype=np.float64); E = np.asarray(E, dtype=np.float64)
+        ul = self.updat_lut
+        if self.axis:
+            X = I.reshape(-1, self.CB, bs).transpose(1, 2, 0)
+            D = E.reshape(-1, self.KB, bs).transpose(1, 2, 0)
+        else:
+            X = I.reshape(self.CB, bs, -1)
+            D = E.reshape(self.KB, bs, -1)
+        return np.matmul(X[ul[:, 0]], np.transpose(D[ul[:, 1]], (0, 2, 1)))
+
+
+if torch is not None:
+    class _BsmmFunction(torch.autograd.Function):
+        """y = bsmm(x, w); backward = (bprop, updat), the registered gradient of matmul.py:485-527."""
+
+        @staticmethod
+        def forward(ctx, x, w, bsmm):
+            ctx.bsmm = bsmm
+            ctx.save_for_backward(x, w)
+            return bsmm.fprop(x, w)
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            bsmm = ctx.bsmm
+            dx = bsmm.bprop(dy, w) if ctx.needs_input_grad[0] else None
+            dw = bsmm.updat(x, dy) if ctx.needs_input_grad[1] else None
+            return dx, dw, None

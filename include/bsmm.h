@@ -1,0 +1,106 @@
+/* bsmm.h -- C ABI of the MI355X-native block-sparse matmul engine (libbsmm_hip.so).
+ *
+ * This is the drop-in boundary for the BlocksparseMatMul hot path of openai/blocksparse.  Every entry
+ * point replaces one piece of the reference's TensorFlow custom-op layer (paths are relative to
+ * /root/reference):
+ *
+ *   bsmm_args            <- struct bsmm_params                       src/gpu_types.h:172-194
+ *                           (+ axis/dtype, which the reference carries as op attrs / template args,
+ *                            src/blocksparse_matmul_op.cc:356-382)
+ *   bsmm_fprop           <- op "BlocksparseMatmul"   -> BsmmXprop_CN<true ,T>  /  hgemm_blocksparse_xn_sdd(OP_T) / nx_dsd(OP_N)
+ *                           src/blocksparse_matmul_op.cc:120-222, src/blocksparse_matmul_op_gpu.cu:2895-2941
+ *   bsmm_bprop           <- op "BlocksparseMatmulDX" -> BsmmXprop_CN<false,T>  (same kernel family, C/K swapped by the
+ *                           caller exactly as blocksparse/matmul.py:506-510 does)
+ *   bsmm_updat           <- ops "BlocksparseMatmulDW" / "BlocksparseMatmulDWA" -> BsmmUpdat_CN<T>
+ *                           src/blocksparse_matmul_op.cc:223-311, src/blocksparse_matmul_op_gpu.cu:2944-2984
+ *                           (up to 8 (x,dy) pairs = Plist<T,8>, src/gpu_types.h:167-170; beta!=0 = the DWA in-place form)
+ *   bsmm_identity_init   <- op "BlocksparseMatmulIdentityInit" -> IdentityInitCK  src/blocksparse_matmul_op_gpu.cu:2988-3028
+ *   bsmm_workspace_bytes <- the scratch the op allocates as output 1 ("temp"/lock scratch), src/blocksparse_matmul_op.cc:150-159
+ *
+ * Conventions (same as the reference boundary):
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees device memory;
+ *   - every call only enqueues work on `stream` (a hipStream_t) and returns immediately; no host sync;
+ *   - return value: 0 = ok; >0 = a hipError_t from the launch; <0 = BSMM_ERR_* (bad arguments); nothing throws;
+ *   - no global mutable state on the data path: concurrent calls on distinct streams are safe.
+ *
+ * Tensor layouts:
+ *   W  [blocks][bsize][bsize]  W[w][ci][ki] = Wdense[c*bsize+ci][k*bsize+ki] with (c,k) = updat_lut[w]
+ *   axis 0: X (C,N)  Y (K,N)  row-major, N contiguous          fprop Y = Wd^T X   bprop DX = Wd DY   updat DW[w] = X[c] DY[k]^T
+ *   axis 1: X (N,C)  Y (N,K)  row-major, features contiguous   fprop Y = X Wd     bprop DX = DY Wd^T updat DW[w] = X[:,c]^T DY[:,k]
+ *   xprop lut  int32[4*segments + 2*blocks]: header (entry_offset/2, n_entries, out_block, lock_id), entry (in_block, w)
+ *   updat lut  int32[blocks][2] = (c, k)
+ * Accumulation is always fp32; 16-bit outputs are rounded once, round-to-nearest-even.
+ */
+#ifndef BSMM_H_
+#define BSMM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSMM_VERSION 100 /* 0.1.0 */
+
+enum { BSMM_F32 = 0, BSMM_F16 = 1, BSMM_BF16 = 2 };
+
+enum {
+    BSMM_OK = 0,
+    BSMM_ERR_ARG = -1,         /* NULL pointer / non-positive size / pcount out of 1..8            */
+    BSMM_ERR_UNSUPPORTED = -2, /* bsize not in {8,16,32}, axis not in {0,1}, unknown dtype, gating */
+    BSMM_ERR_WORKSPACE = -3    /* workspace pointer NULL or smaller than bsmm_workspace_bytes()     */
+};
+
+enum { BSMM_OP_FPROP = 0, BSMM_OP_BPROP = 1, BSMM_OP_UPDAT = 2 };
+
+typedef struct bsmm_args {
+    const int32_t* lut;     /* device: fprop_lut (fprop) / bprop_lut (bprop) / updat_lut (updat)                    */
+    const float* gate;      /* per-block gate (reference: Gate); must be NULL -- gating is not implemented yet      */
+    void* workspace;        /* device scratch of >= bsmm_workspace_bytes(op, args) bytes (may be NULL when that is 0) */
+    size_t workspace_bytes;
+    int32_t blocks;         /* nonzero blocks                                                                        */
+    int32_t bsize;          /* 8, 16 or 32                                                                           */
+    int32_t segments;       /* xprop: number of lut headers (incl. empty output blocks)                              */
+    int32_t locks;          /* xprop: number of output blocks written by more than one segment                       */
+    int32_t C;              /* input features  of this call (bprop: caller passes the layer's K here)                */
+    int32_t K;              /* output features of this call (bprop: caller passes the layer's C here)                */
+    int32_t N;              /* minibatch = product of all non-feature dims                                           */
+    int32_t shared;         /* reference's LDS lut-cache size in bytes; accepted, unused                             */
+    int32_t pcount;         /* updat: number of (x,dy) pairs, 1..8                                                   */
+    int32_t axis;           /* feature axis: 0 => (C,N) activations, 1 => (N,C)                                      */
+    int32_t dtype;          /* BSMM_F32 / BSMM_F16 / BSMM_BF16: type of X, W, Y, DW                                  */
+    float alpha;            /* updat: DW = alpha * sum_p X_p DY_p^T + beta * DW                                      */
+    float beta;
+    void* stream;           /* hipStream_t                                                                           */
+} bsmm_args;
+
+/* Y = fprop(X, W).  args->lut = fprop_lut.  Needs workspace (a transposed copy of W). */
+int bsmm_fprop(const void* X, const void* W, void* Y, const bsmm_args* args);
+
+/* DX = bprop(DY, W).  args->lut = bprop_lut, args->C/K swapped by the caller.  No workspace. */
+int bsmm_bprop(const void* DY, const void* W, void* DX, const bsmm_args* args);
+
+/* DW = alpha * sum_{p<pcount} updat(X[p], DY[p]) + beta * DW.  args->lut = updat_lut.
+ * X and DY are HOST arrays of pcount device pointers. */
+int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm_args* args);
+
+/* W[w] = scale * I if (c % KB) == (k % CB) else 0, (c,k) = updat_lut[w];  dtype as BSMM_* */
+int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks,
+                       int32_t bsize, float scale, int32_t dtype, void* stream);
+
+/* Bytes of device scratch the given op (BSMM_OP_*) needs for these args. */
+size_t bsmm_workspace_bytes(int op, const bsmm_args* args);
+
+/* Test hook: 0 = production kernels (MFMA for bsize 16/32, VALU for 8);
+ *            1 = force the plain VALU kernels for every bsize (independent second implementation). */
+void bsmm_set_kernel_variant(int variant);
+int bsmm_get_kernel_variant(void);
+
+const char* bsmm_error_string(int code);
+int bsmm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSMM_H_ */

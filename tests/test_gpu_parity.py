@@ -1,0 +1,249 @@
+"""GPU parity: the HIP path (through the C ABI via blocksparse_amd.BlocksparseMatMul) vs the NumPy oracle,
+mirroring the matrix of test/blocksparse_matmul_test.py (BA layout with locks, bsize 32/16/8, N sweep) and
+extending it to both feature axes and fp32/fp16/bf16."""
+import os
+
+import numpy as np
+import pytest
+
+import _parity as P
+from oracle import bsmm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from blocksparse_amd import BlocksparseMatMul, _lib
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    _lib.load()     # fail loudly if the HIP extension is missing
+    return torch, BlocksparseMatMul, _lib
+
+
+def _check(res, dtype, ctx):
+    for name, (l2, mx) in res.items():
+        assert l2 <= P.L2_BAR[dtype], "%s %s L2-rel %.3e > %.1e" % (ctx, name, l2, P.L2_BAR[dtype])
+        assert mx <= P.MAX_BAR[dtype], "%s %s max-rel %.3e > %.1e" % (ctx, name, mx, P.MAX_BAR[dtype])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("bs", [32, 16, 8])
+def test_ba_layout_all_passes(env, bs, axis, dtype):
+    torch, BSMM, _ = env
+    layout = P.ba_layout(40, 3, seed=1)
+    for N in (64, 8):
+        res = P.run_case(torch, BSMM, layout, bs, axis, dtype, N, seed=bs + axis)
+        _check(res, dtype, "bs%d a%d %s N%d" % (bs, axis, dtype, N))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("bs", [32, 16, 8])
+def test_ragged_minibatch_and_unaligned(env, bs, axis, dtype):
+    """N not a multiple of the tile / vector width (reference needs N%4==0; we accept any N)."""
+    torch, BSMM, _ = env
+    layout = P.random_layout(6, 9, 0.4, seed=3)
+    for N in (1, 5, 36, 100, 300):
+        res = P.run_case(torch, BSMM, layout, bs, axis, dtype, N, seed=N)
+        _check(res, dtype, "bs%d a%d %s N%d" % (bs, axis, dtype, N))
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("bs", [32, 16, 8])
+def test_empty_rows_cols_and_single_block(env, bs, axis):
+    torch, BSMM, _ = env
+    layout = P.ba_layout(16, 2, seed=3)
+    layout[:, 5] = 0
+    layout[7, :] = 0
+    _check(P.run_case(torch, BSMM, layout, bs, axis, "f32", 24), "f32", "holes")
+    _check(P.run_case(torch, BSMM, np.ones((1, 1), dtype=np.int32), bs, axis, "f32", 8), "f32", "single")
+    _check(P.run_case(torch, BSMM, np.ones((3, 2), dtype=np.int32), bs, axis, "bf16", 40), "bf16", "dense3x2")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("bs", [32, 16, 8])
+def test_segmented_luts_with_locks(env, bs, axis, dtype):
+    """Reference-policy tables (segments + lock ids) fed to the device: shared output blocks accumulate atomically."""
+    torch, BSMM, _ = env
+    layout = P.ba_layout(64, 3, seed=5)
+    b = BSMM(layout, block_size=bs, feature_axis=axis, segmented=True)
+    assert b.fprop_locks > 0 and b.bprop_locks > 0
+    res = P.run_case(torch, BSMM, layout, bs, axis, dtype, 48, seed=9, segmented=True, passes=("Y", "DX"))
+    bar = {"f32": (1e-5, 1e-4), "f16": (3e-3, 2e-2), "bf16": (2e-2, 1e-1)}[dtype]   # per-segment rounding in 16 bit
+    for name, (l2, mx) in res.items():
+        assert l2 <= bar[0] and mx <= bar[1], (name, l2, mx)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("bs,axis", [(32, 0), (32, 1), (16, 0), (16, 1), (8, 0), (8, 1)])
+def test_mfma_and_valu_kernels_agree(env, bs, axis, dtype):
+    """Two independent device implementations (matrix-core and plain VALU) on the same inputs."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(10, 12, 0.35, seed=11)
+    L = lib.load()
+    try:
+        L.bsmm_set_kernel_variant(1)
+        a = P.run_case(torch, BSMM, layout, bs, axis, dtype, 72, seed=2)
+    finally:
+        L.bsmm_set_kernel_variant(0)
+    b = P.run_case(torch, BSMM, layout, bs, axis, dtype, 72, seed=2)
+    _check(a, dtype, "valu")
+    _check(b, dtype, "mfma")
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("bs", [32, 8])
+def test_updat_alpha_beta_and_pairs(env, bs, axis):
+    torch, BSMM, _ = env
+    layout = P.random_layout(5, 7, 0.5, seed=4)
+    b = BSMM(layout, block_size=bs, feature_axis=axis)
+    t = orc.build_layout_luts(layout, bs)
+    N = 40
+    Xs, Es = [], []
+    for p in range(3):
+        _, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=20 + p)
+        Xs.append(X); Es.append(E)
+    dw0 = np.random.RandomState(0).normal(size=b.w_shape).astype(np.float32)
+    ref = orc.updat(t, Xs, Es, axis, alpha=0.5, beta=2.0, dw_in=dw0)
+    dw = P.to_dev(dw0, "f32", torch)
+    out = b.updat([P.to_dev(x, "f32", torch) for x in Xs], [P.to_dev(e, "f32", torch) for e in Es],
+                  alpha=0.5, beta=2.0, dw=dw)
+    assert out.data_ptr() == dw.data_ptr()          # DWA form: accumulates in place
+    l2, mx = P.errors(P.to_host(out), ref)
+    assert l2 < 2e-6, l2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("axis", [0, 1])
+def test_autograd_matches_oracle(env, axis, dtype):
+    torch, BSMM, _ = env
+    layout = P.ba_layout(24, 3, seed=2)
+    bs, N = 32, 64
+    b = BSMM(layout, block_size=bs, feature_axis=axis)
+    t = orc.build_layout_luts(layout, bs)
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=5)
+    w = P.to_dev(W, dtype, torch).requires_grad_()
+    x = P.to_dev(X, dtype, torch).requires_grad_()
+    y = b(x, w)
+    y.backward(P.to_dev(E, dtype, torch))
+    for name, got, ref in (("Y", y, orc.fprop(t, X, W, axis)), ("DX", x.grad, orc.bprop(t, E, W, axis)),
+                           ("DW", w.grad, orc.updat(t, X, E, axis))):
+        l2, mx = P.errors(P.to_host(got), orc.round_to(ref, dtype))
+        assert l2 <= P.L2_BAR[dtype], (name, l2)
+
+
+def test_rank3_inputs_flatten_non_feature_dims(env):
+    torch, BSMM, _ = env
+    layout = P.random_layout(4, 4, 0.6, seed=8)
+    b1 = BSMM(layout, block_size=16, feature_axis=1)
+    w = torch.randn(b1.w_shape, device="cuda") * 0.05
+    x = torch.randn(3, 5, b1.C, device="cuda")
+    y = b1(x, w)
+    assert tuple(y.shape) == (3, 5, b1.K)
+    torch.testing.assert_close(y.reshape(15, -1), b1(x.reshape(15, -1), w))
+    b0 = BSMM(layout, block_size=16, feature_axis=0)
+    x0 = torch.randn(b0.C, 3, 4, device="cuda")
+    y0 = b0(x0, w)
+    assert tuple(y0.shape) == (b0.K, 3, 4)
+    torch.testing.assert_close(y0.reshape(b0.K, 12), b0(x0.reshape(b0.C, 12), w))
+
+
+def test_identity_init_and_one_mode(env):
+    """The reference's `one=1` debug mode (test/blocksparse_matmul_test.py:301-307,330-332): all-ones X with
+    identity blocks gives Y[k,:] = number of blocks in column k."""
+    torch, BSMM, _ = env
+    layout = P.ba_layout(20, 2, seed=7)
+    for bs, axis in ((32, 0), (16, 1), (8, 0)):
+        b = BSMM(layout, block_size=bs, feature_axis=axis)
+        t = orc.build_layout_luts(layout, bs)
+        W = b.identity_init(2.0)()
+        np.testing.assert_array_equal(P.to_host(W), orc.identity_init(t, 2.0))
+        Wi = torch.eye(bs, device="cuda").repeat(b.blocks, 1, 1)
+        x = torch.ones(b.i_shape(16), device="cuda")
+        y = P.to_host(b.fprop(x, Wi))
+        counts = layout.sum(axis=0)
+        want = np.repeat(counts, bs)[:, None] * np.ones((1, 16)) if axis == 0 else np.ones((16, 1)) * np.repeat(counts, bs)[None, :]
+        np.testing.assert_array_equal(y, want)
+
+
+def test_cfg0_golden_on_device(env, golden_dir):
+    """BASELINE.json configs[0] (layout=random(128,128), bs 32, N=64, fp32) against the REFERENCE's own outputs."""
+    torch, BSMM, _ = env
+    z = np.load(os.path.join(golden_dir, "cfg0_rand128.npz"))
+    np.random.seed(0)
+    layout = np.random.randint(2, size=(128, 128))
+    for axis in (0, 1):
+        b = BSMM(layout, block_size=32, feature_axis=axis)
+        rng = np.random.RandomState(int(z["a%d/seed" % axis]))
+        f16 = lambda a: a.astype(np.float16).astype(np.float32)
+        W = f16(rng.normal(0.0, 0.01, b.w_shape))
+        X = f16(rng.normal(0.0, 0.1, b.i_shape(64)))
+        E = f16(rng.normal(0.0, 0.1, b.o_shape(64)))
+        w, x, e = (P.to_dev(a, "f32", torch) for a in (W, X, E))
+        for name, got, ref in (("Y", b.fprop(x, w), z["a%d/Y" % axis]), ("DX", b.bprop(e, w), z["a%d/DX" % axis]),
+                               ("DW", b.updat(x, e)[::64], z["a%d/DW_every64" % axis])):
+            l2, mx = P.errors(P.to_host(got), ref)
+            assert l2 < 2e-6, (axis, name, l2)
+
+
+def test_golden_math_fixtures_on_device(env, golden_dir):
+    """Every small case of tests/golden/math.npz (outputs of the reference's fprop_test/bprop_test/updat_test)."""
+    torch, BSMM, _ = env
+    z = np.load(os.path.join(golden_dir, "math.npz"))
+    for lay in ("ba16", "holes", "rect", "single"):
+        for bs in (8, 16, 32):
+            for axis in (0, 1):
+                g = lambda k: z["%s/bs%d/a%d/%s" % (lay, bs, axis, k)]
+                b = BSMM(g("layout"), block_size=bs, feature_axis=axis)
+                w, x, e = (P.to_dev(g(k).astype(np.float32), "f32", torch) for k in ("W", "X", "E"))
+                for name, got in (("Y", b.fprop(x, w)), ("DX", b.bprop(e, w)), ("DW", b.updat(x, e))):
+                    l2, mx = P.errors(P.to_host(got), g(name))
+                    assert l2 < 2e-6, (lay, bs, axis, name, l2)
+
+
+@pytest.mark.parametrize("dtype,bs,axis", [("f32", 32, 1), ("bf16", 32, 1), ("bf16", 32, 0), ("bf16", 16, 0), ("bf16", 8, 0)])
+def test_full_size_properties(env, dtype, bs, axis):
+    """BASELINE-size layouts (4096^2) checked through size-independent properties:
+    (1) linearity  f(x1 + x2) == f(x1) + f(x2) on inputs whose sums are exactly representable,
+    (2) <dy, fprop(x)> == <bprop(dy), x> == <updat(x, dy), w>  (adjointness of the three passes),
+    (3) a sampled set of output blocks against the oracle."""
+    torch, BSMM, _ = env
+    CB = 4096 // bs
+    layout = P.random_layout(CB, CB, 0.2 if bs == 32 else 0.1, seed=1234)
+    N = 512
+    b = BSMM(layout, block_size=bs, feature_axis=axis)
+    td = getattr(torch, P.TORCH_DT[dtype])
+    g = torch.Generator(device="cuda").manual_seed(1)
+    # small integers / 64: sums and products stay exact enough for tight comparisons
+    w = (torch.randint(-4, 5, b.w_shape, device="cuda", generator=g).float() / 64).to(td)
+    x1 = (torch.randint(-4, 5, b.i_shape(N), device="cuda", generator=g).float() / 8).to(td)
+    x2 = (torch.randint(-4, 5, b.i_shape(N), device="cuda", generator=g).float() / 8).to(td)
+    dy = (torch.randint(-4, 5, b.o_shape(N), device="cuda", generator=g).float() / 8).to(td)
+    y1, y2, y12 = b.fprop(x1, w).float(), b.fprop(x2, w).float(), b.fprop(x1 + x2, w).float()
+    tol = 1e-5 if dtype == "f32" else 2e-2
+    assert (y12 - (y1 + y2)).abs().max().item() <= tol * max(1.0, y12.abs().max().item())
+    dx = b.bprop(dy, w).float()
+    dw = b.updat(x1, dy).float()
+    s1 = (dy.double() * y1.double()).sum().item()
+    s2 = (dx.double() * x1.double()).sum().item()
+    s3 = (dw.double() * w.double()).sum().item()
+    rel = 1e-5 if dtype == "f32" else 5e-3
+    assert abs(s1 - s2) <= rel * abs(s1) and abs(s1 - s3) <= rel * abs(s1), (s1, s2, s3)
+    # sampled output blocks vs oracle
+    t = orc.build_layout_luts(layout, bs)
+    X = P.to_host(x1); Wn = P.to_host(w)
+    Y = P.to_host(y1)
+    cols = dict(t["fprop_list"])
+    for k in (0, CB // 3, CB - 1):
+        ref = np.zeros((bs, N)) if axis == 0 else np.zeros((N, bs))
+        for c, wi in cols[k]:
+            if axis == 0:
+                ref += Wn[wi].astype(np.float64).T @ X[c * bs:(c + 1) * bs, :]
+            else:
+                ref += X[:, c * bs:(c + 1) * bs].astype(np.float64) @ Wn[wi]
+        got = Y[k * bs:(k + 1) * bs, :] if axis == 0 else Y[:, k * bs:(k + 1) * bs]
+        l2, _ = P.errors(got, orc.round_to(ref, dtype))
+        assert l2 <= P.L2_BAR[dtype], (k, l2)
