@@ -7,7 +7,7 @@ TORCH_DT = {"f32": "float32", "f16": "float16", "bf16": "bfloat16"}
 # L2-relative bars (north_star: <=1e-3 rel-err; fp32 far tighter).  16-bit results are compared with the
 # oracle evaluated on the SAME rounded inputs in float64 and rounded ONCE to the storage type.
 L2_BAR = {"f32": 2e-6, "f16": 1e-3, "bf16": 1e-3}
-MAX_BAR = {"f32": 2e-5, "f16": 4e-3, "bf16": 2e-2}   # max|diff| / mean|ref|
+MAX_BAR = {"f32": 2e-5, "f16": 1e-2, "bf16": 6e-2}   # max|diff| / mean|ref|  (one 16-bit ulp flip on the largest element)
 
 
 def ba_layout(n, m, seed):
@@ -33,8 +33,10 @@ def ba_layout(n, m, seed):
 def random_layout(CB, KB, density, seed):
     rng = np.random.default_rng(seed)
     lay = (rng.random((CB, KB)) < density).astype(np.int32)
-    lay[np.arange(CB), rng.integers(0, KB, CB)] = 1      # >= 1 block per row
-    lay[rng.integers(0, CB, KB), np.arange(KB)] = 1      # >= 1 block per column
+    for r in np.nonzero(lay.sum(axis=1) == 0)[0]:        # >= 1 block per row
+        lay[r, rng.integers(0, KB)] = 1
+    for c in np.nonzero(lay.sum(axis=0) == 0)[0]:        # >= 1 block per column
+        lay[rng.integers(0, CB), c] = 1
     return lay
 
 

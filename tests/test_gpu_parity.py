@@ -230,8 +230,12 @@ def test_full_size_properties(env, dtype, bs, axis):
     s1 = (dy.double() * y1.double()).sum().item()
     s2 = (dx.double() * x1.double()).sum().item()
     s3 = (dw.double() * w.double()).sum().item()
-    rel = 1e-5 if dtype == "f32" else 5e-3
-    assert abs(s1 - s2) <= rel * abs(s1) and abs(s1 - s3) <= rel * abs(s1), (s1, s2, s3)
+    # the three inner products differ only by the storage rounding of y / dx / dw (<= 2^-9 relative per element
+    # in bf16): compare against the noise scale sqrt(sum (a_i b_i)^2), not against the (cancelling) sum itself
+    noise = ((dy.double() * y1.double()).square().sum().sqrt() + (dx.double() * x1.double()).square().sum().sqrt()
+             + (dw.double() * w.double()).square().sum().sqrt()).item()
+    rel = 1e-5 if dtype == "f32" else 2.0 ** -7
+    assert abs(s1 - s2) <= rel * noise and abs(s1 - s3) <= rel * noise, (s1, s2, s3, noise)
     # sampled output blocks vs oracle
     t = orc.build_layout_luts(layout, bs)
     X = P.to_host(x1); Wn = P.to_host(w)
