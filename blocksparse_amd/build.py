@@ -7,7 +7,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 OUT = os.path.join(_HERE, "libbsmm_hip.so")
 SOURCES = ["bsmm_api.hip"]
-HEADERS = ["bsmm_common.h", "bsmm_xprop.h", "bsmm_updat.h"]
+HEADERS = ["bsmm_common.h", "bsmm_xprop.h", "bsmm_updat.h", "bsmm_xgroup.h", "bsmm_plan.h"]
 
 
 def _stale():
@@ -28,7 +28,15 @@ def build(force=False, verbose=False):
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    tmp = OUT + ".tmp"
+    cmd[-1] = tmp
+    if os.path.exists(OUT):
+        os.remove(OUT)          # never leave a stale library behind a failed build
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        errs = [ln for ln in (r.stdout + r.stderr).splitlines() if "error" in ln][:10]
+        raise RuntimeError("hipcc failed:\n" + "\n".join(errs))
+    os.replace(tmp, OUT)
     return OUT
 
 

@@ -1,9 +1,12 @@
 // bsmm_api.hip -- C-ABI entry points (include/bsmm.h) and kernel dispatch for gfx950.
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 
 #include "bsmm.h"
+#include "bsmm_plan.h"
 #include "bsmm_updat.h"
+#include "bsmm_xgroup.h"
 #include "bsmm_xprop.h"
 
 using namespace bsmm;
@@ -72,6 +75,59 @@ int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args*
     return (int)hipGetLastError();
 }
 
+// grouped kernel (needs args->plan built by bsmm_xprop_plan_build for args->lut)
+// Group size used by the plan builder AND the launcher (they must agree): process-wide tuning knob,
+// env BSMM_XG_G (axis 1: 8 or 12, default 8; axis 0: BSMM_XG_G0 4 or 8, default 8).
+int xg_group_size(int axis) {
+    static const int g1 = [] { const char* e = getenv("BSMM_XG_G"); const int v = e ? atoi(e) : 8; return v == 12 ? 12 : 8; }();
+    static const int g0 = [] { const char* e = getenv("BSMM_XG_G0"); const int v = e ? atoi(e) : 8; return v == 4 ? 4 : 8; }();
+    return axis == 1 ? g1 : g0;
+}
+
+template <class DT, int G>
+void launch_xs3(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    typedef typename DT::T T;
+    const int n_out = a->K / 32;
+    XMap m;
+    m.ntiles = (a->N + XS3::NT - 1) / XS3::NT;
+    m.segments = (n_out + G - 1) / G;
+    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+    if (m.P > m.segments) m.P = m.segments;
+    m.SP = (m.segments + m.P - 1) / m.P;
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xs3_a1_kernel<DT, G>), hipFuncAttributeMaxDynamicSharedMemorySize, XS3::LDS);
+        attr_set = true;
+    }
+    xs3_a1_kernel<DT, G><<<m.grid(), 256, XS3::LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y),
+                                                          a->plan, m, a->N, a->C, a->K);
+}
+
+template <class DT, int AXIS>
+int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    typedef typename DT::T T;
+    if constexpr (AXIS == 1) {
+        if (xg_group_size(1) == 8) launch_xs3<DT, 8>(X, Wsel, Y, a, st);
+        else                       launch_xs3<DT, 12>(X, Wsel, Y, a, st);
+    } else {
+        const int G = xg_group_size(0);
+        const int n_out = a->K / 32;
+        XMap m;
+        m.ntiles = (a->N + 127) / 128;
+        m.segments = (n_out + G - 1) / G;
+        m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+        if (m.P > m.segments) m.P = m.segments;
+        m.SP = (m.segments + m.P - 1) / m.P;
+        if (G == 8)
+            xgroup32_kernel<DT, AXIS, 8><<<m.grid(), 256, XG_SB * 2048, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
+                                                                            static_cast<T*>(Y), a->plan, m, a->N, a->C, a->K);
+        else
+            xgroup32_kernel<DT, AXIS, 4><<<m.grid(), 256, XG_SB * 2048, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
+                                                                            static_cast<T*>(Y), a->plan, m, a->N, a->C, a->K);
+    }
+    return (int)hipGetLastError();
+}
+
 template <class DT, int BS>
 int launch_transpose(const void* W, void* Wt, int blocks, hipStream_t st) {
     typedef typename DT::T T;
@@ -82,12 +138,14 @@ int launch_transpose(const void* W, void* Wt, int blocks, hipStream_t st) {
 template <class DT, int BS, int AXIS>
 int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
     hipStream_t st = static_cast<hipStream_t>(a->stream);
-    if (a->locks > 0) {   // several segments accumulate into the same output block: start from zero
+    const int variant = g_variant.load(std::memory_order_relaxed);
+    const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
+    const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
+    const bool use_group = !use_valu && BS == 32 && DT::is16 && a->plan != nullptr && variant == 0;
+    if (a->locks > 0 && !use_group) {   // several segments accumulate into the same output block: start from zero
         hipError_t e = hipMemsetAsync(Y, 0, (size_t)a->N * a->K * elem_size(a->dtype), st);
         if (e != hipSuccess) return (int)e;
     }
-    const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
-    const bool use_valu = (BS == 8) || g_variant.load(std::memory_order_relaxed) == 1 || !vec_ok;
     if (use_valu) {
         return fprop ? launch_xprop_valu<DT, BS, AXIS, true>(X, W, Y, a, st)
                      : launch_xprop_valu<DT, BS, AXIS, false>(X, W, Y, a, st);
@@ -100,6 +158,9 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
             int rc = launch_transpose<DT, BS>(W, a->workspace, a->blocks, st);
             if (rc) return rc;
             Wsel = a->workspace;
+        }
+        if constexpr (BS == 32 && DT::is16) {
+            if (use_group) return launch_xgroup32<DT, AXIS>(X, Wsel, Y, a, st);
         }
         return launch_xprop_mfma<DT, BS, AXIS>(X, Wsel, Y, a, st);
     }
@@ -213,6 +274,20 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
     return (int)hipGetLastError();
 }
 
+long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
+                           int32_t dtype, int32_t axis) {
+    if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // grouped kernels: bsize 32, 16-bit types
+    return build_xprop_plan(host_lut, segments, blocks, n_out_blocks, xg_group_size(axis), XG_SB, axis == 1, nullptr);
+}
+
+int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
+                          int32_t dtype, int32_t axis, int32_t* host_plan_out) {
+    if (!host_plan_out) return BSMM_ERR_ARG;
+    if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
+    return build_xprop_plan(host_lut, segments, blocks, n_out_blocks, xg_group_size(axis), XG_SB, axis == 1, host_plan_out) > 0
+               ? BSMM_OK : BSMM_ERR_ARG;
+}
+
 size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     if (!a) return 0;
     // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)
@@ -220,7 +295,7 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     return 0;
 }
 
-void bsmm_set_kernel_variant(int variant) { g_variant.store(variant == 1 ? 1 : 0); }
+void bsmm_set_kernel_variant(int variant) { g_variant.store((variant == 1 || variant == 2) ? variant : 0); }
 int bsmm_get_kernel_variant(void) { return g_variant.load(); }
 
 const char* bsmm_error_string(int code) {

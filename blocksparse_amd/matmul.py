@@ -44,15 +44,38 @@ def _dtype_code(dt):
     raise TypeError("blocksparse_amd: unsupported dtype %s (float32, float16, bfloat16)" % dt)
 
 
-class _DeviceTables(object):
-    """int32 lookup tables resident on one device (the reference keeps them as TF variables, matmul.py:33-53)."""
+def _host_plan(lut, segments, blocks, n_out_blocks, bsize, dtype_code, axis):
+    """Grouped-kernel schedule for one xprop lut (host call into the library: bsmm_xprop_plan_build)."""
+    lib = _lib.load()
+    lut = np.ascontiguousarray(lut, dtype=np.int32)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    words = lib.bsmm_xprop_plan_words(lut.ctypes.data_as(ip), segments, blocks, n_out_blocks, bsize, dtype_code, axis)
+    if words < 0:
+        raise RuntimeError("bsmm_xprop_plan_words rejected the lookup table")
+    if words == 0:
+        return None
+    out = np.empty(words, dtype=np.int32)
+    _lib.check(lib.bsmm_xprop_plan_build(lut.ctypes.data_as(ip), segments, blocks, n_out_blocks, bsize, dtype_code, axis,
+                                         out.ctypes.data_as(ip)), "bsmm_xprop_plan_build")
+    return out
 
-    def __init__(self, tables, device):
+
+class _DeviceTables(object):
+    """int32 lookup tables resident on one device (the reference keeps them as TF variables, matmul.py:33-53),
+    plus the derived schedules ("plans") of the grouped kernels."""
+
+    def __init__(self, tables, device, bsize, axis):
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
         self.fprop = up(tables["fprop"]["lut"])
         self.bprop = up(tables["bprop"]["lut"])
         self.updat = up(tables["updat_lut"])
+        CB, KB, B = tables["CB"], tables["KB"], tables["blocks"]
+        # plans exist only for 16-bit types (they do not depend on which of the two)
+        fp = _host_plan(tables["fprop"]["lut"], tables["fprop"]["segments"], B, KB, bsize, _lib.BF16, axis)
+        bp = _host_plan(tables["bprop"]["lut"], tables["bprop"]["segments"], B, CB, bsize, _lib.BF16, axis)
+        self.fprop_plan = up(fp) if fp is not None else None
+        self.bprop_plan = up(bp) if bp is not None else None
 
 
 class BlocksparseMatMul(object):
@@ -115,7 +138,7 @@ class BlocksparseMatMul(object):
         key = (device.type, device.index)
         t = self._device_cache.get(key)
         if t is None:
-            t = _DeviceTables(self._dev_tables, device)
+            t = _DeviceTables(self._dev_tables, device, self.bsize, self.axis)
             self._device_cache[key] = t
         return t
 
@@ -134,9 +157,10 @@ class BlocksparseMatMul(object):
             raise ValueError("expected %d features on the last axis, got shape %s" % (feat, tuple(x.shape)))
         return int(x.numel() // feat)
 
-    def _args(self, lut_t, side, N, Cin, Kout, dtype, pcount=1, alpha=1.0, beta=0.0, workspace=None):
+    def _args(self, lut_t, side, N, Cin, Kout, dtype, pcount=1, alpha=1.0, beta=0.0, workspace=None, plan=None):
         a = _lib.BsmmArgs()
         a.lut = lut_t.data_ptr()
+        a.plan = plan.data_ptr() if (plan is not None and dtype != torch.float32) else None
         a.gate = None
         a.workspace = workspace.data_ptr() if workspace is not None else None
         a.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
@@ -168,7 +192,7 @@ class BlocksparseMatMul(object):
         lib = _lib.load()
         tabs = self._tables_on(x.device)
         y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
-        a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype)
+        a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype, plan=tabs.fprop_plan)
         need = lib.bsmm_workspace_bytes(_lib.OP_FPROP, ctypes.byref(a))
         ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device) if need else None
         if ws is not None:
@@ -186,7 +210,7 @@ class BlocksparseMatMul(object):
         lib = _lib.load()
         tabs = self._tables_on(dy.device)
         dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)
-        a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype)
+        a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype, plan=tabs.bprop_plan)
         _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
         return dx
 

@@ -59,6 +59,8 @@ typedef struct bsmm_args {
     const float* gate;      /* per-block gate (reference: Gate); must be NULL -- gating is not implemented yet      */
     void* workspace;        /* device scratch of >= bsmm_workspace_bytes(op, args) bytes (may be NULL when that is 0) */
     size_t workspace_bytes;
+    const int32_t* plan;    /* optional device copy of the schedule built by bsmm_xprop_plan_build() for THIS lut
+                               (NULL = generic kernels).  Like the luts it is a constant of the layout.             */
     int32_t blocks;         /* nonzero blocks                                                                        */
     int32_t bsize;          /* 8, 16 or 32                                                                           */
     int32_t segments;       /* xprop: number of lut headers (incl. empty output blocks)                              */
@@ -89,11 +91,23 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
 int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks,
                        int32_t bsize, float scale, int32_t dtype, void* stream);
 
+/* Host-only: derive the grouped-kernel schedule ("plan") from a reference-format xprop lut that lives in HOST
+ * memory (the luts are constants of the layout: the reference builds them in NumPy, blocksparse/matmul.py:137-138).
+ * n_out_blocks = K / bsize of the pass the lut belongs to; axis = feature axis the plan will be used with.  bsmm_xprop_plan_words returns the number of int32 words
+ * (0 if this (bsize, dtype, axis) has no grouped kernel, <0 on malformed input); bsmm_xprop_plan_build fills host_plan_out
+ * (that many words).  The caller uploads the words to the device and passes the pointer as bsmm_args.plan. */
+long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks,
+                           int32_t bsize, int32_t dtype, int32_t axis);
+int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks,
+                          int32_t bsize, int32_t dtype, int32_t axis, int32_t* host_plan_out);
+
 /* Bytes of device scratch the given op (BSMM_OP_*) needs for these args. */
 size_t bsmm_workspace_bytes(int op, const bsmm_args* args);
 
-/* Test hook: 0 = production kernels (MFMA for bsize 16/32, VALU for 8);
- *            1 = force the plain VALU kernels for every bsize (independent second implementation). */
+/* Test hook: 0 = production kernels (grouped MFMA kernel when a plan is given, else per-segment MFMA kernels for
+ *                bsize 16/32, VALU for 8);
+ *            1 = force the plain VALU kernels for every bsize (independent second implementation);
+ *            2 = ignore bsmm_args.plan (per-segment MFMA kernels). */
 void bsmm_set_kernel_variant(int variant);
 int bsmm_get_kernel_variant(void);
 

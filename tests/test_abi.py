@@ -46,7 +46,7 @@ def test_struct_layout_matches_header(lib):
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = [re.search(r"(\w+)\s*;", ln).group(1) for ln in body.splitlines() if ";" in ln]
     assert names == [f[0] for f in lib.BsmmArgs._fields_]
-    assert ctypes.sizeof(lib.BsmmArgs) == 4 * 8 + 11 * 4 + 2 * 4 + 4 + 8   # 3 ptr + size_t, 11 int32, 2 float, pad, ptr
+    assert ctypes.sizeof(lib.BsmmArgs) == 5 * 8 + 11 * 4 + 2 * 4 + 4 + 8   # 4 ptr + size_t, 11 int32, 2 float, pad, ptr
 
 
 def test_argument_validation_without_gpu(lib):
@@ -78,6 +78,63 @@ def test_argument_validation_without_gpu(lib):
     assert L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == 0
     a.bsize = 8
     assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 0
+
+
+def test_plan_builder_covers_every_block_once(lib):
+    """bsmm_xprop_plan_build (host code in the library): every (in_block, w) entry of the lut appears exactly once,
+    under the right output block; steps ascend; stages respect the LDS budget.  axis 0 plans step over single input
+    blocks, axis 1 plans over PAIRS of input blocks (mask bit = 2*member + (c & 1))."""
+    import numpy as np
+    from blocksparse_amd import lut as L
+    from blocksparse_amd.matmul import _host_plan
+    rng = np.random.default_rng(3)
+    for CB, KB, dens, seg in ((40, 52, 0.3, True), (128, 128, 0.2, False), (5, 3, 1.0, False), (1, 1, 1.0, False), (7, 9, 0.5, False)):
+        lay = rng.random((CB, KB)) < dens
+        lay[0, :] = True
+        t = L.build_tables(lay, segmented=seg)
+        for axis in (0, 1):
+            for side, n_out in (("fprop", KB), ("bprop", CB)):
+                f = t[side]
+                plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, axis)
+                assert plan[0] == 0x42534d50 and plan[12] == n_out and plan[14] == axis
+                G, SB, ngroups = int(plan[2]), int(plan[3]), int(plan[4])
+                groups = plan[plan[8]:plan[9]].reshape(-1, 4)
+                stages = plan[plan[9]:plan[10]].reshape(-1, 4)
+                steps = plan[plan[10]:plan[11]].reshape(-1, 2)
+                wlist = plan[plan[11]:plan[13]]
+                meta = plan[plan[13]:]
+                assert len(groups) == ngroups == -(-n_out // G) and len(wlist) == len(meta) == t["blocks"]
+                got = set()
+                for g, (sb, ns, ob0, nob) in enumerate(groups):
+                    assert ob0 == g * G and nob == min(G, n_out - ob0)
+                    last_key = -1
+                    for st in stages[sb:sb + ns]:
+                        assert 0 < st[3] <= SB
+                        wpos = st[2]
+                        for key, mask in steps[st[0]:st[0] + st[1]]:
+                            assert key >= last_key          # equal only when an over-long step was split
+                            last_key = key
+                            first = True
+                            nbits = 2 * G if axis == 1 else G
+                            for bit in range(nbits):
+                                if (int(mask) >> bit) & 1:
+                                    m, c = (bit >> 1, 2 * int(key) + (bit & 1)) if axis == 1 else (bit, int(key))
+                                    assert m < nob
+                                    got.add((ob0 + m, c, int(wlist[wpos])))
+                                    assert int(meta[wpos]) == (bit | (256 if first else 0))
+                                    first = False
+                                    wpos += 1
+                            assert (int(mask) & 0xffffffff) >> nbits == 0
+                        assert wpos == st[2] + st[3]
+                want = set()
+                for ob, col in f["cols"]:
+                    for c, w in col:
+                        want.add((ob, c, w))
+                assert got == want
+    # no grouped kernel for fp32 / other block sizes
+    t = L.build_tables(np.ones((2, 2)))
+    assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 32, lib.F32, 1) is None
+    assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 16, lib.BF16, 1) is None
 
 
 def test_host_class_surface():
