@@ -13,7 +13,7 @@ F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
 
 SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_identity_init", "bsmm_workspace_bytes",
-           "bsmm_xprop_plan_words", "bsmm_xprop_plan_build",
+           "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
            "bsmm_set_kernel_variant", "bsmm_get_kernel_variant", "bsmm_error_string", "bsmm_version")
 
 
@@ -22,6 +22,7 @@ class BsmmArgs(ctypes.Structure):
     _fields_ = [
         ("lut", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
         ("workspace_bytes", ctypes.c_size_t), ("plan", ctypes.c_void_p),
+        ("plan_items", ctypes.c_int32), ("reserved0", ctypes.c_int32),
         ("blocks", ctypes.c_int32), ("bsize", ctypes.c_int32), ("segments", ctypes.c_int32),
         ("locks", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
         ("shared", ctypes.c_int32), ("pcount", ctypes.c_int32), ("axis", ctypes.c_int32),
@@ -67,6 +68,10 @@ def load():
     lib.bsmm_xprop_plan_words.restype = ctypes.c_long
     lib.bsmm_xprop_plan_build.argtypes = [ip, i32, i32, i32, i32, i32, i32, ip]
     lib.bsmm_xprop_plan_build.restype = ctypes.c_int
+    lib.bsmm_updat_plan_words.argtypes = [ip, i32, i32, i32, i32, i32, i32]
+    lib.bsmm_updat_plan_words.restype = ctypes.c_long
+    lib.bsmm_updat_plan_build.argtypes = [ip, i32, i32, i32, i32, i32, i32, ip]
+    lib.bsmm_updat_plan_build.restype = ctypes.c_int
     lib.bsmm_set_kernel_variant.argtypes = [ctypes.c_int]
     lib.bsmm_set_kernel_variant.restype = None
     lib.bsmm_get_kernel_variant.argtypes = []

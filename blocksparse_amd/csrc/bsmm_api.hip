@@ -6,6 +6,8 @@
 #include "bsmm.h"
 #include "bsmm_plan.h"
 #include "bsmm_updat.h"
+#include "bsmm_updat_tr.h"
+#include "bsmm_updat_win.h"
 #include "bsmm_xgroup.h"
 #include "bsmm_xprop.h"
 
@@ -202,7 +204,52 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         vec_ok = vec_ok && (N % (DT::is16 ? 8 : 4) == 0);
         for (int p = 0; p < a->pcount; ++p) vec_ok = vec_ok && aligned16(xs.p[p]) && aligned16(es.p[p]);
     }
-    const bool use_valu = (BS == 8) || g_variant.load(std::memory_order_relaxed) == 1 || !vec_ok;
+    const int variant = g_variant.load(std::memory_order_relaxed);
+    const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
+    if constexpr (BS == 32 && AXIS == 1 && DT::is16) {
+        bool al = aligned16(DW);
+        for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
+        if (!use_valu && al && variant == 0 && a->plan != nullptr) {   // windowed kernel (plan = bsmm_updat_plan_build)
+            static bool attr_set_w = false;
+            if (!attr_set_w) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
+                attr_set_w = true;
+            }
+            const int nitems = a->plan_items;
+            if (nitems <= 0) return BSMM_ERR_ARG;
+            const int nchunks = (N + 31) / 32;
+            int split = 1;
+            while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;   // one workgroup per CU, >= 8 chunks each
+            const char* senv = getenv("BSMM_UPDAT_SPLIT");
+            if (senv) split = atoi(senv) > 0 ? atoi(senv) : split;
+            float* scratch = nullptr;
+            if (split > 1) {
+                const size_t need = (size_t)a->blocks * 1024 * sizeof(float);
+                if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+                scratch = static_cast<float*>(a->workspace);
+                hipError_t e = hipMemsetAsync(scratch, 0, need, st);
+                if (e != hipSuccess) return (int)e;
+            }
+            updat32_a1_win_kernel<DT><<<dim3(nitems, split), 512, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C,
+                                                                                a->K, a->pcount, a->alpha, a->beta);
+            if (split > 1) {
+                const size_t n = (size_t)a->blocks * 1024;
+                updat_finalize_kernel<DT><<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), n, a->alpha, a->beta);
+            }
+            return (int)hipGetLastError();
+        }
+        if (!use_valu && al && variant == 0) {   // LDS-DMA + transposing-read kernel
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_tr_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UT_LDS);
+                attr_set = true;
+            }
+            const int grid = 8 * ((a->blocks + 7) / 8);
+            updat32_a1_tr_kernel<DT><<<grid, 256, UT_LDS, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K, a->pcount,
+                                                              a->alpha, a->beta);
+            return (int)hipGetLastError();
+        }
+    }
     if (use_valu) {
         updat_valu_kernel<DT, BS, AXIS><<<a->blocks, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C,
                                                                    a->K, a->pcount, a->alpha, a->beta);
@@ -288,8 +335,23 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
                ? BSMM_OK : BSMM_ERR_ARG;
 }
 
+long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
+                           int32_t axis) {
+    if (bsize != 32 || dtype == BSMM_F32 || axis != 1) return 0;   // windowed kernel: bsize 32, 16-bit, feature axis 1
+    return build_updat_plan(host_updat_lut, blocks, CB, KB, nullptr);
+}
+
+int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
+                          int32_t axis, int32_t* host_plan_out) {
+    if (!host_plan_out) return BSMM_ERR_ARG;
+    if (bsize != 32 || dtype == BSMM_F32 || axis != 1) return BSMM_ERR_UNSUPPORTED;
+    return build_updat_plan(host_updat_lut, blocks, CB, KB, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
+}
+
 size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     if (!a) return 0;
+    if (op == BSMM_OP_UPDAT && a->plan && a->bsize == 32 && a->dtype != BSMM_F32 && a->axis == 1)
+        return (size_t)a->blocks * 1024 * sizeof(float);   // fp32 partial sums of the split-minibatch path
     // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)
     if (op == BSMM_OP_FPROP && a->bsize != 8) return (size_t)a->blocks * a->bsize * a->bsize * elem_size(a->dtype);
     return 0;

@@ -116,3 +116,82 @@ inline long build_xprop_plan(const int32_t* lut, int segments, int blocks, int n
 }
 
 }  // namespace bsmm
+
+// =================================================================================================
+// updat plan: work items for the windowed weight-gradient kernel (bsmm_updat_win.h).
+// The (CB x KB) block grid is cut into UW x UW windows; the nonzero blocks of a window are dealt to the UP_WAVES waves
+// of a workgroup, up to UP_MAXB per wave (windows with more blocks are split into several items).  Blocks are sorted
+// by (c, k) before dealing so that a wave's consecutive slots often share the X fragment (flag bit 9).
+// Item order: workgroup b runs on XCD b % 8 (observed; speed only), so position 8*j + x holds the j-th item of XCD x,
+// and XCD x is given a compact PATCH of the window grid: the items of a patch share their X slabs (same window row) and
+// DY slabs (same window column) through that XCD's L2.  Shorter lists are padded with empty items.
+//
+// Layout (int32):  [0] magic 'BSUP'  [1] version  [2] UW  [3] UP_MAXB  [4] nitems (multiple of 8)  [5] nblocks
+//                  [6] off_items  [7] UP_WAVES
+//   item: UP_ITEM = 4 + UP_WAVES*UP_MAXB*2 words = (c0_block, k0_block, nblocks_in_item, 0) then for wave v, slot j:
+//         (meta, w)   meta = cidx | kidx << 4 | 1 << 8 (valid) | sameX << 9     (cidx/kidx = block offset inside the window)
+// =================================================================================================
+namespace bsmm {
+
+constexpr int32_t UPLAN_MAGIC = 0x42535550;
+constexpr int32_t UPLAN_VERSION = 2;
+constexpr int UW = 8;
+constexpr int UP_WAVES = 8;
+constexpr int UP_MAXB = 4;
+constexpr int UP_HDR = 8;
+constexpr int UP_ITEM = 4 + UP_WAVES * UP_MAXB * 2;
+
+inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int32_t* out) {
+    if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0) return -1;
+    const int wc = (CB + UW - 1) / UW, wk = (KB + UW - 1) / UW;
+    struct Ent { int c, k, w; };
+    std::vector<std::vector<Ent>> win((size_t)wc * wk);
+    for (int w = 0; w < blocks; ++w) {
+        const int c = updat_lut[2 * w], k = updat_lut[2 * w + 1];
+        if (c < 0 || c >= CB || k < 0 || k >= KB) return -1;
+        win[(size_t)(c / UW) * wk + (k / UW)].push_back({c, k, w});
+    }
+    // patch grid pr x pc = 8 XCDs, as square as the window grid allows
+    int pr = 4, pc = 2;
+    if (wc < 4) { pr = wc >= 2 ? 2 : 1; pc = 8 / pr; }
+    if (wk < pc) { pc = wk >= 1 ? std::min(wk, pc) : 1; }
+    std::vector<std::vector<int32_t>> per_xcd(8);
+    const int cap = UP_WAVES * UP_MAXB;
+    for (int wi = 0; wi < wc; ++wi)
+        for (int wj = 0; wj < wk; ++wj) {
+            auto& v = win[(size_t)wi * wk + wj];
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end(), [](const Ent& a, const Ent& b) { return a.c != b.c ? a.c < b.c : a.k < b.k; });
+            const int xcd = ((wi * pr / wc) * pc + (wj * pc / wk)) & 7;
+            for (size_t beg = 0; beg < v.size(); beg += cap) {
+                const int n = (int)std::min<size_t>(cap, v.size() - beg);
+                std::vector<int32_t> it(UP_ITEM, 0);
+                it[0] = wi * UW; it[1] = wj * UW; it[2] = n;
+                const int per = (n + UP_WAVES - 1) / UP_WAVES;   // contiguous runs per wave keep equal-c blocks together
+                for (int e = 0; e < n; ++e) {
+                    const int wave = e / per, slot = e % per;
+                    const Ent& en = v[beg + e];
+                    const bool same = slot > 0 && v[beg + e - 1].c == en.c;
+                    int32_t* p = &it[4 + (wave * UP_MAXB + slot) * 2];
+                    p[0] = (en.c - wi * UW) | ((en.k - wj * UW) << 4) | (1 << 8) | (same ? (1 << 9) : 0);
+                    p[1] = en.w;
+                }
+                per_xcd[xcd].insert(per_xcd[xcd].end(), it.begin(), it.end());
+            }
+        }
+    size_t longest = 0;
+    for (auto& l : per_xcd) longest = std::max(longest, l.size() / UP_ITEM);
+    const long nitems = (long)longest * 8;
+    const long total = UP_HDR + nitems * UP_ITEM;
+    if (out) {
+        const int32_t hdr[UP_HDR] = {UPLAN_MAGIC, UPLAN_VERSION, UW, UP_MAXB, (int32_t)nitems, blocks, UP_HDR, UP_WAVES};
+        std::copy(hdr, hdr + UP_HDR, out);
+        std::fill(out + UP_HDR, out + total, 0);
+        for (int x = 0; x < 8; ++x)
+            for (size_t j = 0; j < per_xcd[x].size() / UP_ITEM; ++j)
+                std::copy(per_xcd[x].begin() + j * UP_ITEM, per_xcd[x].begin() + (j + 1) * UP_ITEM, out + UP_HDR + (j * 8 + x) * UP_ITEM);
+    }
+    return total;
+}
+
+}  // namespace bsmm

@@ -1,0 +1,185 @@
+// bsmm_updat_win.h -- windowed weight-gradient kernel, feature_axis = 1, bsize 32, 16-bit storage types.
+//
+// Why: with one workgroup per weight block (bsmm_updat_tr.h) every block streams its own X and DY column slabs:
+// 2 * N * 64 B per block = 3.4 GB at 4096^2 / 20% / N = 8192, and the kernel runs at the fabric bandwidth (5.6 TB/s,
+// 608 us).  Here a workgroup owns a UW x UW window of the block grid.  Per 32-row minibatch chunk it DMA-stages ONE
+// X slab (32 rows x UW*64 B: 512 contiguous bytes per row -> full-line L2 requests) and ONE DY slab into LDS, and
+// every nonzero block of the window -- statically owned by one of the 8 waves, <= UP_MAXB per wave -- builds its MFMA
+// fragments from the shared slabs with the transposing read ds_read_b64_tr_b16.  Traffic per block drops from
+// 2 slabs to (2*UW)/(UW*UW*density) slabs (~0.6 at 20%).
+//
+//   LDS slab image: row-major, 512 B per row, the 16-byte pieces of row r XOR-swizzled with 4*(r & 3) so that the four
+//   rows a transposing read touches fall on disjoint bank ranges (a 512-byte stride alone maps them to the same banks).
+//   Ring of UWN_D = 4 slots (slot = X slab + DY slab = 32 KiB): the DMA of chunk q+3 is issued right after the barrier
+//   of chunk q; each wave issues a constant 4 DMA instructions per chunk (chunks past the end re-fetch the last rows),
+//   so `vmcnt(8)` = "my share of chunk q has landed".  One barrier per chunk, 512 threads, one workgroup per CU.
+//   Minibatch split: gridDim.y workgroups share an item; with gridDim.y > 1 partial tiles are added (fp32 atomics) into
+//   a zeroed fp32 scratch and a second kernel applies alpha/beta and rounds once; with gridDim.y == 1 the workgroup
+//   stores directly.
+#pragma once
+#include "bsmm_common.h"
+#include "bsmm_plan.h"
+#include "bsmm_updat_tr.h"
+
+namespace bsmm {
+
+constexpr int UWN_D = 4;
+constexpr int UWN_SLAB = 32 * 512;           // bytes of one operand slab
+constexpr int UWN_SLOT = 2 * UWN_SLAB;
+constexpr int UWN_LDS = UWN_D * UWN_SLOT;
+
+template <class DT>
+__global__ void __launch_bounds__(512, 2)
+updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
+                      const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "windowed updat: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (plan[0] != UPLAN_MAGIC || plan[1] != UPLAN_VERSION || plan[2] != UW || plan[3] != UP_MAXB || plan[7] != UP_WAVES) return;
+    const int32_t* item = plan + plan[6] + (size_t)blockIdx.x * UP_ITEM;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = item[0], k0 = item[1];
+    if (item[2] == 0) return;   // padding item
+    int meta[UP_MAXB], wid[UP_MAXB];
+#pragma unroll
+    for (int j = 0; j < UP_MAXB; ++j) {
+        meta[j] = item[4 + (wave * UP_MAXB + j) * 2];
+        wid[j] = item[4 + (wave * UP_MAXB + j) * 2 + 1];
+    }
+
+    // rows handled by this workgroup: chunks [q_beg, q_end) of 32 rows
+    const int nchunks = (N + 31) >> 5;
+    const int per = (nchunks + gridDim.y - 1) / gridDim.y;
+    const int q_beg = blockIdx.y * per, q_end = min(nchunks, q_beg + per);
+
+    const uint32_t base_addr = lds_addr_of(smem);
+    // DMA: a slab is 16 instructions of 1 KiB (2 rows each); wave v issues instructions 2v, 2v+1 of both slabs.
+    // lane L -> row 2i + (L >> 5), stored piece L & 31, source piece (L & 31) ^ (4 * (row & 3))
+    const int drow_in = lane >> 5, dpiece = lane & 31;
+    int xcol[2], ecol[2];   // source element column of this lane for instruction 2*wave + i (clamped inside the row)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 2 * (2 * wave + i) + drow_in;
+        const int piece = dpiece ^ (4 * (row & 3));
+        xcol[i] = min(c0 * 32 + piece * 8, Cf - 8);
+        ecol[i] = min(k0 * 32 + piece * 8, Kf - 8);
+    }
+    // fragment reads
+    const int g16 = lane >> 4, t16 = lane & 15;
+    const int h = g16 >> 1;
+    const int trow = t16 >> 2;                                            // row inside the 4-row band (= row & 3)
+    const int tsub = (2 * (g16 & 1) + ((t16 & 3) >> 1)) * 16 + (t16 & 1) * 8;   // byte offset inside the block's 64 B
+
+    f32x16 acc[UP_MAXB];
+#pragma unroll
+    for (int j = 0; j < UP_MAXB; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    for (int p = 0; p < pcount; ++p) {
+        const T* X = static_cast<const T*>(Xs.p[p]);
+        const T* E = static_cast<const T*>(Es.p[p]);
+        auto issue = [&](int q, int pos) {
+            const int n0 = min(q, q_end - 1) * 32;   // chunks past the end re-fetch the last one (never read)
+            const uint32_t slot = base_addr + pos * UWN_SLOT;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = min(n0 + 2 * (2 * wave + i) + drow_in, N - 1);   // clamped rows are masked below
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (2 * wave + i) * 1024);
+                glds16_asm(X + (size_t)row * Cf + xcol[i], dst);
+                glds16_asm(E + (size_t)row * Kf + ecol[i], dst + UWN_SLAB);
+            }
+        };
+        if (q_beg >= q_end) break;
+#pragma unroll
+        for (int d = 0; d < UWN_D - 1; ++d) issue(q_beg + d, d);
+        int pos = 0, wpos = UWN_D - 1;
+        for (int q = q_beg; q < q_end; ++q) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UWN_D - 2)) : "memory");   // my share of chunk q landed
+            __syncthreads();                                  // everyone's did; everyone finished chunk q-1
+            issue(q + UWN_D - 1, wpos);                       // refills the slot chunk q-1 used
+            const unsigned char* slot = smem + pos * UWN_SLOT;
+            pos = (pos + 1) & (UWN_D - 1);
+            wpos = (wpos + 1) & (UWN_D - 1);
+            const int n0 = q * 32;
+            const bool tail = n0 + 32 > N;
+            uint4 a[2];
+#pragma unroll
+            for (int j = 0; j < UP_MAXB; ++j) {
+                const int m = meta[j];
+                if (m & 256) {
+                    const int cidx = m & 15, kidx = (m >> 4) & 15;
+                    if (!(m & 512)) {   // new X fragment (consecutive slots with equal c re-use it)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const unsigned char* sp = slot + (16 * kk + 8 * h + trow) * 512 + ((cidx ^ trow) << 6) + tsub;
+                            const uint2 a0 = ds_tr16(sp), a1 = ds_tr16(sp + 4 * 512);
+                            a[kk] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                        }
+                        if (tail) {
+#pragma unroll
+                            for (int kk = 0; kk < 2; ++kk) {
+                                const int nb = n0 + 16 * kk + 8 * h;
+                                uint32_t* u = reinterpret_cast<uint32_t*>(&a[kk]);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
+                                    u[e] &= (lo | hi);
+                                }
+                            }
+                        }
+                    }
+                    uint4 b[2];
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const unsigned char* sp = slot + UWN_SLAB + (16 * kk + 8 * h + trow) * 512 + ((kidx ^ trow) << 6) + tsub;
+                        const uint2 b0 = ds_tr16(sp), b1 = ds_tr16(sp + 4 * 512);
+                        b[kk] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                    }
+                    acc[j] = DT::mfma32(a[0], b[0], acc[j]);
+                    acc[j] = DT::mfma32(a[1], b[1], acc[j]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // ring is re-primed for the next pair
+    }
+
+    // D[ci][ko]: col = ko = lane & 31, row ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < UP_MAXB; ++j) {
+        if (!(meta[j] & 256)) continue;
+        const size_t base = (size_t)wid[j] * 1024 + (lane & 31);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            const size_t idx = base + ci * 32;
+            if (gridDim.y == 1) {
+                float out = alpha * acc[j][reg];
+                if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+                DW[idx] = DT::from_f32(out);
+            } else {
+                __hip_atomic_fetch_add(scratch + idx, acc[j][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// DW = alpha * scratch + beta * DW, rounded once (second pass of the split-minibatch path)
+template <class DT>
+__global__ void __launch_bounds__(256)
+updat_finalize_kernel(const float* __restrict__ scratch, typename DT::T* __restrict__ DW, size_t n, float alpha, float beta) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 s = *reinterpret_cast<const float4*>(scratch + i);
+    float v[4] = {alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w};
+    if (beta != 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += beta * DT::to_f32(DW[i + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) DW[i + e] = DT::from_f32(v[e]);
+}
+
+}  // namespace bsmm

@@ -60,6 +60,22 @@ def _host_plan(lut, segments, blocks, n_out_blocks, bsize, dtype_code, axis):
     return out
 
 
+def _host_updat_plan(updat_lut, blocks, CB, KB, bsize, dtype_code, axis):
+    """Work items of the windowed updat kernel (host call into the library: bsmm_updat_plan_build)."""
+    lib = _lib.load()
+    lut = np.ascontiguousarray(updat_lut, dtype=np.int32)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    words = lib.bsmm_updat_plan_words(lut.ctypes.data_as(ip), blocks, CB, KB, bsize, dtype_code, axis)
+    if words < 0:
+        raise RuntimeError("bsmm_updat_plan_words rejected the lookup table")
+    if words == 0:
+        return None
+    out = np.empty(words, dtype=np.int32)
+    _lib.check(lib.bsmm_updat_plan_build(lut.ctypes.data_as(ip), blocks, CB, KB, bsize, dtype_code, axis,
+                                         out.ctypes.data_as(ip)), "bsmm_updat_plan_build")
+    return out
+
+
 class _DeviceTables(object):
     """int32 lookup tables resident on one device (the reference keeps them as TF variables, matmul.py:33-53),
     plus the derived schedules ("plans") of the grouped kernels."""
@@ -76,6 +92,9 @@ class _DeviceTables(object):
         bp = _host_plan(tables["bprop"]["lut"], tables["bprop"]["segments"], B, CB, bsize, _lib.BF16, axis)
         self.fprop_plan = up(fp) if fp is not None else None
         self.bprop_plan = up(bp) if bp is not None else None
+        upl = _host_updat_plan(tables["updat_lut"], B, CB, KB, bsize, _lib.BF16, axis)
+        self.updat_plan = up(upl) if upl is not None else None
+        self.updat_items = int(upl[4]) if upl is not None else 0
 
 
 class BlocksparseMatMul(object):
@@ -243,7 +262,13 @@ class BlocksparseMatMul(object):
             self._check_tensor(dw, "dw")
             if tuple(dw.shape) != self.w_shape or dw.dtype != xs[0].dtype or not dw.is_contiguous():
                 raise ValueError("dw must be a contiguous %s tensor of dtype %s" % (self.w_shape, xs[0].dtype))
-        a = self._args(tabs.updat, None, N, self.C, self.K, xs[0].dtype, pcount=len(xs), alpha=alpha, beta=beta)
+        a = self._args(tabs.updat, None, N, self.C, self.K, xs[0].dtype, pcount=len(xs), alpha=alpha, beta=beta,
+                       plan=tabs.updat_plan)
+        a.plan_items = tabs.updat_items
+        need = lib.bsmm_workspace_bytes(_lib.OP_UPDAT, ctypes.byref(a))
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev) if need else None
+        if ws is not None:
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         arr = ctypes.c_void_p * len(xs)
         xp = arr(*[t.data_ptr() for t in xs])
         ep = arr(*[t.data_ptr() for t in dys])

@@ -59,8 +59,11 @@ typedef struct bsmm_args {
     const float* gate;      /* per-block gate (reference: Gate); must be NULL -- gating is not implemented yet      */
     void* workspace;        /* device scratch of >= bsmm_workspace_bytes(op, args) bytes (may be NULL when that is 0) */
     size_t workspace_bytes;
-    const int32_t* plan;    /* optional device copy of the schedule built by bsmm_xprop_plan_build() for THIS lut
-                               (NULL = generic kernels).  Like the luts it is a constant of the layout.             */
+    const int32_t* plan;    /* optional device copy of the schedule built by bsmm_xprop_plan_build() (fprop/bprop) or
+                               bsmm_updat_plan_build() (updat) for THIS lut (NULL = generic kernels).  Like the luts
+                               it is a constant of the layout.                                                       */
+    int32_t plan_items;     /* updat only: header word [4] of the updat plan (number of work items = grid size)       */
+    int32_t reserved0;
     int32_t blocks;         /* nonzero blocks                                                                        */
     int32_t bsize;          /* 8, 16 or 32                                                                           */
     int32_t segments;       /* xprop: number of lut headers (incl. empty output blocks)                              */
@@ -100,6 +103,14 @@ long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t bl
                            int32_t bsize, int32_t dtype, int32_t axis);
 int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks,
                           int32_t bsize, int32_t dtype, int32_t axis, int32_t* host_plan_out);
+
+/* Host-only: work items of the windowed weight-gradient kernel for an updat lut in HOST memory (CB/KB = block rows /
+ * columns of the layout).  Same conventions as the xprop plan; word [4] of the result goes to bsmm_args.plan_items.
+ * With a plan, bsmm_updat may need workspace (fp32 partial sums): ask bsmm_workspace_bytes(BSMM_OP_UPDAT, args). */
+long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize,
+                           int32_t dtype, int32_t axis);
+int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize,
+                          int32_t dtype, int32_t axis, int32_t* host_plan_out);
 
 /* Bytes of device scratch the given op (BSMM_OP_*) needs for these args. */
 size_t bsmm_workspace_bytes(int op, const bsmm_args* args);

@@ -46,7 +46,7 @@ def test_struct_layout_matches_header(lib):
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = [re.search(r"(\w+)\s*;", ln).group(1) for ln in body.splitlines() if ";" in ln]
     assert names == [f[0] for f in lib.BsmmArgs._fields_]
-    assert ctypes.sizeof(lib.BsmmArgs) == 5 * 8 + 11 * 4 + 2 * 4 + 4 + 8   # 4 ptr + size_t, 11 int32, 2 float, pad, ptr
+    assert ctypes.sizeof(lib.BsmmArgs) == 5 * 8 + 13 * 4 + 2 * 4 + 4 + 8   # 4 ptr + size_t, 13 int32, 2 float, pad, ptr
 
 
 def test_argument_validation_without_gpu(lib):
