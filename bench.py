@@ -157,6 +157,8 @@ def main():
     layout, b, w, x, dy = setup(a.density)
     el, per = run(b, w, x, dy, a.steps, a.warmup, timed_events=True)
     N = a.n_local
+    workload_name = ("bsmm fprop+bprop+updat %dx%d block_size=%d density=%.0f%% feature_axis=%d, minibatch %d per GPU, "
+                     "layout default_rng(1234)" % (a.hidden, a.hidden, a.bsize, a.density * 100, a.axis, N))
     flops_pass = 2.0 * b.blocks * a.bsize ** 2 * N
     total_flops = 3 * flops_pass * world * a.steps
     ms_step = el / a.steps * 1e3
@@ -179,7 +181,15 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": round(d_bytes / (d_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    # HBM bytes per launch of that kernel, from the committed rocprofv3 PMC passes (separate runs; gfx950-corrected):
+    # only quoted when the profile was taken on exactly this workload
     roof["traffic"] = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if tr.get("workload") == workload_name and dom in tr and world == 1:
+            roof["traffic"] = tr[dom]["hbm_bytes"]
+    except Exception:
+        pass
     roof["kernel"] = dom
     roof["kernel_ms"] = round(d_ms, 4)
     roof["arithmetic_intensity"] = round(ai, 1)
@@ -189,8 +199,7 @@ def main():
         "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": "bsmm fprop+bprop+updat %dx%d block_size=%d density=%.0f%% feature_axis=%d, minibatch %d per GPU, "
-                               "layout default_rng(1234)" % (a.hidden, a.hidden, a.bsize, a.density * 100, a.axis, N),
+        "config": {"workload": workload_name,
                    "blocks": int(b.blocks), "global_minibatch": N * world,
                    "parallelism": "dp%d (minibatch sharded, dw all-reduce over RCCL)" % world if world > 1 else "single GPU"},
         "gbps_algorithmic": round(bytes_step / (ms_step * 1e-3) / 1e9, 1),
