@@ -128,13 +128,14 @@ inline long build_xprop_plan(const int32_t* lut, int segments, int blocks, int n
 //
 // Layout (int32):  [0] magic 'BSUP'  [1] version  [2] UW  [3] UP_MAXB  [4] nitems (multiple of 8)  [5] nblocks
 //                  [6] off_items  [7] UP_WAVES
-//   item: UP_ITEM = 4 + UP_WAVES*UP_MAXB*2 words = (c0_block, k0_block, nblocks_in_item, 0) then for wave v, slot j:
+//   item: UP_ITEM = 4 + UP_WAVES*UP_MAXB*2 words = (c0_block, k0_block, nblocks_in_item, nslots) then for wave v, slot j:
+//         (nslots = slots every wave of the item walks = max blocks owned by one wave; empty slots have meta = 0)
 //         (meta, w)   meta = cidx | kidx << 4 | 1 << 8 (valid) | sameX << 9     (cidx/kidx = block offset inside the window)
 // =================================================================================================
 namespace bsmm {
 
 constexpr int32_t UPLAN_MAGIC = 0x42535550;
-constexpr int32_t UPLAN_VERSION = 2;
+constexpr int32_t UPLAN_VERSION = 4;
 constexpr int UW = 8;
 constexpr int UP_WAVES = 8;
 constexpr int UP_MAXB = 4;
@@ -166,8 +167,8 @@ inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int K
             for (size_t beg = 0; beg < v.size(); beg += cap) {
                 const int n = (int)std::min<size_t>(cap, v.size() - beg);
                 std::vector<int32_t> it(UP_ITEM, 0);
-                it[0] = wi * UW; it[1] = wj * UW; it[2] = n;
-                const int per = (n + UP_WAVES - 1) / UP_WAVES;   // contiguous runs per wave keep equal-c blocks together
+                const int per = (n + UP_WAVES - 1) / UP_WAVES;
+                it[0] = wi * UW; it[1] = wj * UW; it[2] = n; it[3] = per;   // contiguous runs per wave keep equal-c blocks together
                 for (int e = 0; e < n; ++e) {
                     const int wave = e / per, slot = e % per;
                     const Ent& en = v[beg + e];

@@ -10,13 +10,15 @@
 //
 //   LDS slab image: row-major, 512 B per row, the 16-byte pieces of row r XOR-swizzled with 4*(r & 3) so that the four
 //   rows a transposing read touches fall on disjoint bank ranges (a 512-byte stride alone maps them to the same banks).
-//   Ring of UWN_D = 4 slots (slot = X slab + DY slab = 32 KiB): the DMA of chunk q+3 is issued right after the barrier
-//   of chunk q; each wave issues a constant 4 DMA instructions per chunk (chunks past the end re-fetch the last rows),
-//   so `vmcnt(8)` = "my share of chunk q has landed".  One barrier per chunk, 512 threads, one workgroup per CU.
+//   Ring of UWN_D slots (slot = X slab + DY slab): the DMA of chunk q+UWN_D-1 is issued right after the barrier of
+//   chunk q; each wave issues a constant 2*UWN_NI DMA instructions per chunk (chunks past the end re-fetch the last
+//   rows), so a counted `vmcnt` = "my share of chunk q has landed".  One barrier per chunk, 512 threads, 1 WG per CU.
 //   Minibatch split: gridDim.y workgroups share an item; with gridDim.y > 1 partial tiles are added (fp32 atomics) into
 //   a zeroed fp32 scratch and a second kernel applies alpha/beta and rounds once; with gridDim.y == 1 the workgroup
 //   stores directly.
 #pragma once
+#include <type_traits>
+
 #include "bsmm_common.h"
 #include "bsmm_plan.h"
 #include "bsmm_updat_tr.h"
@@ -24,7 +26,9 @@
 namespace bsmm {
 
 constexpr int UWN_D = 4;
-constexpr int UWN_SLAB = 32 * 512;           // bytes of one operand slab
+constexpr int UWN_ROWB = UW * 64;             // bytes per slab row (UW blocks x 64 B)
+constexpr int UWN_SLAB = 32 * UWN_ROWB;       // bytes of one operand slab
+constexpr int UWN_NI = UWN_SLAB / 1024 / UP_WAVES;   // DMA instructions per wave per slab
 constexpr int UWN_SLOT = 2 * UWN_SLAB;
 constexpr int UWN_LDS = UWN_D * UWN_SLOT;
 
@@ -54,13 +58,15 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
     const int q_beg = blockIdx.y * per, q_end = min(nchunks, q_beg + per);
 
     const uint32_t base_addr = lds_addr_of(smem);
-    // DMA: a slab is 16 instructions of 1 KiB (2 rows each); wave v issues instructions 2v, 2v+1 of both slabs.
-    // lane L -> row 2i + (L >> 5), stored piece L & 31, source piece (L & 31) ^ (4 * (row & 3))
-    const int drow_in = lane >> 5, dpiece = lane & 31;
-    int xcol[2], ecol[2];   // source element column of this lane for instruction 2*wave + i (clamped inside the row)
+    // DMA: a slab is UWN_SLAB/1024 instructions of 1 KiB (RPI = 1024/UWN_ROWB rows each); wave v issues instructions
+    // UWN_NI*v .. UWN_NI*v + UWN_NI-1 of both slabs.  lane L -> row RPI*i + L / PPR, stored piece L % PPR,
+    // source piece (L % PPR) ^ (4 * (row & 3))
+    constexpr int PPR = UWN_ROWB / 16, RPI = 1024 / UWN_ROWB;
+    const int drow_in = lane / PPR, dpiece = lane % PPR;
+    int xcol[UWN_NI], ecol[UWN_NI];   // source element column of this lane for instruction UWN_NI*wave + i (clamped inside the row)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 2 * (2 * wave + i) + drow_in;
+    for (int i = 0; i < UWN_NI; ++i) {
+        const int row = RPI * (UWN_NI * wave + i) + drow_in;
         const int piece = dpiece ^ (4 * (row & 3));
         xcol[i] = min(c0 * 32 + piece * 8, Cf - 8);
         ecol[i] = min(k0 * 32 + piece * 8, Kf - 8);
@@ -77,73 +83,86 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-    for (int p = 0; p < pcount; ++p) {
-        const T* X = static_cast<const T*>(Xs.p[p]);
-        const T* E = static_cast<const T*>(Es.p[p]);
-        auto issue = [&](int q, int pos) {
-            const int n0 = min(q, q_end - 1) * 32;   // chunks past the end re-fetch the last one (never read)
-            const uint32_t slot = base_addr + pos * UWN_SLOT;
+    // Every wave of the item walks the same number of slots (item[3]); a wave with fewer blocks computes its empty
+    // slots on block (0,0) of the window into accumulators that are never stored.  No per-slot branches: the chunk body
+    // is straight-line code, specialised on the slot count, so all transposing reads of a chunk are issued up-front.
+    const int nslots = item[3];
+    int aoff[UP_MAXB], boff[UP_MAXB];   // per-slot byte offset of this lane's piece inside a slab row band
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = min(n0 + 2 * (2 * wave + i) + drow_in, N - 1);   // clamped rows are masked below
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (2 * wave + i) * 1024);
-                glds16_asm(X + (size_t)row * Cf + xcol[i], dst);
-                glds16_asm(E + (size_t)row * Kf + ecol[i], dst + UWN_SLAB);
-            }
-        };
-        if (q_beg >= q_end) break;
+    for (int j = 0; j < UP_MAXB; ++j) {
+        const int cidx = meta[j] & 15, kidx = (meta[j] >> 4) & 15;
+        aoff[j] = trow * UWN_ROWB + ((cidx ^ trow) << 6) + tsub;
+        boff[j] = UWN_SLAB + trow * UWN_ROWB + ((kidx ^ trow) << 6) + tsub;
+    }
+    auto run = [&](auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+        for (int p = 0; p < pcount; ++p) {
+            const T* X = static_cast<const T*>(Xs.p[p]);
+            const T* E = static_cast<const T*>(Es.p[p]);
+            auto issue = [&](int q, int pos) {
+                const int n0 = min(q, q_end - 1) * 32;   // chunks past the end re-fetch the last one (never read)
+                const uint32_t slot = base_addr + pos * UWN_SLOT;
 #pragma unroll
-        for (int d = 0; d < UWN_D - 1; ++d) issue(q_beg + d, d);
-        int pos = 0, wpos = UWN_D - 1;
-        for (int q = q_beg; q < q_end; ++q) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UWN_D - 2)) : "memory");   // my share of chunk q landed
-            __syncthreads();                                  // everyone's did; everyone finished chunk q-1
-            issue(q + UWN_D - 1, wpos);                       // refills the slot chunk q-1 used
-            const unsigned char* slot = smem + pos * UWN_SLOT;
-            pos = (pos + 1) & (UWN_D - 1);
-            wpos = (wpos + 1) & (UWN_D - 1);
-            const int n0 = q * 32;
-            const bool tail = n0 + 32 > N;
-            uint4 a[2];
+                for (int i = 0; i < UWN_NI; ++i) {
+                    const int row = min(n0 + RPI * (UWN_NI * wave + i) + drow_in, N - 1);   // clamped rows are masked below
+                    const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (UWN_NI * wave + i) * 1024);
+                    glds16_asm(X + (size_t)row * Cf + xcol[i], dst);
+                    glds16_asm(E + (size_t)row * Kf + ecol[i], dst + UWN_SLAB);
+                }
+            };
+            if (q_beg >= q_end) break;
 #pragma unroll
-            for (int j = 0; j < UP_MAXB; ++j) {
-                const int m = meta[j];
-                if (m & 256) {
-                    const int cidx = m & 15, kidx = (m >> 4) & 15;
-                    if (!(m & 512)) {   // new X fragment (consecutive slots with equal c re-use it)
+            for (int d = 0; d < UWN_D - 1; ++d) issue(q_beg + d, d);
+            int pos = 0, wpos = UWN_D - 1;
+            for (int q = q_beg; q < q_end; ++q) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UWN_NI * (UWN_D - 2)) : "memory");   // my share of chunk q landed
+                __syncthreads();                                  // everyone's did; everyone finished chunk q-1
+                issue(q + UWN_D - 1, wpos);                       // refills the slot chunk q-1 used
+                const unsigned char* slot = smem + pos * UWN_SLOT;
+                pos = (pos + 1) & (UWN_D - 1);
+                wpos = (wpos + 1) & (UWN_D - 1);
+                const int n0 = q * 32;
+                uint4 a[NS][2], b[NS][2];
 #pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) {
-                            const unsigned char* sp = slot + (16 * kk + 8 * h + trow) * 512 + ((cidx ^ trow) << 6) + tsub;
-                            const uint2 a0 = ds_tr16(sp), a1 = ds_tr16(sp + 4 * 512);
-                            a[kk] = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                        }
-                        if (tail) {
-#pragma unroll
-                            for (int kk = 0; kk < 2; ++kk) {
-                                const int nb = n0 + 16 * kk + 8 * h;
-                                uint32_t* u = reinterpret_cast<uint32_t*>(&a[kk]);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
-                                    u[e] &= (lo | hi);
-                                }
-                            }
-                        }
-                    }
-                    uint4 b[2];
+                for (int j = 0; j < NS; ++j)
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
-                        const unsigned char* sp = slot + UWN_SLAB + (16 * kk + 8 * h + trow) * 512 + ((kidx ^ trow) << 6) + tsub;
-                        const uint2 b0 = ds_tr16(sp), b1 = ds_tr16(sp + 4 * 512);
-                        b[kk] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                        const unsigned char* sa = slot + (16 * kk + 8 * h) * UWN_ROWB + aoff[j];
+                        const unsigned char* sb = slot + (16 * kk + 8 * h) * UWN_ROWB + boff[j];
+                        const uint2 a0 = ds_tr16(sa), a1 = ds_tr16(sa + 4 * UWN_ROWB);
+                        const uint2 b0 = ds_tr16(sb), b1 = ds_tr16(sb + 4 * UWN_ROWB);
+                        a[j][kk] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                        b[j][kk] = make_uint4(b0.x, b0.y, b1.x, b1.y);
                     }
-                    acc[j] = DT::mfma32(a[0], b[0], acc[j]);
-                    acc[j] = DT::mfma32(a[1], b[1], acc[j]);
+                if (n0 + 32 > N) {   // ragged tail: rows >= N were clamped re-reads -> zero their contribution (X side suffices)
+#pragma unroll
+                    for (int j = 0; j < NS; ++j)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const int nb = n0 + 16 * kk + 8 * h;
+                            uint32_t* u = reinterpret_cast<uint32_t*>(&a[j][kk]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
+                                u[e] &= (lo | hi);
+                            }
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    acc[j] = DT::mfma32(a[j][0], b[j][0], acc[j]);
+                    acc[j] = DT::mfma32(a[j][1], b[j][1], acc[j]);
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // ring is re-primed for the next pair
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // ring is re-primed for the next pair
+    };
+    switch (nslots) {
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        default: run(std::integral_constant<int, 4>{}); break;
     }
 
     // D[ci][ko]: col = ko = lane & 31, row ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
