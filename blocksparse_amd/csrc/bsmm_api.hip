@@ -8,6 +8,7 @@
 #include "bsmm_updat.h"
 #include "bsmm_updat_tr.h"
 #include "bsmm_updat_win.h"
+#include "bsmm_xcol.h"
 #include "bsmm_xgroup.h"
 #include "bsmm_xprop.h"
 
@@ -105,10 +106,36 @@ void launch_xs3(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hi
                                                           a->plan, m, a->N, a->C, a->K);
 }
 
+// which axis-1 grouped kernel the plan builder and the launcher use: env BSMM_XKERNEL = "xcol" (default) | "s3"
+bool use_xcol() {
+    static const bool v = [] { const char* e = getenv("BSMM_XKERNEL"); return !(e && e[0] == 's'); }();
+    return v;
+}
+
+template <class DT>
+void launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    typedef typename DT::T T;
+    const int n_out = a->K / 32;
+    XMap m;
+    m.ntiles = (a->N + XC_R - 1) / XC_R;
+    m.segments = (n_out + XC_G - 1) / XC_G;
+    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+    if (m.P > m.segments) m.P = m.segments;
+    m.SP = (m.segments + m.P - 1) / m.P;
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32_a1_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, XC_LDS);
+        attr_set = true;
+    }
+    xcol32_a1_kernel<DT><<<m.grid(), 512, XC_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                        a->N, a->C, a->K);
+}
+
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     if constexpr (AXIS == 1) {
+        if (use_xcol()) { launch_xcol<DT>(X, Wsel, Y, a, st); return (int)hipGetLastError(); }
         if (xg_group_size(1) == 8) launch_xs3<DT, 8>(X, Wsel, Y, a, st);
         else                       launch_xs3<DT, 12>(X, Wsel, Y, a, st);
     } else {
@@ -143,7 +170,15 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     const int variant = g_variant.load(std::memory_order_relaxed);
     const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
     const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
-    const bool use_group = !use_valu && BS == 32 && DT::is16 && a->plan != nullptr && variant == 0;
+    // grouped kernels need enough (row tile x group) workgroups to fill 256 CUs; below that the per-segment kernel,
+    // which has segments x tiles workgroups, is faster (measured: N = 512 -> 136 vs 70 TF; N = 2048 -> 189 vs 257 TF)
+    bool enough = false;
+    if (BS == 32 && a->plan != nullptr) {
+        const int rows = (AXIS == 1) ? (use_xcol() ? XC_R : XS3::NT) : 128;
+        const int g = (AXIS == 1) ? (use_xcol() ? XC_G : xg_group_size(1)) : xg_group_size(0);
+        enough = (long)((a->N + rows - 1) / rows) * ((a->K / 32 + g - 1) / g) >= 224;
+    }
+    const bool use_group = !use_valu && BS == 32 && DT::is16 && a->plan != nullptr && variant == 0 && enough;
     if (a->locks > 0 && !use_group) {   // several segments accumulate into the same output block: start from zero
         hipError_t e = hipMemsetAsync(Y, 0, (size_t)a->N * a->K * elem_size(a->dtype), st);
         if (e != hipSuccess) return (int)e;
@@ -238,7 +273,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             }
             return (int)hipGetLastError();
         }
-        if (!use_valu && al && variant == 0) {   // LDS-DMA + transposing-read kernel
+        if (!use_valu && al && (variant == 0 || variant == 2)) {   // LDS-DMA + transposing-read kernel
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_tr_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UT_LDS);
@@ -324,6 +359,7 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
 long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
                            int32_t dtype, int32_t axis) {
     if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // grouped kernels: bsize 32, 16-bit types
+    if (axis == 1 && use_xcol()) return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
     return build_xprop_plan(host_lut, segments, blocks, n_out_blocks, xg_group_size(axis), XG_SB, axis == 1, nullptr);
 }
 
@@ -331,6 +367,8 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
                           int32_t dtype, int32_t axis, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
     if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
+    if (axis == 1 && use_xcol())
+        return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     return build_xprop_plan(host_lut, segments, blocks, n_out_blocks, xg_group_size(axis), XG_SB, axis == 1, host_plan_out) > 0
                ? BSMM_OK : BSMM_ERR_ARG;
 }

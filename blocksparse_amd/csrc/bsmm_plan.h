@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace bsmm {
@@ -191,6 +192,79 @@ inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int K
         for (int x = 0; x < 8; ++x)
             for (size_t j = 0; j < per_xcd[x].size() / UP_ITEM; ++j)
                 std::copy(per_xcd[x].begin() + j * UP_ITEM, per_xcd[x].begin() + (j + 1) * UP_ITEM, out + UP_HDR + (j * 8 + x) * UP_ITEM);
+    }
+    return total;
+}
+
+}  // namespace bsmm
+
+// =================================================================================================
+// xcol plan: schedule of the "wave owns an output column" xprop kernel (bsmm_xcol.h), feature axis 1.
+// XC_G consecutive output blocks form a group; wave v of a workgroup owns output block first+v.  The group walks the
+// union of its input-block PAIRS in ascending order; for every step and wave the table says which weight block (if
+// any) multiplies the even / odd half of the pair.
+// Layout (int32): [0] magic 'BSXC' [1] version [2] XC_G [3] ngroups [4] nsteps_total [5] off_groups [6] off_pairs
+//                 [7] off_wtab [8] n_out_blocks
+//   groups[ngroups][4] = (step_off, nsteps, first_out_block, n_out_blocks_in_group)
+//   pairs [nsteps_total]          pair index p of each step (input blocks 2p, 2p+1)
+//   wtab  [group][wave][half][t]  weight block id or -1; group base = off_wtab + 2*XC_G*step_off, index (2*wave+half)*nsteps + t
+// =================================================================================================
+namespace bsmm {
+
+constexpr int32_t XCPLAN_MAGIC = 0x42535843;
+constexpr int32_t XCPLAN_VERSION = 1;
+constexpr int XC_G = 8;
+constexpr int XC_HDR = 12;
+
+inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
+    const int ngroups = (n_out_blocks + XC_G - 1) / XC_G;
+    struct E { int p, slot, w; };   // slot = 2*wave + half
+    std::vector<std::vector<E>> per_group(ngroups);
+    for (int s = 0; s < segments; ++s) {
+        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
+        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
+        for (int e = 0; e < cnt; ++e) {
+            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
+            if (w < 0 || w >= blocks || c < 0) return -1;
+            per_group[ob / XC_G].push_back({c >> 1, 2 * (ob % XC_G) + (c & 1), w});
+        }
+    }
+    std::vector<int32_t> groups, pairs, wtab;
+    for (int g = 0; g < ngroups; ++g) {
+        auto& v = per_group[g];
+        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : a.slot < b.slot; });
+        std::vector<int32_t> gp0;
+        for (auto& e : v) if (gp0.empty() || gp0.back() != e.p) gp0.push_back(e.p);
+        const int ns = (int)gp0.size();
+        const int step_off = (int)pairs.size();
+        // Optional rotation of the walk (env BSMM_ROTATE=1): group g starts at a different input pair so that concurrent
+        // workgroups are not all on the same pair (a test of the L2-channel-conflict hypothesis).  Measured slightly
+        // SLOWER (373 vs 399 TF): it destroys the L2 reuse between the groups of one row tile.  Off by default.
+        static const bool do_rot = getenv("BSMM_ROTATE") != nullptr;
+        const int rot = (ns > 0 && do_rot) ? (int)((long)g * ns / ngroups) : 0;
+        std::vector<int32_t> gp(ns);
+        for (int t = 0; t < ns; ++t) gp[t] = gp0[(t + rot) % ns];
+        std::vector<int32_t> tab((size_t)2 * XC_G * ns, -1);
+        int t0 = -1, cur = -1;
+        for (auto& e : v) {
+            if (e.p != cur) { cur = e.p; ++t0; }
+            const int t = (t0 - rot + ns) % ns;     // position of original step t0 in the rotated walk
+            tab[(size_t)e.slot * ns + t] = e.w;
+        }
+        pairs.insert(pairs.end(), gp.begin(), gp.end());
+        wtab.insert(wtab.end(), tab.begin(), tab.end());
+        groups.insert(groups.end(), {step_off, ns, g * XC_G, std::min(XC_G, n_out_blocks - g * XC_G)});
+    }
+    const long total = XC_HDR + (long)groups.size() + (long)pairs.size() + (long)wtab.size();
+    if (out) {
+        const int off_groups = XC_HDR, off_pairs = off_groups + (int)groups.size(), off_wtab = off_pairs + (int)pairs.size();
+        const int32_t hdr[XC_HDR] = {XCPLAN_MAGIC, XCPLAN_VERSION, XC_G, ngroups, (int32_t)pairs.size(), off_groups, off_pairs, off_wtab,
+                                     n_out_blocks, 0, 0, 0};
+        std::copy(hdr, hdr + XC_HDR, out);
+        std::copy(groups.begin(), groups.end(), out + off_groups);
+        std::copy(pairs.begin(), pairs.end(), out + off_pairs);
+        std::copy(wtab.begin(), wtab.end(), out + off_wtab);
     }
     return total;
 }

@@ -1,0 +1,150 @@
+// bsmm_xcol.h -- xprop kernel "wave owns an output column", feature_axis = 1, bsize 32, 16-bit storage types.
+//
+// Lesson from the grouped kernels (profiles/): when every wave carries all G accumulators of a group, each
+// 32x32 block costs a dispatch decision, two LDS fragment reads and their latency for only 2 MFMAs -- the control
+// skeleton, not a bandwidth, bounds the kernel (~15% of the MFMA rate).  Here the ownership is transposed:
+//   workgroup = XC_G (8) consecutive output blocks x XC_R (256) minibatch rows, 8 waves;
+//   wave v owns output block v for ALL 256 rows: 8 row tiles x 16 accumulator registers, statically addressed.
+// Per step (one PAIR of input blocks = one 128-byte line per row) the X slab [256 rows x 128 B] is DMA'd once into a
+// 2-deep LDS ring and shared by all waves; a wave whose column has a block in either half of the pair loads that
+// block's fragment straight from global memory (prefetched one step ahead) and issues 16 MFMAs with it; waves without
+// a block skip to the barrier.  One decision per step per wave, ~10 LDS reads per 16 MFMAs.
+//   slab image: rows of 128 B, the eight 16-byte pieces of row r XOR-swizzled with (r >> 1) & 7 (conflict-free b128).
+#pragma once
+#include "bsmm_common.h"
+#include "bsmm_plan.h"
+#include "bsmm_xgroup.h"
+
+namespace bsmm {
+
+constexpr int XC_RT = 4;                  // 32-row tiles per wave
+constexpr int XC_R = 32 * XC_RT;          // minibatch rows per workgroup
+constexpr int XC_SLAB = XC_R * 128;
+constexpr int XC_NI = XC_SLAB / 1024 / XC_G;   // DMA instructions per wave per slab
+constexpr int XC_LDS = 2 * XC_SLAB;
+
+template <class DT>
+__global__ void __launch_bounds__(512, 2)
+xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
+                 typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "xcol kernel: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile, grp;
+    if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
+    if (plan[0] != XCPLAN_MAGIC || plan[1] != XCPLAN_VERSION || plan[2] != XC_G) return;
+    const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
+    const int step_off = gh.x, nsteps = gh.y, ob0 = gh.z, nob = gh.w;
+    const int32_t* pairs = plan + plan[6] + step_off;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t* wt0 = plan + plan[7] + 2 * XC_G * step_off + (2 * wave) * nsteps;   // my column, even half
+    const int32_t* wt1 = wt0 + nsteps;                                                  // odd half
+    const int r = lane & 31, h = lane >> 5;
+    const int n_tile = tile * XC_R;
+
+    // X DMA: slab = 32 instructions of 1 KiB (8 rows each); wave v issues instructions 4v .. 4v+3
+    const uint32_t base_addr = lds_addr_of(smem);
+    const int npairs_full = Cin / 64;
+    const T* xsrc[XC_NI];
+    int oddsub[2];
+#pragma unroll
+    for (int i = 0; i < XC_NI; ++i) {
+        const int row = 8 * (XC_NI * wave + i) + (lane >> 3);
+        const int xr = min(n_tile + row, N - 1);                     // rows past N are clamped (never stored)
+        const int piece = (lane & 7) ^ ((row >> 1) & 7);
+        xsrc[i] = X + (size_t)xr * Cin + piece * 8;
+        if (i < 2) oddsub[i] = (piece & 4) ? 32 : 0;                 // piece pattern repeats every 2 instructions (XC_NI even)
+    }
+    auto issue_x = [&](int p, int pos) {
+        const bool full = p < npairs_full;
+#pragma unroll
+        for (int i = 0; i < XC_NI; ++i)
+            glds16_asm(xsrc[i] + (p * 64 - (full ? 0 : oddsub[i & 1])),
+                       __builtin_amdgcn_readfirstlane(base_addr + pos * XC_SLAB + (XC_NI * wave + i) * 1024));
+    };
+    // fragment read offsets inside a 32-row band of the slab: piece = 4*half + 2*kk + h
+    const int xsw = (r >> 1) & 7;
+    int xrd[2][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xrd[half][kk] = r * 128 + (((4 * half + 2 * kk + h) ^ xsw) << 4);
+
+    f32x16 acc[XC_RT];
+#pragma unroll
+    for (int t = 0; t < XC_RT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    auto load_w = [&](int w, Frag32<DT>& f) {
+        if (w >= 0) f.load_contig(Wsel + (size_t)w * 1024 + r * 32, h);
+    };
+    auto block = [&](const Frag32<DT>& wf, const unsigned char* slab, int half) {
+        // all X fragments first, then the MFMAs with the two K-halves of one accumulator XC_RT instructions apart
+        Frag32<DT> xf[XC_RT];
+#pragma unroll
+        for (int t = 0; t < XC_RT; ++t) {
+            xf[t].q[0] = *reinterpret_cast<const uint4*>(slab + t * 4096 + xrd[half][0]);
+            xf[t].q[1] = *reinterpret_cast<const uint4*>(slab + t * 4096 + xrd[half][1]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < XC_RT; ++t) acc[t] = DT::mfma32(wf.q[kk], xf[t].q[kk], acc[t]);
+    };
+
+    // Ring depth 2: the slab of step t+1 and this wave's fragments for step t+1 are requested right after the barrier
+    // of step t and awaited (vmcnt(0)) at the top of step t+1 -- a deeper ring with counted waits and asm-issued W loads
+    // was measured SLOWER (364 vs 435 TF): it costs registers (one workgroup per CU instead of two).
+    const bool owner = wave < nob;
+    if (nsteps > 0) {
+        for (int tb = 0; tb < nsteps; tb += 64) {     // lane-indexed tables for steps [tb, tb+64)
+            const int idx = min(tb + lane, nsteps - 1);
+            const int pv = pairs[idx];
+            const int w0v = owner ? wt0[idx] : -1, w1v = owner ? wt1[idx] : -1;
+            const int tend = min(64, nsteps - tb);
+            Frag32<DT> wc0, wc1, wn0, wn1;
+            wc0.zero(); wc1.zero(); wn0.zero(); wn1.zero();
+            int c0 = __builtin_amdgcn_readlane(w0v, 0), c1 = __builtin_amdgcn_readlane(w1v, 0);
+            load_w(c0, wc0);
+            load_w(c1, wc1);
+            issue_x(__builtin_amdgcn_readlane(pv, 0), tb & 1);
+            for (int s = 0; s < tend; ++s) {
+                const int t = tb + s;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of this step's slab (and my W fragments) landed
+                __syncthreads();                                  // everyone's share landed; everyone left step t-1
+                int n0 = -1, n1 = -1;
+                if (s + 1 < tend) {                               // next step: slab into the other slot, my fragments into wn*
+                    issue_x(__builtin_amdgcn_readlane(pv, s + 1), (t + 1) & 1);
+                    n0 = __builtin_amdgcn_readlane(w0v, s + 1);
+                    n1 = __builtin_amdgcn_readlane(w1v, s + 1);
+                    load_w(n0, wn0);
+                    load_w(n1, wn1);
+                }
+                const unsigned char* slab = smem + (t & 1) * XC_SLAB;
+                if (c0 >= 0) block(wc0, slab, 0);
+                if (c1 >= 0) block(wc1, slab, 1);
+                wc0 = wn0; wc1 = wn1; c0 = n0; c1 = n1;
+            }
+            __syncthreads();   // the next batch re-primes slot tb&1, last read by step tb+62
+        }
+    }
+    if (wave >= nob) return;
+
+    // D[o][n]: col = n = r (lane), rows o = (reg & 3) + 8 * (reg >> 2) + 4h: 4 consecutive o per register quad
+#pragma unroll
+    for (int t = 0; t < XC_RT; ++t) {
+        const int n = n_tile + t * 32 + r;
+        if (n >= N) continue;
+        T* yrow = Y + (size_t)n * Kout + (ob0 + wave) * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t lo = (uint32_t)DT::from_f32(acc[t][4 * q + 0]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 1]) << 16);
+            uint32_t hi = (uint32_t)DT::from_f32(acc[t][4 * q + 2]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 3]) << 16);
+            *reinterpret_cast<uint2*>(yrow + 8 * q) = make_uint2(lo, hi);
+        }
+    }
+}
+
+}  // namespace bsmm

@@ -8,7 +8,8 @@ from blocksparse_amd import BlocksparseMatMul, _lib
 e = os.environ.get
 what, axis, bs, dens, N = e("PASS", "bprop"), int(e("AXIS", "1")), int(e("BS", "32")), float(e("DENS", "0.2")), int(e("N", "8192"))
 td = torch.bfloat16
-b = BlocksparseMatMul(P.random_layout(4096 // bs, 4096 // bs, dens, seed=1234), block_size=bs, feature_axis=axis)
+H = int(e("HIDDEN", "4096"))
+b = BlocksparseMatMul(P.random_layout(H // bs, H // bs, dens, seed=1234), block_size=bs, feature_axis=axis)
 w = (torch.randn(b.w_shape, device="cuda") * 0.01).to(td)
 x = (torch.randn(b.i_shape(N), device="cuda") * 0.1).to(td)
 dy = (torch.randn(b.o_shape(N), device="cuda") * 0.1).to(td)

@@ -80,10 +80,70 @@ def test_argument_validation_without_gpu(lib):
     assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 0
 
 
+def _check_group_plan(plan, f, t, n_out, axis):
+    """grouped-kernel plan (bsmm_plan.h build_xprop_plan): steps over single input blocks (axis 0) or pairs (pair=1)."""
+    import numpy as np
+    assert plan[0] == 0x42534d50 and plan[12] == n_out
+    pair = int(plan[14])
+    G, SB, ngroups = int(plan[2]), int(plan[3]), int(plan[4])
+    groups = plan[plan[8]:plan[9]].reshape(-1, 4)
+    stages = plan[plan[9]:plan[10]].reshape(-1, 4)
+    steps = plan[plan[10]:plan[11]].reshape(-1, 2)
+    wlist = plan[plan[11]:plan[13]]
+    meta = plan[plan[13]:]
+    assert len(groups) == ngroups == -(-n_out // G) and len(wlist) == len(meta) == t["blocks"]
+    got = set()
+    for g, (sb, ns, ob0, nob) in enumerate(groups):
+        assert ob0 == g * G and nob == min(G, n_out - ob0)
+        last_key = -1
+        for st in stages[sb:sb + ns]:
+            assert 0 < st[3] <= SB
+            wpos = st[2]
+            for key, mask in steps[st[0]:st[0] + st[1]]:
+                assert key >= last_key          # equal only when an over-long step was split
+                last_key = key
+                first = True
+                nbits = 2 * G if pair else G
+                for bit in range(nbits):
+                    if (int(mask) >> bit) & 1:
+                        m, c = (bit >> 1, 2 * int(key) + (bit & 1)) if pair else (bit, int(key))
+                        assert m < nob
+                        got.add((ob0 + m, c, int(wlist[wpos])))
+                        assert int(meta[wpos]) == (bit | (256 if first else 0))
+                        first = False
+                        wpos += 1
+                assert (int(mask) & 0xffffffff) >> nbits == 0
+            assert wpos == st[2] + st[3]
+    return got
+
+
+def _check_xcol_plan(plan, f, t, n_out):
+    """xcol plan (build_xcol_plan): per group the union of input PAIRS (possibly rotated), per wave / half / step a weight id or -1."""
+    assert plan[0] == 0x42535843 and plan[8] == n_out
+    G, ngroups = int(plan[2]), int(plan[3])
+    groups = plan[plan[5]:plan[6]].reshape(-1, 4)
+    pairs = plan[plan[6]:plan[7]]
+    assert len(groups) == ngroups == -(-n_out // G)
+    got = set()
+    for g, (so, ns, ob0, nob) in enumerate(groups):
+        assert ob0 == g * G and nob == min(G, n_out - ob0)
+        gp = pairs[so:so + ns]
+        assert len(set(gp.tolist())) == ns                      # every pair once
+        base = int(plan[7]) + 2 * G * so
+        tab = plan[base:base + 2 * G * ns].reshape(2 * G, ns)
+        for slot in range(2 * G):
+            for tt in range(ns):
+                w = int(tab[slot, tt])
+                if w >= 0:
+                    assert (slot >> 1) < nob
+                    got.add((ob0 + (slot >> 1), 2 * int(gp[tt]) + (slot & 1), w))
+        assert ns == 0 or (tab >= 0).any(axis=0).all()           # no empty step
+    return got
+
+
 def test_plan_builder_covers_every_block_once(lib):
     """bsmm_xprop_plan_build (host code in the library): every (in_block, w) entry of the lut appears exactly once,
-    under the right output block; steps ascend; stages respect the LDS budget.  axis 0 plans step over single input
-    blocks, axis 1 plans over PAIRS of input blocks (mask bit = 2*member + (c & 1))."""
+    under the right output block -- for whichever schedule format the library emits for that axis."""
     import numpy as np
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_plan
@@ -96,36 +156,10 @@ def test_plan_builder_covers_every_block_once(lib):
             for side, n_out in (("fprop", KB), ("bprop", CB)):
                 f = t[side]
                 plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, axis)
-                assert plan[0] == 0x42534d50 and plan[12] == n_out and plan[14] == axis
-                G, SB, ngroups = int(plan[2]), int(plan[3]), int(plan[4])
-                groups = plan[plan[8]:plan[9]].reshape(-1, 4)
-                stages = plan[plan[9]:plan[10]].reshape(-1, 4)
-                steps = plan[plan[10]:plan[11]].reshape(-1, 2)
-                wlist = plan[plan[11]:plan[13]]
-                meta = plan[plan[13]:]
-                assert len(groups) == ngroups == -(-n_out // G) and len(wlist) == len(meta) == t["blocks"]
-                got = set()
-                for g, (sb, ns, ob0, nob) in enumerate(groups):
-                    assert ob0 == g * G and nob == min(G, n_out - ob0)
-                    last_key = -1
-                    for st in stages[sb:sb + ns]:
-                        assert 0 < st[3] <= SB
-                        wpos = st[2]
-                        for key, mask in steps[st[0]:st[0] + st[1]]:
-                            assert key >= last_key          # equal only when an over-long step was split
-                            last_key = key
-                            first = True
-                            nbits = 2 * G if axis == 1 else G
-                            for bit in range(nbits):
-                                if (int(mask) >> bit) & 1:
-                                    m, c = (bit >> 1, 2 * int(key) + (bit & 1)) if axis == 1 else (bit, int(key))
-                                    assert m < nob
-                                    got.add((ob0 + m, c, int(wlist[wpos])))
-                                    assert int(meta[wpos]) == (bit | (256 if first else 0))
-                                    first = False
-                                    wpos += 1
-                            assert (int(mask) & 0xffffffff) >> nbits == 0
-                        assert wpos == st[2] + st[3]
+                if plan[0] == 0x42535843:
+                    got = _check_xcol_plan(plan, f, t, n_out)
+                else:
+                    got = _check_group_plan(plan, f, t, n_out, axis)
                 want = set()
                 for ob, col in f["cols"]:
                     for c, w in col:
