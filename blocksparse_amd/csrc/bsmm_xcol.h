@@ -10,6 +10,11 @@
 // block's fragment straight from global memory (prefetched one step ahead) and issues 16 MFMAs with it; waves without
 // a block skip to the barrier.  One decision per step per wave, ~10 LDS reads per 16 MFMAs.
 //   slab image: rows of 128 B, the eight 16-byte pieces of row r XOR-swizzled with (r >> 1) & 7 (conflict-free b128).
+//
+// Measured (4096^2, 20%, N = 8192, bf16; kernel-trace ablation, profiles/): 133 us total; with the X DMA removed 114,
+// W loads removed 117, MFMA work removed 103, barriers removed 114, all four removed 55 (= ~22 us of Y stores +
+// ~30 us of per-step bookkeeping): no single resource bounds it, the pieces just overlap poorly.  T(density) is about
+// 70 us + 260 us * density; at 100% density it runs 837 TF (hipBLASLt dense GEMM of the same shape: 1090 TF).
 #pragma once
 #include "bsmm_common.h"
 #include "bsmm_plan.h"
