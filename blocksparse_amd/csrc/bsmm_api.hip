@@ -113,6 +113,20 @@ bool use_xcol() {
 }
 
 template <class DT>
+void launch_xcol0(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    typedef typename DT::T T;
+    const int n_out = a->K / 32;
+    XMap m;
+    m.ntiles = (a->N + XC_R - 1) / XC_R;
+    m.segments = (n_out + XC_G - 1) / XC_G;
+    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+    if (m.P > m.segments) m.P = m.segments;
+    m.SP = (m.segments + m.P - 1) / m.P;
+    xcol32_a0_kernel<DT><<<m.grid(), 512, XC0_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                         a->N, a->C, a->K);
+}
+
+template <class DT>
 void launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
@@ -139,6 +153,7 @@ int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a
         if (xg_group_size(1) == 8) launch_xs3<DT, 8>(X, Wsel, Y, a, st);
         else                       launch_xs3<DT, 12>(X, Wsel, Y, a, st);
     } else {
+        if (use_xcol()) { launch_xcol0<DT>(X, Wsel, Y, a, st); return (int)hipGetLastError(); }
         const int G = xg_group_size(0);
         const int n_out = a->K / 32;
         XMap m;
@@ -174,11 +189,13 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     // which has segments x tiles workgroups, is faster (measured: N = 512 -> 136 vs 70 TF; N = 2048 -> 189 vs 257 TF)
     bool enough = false;
     if (BS == 32 && a->plan != nullptr) {
-        const int rows = (AXIS == 1) ? (use_xcol() ? XC_R : XS3::NT) : 128;
-        const int g = (AXIS == 1) ? (use_xcol() ? XC_G : xg_group_size(1)) : xg_group_size(0);
+        const int rows = use_xcol() ? XC_R : ((AXIS == 1) ? XS3::NT : 128);
+        const int g = use_xcol() ? XC_G : ((AXIS == 1) ? xg_group_size(1) : xg_group_size(0));
         enough = (long)((a->N + rows - 1) / rows) * ((a->K / 32 + g - 1) / g) >= 224;
+        if (AXIS == 0 && use_xcol() && (a->N % 8 != 0)) enough = false;   // axis-0 xcol needs 16-byte aligned row pieces
     }
-    const bool use_group = !use_valu && BS == 32 && DT::is16 && a->plan != nullptr && variant == 0 && enough;
+    if (variant == 3 && a->plan != nullptr && !(AXIS == 0 && use_xcol() && (a->N % 8 != 0))) enough = true;   // test hook
+    const bool use_group = !use_valu && BS == 32 && DT::is16 && a->plan != nullptr && (variant == 0 || variant == 3) && enough;
     if (a->locks > 0 && !use_group) {   // several segments accumulate into the same output block: start from zero
         hipError_t e = hipMemsetAsync(Y, 0, (size_t)a->N * a->K * elem_size(a->dtype), st);
         if (e != hipSuccess) return (int)e;
@@ -241,10 +258,40 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     }
     const int variant = g_variant.load(std::memory_order_relaxed);
     const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
+    if constexpr (BS == 32 && AXIS == 0 && DT::is16) {
+        if (!use_valu && vec_ok && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed kernel, axis 0
+            static bool attr_set_w0 = false;
+            if (!attr_set_w0) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a0_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UW0_LDS);
+                attr_set_w0 = true;
+            }
+            const int nitems = a->plan_items;
+            const int nchunks = (N + 63) / 64;
+            int split = 1;
+            while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;
+            const char* senv = getenv("BSMM_UPDAT_SPLIT");
+            if (senv) split = atoi(senv) > 0 ? atoi(senv) : split;
+            float* scratch = nullptr;
+            if (split > 1) {
+                const size_t need = (size_t)a->blocks * 1024 * sizeof(float);
+                if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+                scratch = static_cast<float*>(a->workspace);
+                hipError_t e = hipMemsetAsync(scratch, 0, need, st);
+                if (e != hipSuccess) return (int)e;
+            }
+            updat32_a0_win_kernel<DT><<<dim3(nitems, split), 512, UW0_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C,
+                                                                                a->K, a->pcount, a->alpha, a->beta);
+            if (split > 1) {
+                const size_t n = (size_t)a->blocks * 1024;
+                updat_finalize_kernel<DT><<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), n, a->alpha, a->beta);
+            }
+            return (int)hipGetLastError();
+        }
+    }
     if constexpr (BS == 32 && AXIS == 1 && DT::is16) {
         bool al = aligned16(DW);
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
-        if (!use_valu && al && variant == 0 && a->plan != nullptr) {   // windowed kernel (plan = bsmm_updat_plan_build)
+        if (!use_valu && al && (variant == 0 || variant == 3) && a->plan != nullptr) {   // windowed kernel (plan = bsmm_updat_plan_build)
             static bool attr_set_w = false;
             if (!attr_set_w) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
@@ -273,7 +320,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             }
             return (int)hipGetLastError();
         }
-        if (!use_valu && al && (variant == 0 || variant == 2)) {   // LDS-DMA + transposing-read kernel
+        if (!use_valu && al && variant != 1) {   // LDS-DMA + transposing-read kernel
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_tr_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UT_LDS);
@@ -359,7 +406,7 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
 long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
                            int32_t dtype, int32_t axis) {
     if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // grouped kernels: bsize 32, 16-bit types
-    if (axis == 1 && use_xcol()) return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
+    if (use_xcol()) return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
     return build_xprop_plan(host_lut, segments, blocks, n_out_blocks, xg_group_size(axis), XG_SB, axis == 1, nullptr);
 }
 
@@ -367,7 +414,7 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
                           int32_t dtype, int32_t axis, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
     if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
-    if (axis == 1 && use_xcol())
+    if (use_xcol())
         return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     return build_xprop_plan(host_lut, segments, blocks, n_out_blocks, xg_group_size(axis), XG_SB, axis == 1, host_plan_out) > 0
                ? BSMM_OK : BSMM_ERR_ARG;
@@ -375,27 +422,27 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
 
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
                            int32_t axis) {
-    if (bsize != 32 || dtype == BSMM_F32 || axis != 1) return 0;   // windowed kernel: bsize 32, 16-bit, feature axis 1
+    if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: bsize 32, 16-bit types
     return build_updat_plan(host_updat_lut, blocks, CB, KB, nullptr);
 }
 
 int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
                           int32_t axis, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
-    if (bsize != 32 || dtype == BSMM_F32 || axis != 1) return BSMM_ERR_UNSUPPORTED;
+    if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
     return build_updat_plan(host_updat_lut, blocks, CB, KB, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
 }
 
 size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     if (!a) return 0;
-    if (op == BSMM_OP_UPDAT && a->plan && a->bsize == 32 && a->dtype != BSMM_F32 && a->axis == 1)
+    if (op == BSMM_OP_UPDAT && a->plan && a->bsize == 32 && a->dtype != BSMM_F32)
         return (size_t)a->blocks * 1024 * sizeof(float);   // fp32 partial sums of the split-minibatch path
     // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)
     if (op == BSMM_OP_FPROP && a->bsize != 8) return (size_t)a->blocks * a->bsize * a->bsize * elem_size(a->dtype);
     return 0;
 }
 
-void bsmm_set_kernel_variant(int variant) { g_variant.store((variant == 1 || variant == 2) ? variant : 0); }
+void bsmm_set_kernel_variant(int variant) { g_variant.store((variant >= 1 && variant <= 3) ? variant : 0); }
 int bsmm_get_kernel_variant(void) { return g_variant.load(); }
 
 const char* bsmm_error_string(int code) {

@@ -185,6 +185,148 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// feature_axis = 0 variant: activations are (C, N) / (K, N), the contraction index n is CONTIGUOUS for both operands, so
+// the slabs are [UW*32 feature rows][64 n] (128 B per row, 8-piece XOR swizzle as in bsmm_xcol.h) and the fragments are
+// plain ds_read_b128 -- no transposing reads.  One chunk = 64 minibatch columns = 4 MFMAs per block.
+// Requires N % 8 == 0 (16-byte aligned row pieces); the launcher falls back to the per-block kernel otherwise.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int UW0_ROWS = UW * 32;
+constexpr int UW0_SLAB = UW0_ROWS * 128;                 // 32 KiB
+constexpr int UW0_SLOT = 2 * UW0_SLAB;
+constexpr int UW0_LDS = 2 * UW0_SLOT;                    // ring depth 2
+constexpr int UW0_NI = UW0_SLAB / 1024 / UP_WAVES;       // DMA instructions per wave per slab (8 rows each)
+
+template <class DT>
+__global__ void __launch_bounds__(512, 2)
+updat32_a0_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
+                      const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "windowed updat: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (plan[0] != UPLAN_MAGIC || plan[1] != UPLAN_VERSION || plan[2] != UW || plan[3] != UP_MAXB || plan[7] != UP_WAVES) return;
+    const int32_t* item = plan + plan[6] + (size_t)blockIdx.x * UP_ITEM;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = item[0], k0 = item[1];
+    if (item[2] == 0) return;   // padding item
+    const int nslots = item[3];
+    int meta[UP_MAXB], wid[UP_MAXB];
+#pragma unroll
+    for (int j = 0; j < UP_MAXB; ++j) {
+        meta[j] = item[4 + (wave * UP_MAXB + j) * 2];
+        wid[j] = item[4 + (wave * UP_MAXB + j) * 2 + 1];
+    }
+    const int nchunks = (N + 63) >> 6;
+    const int per = (nchunks + gridDim.y - 1) / gridDim.y;
+    const int q_beg = blockIdx.y * per, q_end = min(nchunks, q_beg + per);
+
+    const uint32_t base_addr = lds_addr_of(smem);
+    // DMA: instruction i of a slab covers rows 8i .. 8i+7; lane -> (row 8i + (lane >> 3), stored piece lane & 7)
+    size_t xrow[UW0_NI], erow[UW0_NI];   // element offset of this lane's source row (rows past the matrix are clamped)
+    int dpiece[UW0_NI];
+#pragma unroll
+    for (int i = 0; i < UW0_NI; ++i) {
+        const int row = 8 * (UW0_NI * wave + i) + (lane >> 3);
+        dpiece[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        xrow[i] = (size_t)min(c0 * 32 + row, Cf - 1) * N;
+        erow[i] = (size_t)min(k0 * 32 + row, Kf - 1) * N;
+    }
+    const int r = lane & 31, h = lane >> 5;
+    int aoff[UP_MAXB], boff[UP_MAXB];   // byte offset of this lane's row inside the X / DY slab
+    const int fsw = (r >> 1) & 7;
+#pragma unroll
+    for (int j = 0; j < UP_MAXB; ++j) {
+        aoff[j] = ((meta[j] & 15) * 32 + r) * 128;
+        boff[j] = UW0_SLAB + (((meta[j] >> 4) & 15) * 32 + r) * 128;
+    }
+    f32x16 acc[UP_MAXB];
+#pragma unroll
+    for (int j = 0; j < UP_MAXB; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    auto run = [&](auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;
+        for (int p = 0; p < pcount; ++p) {
+            const T* X = static_cast<const T*>(Xs.p[p]);
+            const T* E = static_cast<const T*>(Es.p[p]);
+            auto issue = [&](int q, int pos) {
+                const int n0 = q * 64;
+                const uint32_t slot = base_addr + pos * UW0_SLOT;
+#pragma unroll
+                for (int i = 0; i < UW0_NI; ++i) {
+                    const int col = min(n0 + dpiece[i], N - 8);   // pieces past N are clamped re-reads (masked below)
+                    const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (UW0_NI * wave + i) * 1024);
+                    glds16_asm(X + xrow[i] + col, dst);
+                    glds16_asm(E + erow[i] + col, dst + UW0_SLAB);
+                }
+            };
+            if (q_beg >= q_end) break;
+            issue(q_beg, 0);
+            int pos = 0;
+            for (int q = q_beg; q < q_end; ++q) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (q + 1 < q_end) issue(q + 1, pos ^ 1);
+                const unsigned char* slot = smem + pos * UW0_SLOT;
+                pos ^= 1;
+                const int n0 = q * 64;
+                const bool tail = n0 + 64 > N;   // ragged tail (N % 64 != 0): zero the X elements whose n >= N
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {     // K = 16 minibatch columns per sub-step, all slots per sub-step
+                    const int po = ((2 * kk + h) ^ fsw) << 4;
+                    uint4 a[NS], b[NS];
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) {
+                        a[j] = *reinterpret_cast<const uint4*>(slot + aoff[j] + po);
+                        b[j] = *reinterpret_cast<const uint4*>(slot + boff[j] + po);
+                    }
+                    if (tail) {
+                        const int nb = n0 + 16 * kk + 8 * h;
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) {
+                            uint32_t* u = reinterpret_cast<uint32_t*>(&a[j]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
+                                u[e] &= (lo | hi);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) acc[j] = DT::mfma32(a[j], b[j], acc[j]);
+                }
+            }
+            __syncthreads();   // ring is re-primed for the next pair
+        }
+    };
+    switch (nslots) {
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        default: run(std::integral_constant<int, 4>{}); break;
+    }
+
+#pragma unroll
+    for (int j = 0; j < UP_MAXB; ++j) {
+        if (!(meta[j] & 256)) continue;
+        const size_t base = (size_t)wid[j] * 1024 + (lane & 31);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            const size_t idx = base + ci * 32;
+            if (gridDim.y == 1) {
+                float out = alpha * acc[j][reg];
+                if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+                DW[idx] = DT::from_f32(out);
+            } else {
+                __hip_atomic_fetch_add(scratch + idx, acc[j][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 // DW = alpha * scratch + beta * DW, rounded once (second pass of the split-minibatch path)
 template <class DT>
 __global__ void __launch_bounds__(256)

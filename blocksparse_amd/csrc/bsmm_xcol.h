@@ -18,6 +18,7 @@
 #pragma once
 #include "bsmm_common.h"
 #include "bsmm_plan.h"
+#include "bsmm_updat_tr.h"
 #include "bsmm_xgroup.h"
 
 namespace bsmm {
@@ -148,6 +149,138 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             uint32_t lo = (uint32_t)DT::from_f32(acc[t][4 * q + 0]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 1]) << 16);
             uint32_t hi = (uint32_t)DT::from_f32(acc[t][4 * q + 2]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 3]) << 16);
             *reinterpret_cast<uint2*>(yrow + 8 * q) = make_uint2(lo, hi);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// feature_axis = 0 variant: activations (C, N), minibatch contiguous.  The X slab of a pair step is [64 feature rows] x
+// [XC_R minibatch columns] (256 B per row, 16-byte pieces XOR-swizzled with 4*(row & 3)); the MFMA B operand wants, per
+// lane, 8 consecutive FEATURES of one minibatch column, i.e. a column of the slab: built with ds_read_b64_tr_b16.
+// Output rows are features, so stores are 64-byte row segments.  Requires N % 8 == 0 (16-byte aligned row pieces).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int XC0_ROWB = XC_R * 2;                 // bytes per slab row
+constexpr int XC0_SLAB = 64 * XC0_ROWB;            // 16 KiB
+constexpr int XC0_LDS = 2 * XC0_SLAB;
+constexpr int XC0_NI = XC0_SLAB / 1024 / XC_G;     // DMA instructions per wave per slab
+constexpr int XC0_PPR = XC0_ROWB / 16;             // 16-byte pieces per row
+constexpr int XC0_RPI = 1024 / XC0_ROWB;           // rows per DMA instruction
+
+template <class DT>
+__global__ void __launch_bounds__(512, 2)
+xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
+                 typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "xcol kernel: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile, grp;
+    if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
+    if (plan[0] != XCPLAN_MAGIC || plan[1] != XCPLAN_VERSION || plan[2] != XC_G) return;
+    const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
+    const int step_off = gh.x, nsteps = gh.y, ob0 = gh.z, nob = gh.w;
+    const int32_t* pairs = plan + plan[6] + step_off;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t* wt0 = plan + plan[7] + 2 * XC_G * step_off + (2 * wave) * nsteps;
+    const int32_t* wt1 = wt0 + nsteps;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_tile = tile * XC_R;
+
+    const uint32_t base_addr = lds_addr_of(smem);
+    // DMA: instruction i covers rows XC0_RPI*i ..; lane -> (row + lane / PPR, stored piece lane % PPR)
+    int drow[XC0_NI], dcol[XC0_NI];
+#pragma unroll
+    for (int i = 0; i < XC0_NI; ++i) {
+        const int row = XC0_RPI * (XC0_NI * wave + i) + lane / XC0_PPR;
+        const int piece = (lane % XC0_PPR) ^ (4 * (row & 3));
+        drow[i] = row;
+        dcol[i] = min(n_tile + piece * 8, N - 8);          // columns past N are clamped re-reads (never stored)
+    }
+    auto issue_x = [&](int p, int pos) {
+#pragma unroll
+        for (int i = 0; i < XC0_NI; ++i) {
+            const int frow = min(p * 64 + drow[i], Cin - 1);   // an odd half that does not exist re-reads the last row
+            glds16_asm(X + (size_t)frow * N + dcol[i], __builtin_amdgcn_readfirstlane(base_addr + pos * XC0_SLAB + (XC0_NI * wave + i) * 1024));
+        }
+    };
+    // transposing-read addressing: 16-lane group g16 -> minibatch columns 16*(g16&1) .. +15 of a 32-column tile, K half
+    // g16 >> 1; lane t16 points at row (t16 >> 2) of a 4-row band, 8 bytes at column 4*(t16 & 3)
+    const int g16 = lane >> 4, t16 = lane & 15;
+    const int trow = t16 >> 2;
+    const int tcolb = (16 * (g16 & 1) + 4 * (t16 & 3)) * 2;   // byte offset of this lane's 8 bytes inside a 64-byte tile row
+
+    f32x16 acc[XC_RT];
+#pragma unroll
+    for (int t = 0; t < XC_RT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    auto load_w = [&](int w, Frag32<DT>& f) {
+        if (w >= 0) f.load_contig(Wsel + (size_t)w * 1024 + r * 32, h);
+    };
+    auto block = [&](const Frag32<DT>& wf, const unsigned char* slab, int half) {
+        uint4 xf[XC_RT][2];
+#pragma unroll
+        for (int t = 0; t < XC_RT; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                // rows (features) 32*half + 16*kk + 8*(g16>>1) + {0..3 | 4..7}; row & 3 == trow for both bands
+                const int row0 = 32 * half + 16 * kk + 8 * (g16 >> 1) + trow;
+                const int byte = 64 * t + tcolb;                                  // byte inside the row (before swizzle)
+                const int sw = (((byte >> 4) ^ (4 * trow)) << 4) | (byte & 15);
+                const uint2 lo = ds_tr16(slab + row0 * XC0_ROWB + sw), hi = ds_tr16(slab + (row0 + 4) * XC0_ROWB + sw);
+                xf[t][kk] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < XC_RT; ++t) acc[t] = DT::mfma32(wf.q[kk], xf[t][kk], acc[t]);
+    };
+
+    const bool owner = wave < nob;
+    if (nsteps > 0) {
+        for (int tb = 0; tb < nsteps; tb += 64) {
+            const int idx = min(tb + lane, nsteps - 1);
+            const int pv = pairs[idx];
+            const int w0v = owner ? wt0[idx] : -1, w1v = owner ? wt1[idx] : -1;
+            const int tend = min(64, nsteps - tb);
+            Frag32<DT> wc0, wc1, wn0, wn1;
+            wc0.zero(); wc1.zero(); wn0.zero(); wn1.zero();
+            int c0 = __builtin_amdgcn_readlane(w0v, 0), c1 = __builtin_amdgcn_readlane(w1v, 0);
+            load_w(c0, wc0);
+            load_w(c1, wc1);
+            issue_x(__builtin_amdgcn_readlane(pv, 0), tb & 1);
+            for (int s = 0; s < tend; ++s) {
+                const int t = tb + s;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                int n0 = -1, n1 = -1;
+                if (s + 1 < tend) {
+                    issue_x(__builtin_amdgcn_readlane(pv, s + 1), (t + 1) & 1);
+                    n0 = __builtin_amdgcn_readlane(w0v, s + 1);
+                    n1 = __builtin_amdgcn_readlane(w1v, s + 1);
+                    load_w(n0, wn0);
+                    load_w(n1, wn1);
+                }
+                const unsigned char* slab = smem + (t & 1) * XC0_SLAB;
+                if (c0 >= 0) block(wc0, slab, 0);
+                if (c1 >= 0) block(wc1, slab, 1);
+                wc0 = wn0; wc1 = wn1; c0 = n0; c1 = n1;
+            }
+            __syncthreads();
+        }
+    }
+    if (wave >= nob) return;
+
+    // D[o][n]: col = n = r, rows o = (reg & 3) + 8 * (reg >> 2) + 4h  ->  Y[(ob*32 + o) * N + n]
+#pragma unroll
+    for (int t = 0; t < XC_RT; ++t) {
+        const int n = n_tile + t * 32 + r;
+        if (n >= N) continue;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int o = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            Y[(size_t)((ob0 + wave) * 32 + o) * N + n] = DT::from_f32(acc[t][reg]);
         }
     }
 }

@@ -118,7 +118,8 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* args);
 /* Test hook: 0 = production kernels (grouped MFMA kernel when a plan is given, else per-segment MFMA kernels for
  *                bsize 16/32, VALU for 8);
  *            1 = force the plain VALU kernels for every bsize (independent second implementation);
- *            2 = ignore bsmm_args.plan (per-segment MFMA kernels). */
+ *            2 = ignore bsmm_args.plan (per-segment / per-block MFMA kernels);
+ *            3 = use the plan kernels whenever a plan is given, regardless of the problem-size heuristic. */
 void bsmm_set_kernel_variant(int variant);
 int bsmm_get_kernel_variant(void);
 

@@ -214,7 +214,7 @@ def test_updat_plan_covers_every_block_once(lib):
             assert cnt == n
         assert seen == set(range(t["blocks"]))
     assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 32, lib.F32, 1) is None
-    assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 32, lib.BF16, 0) is None
+    assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 16, lib.BF16, 0) is None
 
 
 def test_host_class_surface():

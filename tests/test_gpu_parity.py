@@ -94,6 +94,91 @@ def test_mfma_and_valu_kernels_agree(env, bs, axis, dtype):
     _check(b, dtype, "mfma")
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("axis", [0, 1])
+def test_plan_kernels_forced_on_small_and_ragged_cases(env, axis, dtype):
+    """The grouped (xcol) / windowed kernels normally run only when the problem fills the chip; force them
+    (bsmm_set_kernel_variant(3)) on small, ragged and degenerate cases: BA layout with hubs, empty rows/columns, odd
+    block counts (partial groups, a trailing input pair without its odd block), single block, N not a multiple of the
+    row tile, and N % 8 != 0 on axis 0 (must fall back to the generic kernel, still correct)."""
+    torch, BSMM, lib = env
+    L = lib.load()
+    holes = P.ba_layout(16, 2, seed=3)
+    holes[:, 5] = 0
+    holes[7, :] = 0
+    layouts = [P.ba_layout(40, 3, seed=1), holes, P.random_layout(7, 9, 0.5, seed=2), np.ones((1, 1), dtype=np.int32),
+               P.random_layout(17, 33, 0.3, seed=6)]
+    try:
+        L.bsmm_set_kernel_variant(3)
+        for li, layout in enumerate(layouts):
+            for N in (8, 72, 200, 392) + ((100, 5) if li == 0 else ()):
+                res = P.run_case(torch, BSMM, layout, 32, axis, dtype, N, seed=li * 10 + N)
+                _check(res, dtype, "forced-plan layout%d a%d %s N%d" % (li, axis, dtype, N))
+    finally:
+        L.bsmm_set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_plan_and_generic_kernels_agree_at_scale(env, axis):
+    """4096^2 / 20% at N = 2048 (large enough for the heuristic to pick the plan kernels): plan kernels vs the generic
+    per-segment / per-block kernels (variant 2) on identical inputs."""
+    torch, BSMM, lib = env
+    L = lib.load()
+    layout = P.random_layout(128, 128, 0.2, seed=1234)
+    b = BSMM(layout, block_size=32, feature_axis=axis)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N = 2048
+    w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.01).bfloat16()
+    x = (torch.randn(b.i_shape(N), device="cuda", generator=g) * 0.1).bfloat16()
+    dy = (torch.randn(b.o_shape(N), device="cuda", generator=g) * 0.1).bfloat16()
+    outs = {}
+    for v in (0, 2):
+        L.bsmm_set_kernel_variant(v)
+        try:
+            outs[v] = (b.fprop(x, w).float(), b.bprop(dy, w).float(), b.updat(x, dy).float())
+        finally:
+            L.bsmm_set_kernel_variant(0)
+    for name, p, q in zip(("Y", "DX", "DW"), outs[0], outs[2]):
+        l2 = ((p - q).double().norm() / q.double().norm()).item()
+        assert l2 < 2e-3, (name, l2)        # both are bf16-rounded results of fp32 sums in different orders
+
+
+@pytest.mark.parametrize("split", ["1", "2", "4"])
+@pytest.mark.parametrize("axis", [0, 1])
+def test_windowed_updat_pairs_alpha_beta_and_minibatch_split(env, axis, split):
+    """Windowed updat (bf16): 3 (x,dy) pairs, alpha/beta with DW accumulated in place (DWA form), and the
+    split-minibatch path (fp32 atomics into the workspace + finalize kernel) forced via BSMM_UPDAT_SPLIT."""
+    torch, BSMM, lib = env
+    L = lib.load()
+    layout = P.random_layout(12, 20, 0.4, seed=4)
+    b = BSMM(layout, block_size=32, feature_axis=axis)
+    t = orc.build_layout_luts(layout, 32)
+    N = 328
+    Xs, Es = [], []
+    for p in range(3):
+        _, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "bf16", seed=40 + p)
+        Xs.append(X); Es.append(E)
+    dw0 = orc.round_bf16(np.random.RandomState(1).normal(size=b.w_shape).astype(np.float32) * 0.1)
+    ref = orc.updat(t, Xs, Es, axis, alpha=0.5, beta=2.0, dw_in=dw0)
+    dw = P.to_dev(dw0, "bf16", torch)
+    old = os.environ.get("BSMM_UPDAT_SPLIT")
+    os.environ["BSMM_UPDAT_SPLIT"] = split
+    try:
+        L.bsmm_set_kernel_variant(3)
+        out = b.updat([P.to_dev(x, "bf16", torch) for x in Xs], [P.to_dev(e, "bf16", torch) for e in Es],
+                      alpha=0.5, beta=2.0, dw=dw)
+        torch.cuda.synchronize()
+    finally:
+        L.bsmm_set_kernel_variant(0)
+        if old is None:
+            del os.environ["BSMM_UPDAT_SPLIT"]
+        else:
+            os.environ["BSMM_UPDAT_SPLIT"] = old
+    assert out.data_ptr() == dw.data_ptr()
+    l2, mx = P.errors(P.to_host(out), orc.round_bf16(ref))
+    assert l2 <= P.L2_BAR["bf16"], (l2, mx)
+
+
 @pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("bs", [32, 8])
 def test_updat_alpha_beta_and_pairs(env, bs, axis):
