@@ -97,7 +97,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BSMM_FORCE_DIST") == "1"   # the env forces the RCCL path at world_size 1 (self-test)
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     _lib.load()
 
@@ -134,18 +135,18 @@ def main():
             step()
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)] if timed_events else None
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             step(evs[i] if evs else None)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([el], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -223,7 +224,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -112,7 +112,7 @@ bool use_xcol() {
     return v;
 }
 
-template <class DT>
+template <class DT, bool TRANSW>
 void launch_xcol0(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
@@ -122,11 +122,11 @@ void launch_xcol0(const void* X, const void* Wsel, void* Y, const bsmm_args* a, 
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    xcol32_a0_kernel<DT><<<m.grid(), 512, XC0_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+    xcol32_a0_kernel<DT, TRANSW><<<m.grid(), 512, XC0_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                          a->N, a->C, a->K);
 }
 
-template <class DT>
+template <class DT, bool TRANSW>
 void launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
@@ -138,22 +138,30 @@ void launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, h
     m.SP = (m.segments + m.P - 1) / m.P;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32_a1_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, XC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32_a1_kernel<DT, TRANSW>), hipFuncAttributeMaxDynamicSharedMemorySize, XC_LDS);
         attr_set = true;
     }
-    xcol32_a1_kernel<DT><<<m.grid(), 512, XC_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+    xcol32_a1_kernel<DT, TRANSW><<<m.grid(), 512, XC_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                         a->N, a->C, a->K);
 }
 
 template <class DT, int AXIS>
-int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
     typedef typename DT::T T;
     if constexpr (AXIS == 1) {
-        if (use_xcol()) { launch_xcol<DT>(X, Wsel, Y, a, st); return (int)hipGetLastError(); }
+        if (use_xcol()) {
+            if (transw) launch_xcol<DT, true>(X, Wsel, Y, a, st);
+            else        launch_xcol<DT, false>(X, Wsel, Y, a, st);
+            return (int)hipGetLastError();
+        }
         if (xg_group_size(1) == 8) launch_xs3<DT, 8>(X, Wsel, Y, a, st);
         else                       launch_xs3<DT, 12>(X, Wsel, Y, a, st);
     } else {
-        if (use_xcol()) { launch_xcol0<DT>(X, Wsel, Y, a, st); return (int)hipGetLastError(); }
+        if (use_xcol()) {
+            if (transw) launch_xcol0<DT, true>(X, Wsel, Y, a, st);
+            else        launch_xcol0<DT, false>(X, Wsel, Y, a, st);
+            return (int)hipGetLastError();
+        }
         const int G = xg_group_size(0);
         const int n_out = a->K / 32;
         XMap m;
@@ -204,6 +212,8 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         return fprop ? launch_xprop_valu<DT, BS, AXIS, true>(X, W, Y, a, st)
                      : launch_xprop_valu<DT, BS, AXIS, false>(X, W, Y, a, st);
     }
+    // (xcol can gather the fprop operand transposed itself -- launch_xgroup32(..., transw = true), no workspace and no
+    //  pre-pass -- but that measured SLOWER than the 6 us transpose kernel + contiguous fragment loads: 145 vs 131 us.)
     if constexpr (BS != 8) {
         const void* Wsel = W;
         if (fprop) {
@@ -214,7 +224,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
             Wsel = a->workspace;
         }
         if constexpr (BS == 32 && DT::is16) {
-            if (use_group) return launch_xgroup32<DT, AXIS>(X, Wsel, Y, a, st);
+            if (use_group) return launch_xgroup32<DT, AXIS>(X, Wsel, Y, a, st, false);
         }
         return launch_xprop_mfma<DT, BS, AXIS>(X, Wsel, Y, a, st);
     }

@@ -27,9 +27,13 @@ constexpr int XC_RT = 4;                  // 32-row tiles per wave
 constexpr int XC_R = 32 * XC_RT;          // minibatch rows per workgroup
 constexpr int XC_SLAB = XC_R * 128;
 constexpr int XC_NI = XC_SLAB / 1024 / XC_G;   // DMA instructions per wave per slab
-constexpr int XC_LDS = 2 * XC_SLAB;
+constexpr int XC_STAGE = XC_R * 512;         // epilogue staging tile (XC_G column blocks x 64 B per row)
+constexpr int XC_LDS = (2 * XC_SLAB > XC_STAGE) ? 2 * XC_SLAB : XC_STAGE;
 
-template <class DT>
+// TRANSW = true (fprop): Wsel is W in its natural [c-in-block][k-in-block] layout and each lane gathers its fragment
+// transposed (16 two-byte loads, stride 64 B, prefetched a step ahead) -- no transposed copy of W, no workspace.
+// Measured slower than the transpose pre-pass (fprop 145 vs 131 us), so the launcher passes TRANSW = false today.
+template <class DT, bool TRANSW>
 __global__ void __launch_bounds__(512, 2)
 xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
                  typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
@@ -84,7 +88,10 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     auto load_w = [&](int w, Frag32<DT>& f) {
-        if (w >= 0) f.load_contig(Wsel + (size_t)w * 1024 + r * 32, h);
+        if (w >= 0) {
+            if constexpr (TRANSW) f.load_strided(Wsel + (size_t)w * 1024 + r, 32, h);   // Wop[o][i] = W[i][o]
+            else                  f.load_contig(Wsel + (size_t)w * 1024 + r * 32, h);
+        }
     };
     auto block = [&](const Frag32<DT>& wf, const unsigned char* slab, int half) {
         // all X fragments first, then the MFMAs with the two K-halves of one accumulator XC_RT instructions apart
@@ -136,19 +143,37 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             __syncthreads();   // the next batch re-primes slot tb&1, last read by step tb+62
         }
     }
-    if (wave >= nob) return;
-
-    // D[o][n]: col = n = r (lane), rows o = (reg & 3) + 8 * (reg >> 2) + 4h: 4 consecutive o per register quad
+    // Epilogue.  D[o][n]: col = n = r (lane), rows o = (reg & 3) + 8 * (reg >> 2) + 4h, i.e. 4 consecutive o (8 bytes)
+    // per register quad.  The 8 waves own 8 ADJACENT output blocks = 512 contiguous bytes per minibatch row, so the
+    // tile goes through the (now idle) LDS ring and is stored as full rows: 16 bytes per lane, a wave covers 2 rows x
+    // 512 B per instruction (direct 8-byte stores at an 8 KiB stride cost ~22 us for the 67 MB; this costs ~13).
+    // staging image: [XC_R rows][512 B], 16-byte pieces of row n XOR-swizzled with (n & 31) (bank-conflict free both
+    // ways: writers walk n across lanes, readers walk pieces across lanes).
+    static_assert(XC_STAGE <= XC_LDS, "staging tile must fit");
+    __syncthreads();   // everyone is done with the slabs
+    if (owner) {
 #pragma unroll
-    for (int t = 0; t < XC_RT; ++t) {
-        const int n = n_tile + t * 32 + r;
-        if (n >= N) continue;
-        T* yrow = Y + (size_t)n * Kout + (ob0 + wave) * 32 + 4 * h;
+        for (int t = 0; t < XC_RT; ++t) {
+            const int n = t * 32 + r;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint32_t lo = (uint32_t)DT::from_f32(acc[t][4 * q + 0]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 1]) << 16);
-            uint32_t hi = (uint32_t)DT::from_f32(acc[t][4 * q + 2]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 3]) << 16);
-            *reinterpret_cast<uint2*>(yrow + 8 * q) = make_uint2(lo, hi);
+            for (int q = 0; q < 4; ++q) {
+                uint32_t lo = (uint32_t)DT::from_f32(acc[t][4 * q + 0]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 1]) << 16);
+                uint32_t hi = (uint32_t)DT::from_f32(acc[t][4 * q + 2]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 3]) << 16);
+                const int piece = wave * 4 + q;                     // 16-byte piece inside the 512-byte row: o = 8q + 4h + ...
+                *reinterpret_cast<uint2*>(smem + n * 512 + ((piece ^ (n & 31)) << 4) + 8 * h) = make_uint2(lo, hi);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int rowbytes = nob * 64;                              // partial last group: fewer valid columns
+        T* ybase = Y + (size_t)ob0 * 32;
+        for (int i = threadIdx.x; i < XC_R * 32; i += 512) {        // 32 pieces per row
+            const int n = i >> 5, piece = i & 31;
+            if (n_tile + n < N && piece * 16 < rowbytes) {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + n * 512 + ((piece ^ (n & 31)) << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)(n_tile + n) * Kout) + piece * 16) = v;
+            }
         }
     }
 }
@@ -166,7 +191,7 @@ constexpr int XC0_NI = XC0_SLAB / 1024 / XC_G;     // DMA instructions per wave 
 constexpr int XC0_PPR = XC0_ROWB / 16;             // 16-byte pieces per row
 constexpr int XC0_RPI = 1024 / XC0_ROWB;           // rows per DMA instruction
 
-template <class DT>
+template <class DT, bool TRANSW>
 __global__ void __launch_bounds__(512, 2)
 xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
                  typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
@@ -216,7 +241,10 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     auto load_w = [&](int w, Frag32<DT>& f) {
-        if (w >= 0) f.load_contig(Wsel + (size_t)w * 1024 + r * 32, h);
+        if (w >= 0) {
+            if constexpr (TRANSW) f.load_strided(Wsel + (size_t)w * 1024 + r, 32, h);   // Wop[o][i] = W[i][o]
+            else                  f.load_contig(Wsel + (size_t)w * 1024 + r * 32, h);
+        }
     };
     auto block = [&](const Frag32<DT>& wf, const unsigned char* slab, int half) {
         uint4 xf[XC_RT][2];

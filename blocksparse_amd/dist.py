@@ -43,7 +43,7 @@ class DwAllReduce(object):
         self._dst = None
 
     def start(self, dw):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized():
             self._work = None
             return dw
         if self.accumulate_fp32 and dw.dtype != torch.float32:
