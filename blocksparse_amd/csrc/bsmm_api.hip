@@ -309,7 +309,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             }
             const int nitems = a->plan_items;
             if (nitems <= 0) return BSMM_ERR_ARG;
-            const int nchunks = (N + 31) / 32;
+            const int nchunks = (N + UWN_CH - 1) / UWN_CH;
             int split = 1;
             while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;   // one workgroup per CU, >= 8 chunks each
             const char* senv = getenv("BSMM_UPDAT_SPLIT");

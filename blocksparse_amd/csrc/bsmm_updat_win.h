@@ -25,9 +25,10 @@
 
 namespace bsmm {
 
-constexpr int UWN_D = 4;
+constexpr int UWN_D = 2;
+constexpr int UWN_CH = 64;                    // minibatch rows per chunk
 constexpr int UWN_ROWB = UW * 64;             // bytes per slab row (UW blocks x 64 B)
-constexpr int UWN_SLAB = 32 * UWN_ROWB;       // bytes of one operand slab
+constexpr int UWN_SLAB = UWN_CH * UWN_ROWB;   // bytes of one operand slab
 constexpr int UWN_NI = UWN_SLAB / 1024 / UP_WAVES;   // DMA instructions per wave per slab
 constexpr int UWN_SLOT = 2 * UWN_SLAB;
 constexpr int UWN_LDS = UWN_D * UWN_SLOT;
@@ -52,8 +53,8 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
         wid[j] = item[4 + (wave * UP_MAXB + j) * 2 + 1];
     }
 
-    // rows handled by this workgroup: chunks [q_beg, q_end) of 32 rows
-    const int nchunks = (N + 31) >> 5;
+    // rows handled by this workgroup: chunks [q_beg, q_end) of UWN_CH rows
+    const int nchunks = (N + UWN_CH - 1) / UWN_CH;
     const int per = (nchunks + gridDim.y - 1) / gridDim.y;
     const int q_beg = blockIdx.y * per, q_end = min(nchunks, q_beg + per);
 
@@ -100,7 +101,7 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
             const T* X = static_cast<const T*>(Xs.p[p]);
             const T* E = static_cast<const T*>(Es.p[p]);
             auto issue = [&](int q, int pos) {
-                const int n0 = min(q, q_end - 1) * 32;   // chunks past the end re-fetch the last one (never read)
+                const int n0 = min(q, q_end - 1) * UWN_CH;   // chunks past the end re-fetch the last one (never read)
                 const uint32_t slot = base_addr + pos * UWN_SLOT;
 #pragma unroll
                 for (int i = 0; i < UWN_NI; ++i) {
@@ -121,37 +122,35 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
                 const unsigned char* slot = smem + pos * UWN_SLOT;
                 pos = (pos + 1) & (UWN_D - 1);
                 wpos = (wpos + 1) & (UWN_D - 1);
-                const int n0 = q * 32;
-                uint4 a[NS][2], b[NS][2];
+                const int n0 = q * UWN_CH;
+                constexpr int NK = UWN_CH / 16;     // 16 minibatch rows per MFMA
+                const bool tail = n0 + UWN_CH > N;  // ragged tail: rows >= N were clamped re-reads -> zero them (X side suffices)
 #pragma unroll
-                for (int j = 0; j < NS; ++j)
+                for (int kk = 0; kk < NK; ++kk) {   // fragments of one K sub-step for all slots, then their MFMAs
+                    uint4 a[NS], b[NS];
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
+                    for (int j = 0; j < NS; ++j) {
                         const unsigned char* sa = slot + (16 * kk + 8 * h) * UWN_ROWB + aoff[j];
                         const unsigned char* sb = slot + (16 * kk + 8 * h) * UWN_ROWB + boff[j];
                         const uint2 a0 = ds_tr16(sa), a1 = ds_tr16(sa + 4 * UWN_ROWB);
                         const uint2 b0 = ds_tr16(sb), b1 = ds_tr16(sb + 4 * UWN_ROWB);
-                        a[j][kk] = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                        b[j][kk] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                        a[j] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                        b[j] = make_uint4(b0.x, b0.y, b1.x, b1.y);
                     }
-                if (n0 + 32 > N) {   // ragged tail: rows >= N were clamped re-reads -> zero their contribution (X side suffices)
+                    if (tail) {
+                        const int nb = n0 + 16 * kk + 8 * h;
 #pragma unroll
-                    for (int j = 0; j < NS; ++j)
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) {
-                            const int nb = n0 + 16 * kk + 8 * h;
-                            uint32_t* u = reinterpret_cast<uint32_t*>(&a[j][kk]);
+                        for (int j = 0; j < NS; ++j) {
+                            uint32_t* u = reinterpret_cast<uint32_t*>(&a[j]);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
                                 u[e] &= (lo | hi);
                             }
                         }
-                }
+                    }
 #pragma unroll
-                for (int j = 0; j < NS; ++j) {
-                    acc[j] = DT::mfma32(a[j][0], b[j][0], acc[j]);
-                    acc[j] = DT::mfma32(a[j][1], b[j][1], acc[j]);
+                    for (int j = 0; j < NS; ++j) acc[j] = DT::mfma32(a[j], b[j], acc[j]);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
