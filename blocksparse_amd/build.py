@@ -25,6 +25,7 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC]
+    cmd += os.environ.get("BSMM_EXTRA_CXXFLAGS", "").split()
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))

@@ -23,12 +23,20 @@
 
 namespace bsmm {
 
-constexpr int XC_RT = 4;                  // 32-row tiles per wave
+#ifndef BSMM_XC_RT
+#define BSMM_XC_RT 4
+#endif
+#ifndef BSMM_XC_PH
+#define BSMM_XC_PH 2
+#endif
+constexpr int XC_RT = BSMM_XC_RT;         // 32-row tiles per wave
+constexpr int XC_PH = BSMM_XC_PH;         // steps per phase (one barrier per phase); ring = 2*XC_PH slabs
 constexpr int XC_R = 32 * XC_RT;          // minibatch rows per workgroup
 constexpr int XC_SLAB = XC_R * 128;
 constexpr int XC_NI = XC_SLAB / 1024 / XC_G;   // DMA instructions per wave per slab
 constexpr int XC_STAGE = XC_R * 512;         // epilogue staging tile (XC_G column blocks x 64 B per row)
-constexpr int XC_LDS = (2 * XC_SLAB > XC_STAGE) ? 2 * XC_SLAB : XC_STAGE;
+constexpr int XC_RING = 2 * XC_PH;
+constexpr int XC_LDS = (XC_RING * XC_SLAB > XC_STAGE) ? XC_RING * XC_SLAB : XC_STAGE;   // slab ring / staging tile
 
 // TRANSW = true (fprop): Wsel is W in its natural [c-in-block][k-in-block] layout and each lane gathers its fragment
 // transposed (16 two-byte loads, stride 64 B, prefetched a step ahead) -- no transposed copy of W, no workspace.
@@ -107,42 +115,54 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             for (int t = 0; t < XC_RT; ++t) acc[t] = DT::mfma32(wf.q[kk], xf[t].q[kk], acc[t]);
     };
 
-    // Ring depth 2: the slab of step t+1 and this wave's fragments for step t+1 are requested right after the barrier
-    // of step t and awaited (vmcnt(0)) at the top of step t+1 -- a deeper ring with counted waits and asm-issued W loads
-    // was measured SLOWER (364 vs 435 TF): it costs registers (one workgroup per CU instead of two).
+    // Phases of XC_PH steps, one barrier per phase, ring of 2*XC_PH slabs.  At the phase barrier both slabs of the phase have
+    // landed (each wave waited for its DMA share, issued a whole phase earlier) and everyone has left the previous
+    // phase, so the two slabs of the NEXT phase are requested right away (prefetch distance = one phase); a wave's W
+    // fragments are still fetched one step ahead.  Half the barriers, and the per-step imbalance between waves
+    // (0, 1 or 2 blocks) averages over two steps.  (Deeper rings with counted waits were measured slower: registers.)
     const bool owner = wave < nob;
     if (nsteps > 0) {
         for (int tb = 0; tb < nsteps; tb += 64) {     // lane-indexed tables for steps [tb, tb+64)
             const int idx = min(tb + lane, nsteps - 1);
             const int pv = pairs[idx];
             const int w0v = owner ? wt0[idx] : -1, w1v = owner ? wt1[idx] : -1;
-            const int tend = min(64, nsteps - tb);
+            const int tend = min(64, nsteps - tb);    // steps in this batch (64 % XC_RING == 0: slot = step % XC_RING)
             Frag32<DT> wc0, wc1, wn0, wn1;
             wc0.zero(); wc1.zero(); wn0.zero(); wn1.zero();
             int c0 = __builtin_amdgcn_readlane(w0v, 0), c1 = __builtin_amdgcn_readlane(w1v, 0);
             load_w(c0, wc0);
             load_w(c1, wc1);
-            issue_x(__builtin_amdgcn_readlane(pv, 0), tb & 1);
-            for (int s = 0; s < tend; ++s) {
-                const int t = tb + s;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of this step's slab (and my W fragments) landed
-                __syncthreads();                                  // everyone's share landed; everyone left step t-1
-                int n0 = -1, n1 = -1;
-                if (s + 1 < tend) {                               // next step: slab into the other slot, my fragments into wn*
-                    issue_x(__builtin_amdgcn_readlane(pv, s + 1), (t + 1) & 1);
-                    n0 = __builtin_amdgcn_readlane(w0v, s + 1);
-                    n1 = __builtin_amdgcn_readlane(w1v, s + 1);
-                    load_w(n0, wn0);
-                    load_w(n1, wn1);
+#pragma unroll
+            for (int u = 0; u < XC_PH; ++u)
+                if (u < tend) issue_x(__builtin_amdgcn_readlane(pv, u), u);
+            for (int s = 0; s < tend; s += XC_PH) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my shares of this phase's slabs (+ my W fragments) landed
+                __syncthreads();                                  // everyone's did; everyone left the previous phase
+#pragma unroll
+                for (int u = 0; u < XC_PH; ++u)
+                    if (s + XC_PH + u < tend) issue_x(__builtin_amdgcn_readlane(pv, s + XC_PH + u), (s + XC_PH + u) % XC_RING);
+#pragma unroll
+                for (int u = 0; u < XC_PH; ++u) {
+                    const int ss = s + u;
+                    if (ss >= tend) break;
+                    if (u >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W fragments of this step (slab is already in)
+                    int n0 = -1, n1 = -1;
+                    if (ss + 1 < tend) {
+                        n0 = __builtin_amdgcn_readlane(w0v, ss + 1);
+                        n1 = __builtin_amdgcn_readlane(w1v, ss + 1);
+                        load_w(n0, wn0);
+                        load_w(n1, wn1);
+                    }
+                    const unsigned char* slab = smem + (ss % XC_RING) * XC_SLAB;
+                    if (c0 >= 0) block(wc0, slab, 0);
+                    if (c1 >= 0) block(wc1, slab, 1);
+                    wc0 = wn0; wc1 = wn1; c0 = n0; c1 = n1;
                 }
-                const unsigned char* slab = smem + (t & 1) * XC_SLAB;
-                if (c0 >= 0) block(wc0, slab, 0);
-                if (c1 >= 0) block(wc1, slab, 1);
-                wc0 = wn0; wc1 = wn1; c0 = n0; c1 = n1;
             }
-            __syncthreads();   // the next batch re-primes slot tb&1, last read by step tb+62
+            __syncthreads();   // the next batch re-primes slots 0/1
         }
     }
+
     // Epilogue.  D[o][n]: col = n = r (lane), rows o = (reg & 3) + 8 * (reg >> 2) + 4h, i.e. 4 consecutive o (8 bytes)
     // per register quad.  The 8 waves own 8 ADJACENT output blocks = 512 contiguous bytes per minibatch row, so the
     // tile goes through the (now idle) LDS ring and is stored as full rows: 16 bytes per lane, a wave covers 2 rows x
@@ -186,7 +206,7 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int XC0_ROWB = XC_R * 2;                 // bytes per slab row
 constexpr int XC0_SLAB = 64 * XC0_ROWB;            // 16 KiB
-constexpr int XC0_LDS = 2 * XC0_SLAB;
+constexpr int XC0_LDS = XC_RING * XC0_SLAB;
 constexpr int XC0_NI = XC0_SLAB / 1024 / XC_G;     // DMA instructions per wave per slab
 constexpr int XC0_PPR = XC0_ROWB / 16;             // 16-byte pieces per row
 constexpr int XC0_RPI = 1024 / XC0_ROWB;           // rows per DMA instruction
@@ -266,7 +286,7 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     };
 
     const bool owner = wave < nob;
-    if (nsteps > 0) {
+    if (nsteps > 0) {   // phases of XC_PH steps, one barrier per phase (see xcol32_a1_kernel)
         for (int tb = 0; tb < nsteps; tb += 64) {
             const int idx = min(tb + lane, nsteps - 1);
             const int pv = pairs[idx];
@@ -277,23 +297,32 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             int c0 = __builtin_amdgcn_readlane(w0v, 0), c1 = __builtin_amdgcn_readlane(w1v, 0);
             load_w(c0, wc0);
             load_w(c1, wc1);
-            issue_x(__builtin_amdgcn_readlane(pv, 0), tb & 1);
-            for (int s = 0; s < tend; ++s) {
-                const int t = tb + s;
+#pragma unroll
+            for (int u = 0; u < XC_PH; ++u)
+                if (u < tend) issue_x(__builtin_amdgcn_readlane(pv, u), u);
+            for (int s = 0; s < tend; s += XC_PH) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                int n0 = -1, n1 = -1;
-                if (s + 1 < tend) {
-                    issue_x(__builtin_amdgcn_readlane(pv, s + 1), (t + 1) & 1);
-                    n0 = __builtin_amdgcn_readlane(w0v, s + 1);
-                    n1 = __builtin_amdgcn_readlane(w1v, s + 1);
-                    load_w(n0, wn0);
-                    load_w(n1, wn1);
+#pragma unroll
+                for (int u = 0; u < XC_PH; ++u)
+                    if (s + XC_PH + u < tend) issue_x(__builtin_amdgcn_readlane(pv, s + XC_PH + u), (s + XC_PH + u) % XC_RING);
+#pragma unroll
+                for (int u = 0; u < XC_PH; ++u) {
+                    const int ss = s + u;
+                    if (ss >= tend) break;
+                    if (u >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    int n0 = -1, n1 = -1;
+                    if (ss + 1 < tend) {
+                        n0 = __builtin_amdgcn_readlane(w0v, ss + 1);
+                        n1 = __builtin_amdgcn_readlane(w1v, ss + 1);
+                        load_w(n0, wn0);
+                        load_w(n1, wn1);
+                    }
+                    const unsigned char* slab = smem + (ss % XC_RING) * XC0_SLAB;
+                    if (c0 >= 0) block(wc0, slab, 0);
+                    if (c1 >= 0) block(wc1, slab, 1);
+                    wc0 = wn0; wc1 = wn1; c0 = n0; c1 = n1;
                 }
-                const unsigned char* slab = smem + (t & 1) * XC0_SLAB;
-                if (c0 >= 0) block(wc0, slab, 0);
-                if (c1 >= 0) block(wc1, slab, 1);
-                wc0 = wn0; wc1 = wn1; c0 = n0; c1 = n1;
             }
             __syncthreads();
         }
