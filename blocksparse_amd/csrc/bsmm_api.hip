@@ -342,6 +342,51 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             return (int)hipGetLastError();
         }
     }
+    if constexpr (BS == 16 && DT::is16) {
+        bool al16 = aligned16(DW) && (AXIS == 1 || N % 8 == 0);
+        for (int p = 0; p < a->pcount; ++p) al16 = al16 && aligned16(xs.p[p]) && aligned16(es.p[p]);
+        if (!use_valu && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed, 16x16 blocks
+            static bool attr_set_w16 = false;
+            if (!attr_set_w16) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat16_win_kernel<DT, AXIS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * UWN_SLOT);
+                attr_set_w16 = true;
+            }
+            const int nitems = a->plan_items;
+            const int nchunks = (N + 63) / 64;
+            int split = 1;
+            while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;
+            const char* senv = getenv("BSMM_UPDAT_SPLIT");
+            if (senv) split = atoi(senv) > 0 ? atoi(senv) : split;
+            float* scratch = nullptr;
+            const size_t nel = (size_t)a->blocks * 256;
+            if (split > 1) {
+                if (!a->workspace || a->workspace_bytes < nel * sizeof(float) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+                scratch = static_cast<float*>(a->workspace);
+                hipError_t e = hipMemsetAsync(scratch, 0, nel * sizeof(float), st);
+                if (e != hipSuccess) return (int)e;
+            }
+            updat16_win_kernel<DT, AXIS><<<dim3(nitems, split), 512, 2 * UWN_SLOT, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C,
+                                                                                      a->K, a->pcount, a->alpha, a->beta);
+            if (split > 1)
+                updat_finalize_kernel<DT><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), nel, a->alpha, a->beta);
+            return (int)hipGetLastError();
+        }
+    }
+    if constexpr (BS == 16 && AXIS == 1 && DT::is16) {
+        bool al = aligned16(DW);
+        for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
+        if (!use_valu && al && variant != 1) {   // LDS-DMA + transposing-read kernel, 16x16 blocks
+            static bool attr_set16 = false;
+            if (!attr_set16) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat16_a1_tr_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UT16_LDS);
+                attr_set16 = true;
+            }
+            const int grid = 8 * ((a->blocks + 7) / 8);
+            updat16_a1_tr_kernel<DT><<<grid, 256, UT16_LDS, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K, a->pcount,
+                                                                a->alpha, a->beta);
+            return (int)hipGetLastError();
+        }
+    }
     if (use_valu) {
         updat_valu_kernel<DT, BS, AXIS><<<a->blocks, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C,
                                                                    a->K, a->pcount, a->alpha, a->beta);
@@ -432,21 +477,24 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
 
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
                            int32_t axis) {
-    if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: bsize 32, 16-bit types
-    return build_updat_plan(host_updat_lut, blocks, CB, KB, nullptr);
+    if ((bsize != 32 && bsize != 16) || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: bsize 32/16, 16-bit
+    return bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, UW, UP_MAXB, nullptr)
+                       : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, nullptr);
 }
 
 int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
                           int32_t axis, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
-    if (bsize != 32 || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
-    return build_updat_plan(host_updat_lut, blocks, CB, KB, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
+    if ((bsize != 32 && bsize != 16) || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
+    const long n = bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, UW, UP_MAXB, host_plan_out)
+                               : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, host_plan_out);
+    return n > 0 ? BSMM_OK : BSMM_ERR_ARG;
 }
 
 size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     if (!a) return 0;
-    if (op == BSMM_OP_UPDAT && a->plan && a->bsize == 32 && a->dtype != BSMM_F32)
-        return (size_t)a->blocks * 1024 * sizeof(float);   // fp32 partial sums of the split-minibatch path
+    if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32)
+        return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float);   // fp32 partial sums of the split-minibatch path
     // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)
     if (op == BSMM_OP_FPROP && a->bsize != 8) return (size_t)a->blocks * a->bsize * a->bsize * elem_size(a->dtype);
     return 0;

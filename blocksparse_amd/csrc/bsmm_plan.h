@@ -137,14 +137,19 @@ namespace bsmm {
 
 constexpr int32_t UPLAN_MAGIC = 0x42535550;
 constexpr int32_t UPLAN_VERSION = 4;
-constexpr int UW = 8;
+constexpr int UW = 8;          // bsize 32: 8x8-block windows, 4 slots per wave
 constexpr int UP_WAVES = 8;
 constexpr int UP_MAXB = 4;
 constexpr int UP_HDR = 8;
 constexpr int UP_ITEM = 4 + UP_WAVES * UP_MAXB * 2;
+constexpr int UW16 = 16;       // bsize 16: 16x16-block windows (the same 256x256 features), 8 slots per wave
+constexpr int UP16_MAXB = 8;
+constexpr int UP16_ITEM = 4 + UP_WAVES * UP16_MAXB * 2;
 
-inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int32_t* out) {
-    if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0) return -1;
+// uw = window side in blocks (256 / bsize), maxb = slots per wave (4 for bsize 32, 8 for bsize 16)
+inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int uw, int maxb, int32_t* out) {
+    if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || uw < 1 || uw > 16 || maxb < 1) return -1;
+    const int UW = uw, UP_MAXB = maxb, UP_ITEM = 4 + UP_WAVES * maxb * 2;
     const int wc = (CB + UW - 1) / UW, wk = (KB + UW - 1) / UW;
     struct Ent { int c, k, w; };
     std::vector<std::vector<Ent>> win((size_t)wc * wk);

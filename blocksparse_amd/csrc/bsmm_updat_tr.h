@@ -125,4 +125,85 @@ updat32_a1_tr_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     }
 }
 
+// bsize 16 version: 16x16 blocks, v_mfma_f32_16x16x32 (K = 32 minibatch rows per instruction).  Slabs are 32 rows x
+// 32 B (one 1 KiB DMA instruction each); lane (ci = lane & 15, q = lane >> 4) needs rows 8q .. 8q+7 of feature ci: two
+// transposing reads (rows 8q+{0..3}, 8q+{4..7}); 16-lane group q covers exactly the 16 features.
+constexpr int UT16_SLOT = 2 * 1024;
+constexpr int UT16_D = 8;
+constexpr int UT16_LDS = 4 * UT16_D * UT16_SLOT;   // 64 KiB (also holds the 4 KiB reduction buffer)
+
+template <class DT>
+__global__ void __launch_bounds__(256, 2)
+updat16_a1_tr_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
+                     int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "transposing-read kernel: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = updat_block(blockIdx.x, blocks);
+    if (w < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lut[2 * w], k = lut[2 * w + 1];
+    unsigned char* ring = smem + wave * (UT16_D * UT16_SLOT);
+    const uint32_t ring_addr = lds_addr_of(ring);
+    const int drow = lane >> 1, dpiece = lane & 1;                 // DMA: lane -> (row, 16-byte piece)
+    const int q = lane >> 4, t16 = lane & 15;
+    const int rd_base = (8 * q + (t16 >> 2)) * 32 + (4 * (t16 & 3)) * 2;
+
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nchunks = (N + 31) >> 5;
+    for (int p = 0; p < pcount; ++p) {
+        const T* X = static_cast<const T*>(Xs.p[p]) + c * 16 + dpiece * 8;
+        const T* E = static_cast<const T*>(Es.p[p]) + k * 16 + dpiece * 8;
+        auto issue = [&](int qq, int pos) {
+            const int row = min((wave + 4 * qq) * 32 + drow, N - 1);     // rows past N are clamped (masked below)
+            const uint32_t slot = __builtin_amdgcn_readfirstlane(ring_addr + pos * UT16_SLOT);
+            glds16_asm(X + (size_t)row * Cf, slot);
+            glds16_asm(E + (size_t)row * Kf, slot + 1024);
+        };
+        const int myq = (nchunks > wave) ? (nchunks - wave + 3) / 4 : 0;
+#pragma unroll
+        for (int d = 0; d < UT16_D - 1; ++d) issue(d, d);
+        int rd_pos = 0, wr_pos = UT16_D - 1;
+        for (int qq = 0; qq < myq; ++qq) {
+            issue(qq + UT16_D - 1, wr_pos);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (UT16_D - 1)) : "memory");
+            const unsigned char* slot = ring + rd_pos * UT16_SLOT;
+            rd_pos = (rd_pos + 1) & (UT16_D - 1);
+            wr_pos = (wr_pos + 1) & (UT16_D - 1);
+            const int n0 = (wave + 4 * qq) * 32;
+            const uint2 a0 = ds_tr16(slot + rd_base), a1 = ds_tr16(slot + rd_base + 4 * 32);
+            const uint2 b0 = ds_tr16(slot + 1024 + rd_base), b1 = ds_tr16(slot + 1024 + rd_base + 4 * 32);
+            uint4 a = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            const uint4 b = make_uint4(b0.x, b0.y, b1.x, b1.y);
+            if (n0 + 32 > N) {
+                const int nb = n0 + 8 * q;
+                uint32_t* u = reinterpret_cast<uint32_t*>(&a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
+                    u[e] &= (lo | hi);
+                }
+            }
+            acc = DT::mfma16(a, b, acc);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[wave * 256 + reg * 64 + lane] = acc[reg];
+    __syncthreads();
+    {
+        const int slot = threadIdx.x;
+        const float sum = red[slot] + red[256 + slot] + red[512 + slot] + red[768 + slot];
+        const int reg = slot >> 6, ln = slot & 63;
+        const int ci = 4 * (ln >> 4) + reg, ko = ln & 15;
+        const size_t idx = (size_t)w * 256 + ci * 16 + ko;
+        float out = alpha * sum;
+        if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+        DW[idx] = DT::from_f32(out);
+    }
+}
+
 }  // namespace bsmm

@@ -275,6 +275,20 @@ class BlocksparseMatMul(object):
         _lib.check(lib.bsmm_updat(xp, ep, dw.data_ptr(), ctypes.byref(a)), "bsmm_updat")
         return dw
 
+    def updat_grouped(self, xs, dys, group_size=8, dw=None, alpha=1.0):
+        """dw (+)= alpha * sum over ALL (x, dy) pairs, issued as one DW launch followed by chained DWA launches of up
+        to ``group_size`` (<= 8) pairs each -- what the reference's ``group_param_grads`` graph rewrite produces for
+        weight-tied / recurrent uses (blocksparse/matmul.py:612-731).  ``dw`` given: accumulate into it (beta = 1)."""
+        if not 1 <= group_size <= 8:
+            raise ValueError("group_size must be in 1..8")
+        if len(xs) != len(dys) or len(xs) == 0:
+            raise ValueError("need equally many x and dy tensors")
+        beta = 0.0 if dw is None else 1.0
+        for i in range(0, len(xs), group_size):
+            dw = self.updat(list(xs[i:i + group_size]), list(dys[i:i + group_size]), alpha=alpha, beta=beta, dw=dw)
+            beta = 1.0
+        return dw
+
     # ---- operator interface (matmul.py:455-483) ---------------------------------------------------
     def __call__(self, I, W, gate=None, gate_grad=False, dw_gated=False, name=None, bench=0):
         if gate is not None:

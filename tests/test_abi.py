@@ -182,39 +182,40 @@ def test_updat_plan_covers_every_block_once(lib):
         lay = rng.random((CB, KB)) < dens
         lay[0, 0] = True
         t = L.build_tables(lay)
-        plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1)
-        assert plan[0] == 0x42535550 and plan[5] == t["blocks"]
-        UW, MAXB, nitems, waves = int(plan[2]), int(plan[3]), int(plan[4]), int(plan[7])
-        assert nitems % 8 == 0
-        isz = 4 + waves * MAXB * 2
-        items = plan[plan[6]:].reshape(nitems, isz)
-        seen = set()
-        for it in items:
-            c0, k0, n, nslots = (int(v) for v in it[:4])
-            slots = it[4:].reshape(waves, MAXB, 2)
-            cnt = 0
-            for v in range(waves):
-                per_wave = 0
-                for j in range(MAXB):
-                    meta, w = int(slots[v, j, 0]), int(slots[v, j, 1])
-                    if meta & 256:
-                        c, k = c0 + (meta & 15), k0 + ((meta >> 4) & 15)
-                        assert (meta & 15) < UW and ((meta >> 4) & 15) < UW
-                        assert tuple(t["updat_lut"][w]) == (c, k)
-                        assert w not in seen
-                        seen.add(w)
-                        cnt += 1
-                        per_wave += 1
-                        assert j < nslots
-                        if meta & 512:      # "same X fragment as the previous slot"
-                            assert j > 0 and (int(slots[v, j - 1, 0]) & 15) == (meta & 15)
-                    else:
-                        assert meta == 0
-                assert per_wave <= nslots
-            assert cnt == n
-        assert seen == set(range(t["blocks"]))
+        for bsize in (32, 16):
+            plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, bsize, lib.BF16, 1)
+            assert plan[0] == 0x42535550 and plan[5] == t["blocks"] and plan[2] == 256 // bsize
+            UW, MAXB, nitems, waves = int(plan[2]), int(plan[3]), int(plan[4]), int(plan[7])
+            assert nitems % 8 == 0
+            isz = 4 + waves * MAXB * 2
+            items = plan[plan[6]:].reshape(nitems, isz)
+            seen = set()
+            for it in items:
+                c0, k0, n, nslots = (int(v) for v in it[:4])
+                slots = it[4:].reshape(waves, MAXB, 2)
+                cnt = 0
+                for v in range(waves):
+                    per_wave = 0
+                    for j in range(MAXB):
+                        meta, w = int(slots[v, j, 0]), int(slots[v, j, 1])
+                        if meta & 256:
+                            c, k = c0 + (meta & 15), k0 + ((meta >> 4) & 15)
+                            assert (meta & 15) < UW and ((meta >> 4) & 15) < UW
+                            assert tuple(t["updat_lut"][w]) == (c, k)
+                            assert w not in seen
+                            seen.add(w)
+                            cnt += 1
+                            per_wave += 1
+                            assert j < nslots
+                            if meta & 512:      # "same X fragment as the previous slot"
+                                assert j > 0 and (int(slots[v, j - 1, 0]) & 15) == (meta & 15)
+                        else:
+                            assert meta == 0
+                    assert per_wave <= nslots
+                assert cnt == n
+            assert seen == set(range(t["blocks"]))
     assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 32, lib.F32, 1) is None
-    assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 16, lib.BF16, 0) is None
+    assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 8, lib.BF16, 0) is None
 
 
 def test_host_class_surface():

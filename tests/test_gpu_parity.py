@@ -94,9 +94,10 @@ def test_mfma_and_valu_kernels_agree(env, bs, axis, dtype):
     _check(b, dtype, "mfma")
 
 
+@pytest.mark.parametrize("bs", [32, 16])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("axis", [0, 1])
-def test_plan_kernels_forced_on_small_and_ragged_cases(env, axis, dtype):
+def test_plan_kernels_forced_on_small_and_ragged_cases(env, axis, dtype, bs):
     """The grouped (xcol) / windowed kernels normally run only when the problem fills the chip; force them
     (bsmm_set_kernel_variant(3)) on small, ragged and degenerate cases: BA layout with hubs, empty rows/columns, odd
     block counts (partial groups, a trailing input pair without its odd block), single block, N not a multiple of the
@@ -112,8 +113,8 @@ def test_plan_kernels_forced_on_small_and_ragged_cases(env, axis, dtype):
         L.bsmm_set_kernel_variant(3)
         for li, layout in enumerate(layouts):
             for N in (8, 72, 200, 392) + ((100, 5) if li == 0 else ()):
-                res = P.run_case(torch, BSMM, layout, 32, axis, dtype, N, seed=li * 10 + N)
-                _check(res, dtype, "forced-plan layout%d a%d %s N%d" % (li, axis, dtype, N))
+                res = P.run_case(torch, BSMM, layout, bs, axis, dtype, N, seed=li * 10 + N)
+                _check(res, dtype, "forced-plan bs%d layout%d a%d %s N%d" % (bs, li, axis, dtype, N))
     finally:
         L.bsmm_set_kernel_variant(0)
 
@@ -218,6 +219,24 @@ def test_autograd_matches_oracle(env, axis, dtype):
                            ("DW", w.grad, orc.updat(t, X, E, axis))):
         l2, mx = P.errors(P.to_host(got), orc.round_to(ref, dtype))
         assert l2 <= P.L2_BAR[dtype], (name, l2)
+
+
+@pytest.mark.parametrize("dtype,bs,axis", [("f32", 16, 0), ("bf16", 32, 1)])
+def test_grouped_dw_over_many_pairs(env, dtype, bs, axis):
+    """19 (x, dy) pairs through chained DW / DWA launches of <= 8 pairs (the group_param_grads pattern)."""
+    torch, BSMM, _ = env
+    layout = P.random_layout(6, 5, 0.5, seed=9)
+    b = BSMM(layout, block_size=bs, feature_axis=axis)
+    t = orc.build_layout_luts(layout, bs)
+    N = 40
+    Xs, Es = [], []
+    for p in range(19):
+        _, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=60 + p)
+        Xs.append(X); Es.append(E)
+    ref = orc.updat(t, Xs, Es, axis)
+    out = b.updat_grouped([P.to_dev(x, dtype, torch) for x in Xs], [P.to_dev(e, dtype, torch) for e in Es], group_size=8)
+    l2, _ = P.errors(P.to_host(out), orc.round_to(ref, dtype))
+    assert l2 <= (2e-6 if dtype == "f32" else 4e-3), l2     # bf16: three roundings of the running sum (DWA stores bf16)
 
 
 def test_rank3_inputs_flatten_non_feature_dims(env):
