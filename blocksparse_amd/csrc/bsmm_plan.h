@@ -275,3 +275,66 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
 }
 
 }  // namespace bsmm
+
+// =================================================================================================
+// xcol16 plan (bsize 16): XC16_G = 16 consecutive output blocks per group, wave v owns blocks 2v and 2v+1; a step is a
+// QUAD of input blocks (4q .. 4q+3 = 64 features, one 128-byte line per row on axis 1).
+// Layout (int32): [0] magic 'BSX6' [1] version [2] XC16_G [3] ngroups [4] nsteps_total [5] off_groups [6] off_quads
+//                 [7] off_wtab [8] n_out_blocks
+//   groups[ngroups][4] = (step_off, nsteps, first_out_block, n_out_blocks_in_group)
+//   quads [nsteps_total]
+//   wtab  [group][slot][t]   slot = (member * 4 + sub), member = out block - first, sub = in block & 3; weight id or -1
+//                            group base = off_wtab + 4*XC16_G*step_off, index slot*nsteps + t
+// =================================================================================================
+namespace bsmm {
+
+constexpr int32_t XC16PLAN_MAGIC = 0x42535836;
+constexpr int32_t XC16PLAN_VERSION = 1;
+constexpr int XC16_G = 16;
+
+inline long build_xcol16_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
+    const int ngroups = (n_out_blocks + XC16_G - 1) / XC16_G;
+    struct E { int p, slot, w; };
+    std::vector<std::vector<E>> per_group(ngroups);
+    for (int s = 0; s < segments; ++s) {
+        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
+        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
+        for (int e = 0; e < cnt; ++e) {
+            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
+            if (w < 0 || w >= blocks || c < 0) return -1;
+            per_group[ob / XC16_G].push_back({c >> 2, 4 * (ob % XC16_G) + (c & 3), w});
+        }
+    }
+    std::vector<int32_t> groups, quads, wtab;
+    for (int g = 0; g < ngroups; ++g) {
+        auto& v = per_group[g];
+        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : a.slot < b.slot; });
+        std::vector<int32_t> gp;
+        for (auto& e : v) if (gp.empty() || gp.back() != e.p) gp.push_back(e.p);
+        const int ns = (int)gp.size();
+        const int step_off = (int)quads.size();
+        std::vector<int32_t> tab((size_t)4 * XC16_G * ns, -1);
+        int t = -1, cur = -1;
+        for (auto& e : v) {
+            if (e.p != cur) { cur = e.p; ++t; }
+            tab[(size_t)e.slot * ns + t] = e.w;
+        }
+        quads.insert(quads.end(), gp.begin(), gp.end());
+        wtab.insert(wtab.end(), tab.begin(), tab.end());
+        groups.insert(groups.end(), {step_off, ns, g * XC16_G, std::min(XC16_G, n_out_blocks - g * XC16_G)});
+    }
+    const long total = XC_HDR + (long)groups.size() + (long)quads.size() + (long)wtab.size();
+    if (out) {
+        const int off_groups = XC_HDR, off_quads = off_groups + (int)groups.size(), off_wtab = off_quads + (int)quads.size();
+        const int32_t hdr[XC_HDR] = {XC16PLAN_MAGIC, XC16PLAN_VERSION, XC16_G, ngroups, (int32_t)quads.size(), off_groups, off_quads,
+                                     off_wtab, n_out_blocks, 0, 0, 0};
+        std::copy(hdr, hdr + XC_HDR, out);
+        std::copy(groups.begin(), groups.end(), out + off_groups);
+        std::copy(quads.begin(), quads.end(), out + off_quads);
+        std::copy(wtab.begin(), wtab.end(), out + off_wtab);
+    }
+    return total;
+}
+
+}  // namespace bsmm

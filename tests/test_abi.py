@@ -165,10 +165,30 @@ def test_plan_builder_covers_every_block_once(lib):
                     for c, w in col:
                         want.add((ob, c, w))
                 assert got == want
-    # no grouped kernel for fp32 / other block sizes
+                # bsize 16: quads of input blocks, 16 output blocks per group, slot = 4*member + (c & 3)
+                p16 = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis)
+                assert p16[0] == 0x42535836 and p16[8] == n_out
+                G16 = int(p16[2])
+                groups = p16[p16[5]:p16[6]].reshape(-1, 4)
+                quads = p16[p16[6]:p16[7]]
+                got16 = set()
+                for g, (so, ns, ob0, nob) in enumerate(groups):
+                    assert ob0 == g * G16 and nob == min(G16, n_out - ob0)
+                    gq = quads[so:so + ns]
+                    assert len(set(gq.tolist())) == ns and list(gq) == sorted(gq)
+                    base = int(p16[7]) + 4 * G16 * so
+                    tab = p16[base:base + 4 * G16 * ns].reshape(4 * G16, ns)
+                    for slot in range(4 * G16):
+                        for tt in range(ns):
+                            w = int(tab[slot, tt])
+                            if w >= 0:
+                                assert (slot >> 2) < nob
+                                got16.add((ob0 + (slot >> 2), 4 * int(gq[tt]) + (slot & 3), w))
+                assert got16 == want
+    # no plan kernels for fp32 / bsize 8
     t = L.build_tables(np.ones((2, 2)))
     assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 32, lib.F32, 1) is None
-    assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 16, lib.BF16, 1) is None
+    assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 8, lib.BF16, 1) is None
 
 
 def test_updat_plan_covers_every_block_once(lib):
