@@ -209,6 +209,28 @@ def main():
                         "updat": round(flops_pass / u_ms / 1e9, 2)},
         "roofline": roof,
     }
+    # BASELINE.json configs[1]: same layout, fp32, feature_axis=1, fprop only (MFMA f32: 157.3 TF peak, AI 195 > ridge 20)
+    if rank == 0 and world == 1:
+        b32 = BlocksparseMatMul(layout, block_size=a.bsize, feature_axis=1)
+        g32 = torch.Generator(device="cuda").manual_seed(7)
+        w32 = torch.randn(b32.w_shape, device="cuda", generator=g32) * 0.01
+        x32 = torch.randn(b32.i_shape(N), device="cuda", generator=g32) * 0.1
+        for _ in range(3):
+            b32.fprop(x32, w32)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b32.fprop(x32, w32)
+        e1.record()
+        torch.cuda.synchronize()
+        ms32 = e0.elapsed_time(e1) / 10
+        tf32 = 2.0 * b32.blocks * a.bsize ** 2 * N / ms32 / 1e9
+        out["fp32_fprop_axis1"] = {"workload": "BASELINE configs[1]: %dx%d bs%d d%.0f%% fp32 feature_axis=1 fprop, minibatch %d" %
+                                               (a.hidden, a.hidden, a.bsize, a.density * 100, N),
+                                   "ms": round(ms32, 4), "tflops": round(tf32, 2), "peak": PEAK_MFMA["f32"],
+                                   "frac": round(tf32 / PEAK_MFMA["f32"], 4)}
+        del b32, w32, x32
     if a.sweep:
         sw = {}
         for d in (0.1, 0.5):

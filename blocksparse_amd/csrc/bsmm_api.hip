@@ -133,6 +133,25 @@ int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, 
     return (int)hipGetLastError();
 }
 
+template <int AXIS>
+int launch_xcol32f(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    const int n_out = a->K / 32;
+    XMap m;
+    m.ntiles = (a->N + XC_R - 1) / XC_R;
+    m.segments = (n_out + XC_G - 1) / XC_G;
+    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+    if (m.P > m.segments) m.P = m.segments;
+    m.SP = (m.segments + m.P - 1) / m.P;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32f_kernel<AXIS>), hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS);
+        attr_set = true;
+    }
+    xcol32f_kernel<AXIS><<<m.grid(), 512, XF_LDS, st>>>(static_cast<const float*>(X), static_cast<const float*>(Wsel), static_cast<float*>(Y),
+                                                        a->plan, m, a->N, a->C, a->K);
+    return (int)hipGetLastError();
+}
+
 template <class DT, bool TRANSW>
 void launch_xcol0(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
@@ -222,14 +241,19 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         if (AXIS == 0 && (a->N % 8 != 0)) enough = false;
         if (variant == 3 && !(AXIS == 0 && (a->N % 8 != 0))) enough = true;
     }
-    if (BS == 32 && a->plan != nullptr) {
+    if (BS == 32 && a->plan != nullptr && !DT::is16) {   // fp32: xcol32f (axis 0 needs 16-byte aligned row pieces: N % 4 == 0)
+        enough = use_xcol() && (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
+        if (variant == 3 && use_xcol()) enough = true;
+        if (AXIS == 0 && (a->N % 4 != 0)) enough = false;
+    }
+    if (BS == 32 && a->plan != nullptr && DT::is16) {
         const int rows = use_xcol() ? XC_R : ((AXIS == 1) ? XS3::NT : 128);
         const int g = use_xcol() ? XC_G : ((AXIS == 1) ? xg_group_size(1) : xg_group_size(0));
         enough = (long)((a->N + rows - 1) / rows) * ((a->K / 32 + g - 1) / g) >= 224;
         if (AXIS == 0 && use_xcol() && (a->N % 8 != 0)) enough = false;   // axis-0 xcol needs 16-byte aligned row pieces
     }
     if (variant == 3 && a->plan != nullptr && !(AXIS == 0 && use_xcol() && (a->N % 8 != 0))) enough = true;   // test hook
-    const bool use_group = !use_valu && (BS == 32 || BS == 16) && DT::is16 && a->plan != nullptr && (variant == 0 || variant == 3) && enough;
+    const bool use_group = !use_valu && (BS == 32 || (BS == 16 && DT::is16)) && a->plan != nullptr && (variant == 0 || variant == 3) && enough;
     if (a->locks > 0 && !use_group) {   // several segments accumulate into the same output block: start from zero
         hipError_t e = hipMemsetAsync(Y, 0, (size_t)a->N * a->K * elem_size(a->dtype), st);
         if (e != hipSuccess) return (int)e;
@@ -254,6 +278,9 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         }
         if constexpr (BS == 16 && DT::is16) {
             if (use_group) return launch_xcol16<DT, AXIS>(X, Wsel, Y, a, st);
+        }
+        if constexpr (BS == 32 && !DT::is16) {
+            if (use_group) return launch_xcol32f<AXIS>(X, Wsel, Y, a, st);
         }
         return launch_xprop_mfma<DT, BS, AXIS>(X, Wsel, Y, a, st);
     }
@@ -489,7 +516,8 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
 
 long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
                            int32_t dtype, int32_t axis) {
-    if ((bsize != 32 && bsize != 16) || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // plan kernels: bsize 32/16, 16-bit types
+    if ((bsize != 32 && bsize != 16) || (axis != 0 && axis != 1)) return 0;   // plan kernels: bsize 32 (any dtype) / 16 (16-bit)
+    if (dtype == BSMM_F32) return (bsize == 32 && use_xcol()) ? build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, nullptr) : 0;
     if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
     if (use_xcol()) return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
     return build_xprop_plan(host_lut, segments, blocks, n_out_blocks, xg_group_size(axis), XG_SB, axis == 1, nullptr);
@@ -498,7 +526,11 @@ long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t bl
 int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
                           int32_t dtype, int32_t axis, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
-    if ((bsize != 32 && bsize != 16) || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
+    if ((bsize != 32 && bsize != 16) || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
+    if (dtype == BSMM_F32) {
+        if (bsize != 32 || !use_xcol()) return BSMM_ERR_UNSUPPORTED;
+        return build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
+    }
     if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     if (use_xcol())
         return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;

@@ -92,6 +92,11 @@ class _DeviceTables(object):
         bp = _host_plan(tables["bprop"]["lut"], tables["bprop"]["segments"], B, CB, bsize, _lib.BF16, axis)
         self.fprop_plan = up(fp) if fp is not None else None
         self.bprop_plan = up(bp) if bp is not None else None
+        # fp32 has its own (xprop-only) plan kernels for bsize 32; the schedule format is the library's business
+        fp32 = _host_plan(tables["fprop"]["lut"], tables["fprop"]["segments"], B, KB, bsize, _lib.F32, axis)
+        bp32 = _host_plan(tables["bprop"]["lut"], tables["bprop"]["segments"], B, CB, bsize, _lib.F32, axis)
+        self.fprop_plan_f32 = up(fp32) if fp32 is not None else None
+        self.bprop_plan_f32 = up(bp32) if bp32 is not None else None
         upl = _host_updat_plan(tables["updat_lut"], B, CB, KB, bsize, _lib.BF16, axis)
         self.updat_plan = up(upl) if upl is not None else None
         self.updat_items = int(upl[4]) if upl is not None else 0
@@ -179,7 +184,7 @@ class BlocksparseMatMul(object):
     def _args(self, lut_t, side, N, Cin, Kout, dtype, pcount=1, alpha=1.0, beta=0.0, workspace=None, plan=None):
         a = _lib.BsmmArgs()
         a.lut = lut_t.data_ptr()
-        a.plan = plan.data_ptr() if (plan is not None and dtype != torch.float32) else None
+        a.plan = plan.data_ptr() if plan is not None else None
         a.gate = None
         a.workspace = workspace.data_ptr() if workspace is not None else None
         a.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
@@ -211,7 +216,8 @@ class BlocksparseMatMul(object):
         lib = _lib.load()
         tabs = self._tables_on(x.device)
         y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
-        a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype, plan=tabs.fprop_plan)
+        a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype,
+                       plan=tabs.fprop_plan_f32 if x.dtype == torch.float32 else tabs.fprop_plan)
         need = lib.bsmm_workspace_bytes(_lib.OP_FPROP, ctypes.byref(a))
         ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device) if need else None
         if ws is not None:
@@ -229,7 +235,8 @@ class BlocksparseMatMul(object):
         lib = _lib.load()
         tabs = self._tables_on(dy.device)
         dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)
-        a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype, plan=tabs.bprop_plan)
+        a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype,
+                       plan=tabs.bprop_plan_f32 if dy.dtype == torch.float32 else tabs.bprop_plan)
         _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
         return dx
 
@@ -263,7 +270,7 @@ class BlocksparseMatMul(object):
             if tuple(dw.shape) != self.w_shape or dw.dtype != xs[0].dtype or not dw.is_contiguous():
                 raise ValueError("dw must be a contiguous %s tensor of dtype %s" % (self.w_shape, xs[0].dtype))
         a = self._args(tabs.updat, None, N, self.C, self.K, xs[0].dtype, pcount=len(xs), alpha=alpha, beta=beta,
-                       plan=tabs.updat_plan)
+                       plan=tabs.updat_plan if xs[0].dtype != torch.float32 else None)
         a.plan_items = tabs.updat_items
         need = lib.bsmm_workspace_bytes(_lib.OP_UPDAT, ctypes.byref(a))
         ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev) if need else None

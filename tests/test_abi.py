@@ -187,7 +187,7 @@ def test_plan_builder_covers_every_block_once(lib):
                 assert got16 == want
     # no plan kernels for fp32 / bsize 8
     t = L.build_tables(np.ones((2, 2)))
-    assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 32, lib.F32, 1) is None
+    assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 16, lib.F32, 1) is None
     assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 8, lib.BF16, 1) is None
 
 

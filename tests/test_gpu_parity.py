@@ -120,6 +120,26 @@ def test_plan_kernels_forced_on_small_and_ragged_cases(env, axis, dtype, bs):
 
 
 @pytest.mark.parametrize("axis", [0, 1])
+def test_fp32_plan_kernels_forced(env, axis):
+    """fp32 / bsize 32 has its own grouped kernel (xcol32f): same forced small / ragged cases, fp32 bar; N % 4 != 0 on
+    axis 0 falls back to the generic kernel."""
+    torch, BSMM, lib = env
+    L = lib.load()
+    holes = P.ba_layout(16, 2, seed=3)
+    holes[:, 5] = 0
+    holes[7, :] = 0
+    layouts = [P.ba_layout(40, 3, seed=1), holes, P.random_layout(7, 9, 0.5, seed=2), np.ones((1, 1), dtype=np.int32)]
+    try:
+        L.bsmm_set_kernel_variant(3)
+        for li, layout in enumerate(layouts):
+            for N in (4, 72, 200, 392) + ((100, 5, 130) if li == 0 else ()):
+                res = P.run_case(torch, BSMM, layout, 32, axis, "f32", N, seed=li * 10 + N)
+                _check(res, "f32", "forced-plan f32 layout%d a%d N%d" % (li, axis, N))
+    finally:
+        L.bsmm_set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("axis", [0, 1])
 def test_plan_and_generic_kernels_agree_at_scale(env, axis):
     """4096^2 / 20% at N = 2048 (large enough for the heuristic to pick the plan kernels): plan kernels vs the generic
     per-segment / per-block kernels (variant 2) on identical inputs."""
