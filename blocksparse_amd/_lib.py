@@ -15,6 +15,7 @@ OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
 SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_identity_init", "bsmm_workspace_bytes",
            "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
            "bsmm_set_kernel_variant", "bsmm_get_kernel_variant", "bsmm_error_string", "bsmm_version")
+BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask")
 
 
 class BsmmArgs(ctypes.Structure):
@@ -28,6 +29,16 @@ class BsmmArgs(ctypes.Structure):
         ("shared", ctypes.c_int32), ("pcount", ctypes.c_int32), ("axis", ctypes.c_int32),
         ("dtype", ctypes.c_int32), ("alpha", ctypes.c_float), ("beta", ctypes.c_float),
         ("stream", ctypes.c_void_p),
+    ]
+
+
+class BstArgs(ctypes.Structure):
+    """Mirror of ``struct bst_args`` (include/bst.h)."""
+    _fields_ = [
+        ("lut", ctypes.c_void_p), ("lut_heads", ctypes.c_int32), ("lut_dim", ctypes.c_int32),
+        ("blocks", ctypes.c_int32), ("bsize", ctypes.c_int32), ("batch", ctypes.c_int32), ("heads", ctypes.c_int32),
+        ("head_state", ctypes.c_int32), ("ctx_blks_q", ctypes.c_int32), ("ctx_blks_k", ctypes.c_int32),
+        ("dtype", ctypes.c_int32), ("score_dtype", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
 
 
@@ -80,6 +91,16 @@ def load():
     lib.bsmm_error_string.restype = ctypes.c_char_p
     lib.bsmm_version.argtypes = []
     lib.bsmm_version.restype = ctypes.c_int
+    pbst = ctypes.POINTER(BstArgs)
+    for name in ("bst_nt", "bst_nn", "bst_tn"):
+        getattr(lib, name).argtypes = [vp, vp, vp, pbst]
+        getattr(lib, name).restype = ctypes.c_int
+    lib.bst_masked_softmax.argtypes = [vp, vp, vp, i32, f32, i32, i32, pbst]
+    lib.bst_masked_softmax.restype = ctypes.c_int
+    lib.bst_softmax_grad.argtypes = [vp, vp, vp, f32, i32, pbst]
+    lib.bst_softmax_grad.restype = ctypes.c_int
+    lib.bst_partial_autoregressive_mask.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.bst_partial_autoregressive_mask.restype = ctypes.c_int
     _lib = lib
     return lib
 

@@ -6,15 +6,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 OUT = os.path.join(_HERE, "libbsmm_hip.so")
-SOURCES = ["bsmm_api.hip"]
-HEADERS = ["bsmm_common.h", "bsmm_xprop.h", "bsmm_updat.h", "bsmm_xgroup.h", "bsmm_plan.h", "bsmm_updat_tr.h", "bsmm_updat_win.h", "bsmm_xcol.h", "bsmm_xcol16.h"]
+SOURCES = ["bsmm_api.hip", "bst_api.hip"]
+HEADERS = ["bsmm_common.h", "bsmm_xprop.h", "bsmm_updat.h", "bsmm_xgroup.h", "bsmm_plan.h", "bsmm_updat_tr.h", "bsmm_updat_win.h", "bsmm_xcol.h", "bsmm_xcol16.h", "bst_kernels.h"]
 
 
 def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "bsmm.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "bsmm.h"), os.path.join(INCLUDE, "bst.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
