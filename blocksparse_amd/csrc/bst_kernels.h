@@ -205,36 +205,117 @@ __device__ __forceinline__ float row8_sum(float v) {
     return v;
 }
 
+// VEC consecutive 16-bit elements as packed words (one global access of 2 * VEC bytes)
+template <int VEC> struct Raw16 { uint32_t w[(VEC + 1) / 2]; };
+template <int VEC>
+__device__ __forceinline__ Raw16<VEC> load_raw16(const uint16_t* p) {
+    Raw16<VEC> r;
+    if constexpr (VEC == 1) r.w[0] = *p;
+    else if constexpr (VEC == 2) r.w[0] = *reinterpret_cast<const uint32_t*>(p);
+    else if constexpr (VEC == 4) { const uint2 v = *reinterpret_cast<const uint2*>(p); r.w[0] = v.x; r.w[1] = v.y; }
+    else { const uint4 v = *reinterpret_cast<const uint4*>(p); r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w; }
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void store_raw16(uint16_t* p, const Raw16<VEC>& r) {
+    if constexpr (VEC == 1) *p = (uint16_t)r.w[0];
+    else if constexpr (VEC == 2) *reinterpret_cast<uint32_t*>(p) = r.w[0];
+    else if constexpr (VEC == 4) *reinterpret_cast<uint2*>(p) = make_uint2(r.w[0], r.w[1]);
+    else *reinterpret_cast<uint4*>(p) = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]);
+}
+template <class DT, int VEC>
+__device__ __forceinline__ float raw_get(const Raw16<VEC>& r, int i) { return DT::to_f32((uint16_t)(r.w[i >> 1] >> (16 * (i & 1)))); }
+template <class DT, int VEC>
+__device__ __forceinline__ void raw_set(Raw16<VEC>& r, int i, float v) {
+    const uint32_t x = DT::from_f32(v);
+    if (i & 1) r.w[i >> 1] |= x << 16; else r.w[i >> 1] = x;
+}
+
+// Rows whose block list fits SM_CACHE entries (the usual case: 19 at BASELINE configs[4]) are read ONCE: all loads are
+// issued up front and the (scaled, masked) values live in registers across the max / sum / write steps.  Longer rows
+// fall back to three passes over global memory (the row then stays in L2).
+template <int VEC> struct SmCache { static constexpr int N = VEC >= 8 ? 12 : 24; };
+
 template <class TX, class TY, int BS>
 __global__ void __launch_bounds__(BS * 8)
 bst_softmax_kernel(const typename TX::T* __restrict__ X, typename TY::T* __restrict__ Y, const int32_t* __restrict__ lut, int lut_stride,
                    const typename MaskT<BS>::T* __restrict__ mask, int mask_stride, int blocks, int heads, float scale) {
     constexpr int VEC = BS / 8;
+    constexpr int CACHE = SmCache<VEC>::N;
     typedef typename MaskT<BS>::T MT;
     const int Q = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
     const int row = threadIdx.x >> 3, cg = threadIdx.x & 7;
     const int32_t* hl = lut + (size_t)h * lut_stride;
     const int2 hdr = *reinterpret_cast<const int2*>(hl + 2 * Q);
     if (hdr.y == 0) return;
+    const int32_t* ent = hl + 2 * hdr.x;
     const size_t base = ((size_t)n * heads + h) * blocks * (BS * BS) + (size_t)row * BS + cg * VEC;
     const MT* mrow = mask ? mask + (size_t)h * mask_stride + (size_t)row * blocks : nullptr;
     const float NEG = -3.402823466e+38f;
+    const float sc2 = scale * 1.4426950408889634f;          // exp(x) = exp2(x * log2 e)
 
-    auto load = [&](int e, float (&v)[VEC]) {
-        const int b = hl[2 * (hdr.x + e)];
-        const typename TX::T* p = X + base + (size_t)b * (BS * BS);
-        MT m = mrow ? mrow[b] : (MT)~(MT)0;
+    auto load = [&](int b, float (&v)[VEC]) {
+        const Raw16<VEC> raw = load_raw16<VEC>(X + base + (size_t)b * (BS * BS));
+        const MT m = mrow ? mrow[b] : (MT)~(MT)0;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const bool keep = (m >> (cg * VEC + i)) & 1;
-            v[i] = keep ? TX::to_f32(p[i]) * scale : NEG;
-        }
-        return b;
+        for (int i = 0; i < VEC; ++i) v[i] = ((m >> (cg * VEC + i)) & 1) ? raw_get<TX, VEC>(raw, i) * sc2 : NEG;
     };
+    auto store = [&](int b, const float (&v)[VEC], float mx, float rcp) {
+        Raw16<VEC> out;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) raw_set<TY, VEC>(out, i, exp2f(v[i] - mx) * rcp);
+        store_raw16<VEC>(Y + base + (size_t)b * (BS * BS), out);
+    };
+
+    if (hdr.y <= CACHE) {
+        // loads only in the first loop (each iteration is its own basic block because of the length test: a use of the
+        // loaded value in there would put a full memory round trip into every iteration)
+        Raw16<VEC> raw[CACHE];
+        MT mk[CACHE];
+#pragma unroll
+        for (int e = 0; e < CACHE; ++e)
+            if (e < hdr.y) {
+                const int b = ent[2 * e];
+                raw[e] = load_raw16<VEC>(X + base + (size_t)b * (BS * BS));
+                mk[e] = mrow ? mrow[b] : (MT)~(MT)0;
+            }
+        float v[CACHE][VEC];
+#pragma unroll
+        for (int e = 0; e < CACHE; ++e)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+                v[e][i] = (e < hdr.y && ((mk[e] >> (cg * VEC + i)) & 1)) ? raw_get<TX, VEC>(raw[e], i) * sc2 : NEG;
+        float mx = NEG;
+#pragma unroll
+        for (int e = 0; e < CACHE; ++e)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) mx = fmaxf(mx, v[e][i]);
+        mx = row8_max(mx);
+        // one v_exp_f32 per element (arguments <= 0: no range fix-up needed)
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < CACHE; ++e)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                v[e][i] = __builtin_amdgcn_exp2f(v[e][i] - mx);
+                sum += (e < hdr.y) ? v[e][i] : 0.f;
+            }
+        sum = row8_sum(sum);
+        const float rcp = 1.0f / sum;
+#pragma unroll
+        for (int e = 0; e < CACHE; ++e)
+            if (e < hdr.y) {
+                Raw16<VEC> out;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) raw_set<TY, VEC>(out, i, v[e][i] * rcp);
+                store_raw16<VEC>(Y + base + (size_t)ent[2 * e] * (BS * BS), out);
+            }
+        return;
+    }
     float mx = NEG;
     for (int e = 0; e < hdr.y; ++e) {
         float v[VEC];
-        load(e, v);
+        load(ent[2 * e], v);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) mx = fmaxf(mx, v[i]);
     }
@@ -242,18 +323,17 @@ bst_softmax_kernel(const typename TX::T* __restrict__ X, typename TY::T* __restr
     float sum = 0.f;
     for (int e = 0; e < hdr.y; ++e) {
         float v[VEC];
-        load(e, v);
+        load(ent[2 * e], v);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) sum += __expf(v[i] - mx);
+        for (int i = 0; i < VEC; ++i) sum += exp2f(v[i] - mx);
     }
     sum = row8_sum(sum);
     const float rcp = 1.0f / sum;
     for (int e = 0; e < hdr.y; ++e) {
         float v[VEC];
-        const int b = load(e, v);
-        typename TY::T* q = Y + base + (size_t)b * (BS * BS);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) q[i] = TY::from_f32(__expf(v[i] - mx) * rcp);
+        const int b = ent[2 * e];
+        load(b, v);
+        store(b, v, mx, rcp);
     }
 }
 
@@ -262,23 +342,52 @@ __global__ void __launch_bounds__(BS * 8)
 bst_softmax_grad_kernel(const typename T16::T* __restrict__ DY, const typename T16::T* __restrict__ Y, typename T16::T* __restrict__ DX,
                         const int32_t* __restrict__ lut, int lut_stride, int blocks, int heads, float scale) {
     constexpr int VEC = BS / 8;
+    constexpr int CACHE = SmCache<VEC>::N;
     const int Q = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
     const int row = threadIdx.x >> 3, cg = threadIdx.x & 7;
     const int32_t* hl = lut + (size_t)h * lut_stride;
     const int2 hdr = *reinterpret_cast<const int2*>(hl + 2 * Q);
     if (hdr.y == 0) return;
+    const int32_t* ent = hl + 2 * hdr.x;
     const size_t base = ((size_t)n * heads + h) * blocks * (BS * BS) + (size_t)row * BS + cg * VEC;
+    auto emit = [&](size_t o, const Raw16<VEC>& d, const Raw16<VEC>& y, float s) {
+        Raw16<VEC> out;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) raw_set<T16, VEC>(out, i, (raw_get<T16, VEC>(d, i) - s) * raw_get<T16, VEC>(y, i) * scale);
+        store_raw16<VEC>(DX + o, out);
+    };
+    if (hdr.y <= CACHE) {
+        Raw16<VEC> d[CACHE], y[CACHE];
+#pragma unroll
+        for (int e = 0; e < CACHE; ++e)
+            if (e < hdr.y) {
+                const size_t o = base + (size_t)ent[2 * e] * (BS * BS);
+                d[e] = load_raw16<VEC>(DY + o);
+                y[e] = load_raw16<VEC>(Y + o);
+            }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < CACHE; ++e)
+            if (e < hdr.y)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) s = fmaf(raw_get<T16, VEC>(d[e], i), raw_get<T16, VEC>(y[e], i), s);
+        s = row8_sum(s);
+#pragma unroll
+        for (int e = 0; e < CACHE; ++e)
+            if (e < hdr.y) emit(base + (size_t)ent[2 * e] * (BS * BS), d[e], y[e], s);
+        return;
+    }
     float s = 0.f;
     for (int e = 0; e < hdr.y; ++e) {
-        const size_t o = base + (size_t)hl[2 * (hdr.x + e)] * (BS * BS);
+        const size_t o = base + (size_t)ent[2 * e] * (BS * BS);
+        const Raw16<VEC> d = load_raw16<VEC>(DY + o), y = load_raw16<VEC>(Y + o);
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) s = fmaf(T16::to_f32(DY[o + i]), T16::to_f32(Y[o + i]), s);
+        for (int i = 0; i < VEC; ++i) s = fmaf(raw_get<T16, VEC>(d, i), raw_get<T16, VEC>(y, i), s);
     }
     s = row8_sum(s);
     for (int e = 0; e < hdr.y; ++e) {
-        const size_t o = base + (size_t)hl[2 * (hdr.x + e)] * (BS * BS);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) DX[o + i] = T16::from_f32((T16::to_f32(DY[o + i]) - s) * T16::to_f32(Y[o + i]) * scale);
+        const size_t o = base + (size_t)ent[2 * e] * (BS * BS);
+        emit(o, load_raw16<VEC>(DY + o), load_raw16<VEC>(Y + o), s);
     }
 }
 
