@@ -1,6 +1,7 @@
 // bst_api.hip -- C ABI (include/bst.h) of the block-sparse attention path: argument checks and kernel dispatch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "bst.h"
 #include "bst_kernels.h"
@@ -68,8 +69,21 @@ int bst_nt(const void* a_, const void* b_, void* s_, const bst_args* a) {
             const int rq = a->ctx_blks_q * BS, rk = a->ctx_blks_k * BS;
             if constexpr (BS >= 32) {
                 constexpr int SUB = BS / 32;
-                dim3 grid((a->blocks * SUB * SUB + 3) / 4, a->heads, a->batch);
-                bst_nt_mfma_kernel<TA, TS, BS><<<grid, 256, 0, st>>>(A, B, S, a->lut, lut_stride(a), a->blocks, a->heads, a->head_state, rq, rk);
+                const int ntiles = a->blocks * SUB * SUB;
+                auto staged = [&](auto ch_tag) {
+                    constexpr int CH = decltype(ch_tag)::value;
+                    static const int il = [] { const char* e = getenv("BST_IL"); return e ? atoi(e) : 1; }();
+                    const int grid = xcd_head_grid((ntiles + NT_NB - 1) / NT_NB, a->heads, a->batch, il);
+                    bst_nt_mfma_kernel<TA, TS, BS, CH><<<grid, 64, 0, st>>>(A, B, S, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, rq, rk, il);
+                };
+                // LDS-DMA kernel: whole 32-feature chunks only (1, 2 or 4 of them); other head sizes take the direct kernel
+                if (a->head_state == 32) staged(std::integral_constant<int, 1>{});
+                else if (a->head_state == 64) staged(std::integral_constant<int, 2>{});
+                else if (a->head_state == 128) staged(std::integral_constant<int, 4>{});
+                else {
+                    const int grid = xcd_head_grid((ntiles + 3) / 4, a->heads, a->batch);
+                    bst_nt_mfma_direct_kernel<TA, TS, BS><<<grid, 256, 0, st>>>(A, B, S, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, rq, rk);
+                }
             } else {
                 dim3 grid(a->blocks, a->heads, a->batch);
                 bst_nt_valu_kernel<TA, TS, BS><<<grid, BS * BS, 0, st>>>(A, B, S, a->lut, lut_stride(a), a->blocks, a->heads, a->head_state, rq, rk);
@@ -99,8 +113,8 @@ static int bst_xn(const void* s_, const void* b_, void* c_, const bst_args* a, b
                 if constexpr (BS >= 32) {
                     constexpr int SUB = BS / 32;
                     const int nct = (a->head_state + 31) / 32;
-                    dim3 grid((ctx_c * SUB * nct + 3) / 4, a->heads, a->batch);
-                    bst_xn_mfma_kernel<TS, TB, BS, TR><<<grid, 256, 0, st>>>(S, B, C, a->lut, lut_stride(a), a->blocks, a->heads, a->head_state, ctx_c, rb, rc_);
+                    const int grid = xcd_head_grid((ctx_c * SUB * nct + 3) / 4, a->heads, a->batch);
+                    bst_xn_mfma_kernel<TS, TB, BS, TR><<<grid, 256, 0, st>>>(S, B, C, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, ctx_c, rb, rc_);
                 } else {
                     dim3 grid(ctx_c, a->heads, a->batch);
                     bst_xn_valu_kernel<TS, TB, BS, TR><<<grid, 256, 0, st>>>(S, B, C, a->lut, lut_stride(a), a->blocks, a->heads, a->head_state, rb, rc_);

@@ -17,6 +17,7 @@
 //   nn/tn: M side = output rows, N side = 32 features -> D[row][c], lane = feature c: 128-byte row segments.
 #pragma once
 #include "bsmm_common.h"
+#include "bsmm_xgroup.h"   // glds16_asm, lds_addr_of
 
 namespace bsmm {
 
@@ -45,6 +46,22 @@ __device__ __forceinline__ void load16_f32(const typename DT::T* p, int k0, int 
     }
 }
 
+// Workgroup -> (batch x head, workgroup within the head) so that one (n, h) pair runs entirely on ONE XCD (workgroups
+// are dealt round-robin over the 8 XCDs, each with its own 4 MiB L2): the K / V / Q rows of a head are re-read by every
+// block row that attends to them, and with the plain (x = block, y = head, z = batch) grid every XCD pulled every head
+// through the fabric (nt: 1.5 GB of L2 fills for 134 MB of activations, 202 us; the fabric sustains ~7 TB/s).
+// grid = 8 * ceil(batch * heads / 8) * G workgroups, G = workgroups per head.
+__device__ __forceinline__ bool xcd_head_map(int G, int heads, int batch, int& n, int& h, int& wg, int il = 1) {
+    const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
+    const int grp = j / (il * G), within = j - grp * (il * G);       // il heads of an XCD are interleaved workgroup by workgroup
+    const int hp = xcd + 8 * (grp * il + within % il);
+    wg = within / il;
+    n = hp / heads;
+    h = hp - n * heads;
+    return hp < heads * batch;
+}
+inline int xcd_head_grid(int G, int heads, int batch, int il = 1) { const int per = (heads * batch + 7) / 8; return 8 * ((per + il - 1) / il) * il * G; }
+
 __device__ __forceinline__ void mma32_f32(const float (&a)[16], const float (&b)[16], f32x16& acc) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
@@ -52,18 +69,180 @@ __device__ __forceinline__ void mma32_f32(const float (&a)[16], const float (&b)
 
 // ------------------------------------------------------------------------------------------------------------------
 // nt: one wave per 32x32 tile of a block.  grid (ceil(blocks * SUB^2 / 4), heads, batch), 256 threads.
+//
+// Operand tiles are [32 rows] x [32 features] chunks of row-major activations.  The MFMA wants lane r to hold row r,
+// but a load in that shape touches 32 cache lines per instruction and uses an eighth of each: with ~32 waves per CU
+// the lines are evicted from L1 between the instructions that share them and come from L2 four times (measured: 43 TF,
+// L2 -> L1 bound).  So the wave reads each chunk fully coalesced (8 rows x 128 B per instruction for fp32), all chunks
+// of both operands up front (registers are the in-flight buffer), and transposes through a wave-private LDS tile:
+// 16-byte pieces XOR-swizzled with the row, written as loaded, read back as [row = lane][16 features].
 // ------------------------------------------------------------------------------------------------------------------
+template <class T> struct NtTile {
+    static constexpr int ROWB = 32 * (int)sizeof(T);      // bytes per row of a 32-feature chunk
+    static constexpr int PPR = ROWB / 16;                 // 16-byte pieces per row (8 fp32, 4 16-bit)
+    static constexpr int RPI = 64 / PPR;                  // rows per load instruction
+    static constexpr int NI = 32 / RPI;                   // load instructions per tile
+    static constexpr int EPP = 16 / (int)sizeof(T);       // elements per piece
+    static constexpr int BYTES = 32 * ROWB;
+    static __device__ __forceinline__ int sw(int row) { return (row / (128 / ROWB)) & (PPR - 1); }
+};
+
+// One wave (= one workgroup) walks NT_NB CONSECUTIVE tiles of the block list.  Blocks are numbered row-major, so
+// consecutive tiles nearly always share their query rows: the Q tile stays in LDS until the row changes (1.5 GB of
+// L2 -> CU traffic become ~0.9 GB).  Tiles arrive by LDS-DMA (global_load_lds_dwordx4: 1 KiB of whole rows per
+// instruction, the swizzle applied on the source address); per tile the wave first pulls every fragment into registers,
+// then requests the next tile into the now idle buffers, then runs the 16 * chunks MFMAs with that DMA in flight.
+// Ablation of the previous version (coalesced VGPR loads + ds_write, 215 us): without loads 125, without MFMA 142.
+constexpr int NT_NB = 8;
+
+template <class TA, class TS, int BS, int NCH>
+__global__ void __launch_bounds__(64)
+bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* __restrict__ B, typename TS::T* __restrict__ S,
+                   const int32_t* __restrict__ lut, int lut_stride, int blocks, int heads, int batch, int hs, int rows_q, int rows_k, int il) {
+    typedef typename TA::T T;
+    typedef NtTile<T> TL;
+    constexpr int SUB = BS / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][NCH][TL::BYTES];        // [K | Q][chunk]
+    __shared__ __attribute__((aligned(16))) unsigned char olds[32 * 64];                 // finished 32x32 tile of 16-bit scores
+    const int lane = threadIdx.x;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ntiles = blocks * SUB * SUB;
+    int n, h, wg;
+    if (!xcd_head_map((ntiles + NT_NB - 1) / NT_NB, heads, batch, n, h, wg, il)) return;
+    const int tb0 = wg * NT_NB;
+    const size_t state = (size_t)heads * hs;
+    const int lrow = lane / TL::PPR, lp = lane % TL::PPR;
+    const T* abase = A + (size_t)n * rows_q * state + (size_t)h * hs;
+    const T* bbase = B + (size_t)n * rows_k * state + (size_t)h * hs;
+    const int32_t* hl = lut + (size_t)h * lut_stride;
+    const uint32_t lds_k = lds_addr_of(&lds[0][0][0]), lds_q = lds_addr_of(&lds[1][0][0]);
+
+    // source offsets (elements, relative to the tile's first row) of this lane's piece in every DMA instruction
+    size_t soff[TL::NI];
+#pragma unroll
+    for (int i = 0; i < TL::NI; ++i) {
+        const int row = TL::RPI * i + lrow;
+        soff[i] = (size_t)row * state + (size_t)((lp ^ TL::sw(row)) * TL::EPP);
+    }
+    auto dma_tile = [&](const T* tile0, uint32_t dst) {       // [32 rows][NCH chunks] -> NCH swizzled tile images
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < TL::NI; ++i)
+                glds16_asm(tile0 + soff[i] + 32 * c, __builtin_amdgcn_readfirstlane(dst + c * TL::BYTES + i * 1024));
+    };
+    auto frag = [&](const unsigned char* tile, float (&v)[16]) {               // row r, features 16hh .. 16hh+15
+        constexpr int NP = 16 / TL::EPP;
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const uint4 x = *reinterpret_cast<const uint4*>(tile + r * TL::ROWB + (((NP * hh + g) ^ TL::sw(r)) << 4));
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+            if constexpr (TA::is16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[8 * g + 2 * i] = TA::to_f32((uint16_t)(w[i] & 0xffffu));
+                    v[8 * g + 2 * i + 1] = TA::to_f32((uint16_t)(w[i] >> 16));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * g + i] = __builtin_bit_cast(float, w[i]);
+            }
+        }
+    };
+    auto tile_of = [&](int tb, int& qrow, int& krow) {
+        const int b = tb / (SUB * SUB), ti = (tb / SUB) % SUB, tj = tb % SUB;
+        const int2 qk = *reinterpret_cast<const int2*>(hl + 2 * b);
+        qrow = qk.x * BS + 32 * ti;
+        krow = qk.y * BS + 32 * tj;
+    };
+
+    // Output tile: D[j][i] has 4 consecutive keys j per register quad for query row i = lane, i.e. 8-byte pieces at a 64-byte
+    // stride -- stored directly that is 192 MB of partial-line writes (62 us on their own).  The tile is parked in a 2 KiB
+    // LDS image instead ([32 rows][64 B], 16-byte pieces XOR-swizzled with (row >> 2) & 3) and written one iteration LATER
+    // as two fully contiguous 1 KiB stores, so that the write latency is not in front of the next tile's wait either.
+    auto park = [&](const f32x16& acc) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t lo = (uint32_t)TS::from_f32(acc[4 * g + 0]) | ((uint32_t)TS::from_f32(acc[4 * g + 1]) << 16);
+            const uint32_t hi = (uint32_t)TS::from_f32(acc[4 * g + 2]) | ((uint32_t)TS::from_f32(acc[4 * g + 3]) << 16);
+            *reinterpret_cast<uint2*>(&olds[r * 64 + ((g ^ ((r >> 2) & 3)) << 4) + 8 * hh]) = make_uint2(lo, hi);
+        }
+    };
+    auto flush = [&](typename TS::T* out) {                    // out = first element of the 32x32 tile (row stride BS)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int P = k * 64 + lane, i = P >> 2, p = P & 3;
+            const uint4 v = *reinterpret_cast<const uint4*>(&olds[i * 64 + ((p ^ ((i >> 2) & 3)) << 4)]);
+            *reinterpret_cast<uint4*>(out + (size_t)i * BS + p * 8) = v;
+        }
+    };
+    auto out_of = [&](int tb) {
+        const int b = tb / (SUB * SUB), ti = (tb / SUB) % SUB, tj = tb % SUB;
+        return S + (((size_t)n * heads + h) * blocks + b) * (BS * BS) + (size_t)(32 * ti) * BS + 32 * tj;
+    };
+
+    int qrow, krow, qnext = 0, knext = 0;
+    tile_of(tb0, qrow, krow);
+    if (tb0 + 1 < ntiles) tile_of(tb0 + 1, qnext, knext);
+    dma_tile(bbase + (size_t)krow * state, lds_k);
+    dma_tile(abase + (size_t)qrow * state, lds_q);
+    typename TS::T* pending = nullptr;
+    for (int it = 0; it < NT_NB; ++it) {
+        const int tb = tb0 + it;
+        if (tb >= ntiles) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this tile's DMAs have landed
+        float fk[NCH][16], fq[NCH][16];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            frag(&lds[0][c][0], fk[c]);
+            frag(&lds[1][c][0], fq[c]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // fragments are in registers: the buffers are free
+        const bool more = it + 1 < NT_NB && tb + 1 < ntiles;
+        const int qcur = qrow;
+        if (more) {
+            qrow = qnext; krow = knext;
+            dma_tile(bbase + (size_t)krow * state, lds_k);
+            if (qrow != qcur) dma_tile(abase + (size_t)qrow * state, lds_q);
+            if (tb + 2 < ntiles) tile_of(tb + 2, qnext, knext);
+        }
+        if (pending) flush(pending);                                           // previous tile's scores
+        // two independent accumulator chains (even / odd chunks), interleaved instruction by instruction
+        f32x16 acc, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc1[i] = 0.f; }
+        if constexpr (NCH >= 2) {
+#pragma unroll
+            for (int c = 0; c < NCH; c += 2)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fk[c][t], fq[c][t], acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fk[c + 1][t], fq[c + 1][t], acc1, 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
+        } else {
+            mma32_f32(fk[0], fq[0], acc);
+        }
+        park(acc);
+        pending = out_of(tb);
+    }
+    if (pending) flush(pending);
+}
+
+// any head_state (chunks are loaded, transposed and multiplied one at a time: no register-resident prefetch)
 template <class TA, class TS, int BS>
 __global__ void __launch_bounds__(256)
-bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* __restrict__ B, typename TS::T* __restrict__ S,
-                   const int32_t* __restrict__ lut, int lut_stride, int blocks, int heads, int hs, int rows_q, int rows_k) {
+bst_nt_mfma_direct_kernel(const typename TA::T* __restrict__ A, const typename TA::T* __restrict__ B, typename TS::T* __restrict__ S,
+                          const int32_t* __restrict__ lut, int lut_stride, int blocks, int heads, int batch, int hs, int rows_q, int rows_k) {
     constexpr int SUB = BS / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int tb = blockIdx.x * 4 + wave;
+    int n, h, wg;
+    if (!xcd_head_map((blocks * SUB * SUB + 3) / 4, heads, batch, n, h, wg)) return;
+    const int tb = wg * 4 + wave;
     if (tb >= blocks * SUB * SUB) return;
     const int b = tb / (SUB * SUB), ti = (tb / SUB) % SUB, tj = tb % SUB;
-    const int h = blockIdx.y, n = blockIdx.z;
     const int2 qk = *reinterpret_cast<const int2*>(lut + (size_t)h * lut_stride + 2 * b);
     const size_t state = (size_t)heads * hs;
     const typename TA::T* qrow = A + ((size_t)n * rows_q + (size_t)qk.x * BS + 32 * ti + r) * state + (size_t)h * hs + 16 * hh;
@@ -77,7 +256,6 @@ bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* _
         load16_f32<TA>(qrow + kc, kc + 16 * hh, hs, fq);
         mma32_f32(fk, fq, acc);
     }
-    // D[j][i]: i = r, j = (reg & 3) + 8 * (reg >> 2) + 4 * hh
     typename TS::T* out = S + (((size_t)n * heads + h) * blocks + b) * (BS * BS) + (size_t)(32 * ti + r) * BS + 32 * tj + 4 * hh;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -94,15 +272,16 @@ bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* _
 template <class TS, class TB, int BS, bool TRANS>
 __global__ void __launch_bounds__(256)
 bst_xn_mfma_kernel(const typename TS::T* __restrict__ S, const typename TB::T* __restrict__ Bm, typename TB::T* __restrict__ C,
-                   const int32_t* __restrict__ lut, int lut_stride, int blocks, int heads, int hs, int ctx_c, int rows_b, int rows_c) {
+                   const int32_t* __restrict__ lut, int lut_stride, int blocks, int heads, int batch, int hs, int ctx_c, int rows_b, int rows_c) {
     constexpr int SUB = BS / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int nct = (hs + 31) / 32;
-    const int wid = blockIdx.x * 4 + wave;
+    int n, h, wg;
+    if (!xcd_head_map((ctx_c * SUB * nct + 3) / 4, heads, batch, n, h, wg)) return;
+    const int wid = wg * 4 + wave;
     if (wid >= ctx_c * SUB * nct) return;
     const int ct = wid % nct, ts = (wid / nct) % SUB, oc = wid / (nct * SUB);
-    const int h = blockIdx.y, n = blockIdx.z;
     const int32_t* hl = lut + (size_t)h * lut_stride;
     const int2 hdr = *reinterpret_cast<const int2*>(hl + 2 * oc);
     const size_t state = (size_t)heads * hs;

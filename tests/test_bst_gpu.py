@@ -127,7 +127,7 @@ def test_ragged_layouts_and_head_state(env):
     lay = np.zeros((2, 5, 7), dtype=np.int32)
     lay[0, 1, 2] = lay[0, 1, 6] = lay[0, 4, 0] = 1
     lay[1, 0, 0] = lay[1, 3, 3] = lay[1, 3, 4] = 1
-    for bsize, hs in ((32, 24), (64, 40), (16, 8), (8, 16)):
+    for bsize, hs in ((32, 24), (64, 40), (16, 8), (8, 16), (32, 96), (32, 160), (64, 136), (32, 32), (32, 128), (64, 64)):   # direct and LDS-DMA (1 / 2 / 4 chunk) nt kernels
         res = _run_case(torch, BST, lay, 2, bsize, hs, 2, G.head_cb, 5, "f32", "bf16")
         assert res["NT"] < 1e-3 and res["SM"] < 1e-3 and res["SMG"] < 1e-3 and res["NN"] < 2e-6 and res["TN"] < 2e-6, (bsize, hs, res)
     one = np.ones((1, 1, 1), dtype=np.int32)
