@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--n-local", type=int, default=8192, help="minibatch columns per GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--no-attention", action="store_true", help="skip the BASELINE configs[4] (block-sparse attention) extra")
     p.add_argument("--sweep", action="store_true", help="also time 10%% and 50%% density (extra JSON fields)")
     return p.parse_args()
 
@@ -50,6 +51,73 @@ def alg_bytes_xprop(b, N, s):
 
 def alg_bytes_updat(b, N, s):
     return s * (b.C * N + b.K * N) + s * b.blocks * b.bsize ** 2 + 8 * b.blocks
+
+
+def attention_extra(a):
+    """BASELINE configs[4]: block-sparse attention, batch 4, 16 heads x 64, ctx 4096, bsize 32, local(4)+strided(8) causal
+    layout (1466 blocks per head), fp32 activations / bf16 scores (the reference's fp32 pathway).  Reported per op:
+    ms, effective TFLOP/s (2 * blocks * 32 * 32 * 64 per head and batch entry), algorithmic GB/s, and the bound
+    max(flops / 157.3 TF, algorithmic bytes / 8 TB/s).  CPU baseline: the oracle (NumPy, fp32) on one batch entry and two heads."""
+    import torch
+    from blocksparse_amd import BlocksparseTransformer
+    from oracle import bst_oracle as O
+    B, H, HS, BS, CTX = 4, 16, 64, 32, 128
+    lay = O.local_strided_layout(CTX)
+    bst = BlocksparseTransformer(lay, block_size=BS, heads=H, mask_callback=O.causal_mask_callback)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    q, k, v = (torch.rand(B, CTX * BS, H * HS, device="cuda", generator=g) * 2 - 1 for _ in range(3))
+    sd = torch.bfloat16
+    mask = bst._table("mask", "cuda")
+    scale = 1.0 / np.sqrt(HS)
+    w = bst._nt(q, k, sd)
+    p = bst._softmax_fwd(w, scale, mask, sd)
+    dp = torch.randn(p.shape, device="cuda", generator=g).to(sd)
+
+    def timeit(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    flops = 2.0 * B * H * bst.blocks * BS * BS * HS
+    sbytes = B * H * bst.blocks * BS * BS * 2
+    abytes = q.numel() * 4
+    ops = [("nt", lambda: bst._nt(q, k, sd), flops, 2 * abytes + sbytes),
+           ("masked_softmax", lambda: bst._softmax_fwd(w, scale, mask, sd), 0.0, 2 * sbytes),
+           ("nn", lambda: bst._xn(p, v, False), flops, 2 * abytes + sbytes),
+           ("tn", lambda: bst._xn(p, q, True), flops, 2 * abytes + sbytes),
+           ("softmax_grad", lambda: bst._softmax_bwd(dp, p, scale), 0.0, 3 * sbytes)]
+    res, total = {}, 0.0
+    for name, fn, fl, by in ops:
+        ms = timeit(fn)
+        total += ms
+        bound = max(fl / (PEAK_MFMA["f32"] * 1e12), by / (PEAK_HBM * 1e9)) * 1e3
+        res[name] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "gbps": round(by / ms / 1e6, 1),
+                     "bound": "mfma" if fl / (PEAK_MFMA["f32"] * 1e12) > by / (PEAK_HBM * 1e9) else "hbm",
+                     "bound_ms": round(bound, 4), "frac": round(bound / ms, 4)}
+    # forward + backward of one attention layer = nt, softmax, nn | tn(dv), nt(dp), softmax_grad, nn(dq), tn(dk)
+    fb = res["nt"]["ms"] * 2 + res["masked_softmax"]["ms"] + res["softmax_grad"]["ms"] + res["nn"]["ms"] * 2 + res["tn"]["ms"] * 2
+    out = {"workload": "BASELINE configs[4]: block-sparse attention batch %d heads %d x %d ctx %d bsize %d, %d blocks/head, fp32 activations, bf16 scores"
+                       % (B, H, HS, CTX * BS, BS, bst.blocks),
+           "ops": res, "fwd_bwd_ms": round(fb, 4), "fwd_bwd_tflops": round(6 * flops / fb / 1e9, 2)}
+    if not a.no_cpu_baseline:
+        L = O.build_luts(lay)
+        qc, kc, vc = (t[:1, :, :2 * HS].float().cpu().numpy() for t in (q, k, v))
+        t0 = time.perf_counter()
+        W = O.nt(L, qc, kc, BS, 2)
+        P = O.masked_softmax(L, W, BS, scale, bst.softmax_mask_np)
+        O.nn(L, P, vc, BS, 2)
+        el = time.perf_counter() - t0
+        fl_s = 2 * 2.0 * 2 * bst.blocks * BS * BS * HS          # nt + nn of 1 batch entry x 2 heads
+        out["cpu_baseline"] = {"value": round(fl_s / el / 1e9, 3), "unit": "GFLOP/s (nt + softmax + nn, forward)", "cores": 1, "kind": "port",
+                               "sample": "1 of 4 batch entries, 2 of 16 heads, float64 NumPy oracle, %.2f s" % el}
+    return out
 
 
 def cpu_baseline(layout, bs, axis, seconds):
@@ -231,6 +299,8 @@ def main():
                                    "ms": round(ms32, 4), "tflops": round(tf32, 2), "peak": PEAK_MFMA["f32"],
                                    "frac": round(tf32 / PEAK_MFMA["f32"], 4)}
         del b32, w32, x32
+    if rank == 0 and world == 1 and not a.no_attention:
+        out["attention"] = attention_extra(a)
     if a.sweep:
         sw = {}
         for d in (0.1, 0.5):
