@@ -11,8 +11,9 @@ LIB_PATH = os.path.join(_HERE, "libbsmm_hip.so")
 
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
+FLAG_GATED_DW = 1
 
-SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_identity_init", "bsmm_workspace_bytes",
+SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_workspace_bytes",
            "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
            "bsmm_set_kernel_variant", "bsmm_get_kernel_variant", "bsmm_error_string", "bsmm_version")
 BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask")
@@ -23,7 +24,7 @@ class BsmmArgs(ctypes.Structure):
     _fields_ = [
         ("lut", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
         ("workspace_bytes", ctypes.c_size_t), ("plan", ctypes.c_void_p),
-        ("plan_items", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("plan_items", ctypes.c_int32), ("flags", ctypes.c_int32),
         ("blocks", ctypes.c_int32), ("bsize", ctypes.c_int32), ("segments", ctypes.c_int32),
         ("locks", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
         ("shared", ctypes.c_int32), ("pcount", ctypes.c_int32), ("axis", ctypes.c_int32),
@@ -72,6 +73,8 @@ def load():
     lib.bsmm_updat.restype = ctypes.c_int
     lib.bsmm_identity_init.argtypes = [vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.bsmm_identity_init.restype = ctypes.c_int
+    lib.bsmm_gate_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.bsmm_gate_grad.restype = ctypes.c_int
     lib.bsmm_workspace_bytes.argtypes = [ctypes.c_int, pargs]
     lib.bsmm_workspace_bytes.restype = ctypes.c_size_t
     ip = ctypes.POINTER(ctypes.c_int32)

@@ -27,7 +27,6 @@ int check_common(const bsmm_args* a) {
     if (a->bsize != 8 && a->bsize != 16 && a->bsize != 32) return BSMM_ERR_UNSUPPORTED;
     if (a->axis != 0 && a->axis != 1) return BSMM_ERR_UNSUPPORTED;
     if (a->dtype != BSMM_F32 && a->dtype != BSMM_F16 && a->dtype != BSMM_BF16) return BSMM_ERR_UNSUPPORTED;
-    if (a->gate) return BSMM_ERR_UNSUPPORTED;
     if (a->C % a->bsize || a->K % a->bsize) return BSMM_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(a->lut) & 15) return BSMM_ERR_ARG;
     return BSMM_OK;
@@ -43,7 +42,7 @@ int launch_xprop_valu(const void* X, const void* W, void* Y, const bsmm_args* a,
     typedef typename DT::T T;
     dim3 grid((a->N + 255) / 256, a->segments);
     xprop_valu_kernel<DT, BS, AXIS, FPROP><<<grid, 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(W),
-                                                                 static_cast<T*>(Y), a->lut, a->N, a->C, a->K);
+                                                                 static_cast<T*>(Y), a->lut, a->N, a->C, a->K, a->gate);
     return (int)hipGetLastError();
 }
 
@@ -60,6 +59,15 @@ int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args*
         m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
         if (m.P > m.segments) m.P = m.segments;
         m.SP = (m.segments + m.P - 1) / m.P;
+        if (a->gate) {
+            if constexpr (BS == 32)
+                xprop32_kernel<DT, AXIS, NSUB, true><<<m.grid(), 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
+                                                                               static_cast<T*>(Y), a->lut, m, N, a->C, a->K, a->gate);
+            else
+                xprop16_kernel<DT, AXIS, NSUB, true><<<m.grid(), 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
+                                                                               static_cast<T*>(Y), a->lut, m, N, a->C, a->K, a->gate);
+            return;
+        }
         if constexpr (BS == 32)
             xprop32_kernel<DT, AXIS, NSUB><<<m.grid(), 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
                                                                      static_cast<T*>(Y), a->lut, m, N, a->C, a->K);
@@ -253,7 +261,8 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         if (AXIS == 0 && use_xcol() && (a->N % 8 != 0)) enough = false;   // axis-0 xcol needs 16-byte aligned row pieces
     }
     if (variant == 3 && a->plan != nullptr && !(AXIS == 0 && use_xcol() && (a->N % 8 != 0))) enough = true;   // test hook
-    const bool use_group = !use_valu && (BS == 32 || (BS == 16 && DT::is16)) && a->plan != nullptr && (variant == 0 || variant == 3) && enough;
+    const bool use_group = !use_valu && (BS == 32 || (BS == 16 && DT::is16)) && a->plan != nullptr && (variant == 0 || variant == 3) && enough &&
+                           a->gate == nullptr;   // gated calls take the per-segment kernels
     if (a->locks > 0 && !use_group) {   // several segments accumulate into the same output block: start from zero
         hipError_t e = hipMemsetAsync(Y, 0, (size_t)a->N * a->K * elem_size(a->dtype), st);
         if (e != hipSuccess) return (int)e;
@@ -324,8 +333,10 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     }
     const int variant = g_variant.load(std::memory_order_relaxed);
     const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
+    const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;   // gated dw: per-block kernels only
+    const bool gated = ug != nullptr;
     if constexpr (BS == 32 && AXIS == 0 && DT::is16) {
-        if (!use_valu && vec_ok && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed kernel, axis 0
+        if (!use_valu && !gated && vec_ok && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed kernel, axis 0
             static bool attr_set_w0 = false;
             if (!attr_set_w0) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a0_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UW0_LDS);
@@ -357,7 +368,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     if constexpr (BS == 32 && AXIS == 1 && DT::is16) {
         bool al = aligned16(DW);
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
-        if (!use_valu && al && (variant == 0 || variant == 3) && a->plan != nullptr) {   // windowed kernel (plan = bsmm_updat_plan_build)
+        if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr) {   // windowed kernel (plan = bsmm_updat_plan_build)
             static bool attr_set_w = false;
             if (!attr_set_w) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
@@ -386,7 +397,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             }
             return (int)hipGetLastError();
         }
-        if (!use_valu && al && variant != 1) {   // LDS-DMA + transposing-read kernel
+        if (!use_valu && !gated && al && variant != 1) {   // LDS-DMA + transposing-read kernel
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_tr_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UT_LDS);
@@ -401,7 +412,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     if constexpr (BS == 16 && DT::is16) {
         bool al16 = aligned16(DW) && (AXIS == 1 || N % 8 == 0);
         for (int p = 0; p < a->pcount; ++p) al16 = al16 && aligned16(xs.p[p]) && aligned16(es.p[p]);
-        if (!use_valu && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed, 16x16 blocks
+        if (!use_valu && !gated && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed, 16x16 blocks
             static bool attr_set_w16 = false;
             if (!attr_set_w16) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat16_win_kernel<DT, AXIS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * UWN_SLOT);
@@ -431,7 +442,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     if constexpr (BS == 16 && AXIS == 1 && DT::is16) {
         bool al = aligned16(DW);
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
-        if (!use_valu && al && variant != 1) {   // LDS-DMA + transposing-read kernel, 16x16 blocks
+        if (!use_valu && !gated && al && variant != 1) {   // LDS-DMA + transposing-read kernel, 16x16 blocks
             static bool attr_set16 = false;
             if (!attr_set16) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat16_a1_tr_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UT16_LDS);
@@ -445,15 +456,15 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     }
     if (use_valu) {
         updat_valu_kernel<DT, BS, AXIS><<<a->blocks, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C,
-                                                                   a->K, a->pcount, a->alpha, a->beta);
+                                                                   a->K, a->pcount, a->alpha, a->beta, ug);
     } else if constexpr (BS == 32) {
         const int grid = 8 * ((a->blocks + 7) / 8);
         updat32_kernel<DT, AXIS><<<grid, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K,
-                                                       a->pcount, a->alpha, a->beta);
+                                                       a->pcount, a->alpha, a->beta, ug);
     } else if constexpr (BS == 16) {
         const int grid = 8 * ((a->blocks + 7) / 8);
         updat16_kernel<DT, AXIS><<<grid, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K,
-                                                       a->pcount, a->alpha, a->beta);
+                                                       a->pcount, a->alpha, a->beta, ug);
     }
     return (int)hipGetLastError();
 }
@@ -492,6 +503,20 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
         case BSMM_BF16: return updat_dt<DTbf16>(xs, es, DW, a);
     }
     return BSMM_ERR_UNSUPPORTED;
+}
+
+int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const float* gate, int32_t blocks, int32_t bsize,
+                   int32_t dtype, void* stream) {
+    if (!dw_out || !dg || !dw || !W || !gate || blocks <= 0) return BSMM_ERR_ARG;
+    if (bsize != 8 && bsize != 16 && bsize != 32) return BSMM_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case BSMM_F32: gate_grad_kernel<DTf32><<<blocks, 256, 0, st>>>(static_cast<float*>(dw_out), dg, static_cast<const float*>(dw), static_cast<const float*>(W), gate, bsize); break;
+        case BSMM_F16: gate_grad_kernel<DTf16><<<blocks, 256, 0, st>>>(static_cast<uint16_t*>(dw_out), dg, static_cast<const uint16_t*>(dw), static_cast<const uint16_t*>(W), gate, bsize); break;
+        case BSMM_BF16: gate_grad_kernel<DTbf16><<<blocks, 256, 0, st>>>(static_cast<uint16_t*>(dw_out), dg, static_cast<const uint16_t*>(dw), static_cast<const uint16_t*>(W), gate, bsize); break;
+        default: return BSMM_ERR_UNSUPPORTED;
+    }
+    return (int)hipGetLastError();
 }
 
 int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks, int32_t bsize,

@@ -27,7 +27,7 @@ __device__ __forceinline__ int updat_block(int b, int blocks) {
 template <class DT, int AXIS>
 __global__ void __launch_bounds__(256)
 updat32_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
-               int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+               int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta, const float* __restrict__ gate = nullptr) {
     typedef typename DT::T T;
     __shared__ float red[4 * 1024];
     const int w = updat_block(blockIdx.x, blocks);
@@ -35,6 +35,7 @@ updat32_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int c = lut[2 * w], k = lut[2 * w + 1];
+    if (gate) alpha *= gate[w];                       // gated dw (updat_test(dw_gated=True), blocksparse/matmul.py:412-418)
 
     f32x16 acc;
 #pragma unroll
@@ -74,7 +75,7 @@ updat32_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const 
 template <class DT, int AXIS>
 __global__ void __launch_bounds__(256)
 updat16_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
-               int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+               int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta, const float* __restrict__ gate = nullptr) {
     typedef typename DT::T T;
     constexpr int KS = Frag16<DT>::KS;   // n per MFMA slab: 32 (16-bit) / 16 (f32)
     constexpr int KL = Frag16<DT>::KL;   // n per lane per slab: 8 / 4
@@ -84,6 +85,7 @@ updat16_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int c = lut[2 * w], k = lut[2 * w + 1];
+    if (gate) alpha *= gate[w];                       // gated dw (updat_test(dw_gated=True), blocksparse/matmul.py:412-418)
 
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int p = 0; p < pcount; ++p) {
@@ -130,7 +132,7 @@ updat16_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const 
 template <class DT, int BS, int AXIS>
 __global__ void __launch_bounds__(256)
 updat_valu_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
-                  int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+                  int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta, const float* __restrict__ gate = nullptr) {
     typedef typename DT::T T;
     constexpr int CH = 64;
     constexpr int OUTS = BS * BS;
@@ -143,6 +145,7 @@ updat_valu_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, con
 
     const int w = blockIdx.x;
     const int c = lut[2 * w], k = lut[2 * w + 1];
+    if (gate) alpha *= gate[w];                       // gated dw (updat_test(dw_gated=True), blocksparse/matmul.py:412-418)
     const int tid = threadIdx.x;
     const int slice = (SL == 1) ? 0 : tid / OUTS;
     const int obase = (SL == 1) ? tid : tid % OUTS;
@@ -222,6 +225,28 @@ identity_init_kernel(typename DT::T* __restrict__ W, const int32_t* __restrict__
         const int i = idx / bsize, j = idx % bsize;
         W[(size_t)w * n + idx] = DT::from_f32((diag && i == j) ? scale : 0.f);
     }
+}
+
+// dw_out = dw * gate, dg[w] = sum(dw[w] * W[w])   (blocksparse_gate_grad, src/blocksparse_hgemm_cn_64_op_gpu.cu:1339-1392).
+// One workgroup per block; dw_out may alias dw.
+template <class DT>
+__global__ void __launch_bounds__(256)
+gate_grad_kernel(typename DT::T* __restrict__ dw_out, float* __restrict__ dg, const typename DT::T* __restrict__ dw,
+                 const typename DT::T* __restrict__ W, const float* __restrict__ gate, int bsize) {
+    __shared__ float red[4];
+    const int w = blockIdx.x, n = bsize * bsize;
+    const float g = gate[w];
+    float s = 0.f;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const float d = DT::to_f32(dw[(size_t)w * n + idx]);
+        s = fmaf(d, DT::to_f32(W[(size_t)w * n + idx]), s);
+        dw_out[(size_t)w * n + idx] = DT::from_f32(d * g);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dg[w] = red[0] + red[1] + red[2] + red[3];
 }
 
 }  // namespace bsmm

@@ -36,10 +36,14 @@ __device__ __forceinline__ bool xmap_decode(const XMap& m, int b, int& tile, int
 // MFMA roles: A = Wop (M = o), B = XT (N = n)  ->  D[o][n]; every lane ends up with 4 consecutive o per
 // register quad, which makes the axis-1 store a 8/16-byte vector store.
 // =================================================================================================
-template <class DT, int AXIS, int NSUB>
+// GATED: per-block fp32 gates (hgemm_blocksparse_*_sdd's `Gate`, src/blocksparse_hgemm_cn_64_op_gpu.cu:54-66,96-124): an
+// entry with gate 0 is skipped, otherwise its 32x32 product is formed in a scratch accumulator and added scaled, i.e.
+// the gate multiplies the fp32 block product exactly as in the reference (fprop_test, blocksparse/matmul.py:367-373).
+template <class DT, int AXIS, int NSUB, bool GATED = false>
 __global__ void __launch_bounds__(256)
 xprop32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
-               typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, XMap map, int N, int Cin, int Kout) {
+               typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, XMap map, int N, int Cin, int Kout,
+               const float* __restrict__ gate = nullptr) {
     typedef typename DT::T T;
     constexpr int NT = 4 * 32 * NSUB;
     int tile, seg;
@@ -61,6 +65,11 @@ xprop32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
 
     for (int e = 0; e < cnt; ++e) {
         const int2 cw = ent[e];
+        float g = 1.f;
+        if constexpr (GATED) {
+            g = gate[cw.y];
+            if (g == 0.f) continue;
+        }
         Frag32<DT> wf;
         wf.load_contig(Wsel + (size_t)cw.y * 1024 + r * 32, h);
 #pragma unroll
@@ -73,7 +82,16 @@ xprop32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
             } else {
                 xf.zero();
             }
-            mma32<DT>(wf, xf, acc[s]);
+            if constexpr (GATED) {
+                f32x16 t;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = 0.f;
+                mma32<DT>(wf, xf, t);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[s][i] = fmaf(g, t[i], acc[s][i]);
+            } else {
+                mma32<DT>(wf, xf, acc[s]);
+            }
         }
     }
 
@@ -121,10 +139,12 @@ xprop32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
 //           same on Volta for bsize 8 (src/blocksparse_hgemm_cn_64_op_gpu.cu:541-624).
 //   f32:    v_mfma_f32_16x16x4, 4 instructions per entry.
 // =================================================================================================
-template <class DT, int AXIS, int NSUB>
+// GATED (see xprop32_kernel): entries are taken one at a time (16-bit: the second K half of the instruction is zero).
+template <class DT, int AXIS, int NSUB, bool GATED = false>
 __global__ void __launch_bounds__(256)
 xprop16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
-               typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, XMap map, int N, int Cin, int Kout) {
+               typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, XMap map, int N, int Cin, int Kout,
+               const float* __restrict__ gate = nullptr) {
     typedef typename DT::T T;
     constexpr int NT = 4 * 16 * NSUB;
     int tile, seg;
@@ -145,9 +165,15 @@ xprop16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
     if constexpr (DT::is16) {
         const int sub = q >> 1;          // which entry of the pair this lane follows
         const int i0 = 8 * (q & 1);      // first input feature (within the block) held by this lane
-        for (int e0 = 0; e0 < cnt; e0 += 2) {
-            const int e = e0 + sub;
-            const bool live = e < cnt;
+        for (int e0 = 0; e0 < cnt; e0 += (GATED ? 1 : 2)) {
+            const int e = GATED ? e0 : e0 + sub;
+            bool live = e < cnt;
+            float g = 1.f;
+            if constexpr (GATED) {
+                g = gate[ent[e0].y];                       // wave-uniform
+                if (g == 0.f) continue;
+                live = sub == 0;
+            }
             int2 cw = make_int2(0, 0);
             if (live) cw = ent[e];
             Frag16<DT> wf;
@@ -163,13 +189,25 @@ xprop16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                 } else {
                     xf.zero();
                 }
-                mma16<DT>(wf, xf, acc[s]);
+                if constexpr (GATED) {
+                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma16<DT>(wf, xf, t);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[s][i] = fmaf(g, t[i], acc[s][i]);
+                } else {
+                    mma16<DT>(wf, xf, acc[s]);
+                }
             }
         }
     } else {
         const int i0 = 4 * q;
         for (int e = 0; e < cnt; ++e) {
             const int2 cw = ent[e];
+            float g = 1.f;
+            if constexpr (GATED) {
+                g = gate[cw.y];
+                if (g == 0.f) continue;
+            }
             Frag16<DT> wf;
             wf.load_contig(Wsel + (size_t)cw.y * 256 + r * 16 + i0);
 #pragma unroll
@@ -182,7 +220,14 @@ xprop16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                 } else {
                     xf.zero();
                 }
-                mma16<DT>(wf, xf, acc[s]);
+                if constexpr (GATED) {
+                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma16<DT>(wf, xf, t);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[s][i] = fmaf(g, t[i], acc[s][i]);
+                } else {
+                    mma16<DT>(wf, xf, acc[s]);
+                }
             }
         }
     }
@@ -226,7 +271,8 @@ xprop16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
 template <class DT, int BS, int AXIS, bool FPROP>
 __global__ void __launch_bounds__(256)
 xprop_valu_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ W,
-                  typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, int N, int Cin, int Kout) {
+                  typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, int N, int Cin, int Kout,
+                  const float* __restrict__ gate = nullptr) {
     typedef typename DT::T T;
     __shared__ float Wl[BS * BS];
     const int seg = blockIdx.y;
@@ -241,6 +287,8 @@ xprop_valu_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __
 
     for (int e = 0; e < cnt; ++e) {
         const int2 cw = ent[e];
+        const float g = gate ? gate[cw.y] : 1.f;           // uniform over the workgroup
+        if (g == 0.f) continue;
         __syncthreads();
         for (int idx = threadIdx.x; idx < BS * BS; idx += 256) {
             const int o = idx / BS, i = idx % BS;
@@ -257,10 +305,10 @@ xprop_valu_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __
             }
 #pragma unroll
             for (int o = 0; o < BS; ++o) {
-                float a = acc[o];
+                float a = 0.f;
 #pragma unroll
                 for (int i = 0; i < BS; ++i) a = fmaf(Wl[o * BS + i], x[i], a);
-                acc[o] = a;
+                acc[o] = fmaf(g, a, acc[o]);
             }
         }
     }

@@ -205,10 +205,21 @@ class BlocksparseMatMul(object):
             shp[-1] = feat_out
         return shp
 
+    def _check_gate(self, gate, device):
+        if gate is None:
+            return None
+        if not (isinstance(gate, torch.Tensor) and gate.is_cuda and gate.dtype == torch.float32 and gate.numel() == self.blocks):
+            raise ValueError("gate: expected a float32 CUDA tensor with one entry per block (%d)" % self.blocks)
+        if gate.device != device:
+            raise ValueError("gate lives on another device")
+        return gate.contiguous()
+
     # ---- the three passes ------------------------------------------------------------------------
-    def fprop(self, x, w):
-        """Y = fprop(X, W): axis 0 Y(K,N) = Wd^T X, axis 1 Y(N,K) = X Wd (op BlocksparseMatmul)."""
+    def fprop(self, x, w, gate=None):
+        """Y = fprop(X, W): axis 0 Y(K,N) = Wd^T X, axis 1 Y(N,K) = X Wd (op BlocksparseMatmul).
+        ``gate`` (float32 [blocks]): block w contributes gate[w] times its product, gate 0 = skipped."""
         self._check_tensor(x, "x"); self._check_tensor(w, "w")
+        gate = self._check_gate(gate, x.device)
         if x.dtype != w.dtype:
             raise TypeError("x and w must have the same dtype")
         x = x.contiguous(); w = w.contiguous()
@@ -218,6 +229,7 @@ class BlocksparseMatMul(object):
         y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
         a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype,
                        plan=tabs.fprop_plan_f32 if x.dtype == torch.float32 else tabs.fprop_plan)
+        a.gate = gate.data_ptr() if gate is not None else None
         need = lib.bsmm_workspace_bytes(_lib.OP_FPROP, ctypes.byref(a))
         ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device) if need else None
         if ws is not None:
@@ -225,9 +237,10 @@ class BlocksparseMatMul(object):
         _lib.check(lib.bsmm_fprop(x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(a)), "bsmm_fprop")
         return y
 
-    def bprop(self, dy, w):
-        """DX = bprop(DY, W) (op BlocksparseMatmulDX; C and K swapped as in matmul.py:506-510)."""
+    def bprop(self, dy, w, gate=None):
+        """DX = bprop(DY, W) (op BlocksparseMatmulDX; C and K swapped as in matmul.py:506-510); ``gate`` as in fprop."""
         self._check_tensor(dy, "dy"); self._check_tensor(w, "w")
+        gate = self._check_gate(gate, dy.device)
         if dy.dtype != w.dtype:
             raise TypeError("dy and w must have the same dtype")
         dy = dy.contiguous(); w = w.contiguous()
@@ -237,13 +250,15 @@ class BlocksparseMatMul(object):
         dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)
         a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype,
                        plan=tabs.bprop_plan_f32 if dy.dtype == torch.float32 else tabs.bprop_plan)
+        a.gate = gate.data_ptr() if gate is not None else None
         _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
         return dx
 
-    def updat(self, xs, dys, alpha=1.0, beta=0.0, dw=None):
+    def updat(self, xs, dys, alpha=1.0, beta=0.0, dw=None, gate=None):
         """DW = alpha * sum_p updat(X_p, DY_p) + beta * DW  (ops BlocksparseMatmulDW / ...DWA).
 
-        ``xs``/``dys``: one tensor each or equally long lists of up to 8 tensors (the reference's Plist)."""
+        ``xs``/``dys``: one tensor each or equally long lists of up to 8 tensors (the reference's Plist).
+        ``gate``: gated dw (op attr gated_dw): the sum of block w is scaled by gate[w]."""
         if isinstance(xs, torch.Tensor):
             xs, dys = [xs], [dys]
         if len(xs) != len(dys) or not 1 <= len(xs) <= 8:
@@ -272,6 +287,9 @@ class BlocksparseMatMul(object):
         a = self._args(tabs.updat, None, N, self.C, self.K, xs[0].dtype, pcount=len(xs), alpha=alpha, beta=beta,
                        plan=tabs.updat_plan if xs[0].dtype != torch.float32 else None)
         a.plan_items = tabs.updat_items
+        gate = self._check_gate(gate, dev)
+        if gate is not None:
+            a.gate, a.flags = gate.data_ptr(), _lib.FLAG_GATED_DW
         need = lib.bsmm_workspace_bytes(_lib.OP_UPDAT, ctypes.byref(a))
         ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev) if need else None
         if ws is not None:
@@ -298,10 +316,39 @@ class BlocksparseMatMul(object):
 
     # ---- operator interface (matmul.py:455-483) ---------------------------------------------------
     def __call__(self, I, W, gate=None, gate_grad=False, dw_gated=False, name=None, bench=0):
-        if gate is not None:
-            raise NotImplementedError("per-block gating is not implemented yet")
+        """y = bsmm(x, w[, gate]).  With a gate: blocks are scaled by it in fprop / bprop; ``dw_gated`` scales dw by the
+        gate as well; ``gate_grad`` returns dg = sum(dw * w) per block and gates dw (blocksparse_matmul_grad,
+        blocksparse/matmul.py:485-527)."""
         self.count += 1
-        return _BsmmFunction.apply(I, W, self)
+        if gate is None:
+            return _BsmmFunction.apply(I, W, self)
+        return _BsmmGatedFunction.apply(I, W, gate, self, bool(gate_grad), bool(dw_gated))
+
+    def gate_grad(self, dw, w, gate):
+        """(dw * gate, dg) with dg[b] = sum(dw[b] * w[b])  (op BlocksparseMatmulDG)."""
+        self._check_tensor(dw, "dw"); self._check_tensor(w, "w")
+        gate = self._check_gate(gate, dw.device)
+        if dw.dtype != w.dtype or tuple(dw.shape) != self.w_shape or tuple(w.shape) != self.w_shape:
+            raise ValueError("dw and w must be %s tensors of one dtype" % (self.w_shape,))
+        dw = dw.contiguous(); w = w.contiguous()
+        out = torch.empty_like(dw)
+        dg = torch.empty(self.blocks, dtype=torch.float32, device=dw.device)
+        st = torch.cuda.current_stream(dw.device).cuda_stream
+        _lib.check(_lib.load().bsmm_gate_grad(out.data_ptr(), dg.data_ptr(), dw.data_ptr(), w.data_ptr(), gate.data_ptr(), self.blocks,
+                                              self.bsize, _dtype_code(dw.dtype), st), "bsmm_gate_grad")
+        return out, dg
+
+    def prune(self, param, gate):
+        """Drop the blocks whose gate is 0: returns (new_param, new_gate) and clears those blocks in ``self.layout``
+        (blocksparse/matmul.py:272-290; as there, build a new BlocksparseMatMul from the pruned layout afterwards)."""
+        gate = np.asarray(gate)
+        keep = gate != 0.0
+        if int(keep.sum()) != self.blocks:
+            for w_id, (c, k) in enumerate(self.updat_list):
+                if not keep[w_id]:
+                    self.layout[c, k] = 0
+            param = np.asarray(param)[keep]
+        return param, np.ones((int(keep.sum()),), dtype=gate.dtype)
 
     def matmul(self, I, W, gate=None, gate_grad=False, dw_gated=False, name=None, bench=0):
         return self.__call__(I, W, gate=gate, gate_grad=gate_grad, dw_gated=dw_gated, name=name, bench=bench)
@@ -364,9 +411,10 @@ class BlocksparseMatMul(object):
     # ---- NumPy reference functions shipped with the class (matmul.py:353-419) ----------------------
     # Host-side API parity only (the reference exposes them as methods); the device path never calls them.
     def fprop_test(self, I, W, gate=None):
-        assert gate is None
         bs = self.bsize
         I = np.asarray(I); W = np.asarray(W)
+        if gate is not None:          # the gate scales the block product (matmul.py:367-373); both axes here
+            W = W * np.asarray(gate, dtype=W.dtype)[:, None, None]
         if self.axis:
             n = I.shape[0]
             X = I.reshape(n, self.CB, bs)
@@ -386,9 +434,10 @@ class BlocksparseMatMul(object):
         return O.reshape(-1, n)
 
     def bprop_test(self, E, W, gate=None):
-        assert gate is None
         bs = self.bsize
         E = np.asarray(E); W = np.asarray(W)
+        if gate is not None:
+            W = W * np.asarray(gate, dtype=W.dtype)[:, None, None]
         if self.axis:
             n = E.shape[0]
             D = E.reshape(n, self.KB, bs)
@@ -408,7 +457,6 @@ class BlocksparseMatMul(object):
         return B.reshape(-1, n)
 
     def updat_test(self, I, E, gate=None, dw_gated=False):
-        assert gate is None
         bs = self.bsize
         I = np.asarray(I, dtype=np.float64); E = np.asarray(E, dtype=np.float64)
         ul = self.updat_lut
@@ -418,7 +466,10 @@ class BlocksparseMatMul(object):
         else:
             X = I.reshape(self.CB, bs, -1)
             D = E.reshape(self.KB, bs, -1)
-        return np.matmul(X[ul[:, 0]], np.transpose(D[ul[:, 1]], (0, 2, 1)))
+        U = np.matmul(X[ul[:, 0]], np.transpose(D[ul[:, 1]], (0, 2, 1)))
+        if dw_gated and gate is not None:
+            U = U * np.asarray(gate, dtype=np.float64)[:, None, None]
+        return U
 
 
 if torch is not None:
@@ -438,3 +489,25 @@ if torch is not None:
             dx = bsmm.bprop(dy, w) if ctx.needs_input_grad[0] else None
             dw = bsmm.updat(x, dy) if ctx.needs_input_grad[1] else None
             return dx, dw, None
+
+    class _BsmmGatedFunction(torch.autograd.Function):
+        """y = bsmm(x, w, gate) with the registered gradient of the gated op (blocksparse/matmul.py:485-527): dx through the
+        gated bprop, dw optionally gated (``dw_gated``), and with ``gate_grad`` (dw, dg) = blocksparse_matmul_dg(dw, w, gate)."""
+
+        @staticmethod
+        def forward(ctx, x, w, gate, bsmm, gate_grad, dw_gated):
+            ctx.bsmm, ctx.gate_grad, ctx.dw_gated = bsmm, gate_grad, dw_gated
+            ctx.save_for_backward(x, w, gate)
+            return bsmm.fprop(x, w, gate=gate)
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w, gate = ctx.saved_tensors
+            bsmm = ctx.bsmm
+            dx = bsmm.bprop(dy, w, gate=gate) if ctx.needs_input_grad[0] else None
+            dw = dg = None
+            if ctx.needs_input_grad[1] or (ctx.gate_grad and ctx.needs_input_grad[2]):
+                dw = bsmm.updat(x, dy, gate=gate if ctx.dw_gated else None)
+                if ctx.gate_grad:
+                    dw, dg = bsmm.gate_grad(dw, w, gate)
+            return dx, dw, dg, None, None, None

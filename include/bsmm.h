@@ -44,6 +44,7 @@ extern "C" {
 #define BSMM_VERSION 100 /* 0.1.0 */
 
 enum { BSMM_F32 = 0, BSMM_F16 = 1, BSMM_BF16 = 2 };
+enum { BSMM_FLAG_GATED_DW = 1 };   /* updat: scale dw by the gate (op attr gated_dw, src/blocksparse_matmul_op.cc:363,403) */
 
 enum {
     BSMM_OK = 0,
@@ -56,14 +57,17 @@ enum { BSMM_OP_FPROP = 0, BSMM_OP_BPROP = 1, BSMM_OP_UPDAT = 2 };
 
 typedef struct bsmm_args {
     const int32_t* lut;     /* device: fprop_lut (fprop) / bprop_lut (bprop) / updat_lut (updat)                    */
-    const float* gate;      /* per-block gate (reference: Gate); must be NULL -- gating is not implemented yet      */
+    const float* gate;      /* optional per-block fp32 gate [blocks] (reference: Gate, src/gpu_types.h:175).  xprop: block
+                               w contributes gate[w] * (its product), gate 0 = skipped; updat: only read when
+                               flags & BSMM_FLAG_GATED_DW, then DW[w] = alpha * gate[w] * sum + beta * DW[w].  A gated call
+                               runs the per-segment / per-block kernels (the plan is ignored).                          */
     void* workspace;        /* device scratch of >= bsmm_workspace_bytes(op, args) bytes (may be NULL when that is 0) */
     size_t workspace_bytes;
     const int32_t* plan;    /* optional device copy of the schedule built by bsmm_xprop_plan_build() (fprop/bprop) or
                                bsmm_updat_plan_build() (updat) for THIS lut (NULL = generic kernels).  Like the luts
                                it is a constant of the layout.                                                       */
     int32_t plan_items;     /* updat only: header word [4] of the updat plan (number of work items = grid size)       */
-    int32_t reserved0;
+    int32_t flags;          /* BSMM_FLAG_* (0 = none)                                                                 */
     int32_t blocks;         /* nonzero blocks                                                                        */
     int32_t bsize;          /* 8, 16 or 32                                                                           */
     int32_t segments;       /* xprop: number of lut headers (incl. empty output blocks)                              */
@@ -93,6 +97,12 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
 /* W[w] = scale * I if (c % KB) == (k % CB) else 0, (c,k) = updat_lut[w];  dtype as BSMM_* */
 int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks,
                        int32_t bsize, float scale, int32_t dtype, void* stream);
+
+/* Gate gradient (BlocksparseMatmulDG, src/blocksparse_matmul_op.cc:492-540; blocksparse_gate_grad,
+ * src/blocksparse_hgemm_cn_64_op_gpu.cu:1339-1412):  dw_out[w] = dw[w] * gate[w],  dg[w] = sum(dw[w] * W[w]).
+ * dw_out may alias dw.  dg is fp32 [blocks]. */
+int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const float* gate, int32_t blocks,
+                   int32_t bsize, int32_t dtype, void* stream);
 
 /* Host-only: derive the grouped-kernel schedule ("plan") from a reference-format xprop lut that lives in HOST
  * memory (the luts are constants of the layout: the reference builds them in NumPy, blocksparse/matmul.py:137-138).

@@ -172,11 +172,20 @@ def build_layout_luts(layout, block_size=32, z_order=True):
 # math (float64 accumulation); W is (blocks, bs, bs) with W[w] = Wdense[c*bs:(c+1)*bs, k*bs:(k+1)*bs]
 # ----------------------------------------------------------------------------------------------
 
-def fprop(t, I, W, axis):
+def _gated(W, gate):
+    """Per-block gate: block w contributes gate[w] * (its product), gate 0 = skipped (matmul.py:367-373,391-397).
+    The gate multiplies the exact block product, so scaling the float64 weights is the same thing."""
+    W = np.asarray(W, dtype=np.float64)
+    if gate is None:
+        return W
+    return W * np.asarray(gate, dtype=np.float64)[:, None, None]
+
+
+def fprop(t, I, W, axis, gate=None):
     """axis 0: Y(K,N) = Wd^T X ; axis 1: Y(N,K) = X Wd   (matmul.py:353-375)."""
     bs, CB, KB = t["bsize"], t["CB"], t["KB"]
     I = np.asarray(I, dtype=np.float64)
-    W = np.asarray(W, dtype=np.float64)
+    W = _gated(W, gate)
     if axis:
         n = I.shape[0]
         X = I.reshape(n, CB, bs)
@@ -194,11 +203,11 @@ def fprop(t, I, W, axis):
     return Y.reshape(KB * bs, n)
 
 
-def bprop(t, E, W, axis):
+def bprop(t, E, W, axis, gate=None):
     """axis 0: DX(C,N) = Wd DY ; axis 1: DX(N,C) = DY Wd^T   (matmul.py:377-399)."""
     bs, CB, KB = t["bsize"], t["CB"], t["KB"]
     E = np.asarray(E, dtype=np.float64)
-    W = np.asarray(W, dtype=np.float64)
+    W = _gated(W, gate)
     if axis:
         n = E.shape[0]
         D = E.reshape(n, KB, bs)
@@ -216,9 +225,10 @@ def bprop(t, E, W, axis):
     return B.reshape(CB * bs, n)
 
 
-def updat(t, Is, Es, axis, alpha=1.0, beta=0.0, dw_in=None):
+def updat(t, Is, Es, axis, alpha=1.0, beta=0.0, dw_in=None, gate=None):
     """DW[w] = alpha * sum_p X_p[c] DY_p[k]^T + beta * DW_in[w]   (matmul.py:401-419; kernel
-    semantics for alpha/beta/pairs: src/blocksparse_matmul_op_gpu.cu:2684-2814,2865)."""
+    semantics for alpha/beta/pairs: src/blocksparse_matmul_op_gpu.cu:2684-2814,2865).  gate (with dw_gated=True in the
+    reference, matmul.py:412-418): the sum of block w is scaled by gate[w]."""
     bs, CB, KB = t["bsize"], t["CB"], t["KB"]
     if isinstance(Is, np.ndarray):
         Is, Es = [Is], [Es]
@@ -236,10 +246,21 @@ def updat(t, Is, Es, axis, alpha=1.0, beta=0.0, dw_in=None):
             D = E.reshape(KB, bs, -1)
             for w, (c, k) in enumerate(t["updat_list"]):
                 U[w] += X[c] @ D[k].T
+    if gate is not None:
+        U *= np.asarray(gate, dtype=np.float64)[:, None, None]
     U *= alpha
     if beta != 0.0:
         U += beta * np.asarray(dw_in, dtype=np.float64)
     return U
+
+
+def gate_grad(dw, W, gate):
+    """(dw * gate, dg) with dg[w] = sum(dw[w] * W[w])   (blocksparse_gate_grad,
+    src/blocksparse_hgemm_cn_64_op_gpu.cu:1339-1392)."""
+    dw = np.asarray(dw, dtype=np.float64)
+    W = np.asarray(W, dtype=np.float64)
+    g = np.asarray(gate, dtype=np.float64)
+    return dw * g[:, None, None], (dw * W).sum(axis=(1, 2))
 
 
 def to_dense(t, W):

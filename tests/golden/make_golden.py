@@ -115,6 +115,37 @@ def cfg0_inputs(w_shape, i_shape, o_shape, seed):
     return W, X, E
 
 
+def gate_inputs(blocks, seed):
+    """Per-block gates of the gated fixtures: a third exactly 0, the rest fp16-representable values in (0.25, 1.75)."""
+    rng = np.random.RandomState(seed)
+    g = rng.uniform(0.25, 1.75, blocks).astype(np.float16).astype(np.float32)
+    g[rng.permutation(blocks)[: blocks // 3]] = 0.0
+    return g
+
+
+def main_gate():
+    """gate.npz: the reference's gated fprop_test / bprop_test / updat_test(dw_gated=True) (feature axis 0 only there,
+    blocksparse/matmul.py:367-373,391-397,412-418).  Inputs are regenerated by the tests (cfg0_inputs + gate_inputs)."""
+    mm = import_reference_matmul()
+    holes = ba_layout(16, 2, seed=3)
+    holes[:, 5] = 0
+    holes[7, :] = 0
+    out = {}
+    for name, lay, bs, N, seed in (("holes", holes, 32, 40, 31), ("holes", holes, 16, 24, 32), ("holes", holes, 8, 64, 33)):
+        b = mm.BlocksparseMatMul(lay, block_size=bs, feature_axis=0)
+        W, X, E = cfg0_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), seed)
+        g = gate_inputs(b.blocks, seed)
+        key = "%s/bs%d/" % (name, bs)
+        out[key + "layout"] = np.asarray(lay, dtype=np.uint8)
+        out[key + "meta"] = np.array([bs, N, seed], dtype=np.int64)
+        out[key + "Y"] = b.fprop_test(X, W, gate=g).astype(np.float32)
+        out[key + "DX"] = b.bprop_test(E, W, gate=g).astype(np.float32)
+        out[key + "DW"] = b.updat_test(X, E, gate=g, dw_gated=True).astype(np.float32)
+    path = os.path.join(HERE, "gate.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     mm = import_reference_matmul()
 
@@ -168,4 +199,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "gate":
+        main_gate()
+    else:
+        main()

@@ -63,9 +63,6 @@ def test_argument_validation_without_gpu(lib):
     a.axis, a.dtype = 0, 9
     assert L.bsmm_fprop(one, one, one, ctypes.byref(a)) == -2
     a.dtype = lib.BF16
-    a.gate = 256
-    assert L.bsmm_fprop(one, one, one, ctypes.byref(a)) == -2
-    a.gate = None
     a.C = 65                                     # not a multiple of bsize
     assert L.bsmm_fprop(one, one, one, ctypes.byref(a)) == -1
     a.C = 64
@@ -78,6 +75,8 @@ def test_argument_validation_without_gpu(lib):
     assert L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == 0
     a.bsize = 8
     assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 0
+    assert L.bsmm_gate_grad(one, None, one, one, one, 4, 32, lib.F32, None) == -1
+    assert L.bsmm_gate_grad(one, one, one, one, one, 4, 64, lib.F32, None) == -2
 
 
 def _check_group_plan(plan, f, t, n_out, axis):

@@ -1,0 +1,144 @@
+"""Per-block gating: CPU tier pins oracle + host NumPy methods to fixtures generated from the
+reference (tests/golden/make_golden.py gate); GPU tier checks the gated kernels, the gate gradient and the autograd wiring."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as MG
+import _parity as P
+from oracle import bsmm_oracle as O
+
+
+def _case(gold, bs):
+    key = "holes/bs%d/" % bs
+    lay = gold[key + "layout"].astype(np.int32)
+    _, N, seed = (int(v) for v in gold[key + "meta"])
+    t = O.build_layout_luts(lay, bs)
+    W, X, E = MG.cfg0_inputs((t["blocks"], bs, bs), (t["C"], N), (t["K"], N), seed)
+    return key, lay, t, W, X, E, MG.gate_inputs(t["blocks"], seed)
+
+
+@pytest.mark.parametrize("bs", [32, 16, 8])
+def test_oracle_and_host_methods_match_reference_fixtures(bs):
+    from blocksparse_amd import BlocksparseMatMul
+    gold = np.load(os.path.join(HERE, "golden", "gate.npz"))
+    key, lay, t, W, X, E, g = _case(gold, bs)
+    b = BlocksparseMatMul(lay, block_size=bs, feature_axis=0)
+    assert (g == 0).sum() == t["blocks"] // 3
+    for name, ref, host, orc in (("Y", gold[key + "Y"], b.fprop_test(X, W, gate=g), O.fprop(t, X, W, 0, gate=g)),
+                                 ("DX", gold[key + "DX"], b.bprop_test(E, W, gate=g), O.bprop(t, E, W, 0, gate=g)),
+                                 ("DW", gold[key + "DW"], b.updat_test(X, E, gate=g, dw_gated=True), O.updat(t, X, E, 0, gate=g))):
+        for what, got in (("host", host), ("oracle", orc)):
+            err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+            assert err < 1e-6, (bs, name, what, err)
+    # blocks with gate 0 contribute nothing: same result with those weights replaced by garbage
+    W2 = W.copy()
+    W2[g == 0] = 1e6
+    assert np.array_equal(O.fprop(t, X, W, 0, gate=g), O.fprop(t, X, W2, 0, gate=g))
+
+
+def test_prune_drops_gated_off_blocks():
+    from blocksparse_amd import BlocksparseMatMul
+    lay = P.ba_layout(12, 2, seed=4)
+    b = BlocksparseMatMul(lay, block_size=8, feature_axis=0)
+    rng = np.random.RandomState(0)
+    W = rng.normal(size=b.w_shape).astype(np.float32)
+    g = np.ones(b.blocks, dtype=np.float32)
+    off = rng.permutation(b.blocks)[:5]
+    g[off] = 0
+    W2, g2 = b.prune(W, g)
+    assert W2.shape[0] == b.blocks - 5 and g2.shape == (b.blocks - 5,) and np.all(g2 == 1)
+    b2 = BlocksparseMatMul(b.layout, block_size=8, feature_axis=0)        # rebuilt from the pruned layout
+    assert b2.blocks == b.blocks - 5
+    x = rng.normal(size=b.i_shape(16)).astype(np.float32)
+    assert np.allclose(b2.fprop_test(x, W2), b.fprop_test(x, W, gate=g), atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import __graft_entry__ as g
+    g.build()
+    from blocksparse_amd import BlocksparseMatMul
+    return torch, BlocksparseMatMul
+
+
+def _t(torch, a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda().to(getattr(torch, P.TORCH_DT[dtype]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("bs", [32, 16, 8])
+def test_gated_passes_match_oracle(env, bs, axis, dtype):
+    torch, BSMM = env
+    holes = P.ba_layout(16, 2, seed=3)
+    holes[:, 5] = 0
+    holes[7, :] = 0
+    for li, lay in enumerate((holes, P.random_layout(9, 7, 0.4, seed=8))):
+        for N in (8, 72, 200):
+            b = BSMM(lay, block_size=bs, feature_axis=axis)
+            t = O.build_layout_luts(lay, bs)
+            W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=40 + N)
+            g = MG.gate_inputs(b.blocks, 50 + li)
+            tg = torch.from_numpy(g).cuda()
+            tw, tx, te = _t(torch, W, dtype), _t(torch, X, dtype), _t(torch, E, dtype)
+            rnd = lambda a: O.round_to(a, dtype)
+            for name, got, ref in (("Y", b.fprop(tx, tw, gate=tg), rnd(O.fprop(t, X, W, axis, gate=g))),
+                                   ("DX", b.bprop(te, tw, gate=tg), rnd(O.bprop(t, E, W, axis, gate=g))),
+                                   ("DW", b.updat(tx, te, gate=tg), rnd(O.updat(t, X, E, axis, gate=g)))):
+                l2, _ = P.errors(got.float().cpu().numpy(), ref)
+                assert l2 <= P.L2_BAR[dtype], (bs, axis, dtype, li, N, name, l2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bs", [32, 16, 8])
+def test_gated_kernels_against_reference_fixtures(env, bs):
+    torch, BSMM = env
+    gold = np.load(os.path.join(HERE, "golden", "gate.npz"))
+    key, lay, t, W, X, E, g = _case(gold, bs)
+    b = BSMM(lay, block_size=bs, feature_axis=0)
+    tg = torch.from_numpy(g).cuda()
+    tw, tx, te = _t(torch, W, "f32"), _t(torch, X, "f32"), _t(torch, E, "f32")
+    for name, got in (("Y", b.fprop(tx, tw, gate=tg)), ("DX", b.bprop(te, tw, gate=tg)), ("DW", b.updat(tx, te, gate=tg))):
+        l2, _ = P.errors(got.cpu().numpy(), gold[key + name])
+        assert l2 < 2e-6, (bs, name, l2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gate_grad_and_autograd(env, dtype):
+    torch, BSMM = env
+    lay = P.ba_layout(16, 2, seed=3)
+    bs, N = 32, 96
+    b = BSMM(lay, block_size=bs, feature_axis=1)
+    t = O.build_layout_luts(lay, bs)
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=77)
+    g = MG.gate_inputs(b.blocks, 78)
+    tg = torch.from_numpy(g).cuda().requires_grad_(True)
+    tw, tx = _t(torch, W, dtype).requires_grad_(True), _t(torch, X, dtype).requires_grad_(True)
+    y = b(tx, tw, gate=tg, gate_grad=True, dw_gated=False)
+    y.backward(_t(torch, E, dtype))
+    rnd = lambda a: O.round_to(a, dtype)
+    DW = rnd(O.updat(t, X, E, 1))                               # ungated dw, rounded to storage as the kernel leaves it
+    dw_ref, dg_ref = O.gate_grad(DW, W, g)
+    for name, got, ref in (("Y", y, rnd(O.fprop(t, X, W, 1, gate=g))), ("DX", tx.grad, rnd(O.bprop(t, E, W, 1, gate=g))),
+                           ("DW", tw.grad, rnd(dw_ref)), ("DG", tg.grad, dg_ref)):
+        l2, _ = P.errors(got.detach().float().cpu().numpy(), ref)
+        assert l2 <= max(P.L2_BAR[dtype], 2e-6), (dtype, name, l2)
+    # dw_gated without gate_grad: dw scaled inside updat, no dg
+    tw2 = _t(torch, W, dtype).requires_grad_(True)
+    b(tx.detach(), tw2, gate=tg.detach(), dw_gated=True).backward(_t(torch, E, dtype))
+    l2, _ = P.errors(tw2.grad.float().cpu().numpy(), rnd(O.updat(t, X, E, 1, gate=g)))
+    assert l2 <= P.L2_BAR[dtype], l2
+    with pytest.raises(ValueError):
+        b.fprop(tx.detach(), tw.detach(), gate=tg.detach()[:-1])
