@@ -5,6 +5,7 @@
 
 #include "bsmm.h"
 #include "bsmm_plan.h"
+#include "bsmm_l2norm.h"
 #include "bsmm_updat.h"
 #include "bsmm_updat_tr.h"
 #include "bsmm_updat_win.h"
@@ -480,6 +481,30 @@ int updat_dt(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* 
 
 }  // namespace
 
+namespace {
+template <class F>
+int l2_by_types(int xd, int yd, int bsize, F&& f) {
+    auto with_bs = [&](auto tx, auto ty) {
+        switch (bsize) {
+            case 8: return f(tx, ty, std::integral_constant<int, 8>{});
+            case 16: return f(tx, ty, std::integral_constant<int, 16>{});
+            case 32: return f(tx, ty, std::integral_constant<int, 32>{});
+            default: return (int)BSMM_ERR_UNSUPPORTED;
+        }
+    };
+    auto with_y = [&](auto tx) {
+        if (yd == BSMM_F32) return with_bs(tx, DTf32{});
+        if (yd == BSMM_F16) return with_bs(tx, DTf16{});
+        if (yd == BSMM_BF16) return with_bs(tx, DTbf16{});
+        return (int)BSMM_ERR_UNSUPPORTED;
+    };
+    if (xd == BSMM_F32) return with_y(DTf32{});
+    if (xd == BSMM_F16) return with_y(DTf16{});
+    if (xd == BSMM_BF16) return with_y(DTbf16{});
+    return (int)BSMM_ERR_UNSUPPORTED;
+}
+}  // namespace
+
 extern "C" {
 
 int bsmm_fprop(const void* X, const void* W, void* Y, const bsmm_args* args) { return xprop(true, X, W, Y, args); }
@@ -503,6 +528,35 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
         case BSMM_BF16: return updat_dt<DTbf16>(xs, es, DW, a);
     }
     return BSMM_ERR_UNSUPPORTED;
+}
+
+int bsmm_l2_normalize(void* y, float* sum_sqr, const void* x, const float* gain, const int32_t* l2_lut, int32_t cols, int32_t bsize,
+                      int32_t x_dtype, int32_t y_dtype, float epsilon, void* stream) {
+    if (!y || !sum_sqr || !x || !l2_lut || cols <= 0) return BSMM_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(l2_lut) & 15) return BSMM_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return l2_by_types(x_dtype, y_dtype, bsize, [&](auto tx, auto ty, auto bs) {
+        typedef decltype(tx) TX;
+        typedef decltype(ty) TY;
+        l2_normalize_kernel<TX, TY, decltype(bs)::value><<<cols, 256, 0, st>>>(static_cast<typename TY::T*>(y), sum_sqr, static_cast<const typename TX::T*>(x),
+                                                                               gain, l2_lut, epsilon);
+        return (int)hipGetLastError();
+    });
+}
+
+int bsmm_l2_normalize_grad(void* dx, float* dgain, const void* dy, const void* x, const float* gain, const float* sum_sqr, const int32_t* l2_lut,
+                           int32_t cols, int32_t bsize, int32_t x_dtype, int32_t y_dtype, float epsilon, void* stream) {
+    if (!dx || !dy || !x || !sum_sqr || !l2_lut || cols <= 0) return BSMM_ERR_ARG;
+    if (gain && !dgain) return BSMM_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(l2_lut) & 15) return BSMM_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return l2_by_types(x_dtype, y_dtype, bsize, [&](auto tx, auto ty, auto bs) {
+        typedef decltype(tx) TX;
+        typedef decltype(ty) TY;
+        l2_normalize_grad_kernel<TX, TY, decltype(bs)::value><<<cols, 256, 0, st>>>(static_cast<typename TX::T*>(dx), dgain, static_cast<const typename TY::T*>(dy),
+                                                                                    static_cast<const typename TX::T*>(x), gain, sum_sqr, l2_lut, epsilon);
+        return (int)hipGetLastError();
+    });
 }
 
 int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const float* gate, int32_t blocks, int32_t bsize,

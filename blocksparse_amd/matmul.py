@@ -338,6 +338,74 @@ class BlocksparseMatMul(object):
                                               self.bsize, _dtype_code(dw.dtype), st), "bsmm_gate_grad")
         return out, dg
 
+    # ---- block-sparse L2 weight norm (blocksparse/matmul.py:421-453) ------------------------------
+    def l2_normalize(self, W, gain=None, epsilon=1e-12, dtype=None):
+        """y = gain * W / sqrt(max(sum of W^2 over each output feature, epsilon)) on the device, differentiable
+        (ops L2NormalizeCK / L2NormalizeGainCK and their registered gradients, blocksparse/matmul.py:447-453,529-553)."""
+        return _L2NormFunction.apply(W, gain, self, float(epsilon), dtype or W.dtype)
+
+    def _l2_tables(self, device):
+        key = ("l2", str(device))
+        t = self._l2_dev.get(key) if hasattr(self, "_l2_dev") else None
+        if t is None:
+            if not hasattr(self, "_l2_dev"):
+                self._l2_dev = {}
+            t = torch.from_numpy(np.ascontiguousarray(self.l2_lut)).to(device)
+            self._l2_dev[key] = t
+        return t
+
+    def _l2_fwd(self, W, gain, epsilon, y_dtype):
+        self._check_tensor(W, "W")
+        if tuple(W.shape) != self.w_shape:
+            raise ValueError("W must have shape %s" % (self.w_shape,))
+        W = W.contiguous()
+        if gain is not None:
+            if not (gain.is_cuda and gain.dtype == torch.float32 and gain.numel() == self.K):
+                raise ValueError("gain: expected a float32 CUDA tensor with K = %d entries" % self.K)
+            gain = gain.contiguous()
+        lut = self._l2_tables(W.device)
+        y = torch.empty(self.w_shape, dtype=y_dtype, device=W.device)
+        ss = torch.empty(self.K, dtype=torch.float32, device=W.device)
+        st = torch.cuda.current_stream(W.device).cuda_stream
+        _lib.check(_lib.load().bsmm_l2_normalize(y.data_ptr(), ss.data_ptr(), W.data_ptr(), gain.data_ptr() if gain is not None else None,
+                                                 lut.data_ptr(), self.KB, self.bsize, _dtype_code(W.dtype), _dtype_code(y_dtype), epsilon, st),
+                   "bsmm_l2_normalize")
+        return y, ss
+
+    def _l2_bwd(self, dy, W, gain, ss, epsilon):
+        dy = dy.contiguous()
+        lut = self._l2_tables(W.device)
+        dx = torch.empty_like(W)
+        dg = torch.empty(self.K, dtype=torch.float32, device=W.device) if gain is not None else None
+        st = torch.cuda.current_stream(W.device).cuda_stream
+        _lib.check(_lib.load().bsmm_l2_normalize_grad(dx.data_ptr(), dg.data_ptr() if dg is not None else None, dy.data_ptr(), W.data_ptr(),
+                                                      gain.data_ptr() if gain is not None else None, ss.data_ptr(), lut.data_ptr(), self.KB,
+                                                      self.bsize, _dtype_code(W.dtype), _dtype_code(dy.dtype), epsilon, st),
+                   "bsmm_l2_normalize_grad")
+        return dx, dg
+
+    def l2_normalize_test(self, W, epsilon=1e-12):
+        W = np.array(W, dtype=np.float64)
+        for k, col in self.fprop_list:
+            ws = [w for _, w in col]
+            if ws:
+                W2 = W[ws].reshape(-1, self.bsize)
+                W[ws] = W[ws] / np.sqrt(np.maximum(np.square(W2).sum(axis=0, keepdims=True), epsilon))
+        return W
+
+    def l2_normalize_grad_test(self, W, U, epsilon=1e-12):
+        W = np.asarray(W, dtype=np.float64)
+        U = np.array(U, dtype=np.float64)
+        for k, col in self.fprop_list:
+            ws = [w for _, w in col]
+            if ws:
+                W2, U2 = W[ws].reshape(-1, self.bsize), U[ws].reshape(-1, self.bsize)
+                ss = np.square(W2).sum(axis=0, keepdims=True)
+                mx = np.maximum(ss, epsilon)
+                g = (U2 + W2 * (ss >= epsilon) * (-U2 * W2 / mx).sum(axis=0, keepdims=True)) / np.sqrt(mx)
+                U[ws] = g.reshape(-1, self.bsize, self.bsize)
+        return U
+
     def prune(self, param, gate):
         """Drop the blocks whose gate is 0: returns (new_param, new_gate) and clears those blocks in ``self.layout``
         (blocksparse/matmul.py:272-290; as there, build a new BlocksparseMatMul from the pruned layout afterwards)."""
@@ -489,6 +557,20 @@ if torch is not None:
             dx = bsmm.bprop(dy, w) if ctx.needs_input_grad[0] else None
             dw = bsmm.updat(x, dy) if ctx.needs_input_grad[1] else None
             return dx, dw, None
+
+    class _L2NormFunction(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, W, gain, bsmm, epsilon, y_dtype):
+            y, ss = bsmm._l2_fwd(W, gain, epsilon, y_dtype)
+            ctx.bsmm, ctx.epsilon = bsmm, epsilon
+            ctx.save_for_backward(W, gain, ss)
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            W, gain, ss = ctx.saved_tensors
+            dx, dg = ctx.bsmm._l2_bwd(dy, W, gain, ss, ctx.epsilon)
+            return dx, dg, None, None, None
 
     class _BsmmGatedFunction(torch.autograd.Function):
         """y = bsmm(x, w, gate) with the registered gradient of the gated op (blocksparse/matmul.py:485-527): dx through the

@@ -104,6 +104,18 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
 int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const float* gate, int32_t blocks,
                    int32_t bsize, int32_t dtype, void* stream);
 
+/* Block-sparse L2 normalisation of W over each output feature (L2NormalizeCK / L2NormalizeGainCK and their gradients,
+ * src/blocksparse_l2_norm_op_gpu.cu:396-426,911-934; Python: blocksparse/matmul.py:421-453):
+ *   y = gain * x / sqrt(max(sum_sqr, eps)),  sum_sqr[k] = sum of x^2 over the rows of every block in k's column block.
+ * l2_lut: device table, header (offset, size, K, 0) per column block then weight ids (blocksparse/matmul.py:254-268);
+ * cols = number of headers (= K / bsize).  gain: fp32 [K] or NULL.  sum_sqr: fp32 [K], written by the forward call and
+ * read by the gradient.  x_dtype: type of x / dx, y_dtype: type of y / dy.  dgain may be NULL when gain is NULL. */
+int bsmm_l2_normalize(void* y, float* sum_sqr, const void* x, const float* gain, const int32_t* l2_lut, int32_t cols,
+                      int32_t bsize, int32_t x_dtype, int32_t y_dtype, float epsilon, void* stream);
+int bsmm_l2_normalize_grad(void* dx, float* dgain, const void* dy, const void* x, const float* gain, const float* sum_sqr,
+                           const int32_t* l2_lut, int32_t cols, int32_t bsize, int32_t x_dtype, int32_t y_dtype,
+                           float epsilon, void* stream);
+
 /* Host-only: derive the grouped-kernel schedule ("plan") from a reference-format xprop lut that lives in HOST
  * memory (the luts are constants of the layout: the reference builds them in NumPy, blocksparse/matmul.py:137-138).
  * n_out_blocks = K / bsize of the pass the lut belongs to; axis = feature axis the plan will be used with.  bsmm_xprop_plan_words returns the number of int32 words

@@ -263,6 +263,48 @@ def gate_grad(dw, W, gate):
     return dw * g[:, None, None], (dw * W).sum(axis=(1, 2))
 
 
+def l2_normalize(t, W, gain=None, epsilon=1e-12):
+    """(Y, sum_sqr): Y = gain * W / sqrt(max(sum_sqr, eps)), sum_sqr[k] over all rows of all blocks in k's column block
+    (l2_normalize_test, blocksparse/matmul.py:421-429; gain and the returned sums: l2_normalize_CK_32,
+    src/blocksparse_l2_norm_op_gpu.cu:151-235)."""
+    bs = t["bsize"]
+    W = np.asarray(W, dtype=np.float64)
+    Y = np.zeros_like(W)
+    S = np.zeros(t["K"])
+    for k, col in t["fprop_list"]:
+        ws = [w for _, w in col]
+        if not ws:
+            continue
+        W2 = W[ws].reshape(-1, bs)
+        ss = np.square(W2).sum(axis=0)
+        S[k * bs:(k + 1) * bs] = ss
+        g = 1.0 if gain is None else np.asarray(gain, dtype=np.float64)[k * bs:(k + 1) * bs]
+        Y[ws] = W[ws] * (g / np.sqrt(np.maximum(ss, epsilon)))
+    return Y, S
+
+
+def l2_normalize_grad(t, W, U, gain=None, epsilon=1e-12):
+    """(dW, dgain) (l2_normalize_grad_test, blocksparse/matmul.py:431-445; gain terms: the formula block at
+    src/blocksparse_l2_norm_op_gpu.cu:705-708)."""
+    bs = t["bsize"]
+    W = np.asarray(W, dtype=np.float64)
+    U = np.asarray(U, dtype=np.float64)
+    D = np.zeros_like(W)
+    DG = np.zeros(t["K"])
+    for k, col in t["fprop_list"]:
+        ws = [w for _, w in col]
+        if not ws:
+            continue
+        W2, U2 = W[ws].reshape(-1, bs), U[ws].reshape(-1, bs)
+        g = np.ones(bs) if gain is None else np.asarray(gain, dtype=np.float64)[k * bs:(k + 1) * bs]
+        ss = np.square(W2).sum(axis=0)
+        mx = np.maximum(ss, epsilon)
+        red = (-(U2 * g) * W2 / mx).sum(axis=0) * (ss >= epsilon)
+        D[ws] = (((U2 * g) + W2 * red) / np.sqrt(mx)).reshape(-1, bs, bs)
+        DG[k * bs:(k + 1) * bs] = (U2 * W2 / np.sqrt(mx)).sum(axis=0)
+    return D, DG
+
+
 def to_dense(t, W):
     bs = t["bsize"]
     Wd = np.zeros((t["C"], t["K"]), dtype=np.float64)

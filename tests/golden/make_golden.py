@@ -146,6 +146,33 @@ def main_gate():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def main_l2():
+    """l2norm.npz: the reference's l2_normalize_test / l2_normalize_grad_test (blocksparse/matmul.py:421-445); inputs are
+    regenerated by the tests with cfg0_inputs (W) and RandomState(seed + 1) (U)."""
+    mm = import_reference_matmul()
+    holes = ba_layout(16, 2, seed=3)
+    holes[:, 5] = 0
+    holes[7, :] = 0
+    rng0 = np.random.default_rng(1234)
+    rect = (rng0.random((6, 10)) < 0.3).astype(np.int32)
+    rect[0, :] = 1
+    rect[:, 0] = 1
+    out = {}
+    for name, lay, bs, seed in (("holes", holes, 32, 41), ("holes", holes, 8, 42), ("rect", rect, 16, 43)):
+        b = mm.BlocksparseMatMul(lay, block_size=bs, feature_axis=0)
+        W, _, _ = cfg0_inputs(b.w_shape, (1, 1), (1, 1), seed)
+        W[0, :, 0] = 0.0                                   # (only reaches the epsilon branch if block 0 is alone in its column)
+        U = np.random.RandomState(seed + 1).normal(0.0, 1.0, b.w_shape).astype(np.float16).astype(np.float32)
+        key = "%s/bs%d/" % (name, bs)
+        out[key + "layout"] = np.asarray(lay, dtype=np.uint8)
+        out[key + "meta"] = np.array([bs, seed], dtype=np.int64)
+        out[key + "Y"] = b.l2_normalize_test(W.astype(np.float64)).astype(np.float32)
+        out[key + "DW"] = b.l2_normalize_grad_test(W.astype(np.float64), U.astype(np.float64).copy()).astype(np.float32)
+    path = os.path.join(HERE, "l2norm.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     mm = import_reference_matmul()
 
@@ -201,5 +228,7 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "gate":
         main_gate()
+    elif len(sys.argv) > 1 and sys.argv[1] == "l2":
+        main_l2()
     else:
         main()

@@ -19,7 +19,7 @@ def lib():
 
 def test_header_symbols_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "bsmm.h")).read()
-    declared = set(re.findall(r"\b(bsmm_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(bsmm_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"bsmm_args", "bsmm_params"}
     assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
     L = lib.load()
