@@ -368,8 +368,16 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
 //           lane's column: 16 ds_read_b32 of 128 contiguous bytes per half wave; rows 16..31 / 48..63 are stored with
 //           address bit 7 flipped so that the two half waves hit different banks.
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef BSMM_XF_PH
+#define BSMM_XF_PH 2
+#endif
+constexpr int XF_PH = BSMM_XF_PH;                   // steps per phase
+constexpr int XF_RING = 2 * XF_PH;
 constexpr int XF_SLAB = XC_R * 256;                 // 32 KiB (either axis)
-constexpr int XF_LDS = XC_RING * XF_SLAB;           // 128 KiB = the axis-1 epilogue tile [128 rows][8 blocks x 128 B]
+constexpr int XF_LDS = XF_RING * XF_SLAB;           // 128 KiB = the axis-1 epilogue tile [128 rows][8 blocks x 128 B].  (XF_PH = 1:
+                                                    // 64 KiB, two workgroups per CU at 88 VGPRs, epilogue staged in two
+                                                    // halves -- measured SLOWER, 0.80 vs 0.645 ms: a barrier per step and
+                                                    // twice the groups competing for L2.)
 constexpr int XF_NI = XF_SLAB / 1024 / XC_G;        // DMA instructions per wave per slab
 
 template <int AXIS>
@@ -456,18 +464,18 @@ xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, floa
     wc.zero(); wn.zero();
     if (cur.x >= 0) load_w(cur.x, wc);
 #pragma unroll
-    for (int u = 0; u < XC_PH; ++u)
+    for (int u = 0; u < XF_PH; ++u)
         if (u < nsteps) issue_x(pairs[u], u);
-    for (int s = 0; s < nsteps; s += XC_PH) {
+    for (int s = 0; s < nsteps; s += XF_PH) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < XC_PH; ++u)
-            if (s + XC_PH + u < nsteps) issue_x(pairs[s + XC_PH + u], (s + XC_PH + u) % XC_RING);
-        while ((cur.y >> 3) < s + XC_PH) {
+        for (int u = 0; u < XF_PH; ++u)
+            if (s + XF_PH + u < nsteps) issue_x(pairs[s + XF_PH + u], (s + XF_PH + u) % XF_RING);
+        while ((cur.y >> 3) < s + XF_PH) {
             if (nxt.x >= 0) load_w(nxt.x, wn);
             const int2 nn = fetch(e + 2);
-            const unsigned char* slab = smem + ((cur.y >> 3) % XC_RING) * XF_SLAB;
+            const unsigned char* slab = smem + ((cur.y >> 3) % XF_RING) * XF_SLAB;
             Frag32<DT> xf;
             load_x(slab, cur.y & 1, xf);
             switch ((cur.y >> 1) & 3) {
@@ -483,27 +491,35 @@ xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, floa
     if constexpr (AXIS == 1) {
         // D[o][n]: col = n = r, rows o = (reg & 3) + 8 * (reg >> 2) + 4h: 4 consecutive o = one 16-byte piece.
         // Staged as [128 rows][1024 B] (pieces XOR-swizzled with n & 63) and stored as full rows.
-        __syncthreads();
-        const int n = 32 * tw + r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (4 * cls + j < nob) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int piece = (4 * cls + j) * 8 + 2 * g + h;
-                    *reinterpret_cast<float4*>(smem + n * 1024 + ((piece ^ (n & 63)) << 4)) =
-                        make_float4(acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-                }
-            }
-        }
-        __syncthreads();
+        constexpr int HALF = XF_LDS >= XC_R * 1024 ? 1 : 2;       // staging passes (rows per pass = XC_R / HALF)
+        constexpr int ROWS = XC_R / HALF;
+        static_assert(ROWS * 1024 <= XF_LDS, "staging tile must fit");
         const int rowbytes = nob * 128;
         float* ybase = Y + (size_t)ob0 * 32;
-        for (int i = threadIdx.x; i < XC_R * 64; i += 512) {
-            const int nn = i >> 6, piece = i & 63;
-            if (n_tile + nn < N && piece * 16 < rowbytes) {
-                const float4 v = *reinterpret_cast<const float4*>(smem + nn * 1024 + ((piece ^ (nn & 63)) << 4));
-                *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)(n_tile + nn) * Kout) + piece * 16) = v;
+#pragma unroll
+        for (int hp = 0; hp < HALF; ++hp) {
+            __syncthreads();
+            const int n = 32 * tw + r - hp * ROWS;               // row inside this pass
+            if (n >= 0 && n < ROWS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (4 * cls + j < nob) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int piece = (4 * cls + j) * 8 + 2 * g + h;
+                            *reinterpret_cast<float4*>(smem + n * 1024 + ((piece ^ (n & 63)) << 4)) =
+                                make_float4(acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < ROWS * 64; i += 512) {
+                const int nn = i >> 6, piece = i & 63, row = n_tile + hp * ROWS + nn;
+                if (row < N && piece * 16 < rowbytes) {
+                    const float4 v = *reinterpret_cast<const float4*>(smem + nn * 1024 + ((piece ^ (nn & 63)) << 4));
+                    *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)row * Kout) + piece * 16) = v;
+                }
             }
         }
     } else {
