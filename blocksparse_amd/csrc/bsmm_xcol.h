@@ -123,6 +123,16 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
 #ifdef BSMM_XC_BATCH
         __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef BSMM_XC_SGB
+        // software pipeline inside the block: BSMM_XC_SGB reads ahead, then one read per MFMA, then the remaining MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, BSMM_XC_SGB, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * XC_RT - BSMM_XC_SGB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, BSMM_XC_SGB, 0);
+#endif
     };
 
     // Phases of XC_PH steps, one barrier per phase, ring of 2*XC_PH slabs.  At the phase barrier both slabs of the phase have

@@ -113,7 +113,7 @@ static int bst_xn(const void* s_, const void* b_, void* c_, const bst_args* a, b
                 if constexpr (BS >= 32) {
                     constexpr int SUB = BS / 32;
                     const int nct = (a->head_state + 31) / 32;
-                    const int grid = xcd_head_grid((ctx_c * SUB * nct + 3) / 4, a->heads, a->batch);
+                    const int grid = xcd_head_grid(ctx_c * SUB * nct, a->heads, a->batch);
                     bst_xn_mfma_kernel<TS, TB, BS, TR><<<grid, 256, 0, st>>>(S, B, C, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, ctx_c, rb, rc_);
                 } else {
                     dim3 grid(ctx_c, a->heads, a->batch);

@@ -62,6 +62,8 @@ __device__ __forceinline__ bool xcd_head_map(int G, int heads, int batch, int& n
 }
 inline int xcd_head_grid(int G, int heads, int batch, int il = 1) { const int per = (heads * batch + 7) / 8; return 8 * ((per + il - 1) / il) * il * G; }
 
+// (Raising the wave priority around the MFMA phase, which helps a bare LDS-fed MFMA loop by 10 % in
+// scripts/micro/mfma_lds_chain.hip, made nn / tn slower here: 0.24 vs 0.20 ms.)
 __device__ __forceinline__ void mma32_f32(const float (&a)[16], const float (&b)[16], f32x16& acc) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
@@ -266,8 +268,9 @@ bst_nt_mfma_direct_kernel(const typename TA::T* __restrict__ A, const typename T
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// nn (TRANS = false) / tn (TRANS = true): one wave per (output block, 32-row sub tile, 32-feature tile).
-// grid (ceil(ctx_c * SUB * NCT / 4), heads, batch), 256 threads.  lut = nn_lut / tn_lut (header + entries).
+// nn (TRANS = false) / tn (TRANS = true): one WORKGROUP per (output block, 32-row sub tile, 32-feature tile); its four waves
+// take every fourth step of the block list (rows of a causal layout have 1 .. nn_max blocks: one wave per tile left the
+// longest rows as a serial chain) and reduce through LDS.  lut = nn_lut / tn_lut (header + entries).
 // ------------------------------------------------------------------------------------------------------------------
 template <class TS, class TB, int BS, bool TRANS>
 __global__ void __launch_bounds__(256)
@@ -277,10 +280,8 @@ bst_xn_mfma_kernel(const typename TS::T* __restrict__ S, const typename TB::T* _
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int nct = (hs + 31) / 32;
-    int n, h, wg;
-    if (!xcd_head_map((ctx_c * SUB * nct + 3) / 4, heads, batch, n, h, wg)) return;
-    const int wid = wg * 4 + wave;
-    if (wid >= ctx_c * SUB * nct) return;
+    int n, h, wid;
+    if (!xcd_head_map(ctx_c * SUB * nct, heads, batch, n, h, wid)) return;      // one output tile per workgroup, 4 waves split its steps
     const int ct = wid % nct, ts = (wid / nct) % SUB, oc = wid / (nct * SUB);
     const int32_t* hl = lut + (size_t)h * lut_stride;
     const int2 hdr = *reinterpret_cast<const int2*>(hl + 2 * oc);
@@ -292,30 +293,73 @@ bst_xn_mfma_kernel(const typename TS::T* __restrict__ S, const typename TB::T* _
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int e = 0; e < hdr.y; ++e) {
+    // Steps q = (entry, 32-wide slice of the contraction index); the operands of step q+1 are requested before the 16 MFMAs
+    // of step q, so a wave's chain over its (up to nn_max) entries is bound by max(load latency, MFMA time) per step instead
+    // of their sum (the longest rows set the kernel time: causal layouts have rows of 1 .. nn_max blocks).
+    constexpr int NRA = TRANS ? 16 : (TS::is16 ? 2 : 4);                          // raw A registers (16-byte units or single elements)
+    uint4 ra4[TRANS ? 1 : NRA];
+    typename TS::T ra1[TRANS ? 16 : 1];
+    typename TB::T rb[16];
+    const int nsteps = hdr.y * SUB;
+    auto request = [&](int q) {
+        const int e = q / SUB, tk = q % SUB;
         const int2 ent = *reinterpret_cast<const int2*>(hl + 2 * (hdr.x + e));     // (block id, other-side block)
         const typename TS::T* sb = sbase + (size_t)ent.x * (BS * BS);
+        if constexpr (!TRANS) {       // A[i][j] = S_b[32ts + i][32tk + j], j = 16hh + t: contiguous
+            const typename TS::T* p = sb + (size_t)(32 * ts + r) * BS + 32 * tk + 16 * hh;
 #pragma unroll
-        for (int tk = 0; tk < SUB; ++tk) {
-            float fa[16], fb[16];
-            if constexpr (!TRANS) {       // A[i][j] = S_b[32ts + i][32tk + j], j = 16hh + t: contiguous
-                load16_f32<TS>(sb + (size_t)(32 * ts + r) * BS + 32 * tk + 16 * hh, 0, 16, fa);
-            } else {                      // A[j][i] = S_b[32tk + i][32ts + j], i = 16hh + t: stride BS (lanes walk j)
+            for (int g = 0; g < NRA; ++g) ra4[g] = *reinterpret_cast<const uint4*>(p + g * (16 / sizeof(typename TS::T)));
+        } else {                      // A[j][i] = S_b[32tk + i][32ts + j], i = 16hh + t: stride BS (lanes walk j)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) fa[t] = TS::to_f32(sb[(size_t)(32 * tk + 16 * hh + t) * BS + 32 * ts + r]);
-            }
-            const typename TB::T* bp = bcol + ((size_t)ent.y * BS + 32 * tk + 16 * hh) * state;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) fb[t] = cvalid ? TB::to_f32(bp[(size_t)t * state]) : 0.f;
-            mma32_f32(fa, fb, acc);
+            for (int t = 0; t < 16; ++t) ra1[t] = sb[(size_t)(32 * tk + 16 * hh + t) * BS + 32 * ts + r];
         }
+        const typename TB::T* bp = bcol + ((size_t)ent.y * BS + 32 * tk + 16 * hh) * state;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) rb[t] = cvalid ? bp[(size_t)t * state] : (typename TB::T)0;
+    };
+    if (wave < nsteps) request(wave);
+    for (int q = wave; q < nsteps; q += 4) {
+        float fa[16], fb[16];
+        if constexpr (!TRANS) {
+            if constexpr (TS::is16) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const uint32_t w[4] = {ra4[g].x, ra4[g].y, ra4[g].z, ra4[g].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        fa[8 * g + 2 * i] = TS::to_f32((uint16_t)(w[i] & 0xffffu));
+                        fa[8 * g + 2 * i + 1] = TS::to_f32((uint16_t)(w[i] >> 16));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    fa[4 * g] = __builtin_bit_cast(float, ra4[g].x); fa[4 * g + 1] = __builtin_bit_cast(float, ra4[g].y);
+                    fa[4 * g + 2] = __builtin_bit_cast(float, ra4[g].z); fa[4 * g + 3] = __builtin_bit_cast(float, ra4[g].w);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) fa[t] = TS::to_f32(ra1[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) fb[t] = TB::to_f32(rb[t]);
+        if (q + 4 < nsteps) request(q + 4);
+        mma32_f32(fa, fb, acc);
     }
+    // the four partial tiles meet in LDS; wave w then owns registers 4w .. 4w+3 (rows 8w + {0..3} + 4hh) of the sum
+    __shared__ float red[4][16][64];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[wave][reg][lane] = acc[reg];
+    __syncthreads();
     if (!cvalid) return;
     typename TB::T* out = C + ((size_t)n * rows_c + (size_t)oc * BS + 32 * ts) * state + (size_t)h * hs + c;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
+    for (int i = 0; i < 4; ++i) {
+        const int reg = 4 * wave + i;
+        const float v = red[0][reg][lane] + red[1][reg][lane] + red[2][reg][lane] + red[3][reg][lane];
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-        out[(size_t)row * state] = TB::from_f32(acc[reg]);
+        out[(size_t)row * state] = TB::from_f32(v);
     }
 }
 
