@@ -146,7 +146,7 @@ template <int AXIS>
 int launch_xcol32f(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     const int n_out = a->K / 32;
     XMap m;
-    m.ntiles = (a->N + XC_R - 1) / XC_R;
+    m.ntiles = (a->N + XF_R - 1) / XF_R;
     m.segments = (n_out + XC_G - 1) / XC_G;
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
@@ -251,7 +251,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         if (variant == 3 && !(AXIS == 0 && (a->N % 8 != 0))) enough = true;
     }
     if (BS == 32 && a->plan != nullptr && !DT::is16) {   // fp32: xcol32f (axis 0 needs 16-byte aligned row pieces: N % 4 == 0)
-        enough = use_xcol() && (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
+        enough = use_xcol() && (long)((a->N + XF_R - 1) / XF_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
         if (variant == 3 && use_xcol()) enough = true;
         if (AXIS == 0 && (a->N % 4 != 0)) enough = false;
     }

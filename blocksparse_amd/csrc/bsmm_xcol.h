@@ -381,9 +381,14 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
 #ifndef BSMM_XF_PH
 #define BSMM_XF_PH 2
 #endif
+#ifndef BSMM_XF_RT
+#define BSMM_XF_RT 1
+#endif
 constexpr int XF_PH = BSMM_XF_PH;                   // steps per phase
 constexpr int XF_RING = 2 * XF_PH;
-constexpr int XF_SLAB = XC_R * 256;                 // 32 KiB (either axis)
+constexpr int XF_RT = BSMM_XF_RT;                   // 32-row tiles per wave (each for 4 output blocks)
+constexpr int XF_R = 128 * XF_RT;                   // minibatch rows per workgroup
+constexpr int XF_SLAB = XF_R * 256;                 // 32 KiB per 128 rows (either axis)
 constexpr int XF_LDS = XF_RING * XF_SLAB;           // 128 KiB = the axis-1 epilogue tile [128 rows][8 blocks x 128 B].  (XF_PH = 1:
                                                     // 64 KiB, two workgroups per CU at 88 VGPRs, epilogue staged in two
                                                     // halves -- measured SLOWER, 0.80 vs 0.645 ms: a barrier per step and
@@ -407,7 +412,7 @@ xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, floa
     const int tw = wave & 3, cls = wave >> 2;
     const int2* ent = reinterpret_cast<const int2*>(plan + plan[7]) + gh[4 + 2 * cls];
     const int r = lane & 31, h = lane >> 5;
-    const int n_tile = tile * XC_R;
+    const int n_tile = tile * XF_R;
     const uint32_t base_addr = lds_addr_of(smem);
     const int npairs_full = Cin / 64;
 
@@ -419,10 +424,11 @@ xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, floa
             const int row = 4 * (XF_NI * wave + i) + (lane >> 4);
             srow[i] = (size_t)min(n_tile + row, N - 1) * Cin;
             scol[i] = ((lane & 15) ^ (row & 15)) * 4;              // element offset of the source piece inside the pair
-        } else {                       // 2 feature rows of 512 B per instruction
-            const int row = 2 * (XF_NI * wave + i) + (lane >> 5);
+        } else {                       // feature rows of XF_R * 4 bytes: 1024 / that many rows per instruction
+            constexpr int LPR = XF_R / 4;                              // lanes (16-byte pieces) per row: 32 or 64
+            const int row = (64 / LPR) * (XF_NI * wave + i) + lane / LPR;
             srow[i] = row;
-            scol[i] = min(n_tile + (((lane & 31) ^ (8 * ((row >> 4) & 1))) * 4), N - 4);
+            scol[i] = min(n_tile + (((lane % LPR) ^ (8 * ((row >> 4) & 1))) * 4), N - 4);
         }
     }
     auto issue_x = [&](int p, int pos) {
@@ -439,16 +445,18 @@ xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, floa
         }
     };
 
-    f32x16 acc[4];
+    f32x16 acc[4][XF_RT];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        for (int u = 0; u < XF_RT; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][u][i] = 0.f;
 
     auto load_w = [&](int w, Frag32<DT>& f) { f.load_contig(Wsel + (size_t)w * 1024 + r * 32, h); };
-    auto load_x = [&](const unsigned char* slab, int half, Frag32<DT>& xf) {
+    auto load_x = [&](const unsigned char* slab, int half, int u, Frag32<DT>& xf) {      // tile XF_RT * tw + u of the workgroup
         if constexpr (AXIS == 1) {
-            const int row = 32 * tw + r;
+            const int row = 32 * (XF_RT * tw + u) + r;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 v = *reinterpret_cast<const float4*>(slab + row * 256 + (((8 * half + 4 * h + g) ^ (row & 15)) << 4));
@@ -457,7 +465,7 @@ xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, floa
         } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k)
-                xf.v[k] = *reinterpret_cast<const float*>(slab + (32 * half + 16 * h + k) * 512 + (((32 * tw + r) * 4) ^ (128 * h)));
+                xf.v[k] = *reinterpret_cast<const float*>(slab + (32 * half + 16 * h + k) * (XF_R * 4) + (((32 * (XF_RT * tw + u) + r) * 4) ^ (128 * h)));
         }
     };
 
@@ -486,13 +494,16 @@ xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, floa
             if (nxt.x >= 0) load_w(nxt.x, wn);
             const int2 nn = fetch(e + 2);
             const unsigned char* slab = smem + ((cur.y >> 3) % XF_RING) * XF_SLAB;
-            Frag32<DT> xf;
-            load_x(slab, cur.y & 1, xf);
-            switch ((cur.y >> 1) & 3) {
-                case 0: mma32<DT>(wc, xf, acc[0]); break;
-                case 1: mma32<DT>(wc, xf, acc[1]); break;
-                case 2: mma32<DT>(wc, xf, acc[2]); break;
-                default: mma32<DT>(wc, xf, acc[3]); break;
+#pragma unroll
+            for (int u = 0; u < XF_RT; ++u) {
+                Frag32<DT> xf;
+                load_x(slab, cur.y & 1, u, xf);
+                switch ((cur.y >> 1) & 3) {
+                    case 0: mma32<DT>(wc, xf, acc[0][u]); break;
+                    case 1: mma32<DT>(wc, xf, acc[1][u]); break;
+                    case 2: mma32<DT>(wc, xf, acc[2][u]); break;
+                    default: mma32<DT>(wc, xf, acc[3][u]); break;
+                }
             }
             wc = wn; cur = nxt; nxt = nn; ++e;
         }
@@ -501,24 +512,27 @@ xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, floa
     if constexpr (AXIS == 1) {
         // D[o][n]: col = n = r, rows o = (reg & 3) + 8 * (reg >> 2) + 4h: 4 consecutive o = one 16-byte piece.
         // Staged as [128 rows][1024 B] (pieces XOR-swizzled with n & 63) and stored as full rows.
-        constexpr int HALF = XF_LDS >= XC_R * 1024 ? 1 : 2;       // staging passes (rows per pass = XC_R / HALF)
-        constexpr int ROWS = XC_R / HALF;
-        static_assert(ROWS * 1024 <= XF_LDS, "staging tile must fit");
+        constexpr int ROWS = (XF_LDS / 1024 < XF_R) ? XF_LDS / 1024 : XF_R;       // rows staged per pass
+        constexpr int PASSES = XF_R / ROWS;
+        static_assert(ROWS % 32 == 0 && PASSES * ROWS == XF_R, "staging passes must cover whole tiles");
         const int rowbytes = nob * 128;
         float* ybase = Y + (size_t)ob0 * 32;
 #pragma unroll
-        for (int hp = 0; hp < HALF; ++hp) {
+        for (int hp = 0; hp < PASSES; ++hp) {
             __syncthreads();
-            const int n = 32 * tw + r - hp * ROWS;               // row inside this pass
-            if (n >= 0 && n < ROWS) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (4 * cls + j < nob) {
+            for (int u = 0; u < XF_RT; ++u) {
+                const int n = 32 * (XF_RT * tw + u) + r - hp * ROWS;               // row inside this pass
+                if (n >= 0 && n < ROWS) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int piece = (4 * cls + j) * 8 + 2 * g + h;
-                            *reinterpret_cast<float4*>(smem + n * 1024 + ((piece ^ (n & 63)) << 4)) =
-                                make_float4(acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (4 * cls + j < nob) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int piece = (4 * cls + j) * 8 + 2 * g + h;
+                                *reinterpret_cast<float4*>(smem + n * 1024 + ((piece ^ (n & 63)) << 4)) =
+                                    make_float4(acc[j][u][4 * g + 0], acc[j][u][4 * g + 1], acc[j][u][4 * g + 2], acc[j][u][4 * g + 3]);
+                            }
                         }
                     }
                 }
@@ -533,15 +547,18 @@ xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, floa
             }
         }
     } else {
-        const int n = n_tile + 32 * tw + r;
-        if (n < N) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (4 * cls + j < nob) {
+        for (int u = 0; u < XF_RT; ++u) {
+            const int n = n_tile + 32 * (XF_RT * tw + u) + r;
+            if (n < N) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int o = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                        Y[(size_t)((ob0 + 4 * cls + j) * 32 + o) * N + n] = acc[j][reg];
+                for (int j = 0; j < 4; ++j) {
+                    if (4 * cls + j < nob) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int o = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                            Y[(size_t)((ob0 + 4 * cls + j) * 32 + o) * N + n] = acc[j][u][reg];
+                        }
                     }
                 }
             }
