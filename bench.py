@@ -103,9 +103,17 @@ def attention_extra(a):
                      "bound_ms": round(bound, 4), "frac": round(bound / ms, 4)}
     # forward + backward of one attention layer = nt, softmax, nn | tn(dv), nt(dp), softmax_grad, nn(dq), tn(dk)
     fb = res["nt"]["ms"] * 2 + res["masked_softmax"]["ms"] + res["softmax_grad"]["ms"] + res["nn"]["ms"] * 2 + res["tn"]["ms"] * 2
+    # the same operators with bf16 activations (native 16-bit MFMA, HBM-bound): not the BASELINE configuration, for reference
+    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    res16 = {}
+    for name, fn in (("nt", lambda: bst._nt(qb, kb, sd)), ("nn", lambda: bst._xn(p, vb, False)), ("tn", lambda: bst._xn(p, qb, True))):
+        ms = timeit(fn)
+        by = 2 * qb.numel() * 2 + sbytes
+        res16[name] = {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2), "gbps": round(by / ms / 1e6, 1), "bound": "hbm",
+                       "bound_ms": round(by / (PEAK_HBM * 1e9) * 1e3, 4), "frac": round(by / (PEAK_HBM * 1e9) * 1e3 / ms, 4)}
     out = {"workload": "BASELINE configs[4]: block-sparse attention batch %d heads %d x %d ctx %d bsize %d, %d blocks/head, fp32 activations, bf16 scores"
                        % (B, H, HS, CTX * BS, BS, bst.blocks),
-           "ops": res, "fwd_bwd_ms": round(fb, 4), "fwd_bwd_tflops": round(6 * flops / fb / 1e9, 2)}
+           "ops": res, "fwd_bwd_ms": round(fb, 4), "fwd_bwd_tflops": round(6 * flops / fb / 1e9, 2), "ops_bf16_activations": res16}
     if not a.no_cpu_baseline:
         L = O.build_luts(lay)
         qc, kc, vc = (t[:1, :, :2 * HS].float().cpu().numpy() for t in (q, k, v))

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "bst.h"
 #include "bst_kernels.h"
@@ -110,6 +111,14 @@ static int bst_xn(const void* s_, const void* b_, void* c_, const bst_args* a, b
             const int rb = ctx_b * BS, rc_ = ctx_c * BS;
             auto launch = [&](auto tr) {
                 constexpr bool TR = decltype(tr)::value;
+                if constexpr (BS >= 32 && TB::is16 && std::is_same<TB, TS>::value) {   // 16-bit scores and activations of one type: native 16-bit MFMA
+                    if (a->head_state % 32 == 0) {
+                        constexpr int SUB16 = BS / 32;
+                        const int grid16 = xcd_head_grid(ctx_c * SUB16 * (a->head_state / 32), a->heads, a->batch);
+                        bst_xn_mfma16_kernel<TB, BS, TR><<<grid16, 256, 0, st>>>(S, B, C, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, ctx_c, rb, rc_);
+                        return;
+                    }
+                }
                 if constexpr (BS >= 32) {
                     constexpr int SUB = BS / 32;
                     const int nct = (a->head_state + 31) / 32;

@@ -18,6 +18,7 @@
 #pragma once
 #include "bsmm_common.h"
 #include "bsmm_xgroup.h"   // glds16_asm, lds_addr_of
+#include "bsmm_updat_tr.h" // ds_tr16
 
 namespace bsmm {
 
@@ -193,11 +194,23 @@ bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* _
         const int tb = tb0 + it;
         if (tb >= ntiles) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this tile's DMAs have landed
-        float fk[NCH][16], fq[NCH][16];
+        // fp32 activations: fragments of 16 floats for v_mfma_f32_32x32x2_f32.  16-bit activations: the raw 16-byte pieces ARE the
+        // operands of v_mfma_f32_32x32x16_{f16,bf16} (q[0]: k = 8hh + j -> piece hh, q[1]: k = 16 + 8hh + j -> piece 2 + hh)
+        float fk[TA::is16 ? 1 : NCH][16], fq[TA::is16 ? 1 : NCH][16];
+        uint4 rk[TA::is16 ? NCH : 1][2], rq[TA::is16 ? NCH : 1][2];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            frag(&lds[0][c][0], fk[c]);
-            frag(&lds[1][c][0], fq[c]);
+            if constexpr (TA::is16) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int off = r * TL::ROWB + (((2 * kk + hh) ^ TL::sw(r)) << 4);
+                    rk[c][kk] = *reinterpret_cast<const uint4*>(&lds[0][c][0] + off);
+                    rq[c][kk] = *reinterpret_cast<const uint4*>(&lds[1][c][0] + off);
+                }
+            } else {
+                frag(&lds[0][c][0], fk[c]);
+                frag(&lds[1][c][0], fq[c]);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // fragments are in registers: the buffers are free
         const bool more = it + 1 < NT_NB && tb + 1 < ntiles;
@@ -213,7 +226,15 @@ bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* _
         f32x16 acc, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc1[i] = 0.f; }
-        if constexpr (NCH >= 2) {
+        if constexpr (TA::is16) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                acc = TA::mfma32(rk[c][0], rq[c][0], acc);
+                acc1 = TA::mfma32(rk[c][1], rq[c][1], acc1);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
+        } else if constexpr (NCH >= 2) {
 #pragma unroll
             for (int c = 0; c < NCH; c += 2)
 #pragma unroll
@@ -360,6 +381,96 @@ bst_xn_mfma_kernel(const typename TS::T* __restrict__ S, const typename TB::T* _
         const float v = red[0][reg][lane] + red[1][reg][lane] + red[2][reg][lane] + red[3][reg][lane];
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
         out[(size_t)row * state] = TB::from_f32(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// nn / tn with 16-bit scores AND 16-bit activations (the reference's fp16 tensor-core pathway, bst_hgemm_xn,
+// src/bst_hgemm_op_gpu.cu): v_mfma_f32_32x32x16_{f16,bf16}, no widening.  Same decomposition as bst_xn_mfma_kernel
+// (workgroup = output tile, waves split the steps, LDS reduction).  The operand whose contraction index is its ROW
+// index (the activation tile always; the score block too for tn) is staged as a plain [32 rows][64 B] LDS image by
+// LDS-DMA and read with ds_read_b64_tr_b16 (lane t of a 16-lane group receives column t of the 4 x 16 patch its group
+// points at: profiles/r01_tr_probe.log); the nn score fragment is two contiguous 16-byte loads.  Needs head_state % 32 == 0.
+// ------------------------------------------------------------------------------------------------------------------
+template <class T16, int BS, bool TRANS>
+__global__ void __launch_bounds__(256)
+bst_xn_mfma16_kernel(const typename T16::T* __restrict__ S, const typename T16::T* __restrict__ Bm, typename T16::T* __restrict__ C,
+                     const int32_t* __restrict__ lut, int lut_stride, int blocks, int heads, int batch, int hs, int ctx_c, int rows_b, int rows_c) {
+    typedef typename T16::T T;
+    constexpr int SUB = BS / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char tiles[4][2][2][2048];     // [wave][buffer][B tile | S tile]
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int nct = hs / 32;
+    int n, h, wid;
+    if (!xcd_head_map(ctx_c * SUB * nct, heads, batch, n, h, wid)) return;
+    const int ct = wid % nct, ts = (wid / nct) % SUB, oc = wid / (nct * SUB);
+    const int32_t* hl = lut + (size_t)h * lut_stride;
+    const int2 hdr = *reinterpret_cast<const int2*>(hl + 2 * oc);
+    const size_t state = (size_t)heads * hs;
+    const T* sbase = S + ((size_t)n * heads + h) * blocks * (BS * BS);
+    const T* bbase = Bm + (size_t)n * rows_b * state + (size_t)h * hs + 32 * ct;
+    const int drow = lane >> 2, dpiece = lane & 3;                                   // DMA: 16 rows x 64 B per instruction
+    const int g16 = lane >> 4, t16 = lane & 15;
+    const int rd_base = (t16 >> 2) * 64 + (16 * (g16 & 1) + 4 * (t16 & 3)) * 2;      // transposing read, see bsmm_updat_tr.h
+    const uint32_t my_lds = lds_addr_of(&tiles[wave][0][0][0]);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nsteps = hdr.y * SUB;
+    uint4 sa[2];                                                                      // nn: score fragment of the step in flight
+    auto request = [&](int q, int buf) {
+        const int e = q / SUB, tk = q % SUB;
+        const int2 ent = *reinterpret_cast<const int2*>(hl + 2 * (hdr.x + e));      // (block id, other-side block)
+        const T* bt = bbase + ((size_t)ent.y * BS + 32 * tk) * state;               // 32 rows (contraction index) x 32 features
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(my_lds + buf * 4096);
+        glds16_asm(bt + (size_t)drow * state + dpiece * 8, dst);
+        glds16_asm(bt + (size_t)(16 + drow) * state + dpiece * 8, dst + 1024);
+        const T* sb = sbase + (size_t)ent.x * (BS * BS);
+        if constexpr (TRANS) {        // rows i = contraction index 32tk.., features j = 32ts..: [32][32] patch of the score block
+            const T* st = sb + (size_t)(32 * tk) * BS + 32 * ts;
+            glds16_asm(st + (size_t)drow * BS + dpiece * 8, dst + 2048);
+            glds16_asm(st + (size_t)(16 + drow) * BS + dpiece * 8, dst + 3072);
+        } else {                      // A[i][j] = S_b[32ts + i][32tk + j]: k = j contiguous per lane
+            const T* p = sb + (size_t)(32 * ts + r) * BS + 32 * tk + 8 * hh;
+            sa[0] = *reinterpret_cast<const uint4*>(p);
+            sa[1] = *reinterpret_cast<const uint4*>(p + 16);
+        }
+    };
+    auto tr_frag = [&](const unsigned char* tile, uint4 (&f)[2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned char* sp = tile + (16 * kk + 8 * hh) * 64 + rd_base;
+            const uint2 lo = ds_tr16(sp), hi = ds_tr16(sp + 4 * 64);
+            f[kk] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    };
+    if (wave < nsteps) request(wave, 0);
+    int buf = 0;
+    for (int q = wave; q < nsteps; q += 4) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // this step's tiles (and score fragment) are here
+        uint4 fa[2], fb[2];
+        tr_frag(&tiles[wave][buf][0][0], fb);
+        if constexpr (TRANS) tr_frag(&tiles[wave][buf][1][0], fa);
+        else { fa[0] = sa[0]; fa[1] = sa[1]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (q + 4 < nsteps) request(q + 4, buf ^ 1);
+        acc = T16::mfma32(fa[0], fb[0], acc);
+        acc = T16::mfma32(fa[1], fb[1], acc);
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[wave][reg][lane] = acc[reg];
+    __syncthreads();
+    T* out = C + ((size_t)n * rows_c + (size_t)oc * BS + 32 * ts) * state + (size_t)h * hs + 32 * ct + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int reg = 4 * wave + i;
+        const float v = red[0][reg][lane] + red[1][reg][lane] + red[2][reg][lane] + red[3][reg][lane];
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        out[(size_t)row * state] = T16::from_f32(v);
     }
 }
 

@@ -43,7 +43,7 @@ rows = [
     ("tn", lambda: bst._xn(a, q, True), flops, 2 * abytes + sbytes),
     ("softmax_grad", lambda: bst._softmax_bwd(da, a, 0.125), 0, 3 * sbytes),
 ]
-peak = 157.3e12 if act == torch.float32 else 157.3e12     # every dtype currently multiplies on the f32 MFMA
+peak = 157.3e12 if act == torch.float32 else 2500e12      # fp32 activations: f32 MFMA; 16-bit: v_mfma_f32_32x32x16
 tot = 0.0
 for name, fn, fl, by in rows:
     t = timeit(fn)

@@ -135,6 +135,20 @@ def test_ragged_layouts_and_head_state(env):
     assert max(res["NN"], res["TN"]) < 2e-6 and max(res["NT"], res["SM"], res["SMG"]) < 1e-3, res
 
 
+@pytest.mark.parametrize("act", ["f16", "bf16"])
+def test_native_16bit_mfma_kernels(env, act):
+    """16-bit activations with scores of the same type run on v_mfma_f32_32x32x16 without widening (LDS-DMA tiles +
+    transposing reads); head sizes 32 / 64 / 128 take those kernels, 96 the widening ones; bsize 64 = 2 x 2 tiles."""
+    torch, BST = env
+    lay = G.layouts()["rect_3heads"]
+    for bsize, hs in ((32, 64), (32, 32), (32, 128), (32, 96), (64, 64), (64, 32)):
+        res = _run_case(torch, BST, lay, 3, bsize, hs, 2, G.head_cb, 17 + hs, act, act)
+        assert max(res.values()) < 1e-3, (act, bsize, hs, res)
+    tri = G.layouts()["causal_2heads"]
+    res = _run_case(torch, BST, tri, 2, 32, 64, 3, G.causal_cb, 23, act, act)
+    assert max(res.values()) < 1e-3, (act, res)
+
+
 def test_fully_masked_row_is_uniform(env):
     """A query row with no visible key: the reference's NumPy oracle yields a uniform row; so do we (include/bst.h)."""
     torch, BST = env
