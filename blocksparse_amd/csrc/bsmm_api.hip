@@ -573,6 +573,10 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
     return (int)hipGetLastError();
 }
 
+#ifdef BSMM_XC_TRACE
+int bsmm_debug_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_xc_trace), sizeof(bsmm::g_xc_trace)); }
+#endif
+
 int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks, int32_t bsize,
                        float scale, int32_t dtype, void* stream) {
     if (!W || !updat_lut || CB <= 0 || KB <= 0 || blocks <= 0 || bsize <= 0) return BSMM_ERR_ARG;

@@ -44,6 +44,14 @@ constexpr int XC_LDS = (XC_RING * XC_SLAB > XC_STAGE) ? XC_RING * XC_SLAB : XC_S
 #ifndef BSMM_XC_OCC
 #define BSMM_XC_OCC 2
 #endif
+#ifdef BSMM_XC_TRACE
+// cycle stamps of the first 8 workgroups: [wg][wave][phase][6] = before wait, after wait, after barrier, after DMA issue,
+// after step 0, after step 1 (s_memtime); read back with bsmm_debug_trace_copy().  Debug builds only.
+__device__ unsigned long long g_xc_trace[8 * 8 * 40 * 6];
+#define XC_STAMP(k) do { if (blockIdx.x < 8 && (s / XC_PH) < 40 && lane == 0) g_xc_trace[((blockIdx.x * 8 + wave) * 40 + (s / XC_PH)) * 6 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define XC_STAMP(k) do { } while (0)
+#endif
 template <class DT, bool TRANSW>
 __global__ void __launch_bounds__(512, BSMM_XC_OCC)
 xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
@@ -140,6 +148,10 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     // phase, so the two slabs of the NEXT phase are requested right away (prefetch distance = one phase); a wave's W
     // fragments are still fetched one step ahead.  Half the barriers, and the per-step imbalance between waves
     // (0, 1 or 2 blocks) averages over two steps.  (Deeper rings with counted waits were measured slower: registers.)
+    // Cycle stamps (-DBSMM_XC_TRACE, scripts/gpu_xc_trace.py, profiles/r01_xcol_phase_stamps.txt): of a 3956-cycle phase a wave
+    // spends 361 in the vmcnt(0), 757 at the barrier, 635 issuing its 4 slab DMAs and ~1030 in each step.  Requesting the
+    // second step's weight fragments BEFORE the DMAs (asm loads into a second register set, vmcnt(8) instead of a drain)
+    // was measured slower, 141 vs 120 us.
     const bool owner = wave < nob;
     if (nsteps > 0) {
         for (int tb = 0; tb < nsteps; tb += 64) {     // lane-indexed tables for steps [tb, tb+64)
@@ -156,15 +168,20 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             for (int u = 0; u < XC_PH; ++u)
                 if (u < tend) issue_x(__builtin_amdgcn_readlane(pv, u), u);
             for (int s = 0; s < tend; s += XC_PH) {
+                XC_STAMP(0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my shares of this phase's slabs (+ my W fragments) landed
+                XC_STAMP(1);
                 __syncthreads();                                  // everyone's did; everyone left the previous phase
+                XC_STAMP(2);
 #pragma unroll
                 for (int u = 0; u < XC_PH; ++u)
                     if (s + XC_PH + u < tend) issue_x(__builtin_amdgcn_readlane(pv, s + XC_PH + u), (s + XC_PH + u) % XC_RING);
+                XC_STAMP(3);
 #pragma unroll
                 for (int u = 0; u < XC_PH; ++u) {
                     const int ss = s + u;
                     if (ss >= tend) break;
+                    if (u >= 1) { XC_STAMP(4); }
                     if (u >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // W fragments of this step (slab is already in)
                     int n0 = -1, n1 = -1;
                     if (ss + 1 < tend) {
@@ -178,6 +195,7 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
                     if (c1 >= 0) block(wc1, slab, 1);
                     wc0 = wn0; wc1 = wn1; c0 = n0; c1 = n1;
                 }
+                XC_STAMP(5);
             }
             __syncthreads();   // the next batch re-primes slots 0/1
         }
