@@ -11,7 +11,6 @@
 #include "bsmm_updat_win.h"
 #include "bsmm_xcol.h"
 #include "bsmm_xcol16.h"
-#include "bsmm_xgroup.h"
 #include "bsmm_xprop.h"
 
 using namespace bsmm;
@@ -88,39 +87,8 @@ int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args*
     return (int)hipGetLastError();
 }
 
-// grouped kernel (needs args->plan built by bsmm_xprop_plan_build for args->lut)
-// Group size used by the plan builder AND the launcher (they must agree): process-wide tuning knob,
-// env BSMM_XG_G (axis 1: 8 or 12, default 8; axis 0: BSMM_XG_G0 4 or 8, default 8).
-int xg_group_size(int axis) {
-    static const int g1 = [] { const char* e = getenv("BSMM_XG_G"); const int v = e ? atoi(e) : 8; return v == 12 ? 12 : 8; }();
-    static const int g0 = [] { const char* e = getenv("BSMM_XG_G0"); const int v = e ? atoi(e) : 8; return v == 4 ? 4 : 8; }();
-    return axis == 1 ? g1 : g0;
-}
-
-template <class DT, int G>
-void launch_xs3(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    typedef typename DT::T T;
-    const int n_out = a->K / 32;
-    XMap m;
-    m.ntiles = (a->N + XS3::NT - 1) / XS3::NT;
-    m.segments = (n_out + G - 1) / G;
-    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
-    if (m.P > m.segments) m.P = m.segments;
-    m.SP = (m.segments + m.P - 1) / m.P;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xs3_a1_kernel<DT, G>), hipFuncAttributeMaxDynamicSharedMemorySize, XS3::LDS);
-        attr_set = true;
-    }
-    xs3_a1_kernel<DT, G><<<m.grid(), 256, XS3::LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y),
-                                                          a->plan, m, a->N, a->C, a->K);
-}
-
-// which axis-1 grouped kernel the plan builder and the launcher use: env BSMM_XKERNEL = "xcol" (default) | "s3"
-bool use_xcol() {
-    static const bool v = [] { const char* e = getenv("BSMM_XKERNEL"); return !(e && e[0] == 's'); }();
-    return v;
-}
+// grouped (xcol) kernels need args->plan built by bsmm_xprop_plan_build for args->lut
+inline bool use_xcol() { return true; }
 
 template <class DT, int AXIS>
 int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
@@ -196,35 +164,12 @@ void launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, h
 
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
-    typedef typename DT::T T;
     if constexpr (AXIS == 1) {
-        if (use_xcol()) {
-            if (transw) launch_xcol<DT, true>(X, Wsel, Y, a, st);
-            else        launch_xcol<DT, false>(X, Wsel, Y, a, st);
-            return (int)hipGetLastError();
-        }
-        if (xg_group_size(1) == 8) launch_xs3<DT, 8>(X, Wsel, Y, a, st);
-        else                       launch_xs3<DT, 12>(X, Wsel, Y, a, st);
+        if (transw) launch_xcol<DT, true>(X, Wsel, Y, a, st);
+        else        launch_xcol<DT, false>(X, Wsel, Y, a, st);
     } else {
-        if (use_xcol()) {
-            if (transw) launch_xcol0<DT, true>(X, Wsel, Y, a, st);
-            else        launch_xcol0<DT, false>(X, Wsel, Y, a, st);
-            return (int)hipGetLastError();
-        }
-        const int G = xg_group_size(0);
-        const int n_out = a->K / 32;
-        XMap m;
-        m.ntiles = (a->N + 127) / 128;
-        m.segments = (n_out + G - 1) / G;
-        m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
-        if (m.P > m.segments) m.P = m.segments;
-        m.SP = (m.segments + m.P - 1) / m.P;
-        if (G == 8)
-            xgroup32_kernel<DT, AXIS, 8><<<m.grid(), 256, XG_SB * 2048, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
-                                                                            static_cast<T*>(Y), a->plan, m, a->N, a->C, a->K);
-        else
-            xgroup32_kernel<DT, AXIS, 4><<<m.grid(), 256, XG_SB * 2048, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
-                                                                            static_cast<T*>(Y), a->plan, m, a->N, a->C, a->K);
+        if (transw) launch_xcol0<DT, true>(X, Wsel, Y, a, st);
+        else        launch_xcol0<DT, false>(X, Wsel, Y, a, st);
     }
     return (int)hipGetLastError();
 }
@@ -256,8 +201,8 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         if (AXIS == 0 && (a->N % 4 != 0)) enough = false;
     }
     if (BS == 32 && a->plan != nullptr && DT::is16) {
-        const int rows = use_xcol() ? XC_R : ((AXIS == 1) ? XS3::NT : 128);
-        const int g = use_xcol() ? XC_G : ((AXIS == 1) ? xg_group_size(1) : xg_group_size(0));
+        const int rows = XC_R;
+        const int g = XC_G;
         enough = (long)((a->N + rows - 1) / rows) * ((a->K / 32 + g - 1) / g) >= 224;
         if (AXIS == 0 && use_xcol() && (a->N % 8 != 0)) enough = false;   // axis-0 xcol needs 16-byte aligned row pieces
     }
@@ -602,8 +547,7 @@ long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t bl
     if ((bsize != 32 && bsize != 16) || (axis != 0 && axis != 1)) return 0;   // plan kernels: bsize 32 (any dtype) / 16 (16-bit)
     if (dtype == BSMM_F32) return (bsize == 32 && use_xcol()) ? build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, nullptr) : 0;
     if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
-    if (use_xcol()) return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
-    return build_xprop_plan(host_lut, segments, blocks, n_out_blocks, xg_group_size(axis), XG_SB, axis == 1, nullptr);
+    return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
 }
 
 int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
@@ -615,10 +559,7 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
         return build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     }
     if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
-    if (use_xcol())
-        return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
-    return build_xprop_plan(host_lut, segments, blocks, n_out_blocks, xg_group_size(axis), XG_SB, axis == 1, host_plan_out) > 0
-               ? BSMM_OK : BSMM_ERR_ARG;
+    return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
 }
 
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,

@@ -243,4 +243,18 @@ struct PtrList8 {
     const void* p[8];
 };
 
+// LDS-DMA of 16 bytes per lane (1 KiB per wave) to LDS byte address `lds_byte_addr` + lane * 16, issued from inline asm: with the
+// builtin form hipcc drains vmcnt(0) in front of every later LDS read, and DMAs issued from asm are neither counted nor
+// drained by the compiler's own waits (callers place s_waitcnt vmcnt themselves).  M0 is saved and restored.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 }  // namespace bsmm

@@ -15,7 +15,6 @@
 #pragma once
 #include "bsmm_common.h"
 #include "bsmm_updat.h"
-#include "bsmm_xgroup.h"
 
 namespace bsmm {
 

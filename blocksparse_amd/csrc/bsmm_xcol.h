@@ -18,8 +18,8 @@
 #pragma once
 #include "bsmm_common.h"
 #include "bsmm_plan.h"
+#include "bsmm_xprop.h"   // XMap
 #include "bsmm_updat_tr.h"
-#include "bsmm_xgroup.h"
 
 namespace bsmm {
 

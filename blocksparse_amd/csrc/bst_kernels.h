@@ -17,7 +17,6 @@
 //   nn/tn: M side = output rows, N side = 32 features -> D[row][c], lane = feature c: 128-byte row segments.
 #pragma once
 #include "bsmm_common.h"
-#include "bsmm_xgroup.h"   // glds16_asm, lds_addr_of
 #include "bsmm_updat_tr.h" // ds_tr16
 
 namespace bsmm {

@@ -79,43 +79,6 @@ def test_argument_validation_without_gpu(lib):
     assert L.bsmm_gate_grad(one, one, one, one, one, 4, 64, lib.F32, None) == -2
 
 
-def _check_group_plan(plan, f, t, n_out, axis):
-    """grouped-kernel plan (bsmm_plan.h build_xprop_plan): steps over single input blocks (axis 0) or pairs (pair=1)."""
-    import numpy as np
-    assert plan[0] == 0x42534d50 and plan[12] == n_out
-    pair = int(plan[14])
-    G, SB, ngroups = int(plan[2]), int(plan[3]), int(plan[4])
-    groups = plan[plan[8]:plan[9]].reshape(-1, 4)
-    stages = plan[plan[9]:plan[10]].reshape(-1, 4)
-    steps = plan[plan[10]:plan[11]].reshape(-1, 2)
-    wlist = plan[plan[11]:plan[13]]
-    meta = plan[plan[13]:]
-    assert len(groups) == ngroups == -(-n_out // G) and len(wlist) == len(meta) == t["blocks"]
-    got = set()
-    for g, (sb, ns, ob0, nob) in enumerate(groups):
-        assert ob0 == g * G and nob == min(G, n_out - ob0)
-        last_key = -1
-        for st in stages[sb:sb + ns]:
-            assert 0 < st[3] <= SB
-            wpos = st[2]
-            for key, mask in steps[st[0]:st[0] + st[1]]:
-                assert key >= last_key          # equal only when an over-long step was split
-                last_key = key
-                first = True
-                nbits = 2 * G if pair else G
-                for bit in range(nbits):
-                    if (int(mask) >> bit) & 1:
-                        m, c = (bit >> 1, 2 * int(key) + (bit & 1)) if pair else (bit, int(key))
-                        assert m < nob
-                        got.add((ob0 + m, c, int(wlist[wpos])))
-                        assert int(meta[wpos]) == (bit | (256 if first else 0))
-                        first = False
-                        wpos += 1
-                assert (int(mask) & 0xffffffff) >> nbits == 0
-            assert wpos == st[2] + st[3]
-    return got
-
-
 def _check_xcol_plan(plan, f, t, n_out):
     """xcol plan (build_xcol_plan): per group the union of input PAIRS (possibly rotated), per wave / half / step a weight id or -1."""
     assert plan[0] == 0x42535843 and plan[8] == n_out
@@ -155,15 +118,28 @@ def test_plan_builder_covers_every_block_once(lib):
             for side, n_out in (("fprop", KB), ("bprop", CB)):
                 f = t[side]
                 plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, axis)
-                if plan[0] == 0x42535843:
-                    got = _check_xcol_plan(plan, f, t, n_out)
-                else:
-                    got = _check_group_plan(plan, f, t, n_out, axis)
+                got = _check_xcol_plan(plan, f, t, n_out)
+                # fp32 (bsize 32): same groups / pairs, compacted entry lists per wave class with four sentinels each
+                pf = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.F32, axis)
+                assert pf[0] == 0x42535846 and pf[8] == n_out
+                gf = pf[pf[5]:pf[6]].reshape(-1, 8)
+                pairs_f = pf[pf[6]:pf[6] + pf[4]]
+                ents = pf[pf[7]:pf[7] + 2 * pf[9]].reshape(-1, 2)
+                gotf = set()
+                for g, (so, ns, ob0, nob, o0, c0, o1, c1) in enumerate(gf):
+                    for cls, (o, cnt) in enumerate(((o0, c0), (o1, c1))):
+                        last = -1
+                        for w, code in ents[o:o + cnt]:
+                            st, j, half = int(code) >> 3, (int(code) >> 1) & 3, int(code) & 1
+                            assert 0 <= st < ns and st >= last and 4 * cls + j < nob
+                            last = st
+                            gotf.add((ob0 + 4 * cls + j, 2 * int(pairs_f[so + st]) + half, int(w)))
+                        assert all(int(x) == -1 and int(y) == 0x7fffffff for x, y in ents[o + cnt:o + cnt + 4])
                 want = set()
                 for ob, col in f["cols"]:
                     for c, w in col:
                         want.add((ob, c, w))
-                assert got == want
+                assert got == want and gotf == want
                 # bsize 16: quads of input blocks, 16 output blocks per group, slot = 4*member + (c & 3)
                 p16 = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis)
                 assert p16[0] == 0x42535836 and p16[8] == n_out
