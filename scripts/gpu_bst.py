@@ -7,8 +7,8 @@ import numpy as np
 import torch
 from blocksparse_amd import BlocksparseTransformer
 
-def timeit(fn, reps=20):
-    for _ in range(3): fn()
+def timeit(fn, reps=100):
+    for _ in range(30): fn()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
