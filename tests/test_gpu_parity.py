@@ -375,3 +375,39 @@ def test_full_size_properties(env, dtype, bs, axis):
         got = Y[k * bs:(k + 1) * bs, :] if axis == 0 else Y[:, k * bs:(k + 1) * bs]
         l2, _ = P.errors(got, orc.round_to(ref, dtype))
         assert l2 <= P.L2_BAR[dtype], (k, l2)
+
+
+def test_step_is_capturable_in_a_hip_graph(env):
+    """The C-ABI launches go to torch's current stream with no host synchronisation or allocation of their own, so a whole
+    fprop + updat + bprop step can be captured once (torch.cuda.CUDAGraph = hipGraph) and replayed; results are bitwise
+    those of the eager launches."""
+    torch, BSMM, lib = env
+    b = BSMM(P.random_layout(16, 16, 0.3, seed=4), block_size=32, feature_axis=1)
+    N = 96
+    g0 = torch.Generator(device="cuda").manual_seed(5)
+    w = (torch.randn(b.w_shape, device="cuda", generator=g0) * 0.01).bfloat16()
+    x = (torch.randn(b.i_shape(N), device="cuda", generator=g0) * 0.1).bfloat16()
+    dy = (torch.randn(b.o_shape(N), device="cuda", generator=g0) * 0.1).bfloat16()
+    dw = torch.empty(b.w_shape, dtype=torch.bfloat16, device="cuda")
+
+    def step():
+        y = b.fprop(x, w)
+        b.updat(x, dy, dw=dw)
+        return y, b.bprop(dy, w)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()                                   # warm-up outside the capture (function attributes, table uploads)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y_g, dx_g = step()
+    x.mul_(0.5)                                      # new inputs in the captured buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    dw_g = dw.clone()
+    y_e, dx_e = step()
+    torch.cuda.synchronize()
+    assert torch.equal(y_g, y_e) and torch.equal(dx_g, dx_e) and torch.equal(dw_g, dw)
