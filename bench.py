@@ -20,10 +20,20 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_MFMA = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                                            # GB/s (spec)
+
+
+def random_layout(CB, KB, density, seed):
+    """rng.random < density with at least one block per row and column (same generator as tests/_parity.py)."""
+    rng = np.random.default_rng(seed)
+    lay = (rng.random((CB, KB)) < density).astype(np.int32)
+    for r in np.nonzero(lay.sum(axis=1) == 0)[0]:
+        lay[r, rng.integers(0, KB)] = 1
+    for c in np.nonzero(lay.sum(axis=0) == 0)[0]:
+        lay[rng.integers(0, CB), c] = 1
+    return lay
 
 
 def parse():
@@ -63,10 +73,15 @@ def attention_extra(a):
     max(flops / 157.3 TF, algorithmic bytes / 8 TB/s).  CPU baseline: the oracle (NumPy, fp32) on one batch entry and two heads."""
     import torch
     from blocksparse_amd import BlocksparseTransformer
-    from oracle import bst_oracle as O
     B, H, HS, BS, CTX = 4, 16, 64, 32, 128
-    lay = O.local_strided_layout(CTX)
-    bst = BlocksparseTransformer(lay, block_size=BS, heads=H, mask_callback=O.causal_mask_callback)
+    qi, ki = np.indices((CTX, CTX))
+    lay = ((ki <= qi) & ((qi - ki < 4) | ((qi - ki) % 8 == 0))).astype(np.int32)      # local 4 blocks + every 8th, causal
+
+    def causal(blk_shape, head, q, k, b):                                            # diagonal blocks: lower triangle
+        m = np.ones(blk_shape, dtype=bool)
+        return np.tril(m) if q == k else m
+
+    bst = BlocksparseTransformer(lay, block_size=BS, heads=H, mask_callback=causal)
     g = torch.Generator(device="cuda").manual_seed(7)
     q, k, v = (torch.rand(B, CTX * BS, H * HS, device="cuda", generator=g) * 2 - 1 for _ in range(3))
     sd = torch.bfloat16
@@ -118,6 +133,7 @@ def attention_extra(a):
                        % (B, H, HS, CTX * BS, BS, bst.blocks),
            "ops": res, "fwd_bwd_ms": round(fb, 4), "fwd_bwd_tflops": round(6 * flops / fb / 1e9, 2), "ops_bf16_activations": res16}
     if not a.no_cpu_baseline:
+        from oracle import bst_oracle as O            # the oracle is only the timed CPU baseline here
         L = O.build_luts(lay)
         qc, kc, vc = (t[:1, :, :2 * HS].float().cpu().numpy() for t in (q, k, v))
         t0 = time.perf_counter()
@@ -167,7 +183,6 @@ def main():
     a = parse()
     import torch
     import torch.distributed as dist
-    import _parity as P
     from blocksparse_amd import BlocksparseMatMul, _lib
     from blocksparse_amd.dist import DwAllReduce
 
@@ -186,7 +201,7 @@ def main():
     CB = a.hidden // a.bsize
 
     def setup(density):
-        layout = P.random_layout(CB, CB, density, seed=1234)
+        layout = random_layout(CB, CB, density, seed=1234)
         b = BlocksparseMatMul(layout, block_size=a.bsize, feature_axis=a.axis)
         g = torch.Generator(device="cuda").manual_seed(1 + rank)
         w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.01).to(td)
