@@ -340,7 +340,7 @@ def main():
             el2, per2 = run(b2, w2, x2, dy2, max(3, a.steps // 2), 5, timed_events=True)
             fp = 2.0 * b2.blocks * a.bsize ** 2 * N
             sw["d%d" % round(d * 100)] = {"tflops": round(3 * fp * world * max(3, a.steps // 2) / el2 / 1e12, 2),
-                                          "pass_ms": [round(v, 4) for v in per2], "blocks": int(b2.blocks)}
+                                          "pass_ms": {"fprop": round(per2[0], 4), "updat": round(per2[1], 4), "bprop": round(per2[2], 4)}, "blocks": int(b2.blocks)}
         out["density_sweep"] = sw
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(layout, a.bsize, a.axis, a.cpu_seconds)
