@@ -13,7 +13,7 @@ F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
 FLAG_GATED_DW = 1
 
-SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_workspace_bytes",
+SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_sparse_op", "bsmm_sparse_mul_grad", "bsmm_workspace_bytes",
            "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
            "bsmm_set_kernel_variant", "bsmm_get_kernel_variant", "bsmm_error_string", "bsmm_version")
 BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask")
@@ -79,6 +79,10 @@ def load():
     lib.bsmm_l2_normalize.restype = ctypes.c_int
     lib.bsmm_l2_normalize_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
     lib.bsmm_l2_normalize_grad.restype = ctypes.c_int
+    lib.bsmm_sparse_op.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.bsmm_sparse_op.restype = ctypes.c_int
+    lib.bsmm_sparse_mul_grad.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.bsmm_sparse_mul_grad.restype = ctypes.c_int
     lib.bsmm_workspace_bytes.argtypes = [ctypes.c_int, pargs]
     lib.bsmm_workspace_bytes.restype = ctypes.c_size_t
     ip = ctypes.POINTER(ctypes.c_int32)

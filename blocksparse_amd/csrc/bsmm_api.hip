@@ -6,6 +6,7 @@
 #include "bsmm.h"
 #include "bsmm_plan.h"
 #include "bsmm_l2norm.h"
+#include "bsmm_sparse_proj.h"
 #include "bsmm_updat.h"
 #include "bsmm_updat_tr.h"
 #include "bsmm_updat_win.h"
@@ -502,6 +503,59 @@ int bsmm_l2_normalize_grad(void* dx, float* dgain, const void* dy, const void* x
                                                                                     static_cast<const typename TX::T*>(x), gain, sum_sqr, l2_lut, epsilon);
         return (int)hipGetLastError();
     });
+}
+
+int bsmm_sparse_op(void* z, const void* x, const void* y, const int32_t* lut, int32_t op, int32_t K, int32_t rows_z, int32_t N, int32_t dtype,
+                   void* stream) {
+    if (!z || !x || !lut || K <= 0 || N <= 0 || rows_z <= 0) return BSMM_ERR_ARG;
+    if ((op == SP_ADD || op == SP_MUL) && !y) return BSMM_ERR_ARG;
+    if (op < SP_GAT || op > SP_MUL) return BSMM_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype != BSMM_F32 && dtype != BSMM_F16 && dtype != BSMM_BF16) return BSMM_ERR_UNSUPPORTED;
+    const size_t esz = elem_size(dtype);
+    if (op == SP_ADD && z != x) {                        // the unmapped rows pass through
+        hipError_t e = hipMemcpyAsync(z, x, (size_t)rows_z * N * esz, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(std::min((N + 255) / 256, 64), K);
+    auto go = [&](auto t) {
+        typedef decltype(t) DT;
+        typedef typename DT::T T;
+        switch (op) {
+            case SP_GAT: sparse_proj_kernel<DT, SP_GAT><<<grid, 256, 0, st>>>(static_cast<T*>(z), static_cast<const T*>(x), nullptr, lut, K, N); break;
+            case SP_SCT: sparse_proj_kernel<DT, SP_SCT><<<grid, 256, 0, st>>>(static_cast<T*>(z), static_cast<const T*>(x), nullptr, lut, K, N); break;
+            case SP_ADD: sparse_proj_kernel<DT, SP_ADD><<<grid, 256, 0, st>>>(static_cast<T*>(z), static_cast<const T*>(z), static_cast<const T*>(y), lut, K, N); break;
+            default:     sparse_proj_kernel<DT, SP_MUL><<<grid, 256, 0, st>>>(static_cast<T*>(z), static_cast<const T*>(x), static_cast<const T*>(y), lut, K, N); break;
+        }
+        return (int)hipGetLastError();
+    };
+    if (dtype == BSMM_F32) return go(DTf32{});
+    if (dtype == BSMM_F16) return go(DTf16{});
+    return go(DTbf16{});
+}
+
+int bsmm_sparse_mul_grad(void* dx, void* dy, const void* dz, const void* x, const void* y, const int32_t* lut, int32_t K, int32_t rows_x, int32_t N,
+                         int32_t dtype, void* stream) {
+    if (!dx || !dy || !dz || !x || !y || !lut || K <= 0 || N <= 0 || rows_x <= 0) return BSMM_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype != BSMM_F32 && dtype != BSMM_F16 && dtype != BSMM_BF16) return BSMM_ERR_UNSUPPORTED;
+    const size_t esz = elem_size(dtype);
+    if (dx != dz) {
+        hipError_t e = hipMemcpyAsync(dx, dz, (size_t)rows_x * N * esz, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(std::min((N + 255) / 256, 64), K);
+    auto go = [&](auto t) {
+        typedef decltype(t) DT;
+        typedef typename DT::T T;
+        // reads dz through dx (identical after the copy / when aliased): every mapped element is read before it is overwritten by the same thread
+        sparse_mul_grad_kernel<DT><<<grid, 256, 0, st>>>(static_cast<T*>(dx), static_cast<T*>(dy), static_cast<const T*>(dx), static_cast<const T*>(x),
+                                                         static_cast<const T*>(y), lut, K, N);
+        return (int)hipGetLastError();
+    };
+    if (dtype == BSMM_F32) return go(DTf32{});
+    if (dtype == BSMM_F16) return go(DTf16{});
+    return go(DTbf16{});
 }
 
 int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const float* gate, int32_t blocks, int32_t bsize,

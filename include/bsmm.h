@@ -116,6 +116,19 @@ int bsmm_l2_normalize_grad(void* dx, float* dgain, const void* dy, const void* x
                            const int32_t* l2_lut, int32_t cols, int32_t bsize, int32_t x_dtype, int32_t y_dtype,
                            float epsilon, void* stream);
 
+/* SparseProj row gather / scatter on (rows, N) tensors, N contiguous (GatherScatterOp / ScatterAddMulOp / ScatterMulGradOp,
+ * launcher SparseOp / SparseMulGrad, src/layer_norm_cn_op_gpu.cu:718-830; Python: blocksparse/matmul.py:835-921).
+ *   op 0 gather      z[k] = x[lut[k]]                      k < K = rows of z
+ *   op 1 scatter     z[k] = lut[k] >= 0 ? x[lut[k]] : 0    k < K = rows of z
+ *   op 2 scatter_add z = x, z[lut[k]] += y[k]              k < K = rows of y; rows_z = rows of x and z (z may alias x)
+ *   op 3 scatter_mul z[k] = lut[k] >= 0 ? x[k] * y[lut[k]] : x[k]     k < K = rows of x and z
+ * bsmm_sparse_mul_grad: dx = dz with dx[lut[k]] = dz[lut[k]] * y[k], dy[k] = dz[lut[k]] * x[lut[k]], k < K = rows of y
+ * (dx may alias dz; rows_x = rows of x, dz, dx). */
+int bsmm_sparse_op(void* z, const void* x, const void* y, const int32_t* lut, int32_t op, int32_t K, int32_t rows_z, int32_t N,
+                   int32_t dtype, void* stream);
+int bsmm_sparse_mul_grad(void* dx, void* dy, const void* dz, const void* x, const void* y, const int32_t* lut, int32_t K,
+                         int32_t rows_x, int32_t N, int32_t dtype, void* stream);
+
 /* Host-only: derive the grouped-kernel schedule ("plan") from a reference-format xprop lut that lives in HOST
  * memory (the luts are constants of the layout: the reference builds them in NumPy, blocksparse/matmul.py:137-138).
  * n_out_blocks = K / bsize of the pass the lut belongs to; axis = feature axis the plan will be used with.  bsmm_xprop_plan_words returns the number of int32 words
