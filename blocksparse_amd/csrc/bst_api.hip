@@ -75,6 +75,13 @@ int bst_nt(const void* a_, const void* b_, void* s_, const bst_args* a) {
                     constexpr int CH = decltype(ch_tag)::value;
                     static const int il = [] { const char* e = getenv("BST_IL"); return e ? atoi(e) : 1; }();
                     const int grid = xcd_head_grid((ntiles + NT_NB - 1) / NT_NB, a->heads, a->batch, il);
+                    static const bool split = [] { const char* e = getenv("BST_NT_SPLIT"); return e ? atoi(e) != 0 : true; }();
+                    if constexpr (!TA::is16) {
+                        if (split) {     // fp32 activations: exact bf16 piece products on the 16-bit matrix core
+                            bst_nt_mfma_kernel<TA, TS, BS, CH, true><<<grid, 64, 0, st>>>(A, B, S, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, rq, rk, il);
+                            return;
+                        }
+                    }
                     bst_nt_mfma_kernel<TA, TS, BS, CH><<<grid, 64, 0, st>>>(A, B, S, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, rq, rk, il);
                 };
                 // LDS-DMA kernel: whole 32-feature chunks only (1, 2 or 4 of them); other head sizes take the direct kernel
@@ -116,6 +123,16 @@ static int bst_xn(const void* s_, const void* b_, void* c_, const bst_args* a, b
                         constexpr int SUB16 = BS / 32;
                         const int grid16 = xcd_head_grid(ctx_c * SUB16 * (a->head_state / 32), a->heads, a->batch);
                         bst_xn_mfma16_kernel<TB, BS, TR><<<grid16, 256, 0, st>>>(S, B, C, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, ctx_c, rb, rc_);
+                        return;
+                    }
+                }
+                if constexpr (BS >= 32 && std::is_same<TB, DTf32>::value && std::is_same<TS, DTbf16>::value) {
+                    // fp32 activations x bf16 scores: exact three-way bf16 split on the 16-bit matrix core (BST_XN_SPLIT=0: fp32 MFMA)
+                    static const bool split = [] { const char* e = getenv("BST_XN_SPLIT"); return e ? atoi(e) != 0 : true; }();
+                    if (split) {
+                        constexpr int SUBS = BS / 32;
+                        const int grids = xcd_head_grid(ctx_c * SUBS * ((a->head_state + 31) / 32), a->heads, a->batch);
+                        bst_xn_split_kernel<BS, TR><<<grids, 256, 0, st>>>(S, B, C, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, ctx_c, rb, rc_);
                         return;
                     }
                 }

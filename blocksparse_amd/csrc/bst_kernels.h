@@ -97,7 +97,12 @@ template <class T> struct NtTile {
 // Ablation of the previous version (coalesced VGPR loads + ds_write, 215 us): without loads 125, without MFMA 142.
 constexpr int NT_NB = 8;
 
-template <class TA, class TS, int BS, int NCH>
+// SPLIT (fp32 activations only): both operands are split exactly into three bf16 pieces (see bst_xn_split_kernel) and the six
+// largest of the nine piece products run on v_mfma_f32_32x32x16_bf16 (the dropped ones are below 2^-24 of the leading term):
+// 12 MFMAs of 32 cycles per 32-feature chunk instead of 16 fp32 MFMAs of 64.  The split Q pieces live in registers while
+// the query row does not change.  K labels: MFMA kk of a chunk takes this lane's values 8kk .. 8kk+7 (k = 16hh + 8kk + j) on
+// both sides, which is all the hardware needs.
+template <class TA, class TS, int BS, int NCH, bool SPLIT = false>
 __global__ void __launch_bounds__(64)
 bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* __restrict__ B, typename TS::T* __restrict__ S,
                    const int32_t* __restrict__ lut, int lut_stride, int blocks, int heads, int batch, int hs, int rows_q, int rows_k, int il) {
@@ -189,6 +194,8 @@ bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* _
     dma_tile(bbase + (size_t)krow * state, lds_k);
     dma_tile(abase + (size_t)qrow * state, lds_q);
     typename TS::T* pending = nullptr;
+    uint4 qp[(SPLIT && !TA::is16) ? NCH : 1][3][2];           // SPLIT: bf16 pieces of the current Q fragments
+    int qsplit_row = -1;
     for (int it = 0; it < NT_NB; ++it) {
         const int tb = tb0 + it;
         if (tb >= ntiles) break;
@@ -225,7 +232,47 @@ bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* _
         f32x16 acc, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc1[i] = 0.f; }
-        if constexpr (TA::is16) {
+        if constexpr (SPLIT && !TA::is16) {
+            auto split3 = [](const float (&v)[16], uint4 (&p)[3][2]) {          // 16 floats -> 3 pieces x 2 MFMA operands
+                auto pack2 = [](float lo, float hi) { return (uint32_t)DTbf16::from_f32(lo) | ((uint32_t)DTbf16::from_f32(hi) << 16); };
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    uint32_t a[4], b[4], c3[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v0 = v[8 * kk + 2 * i], v1 = v[8 * kk + 2 * i + 1];
+                        a[i] = pack2(v0, v1);
+                        const float r0 = v0 - __builtin_bit_cast(float, a[i] << 16), r1 = v1 - __builtin_bit_cast(float, a[i] & 0xffff0000u);
+                        b[i] = pack2(r0, r1);
+                        c3[i] = pack2(r0 - __builtin_bit_cast(float, b[i] << 16), r1 - __builtin_bit_cast(float, b[i] & 0xffff0000u));
+                    }
+                    p[0][kk] = make_uint4(a[0], a[1], a[2], a[3]);
+                    p[1][kk] = make_uint4(b[0], b[1], b[2], b[3]);
+                    p[2][kk] = make_uint4(c3[0], c3[1], c3[2], c3[3]);
+                }
+            };
+            if (qsplit_row != qcur) {                                          // new query rows: split the Q fragments once
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) split3(fq[c], qp[c]);
+                qsplit_row = qcur;
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                uint4 kp[3][2];
+                split3(fk[c], kp);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {                               // smallest products first; M side = keys, N side = queries
+                    acc1 = DTbf16::mfma32(kp[2][kk], qp[c][0][kk], acc1);
+                    acc1 = DTbf16::mfma32(kp[0][kk], qp[c][2][kk], acc1);
+                    acc1 = DTbf16::mfma32(kp[1][kk], qp[c][1][kk], acc1);
+                    acc = DTbf16::mfma32(kp[1][kk], qp[c][0][kk], acc);
+                    acc = DTbf16::mfma32(kp[0][kk], qp[c][1][kk], acc);
+                    acc = DTbf16::mfma32(kp[0][kk], qp[c][0][kk], acc);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
+        } else if constexpr (TA::is16) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 acc = TA::mfma32(rk[c][0], rq[c][0], acc);
@@ -380,6 +427,112 @@ bst_xn_mfma_kernel(const typename TS::T* __restrict__ S, const typename TB::T* _
         const float v = red[0][reg][lane] + red[1][reg][lane] + red[2][reg][lane] + red[3][reg][lane];
         const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
         out[(size_t)row * state] = TB::from_f32(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// nn / tn with bf16 scores and fp32 activations (BASELINE configs[4]) on the 16-bit matrix core, EXACTLY: every fp32
+// activation value v is split into three bf16 pieces b1 = bf16(v), b2 = bf16(v - b1), b3 = bf16(v - b1 - b2) (8 + 8 + 8
+// significand bits: v = b1 + b2 + b3, the subtractions are exact), the scores are bf16 already, bf16 x bf16 products are
+// exact in fp32 and the accumulation is fp32 as before -- the result differs from the fp32-MFMA kernel only by the
+// order of the fp32 additions.  Three v_mfma_f32_32x32x16_bf16 pairs (192 cycles) replace 16 v_mfma_f32_32x32x2_f32
+// (1024 cycles) per step; the split costs ~90 VALU operations per step and lane.  Same decomposition as
+// bst_xn_mfma_kernel (workgroup = output tile, waves split the steps, next step's operands requested ahead, LDS reduce).
+// K labels of the 16-bit MFMA: q[kk] holds k = 16 kk + 8 hh + j, so this lane's 16 activation rows are
+// 8hh .. 8hh+7 and 16+8hh .. 16+8hh+7 of the 32-row slice.
+// ------------------------------------------------------------------------------------------------------------------
+template <int BS, bool TRANS>
+__global__ void __launch_bounds__(256)
+bst_xn_split_kernel(const uint16_t* __restrict__ S, const float* __restrict__ Bm, float* __restrict__ C,
+                    const int32_t* __restrict__ lut, int lut_stride, int blocks, int heads, int batch, int hs, int ctx_c, int rows_b, int rows_c) {
+    constexpr int SUB = BS / 32;
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nct = (hs + 31) / 32;
+    int n, h, wid;
+    if (!xcd_head_map(ctx_c * SUB * nct, heads, batch, n, h, wid)) return;
+    const int ct = wid % nct, ts = (wid / nct) % SUB, oc = wid / (nct * SUB);
+    const int32_t* hl = lut + (size_t)h * lut_stride;
+    const int2 hdr = *reinterpret_cast<const int2*>(hl + 2 * oc);
+    const size_t state = (size_t)heads * hs;
+    const int c = 32 * ct + r;
+    const bool cvalid = c < hs;
+    const uint16_t* sbase = S + ((size_t)n * heads + h) * blocks * (BS * BS);
+    const float* bcol = Bm + (size_t)n * rows_b * state + (size_t)h * hs + c;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    uint4 ra[2];                 // score fragment (nn: two contiguous 16-byte loads)
+    uint16_t ra1[TRANS ? 16 : 1];
+    float rb[16];
+    const int nsteps = hdr.y * SUB;
+    auto request = [&](int q) {
+        const int e = q / SUB, tk = q % SUB;
+        const int2 ent = *reinterpret_cast<const int2*>(hl + 2 * (hdr.x + e));
+        const uint16_t* sb = sbase + (size_t)ent.x * (BS * BS);
+        if constexpr (!TRANS) {       // A[i][k = j] = S_b[32ts + i][32tk + j]
+            const uint16_t* p = sb + (size_t)(32 * ts + r) * BS + 32 * tk + 8 * hh;
+            ra[0] = *reinterpret_cast<const uint4*>(p);
+            ra[1] = *reinterpret_cast<const uint4*>(p + 16);
+        } else {                      // A[j][k = i] = S_b[32tk + i][32ts + j]
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ra1[8 * kk + j] = sb[(size_t)(32 * tk + 16 * kk + 8 * hh + j) * BS + 32 * ts + r];
+        }
+        const float* bp = bcol + ((size_t)ent.y * BS + 32 * tk + 8 * hh) * state;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rb[8 * kk + j] = cvalid ? bp[(size_t)(16 * kk + j) * state] : 0.f;
+    };
+    auto pack2 = [](float lo, float hi) { return (uint32_t)DTbf16::from_f32(lo) | ((uint32_t)DTbf16::from_f32(hi) << 16); };
+    if (wave < nsteps) request(wave);
+    for (int q = wave; q < nsteps; q += 4) {
+        uint4 fa[2];
+        if constexpr (!TRANS) {
+            fa[0] = ra[0];
+            fa[1] = ra[1];
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                fa[kk] = make_uint4((uint32_t)ra1[8 * kk + 0] | ((uint32_t)ra1[8 * kk + 1] << 16), (uint32_t)ra1[8 * kk + 2] | ((uint32_t)ra1[8 * kk + 3] << 16),
+                                    (uint32_t)ra1[8 * kk + 4] | ((uint32_t)ra1[8 * kk + 5] << 16), (uint32_t)ra1[8 * kk + 6] | ((uint32_t)ra1[8 * kk + 7] << 16));
+        }
+        uint32_t p1[2][4], p2[2][4], p3[2][4];         // the three bf16 pieces of this lane's 16 activation values, packed
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v0 = rb[8 * kk + 2 * i], v1 = rb[8 * kk + 2 * i + 1];
+                const uint32_t a = pack2(v0, v1);
+                const float r0 = v0 - __builtin_bit_cast(float, a << 16), r1 = v1 - __builtin_bit_cast(float, a & 0xffff0000u);
+                const uint32_t b = pack2(r0, r1);
+                const float s0 = r0 - __builtin_bit_cast(float, b << 16), s1 = r1 - __builtin_bit_cast(float, b & 0xffff0000u);
+                p1[kk][i] = a;
+                p2[kk][i] = b;
+                p3[kk][i] = pack2(s0, s1);
+            }
+        if (q + 4 < nsteps) request(q + 4);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            acc = DTbf16::mfma32(fa[kk], make_uint4(p3[kk][0], p3[kk][1], p3[kk][2], p3[kk][3]), acc);     // smallest pieces first
+            acc = DTbf16::mfma32(fa[kk], make_uint4(p2[kk][0], p2[kk][1], p2[kk][2], p2[kk][3]), acc);
+            acc = DTbf16::mfma32(fa[kk], make_uint4(p1[kk][0], p1[kk][1], p1[kk][2], p1[kk][3]), acc);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[wave][reg][lane] = acc[reg];
+    __syncthreads();
+    if (!cvalid) return;
+    float* out = C + ((size_t)n * rows_c + (size_t)oc * BS + 32 * ts) * state + (size_t)h * hs + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int reg = 4 * wave + i;
+        const float v = red[0][reg][lane] + red[1][reg][lane] + red[2][reg][lane] + red[3][reg][lane];
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        out[(size_t)row * state] = v;
     }
 }
 
