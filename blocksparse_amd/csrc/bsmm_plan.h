@@ -136,19 +136,14 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
         for (auto& e : v) if (gp0.empty() || gp0.back() != e.p) gp0.push_back(e.p);
         const int ns = (int)gp0.size();
         const int step_off = (int)pairs.size();
-        // Optional rotation of the walk (env BSMM_ROTATE=1): group g starts at a different input pair so that concurrent
-        // workgroups are not all on the same pair (a test of the L2-channel-conflict hypothesis).  Measured slightly
-        // SLOWER (373 vs 399 TF): it destroys the L2 reuse between the groups of one row tile.  Off by default.
-        static const bool do_rot = getenv("BSMM_ROTATE") != nullptr;
-        const int rot = (ns > 0 && do_rot) ? (int)((long)g * ns / ngroups) : 0;
-        std::vector<int32_t> gp(ns);
-        for (int t = 0; t < ns; ++t) gp[t] = gp0[(t + rot) % ns];
+        // (Starting every group at a different pair, to spread the L2 channels, measured slower: 373 vs 399 TF -- it destroys
+        //  the L2 reuse between the groups of one row tile.)
+        const std::vector<int32_t>& gp = gp0;
         std::vector<int32_t> tab((size_t)2 * XC_G * ns, -1);
         int t0 = -1, cur = -1;
         for (auto& e : v) {
             if (e.p != cur) { cur = e.p; ++t0; }
-            const int t = (t0 - rot + ns) % ns;     // position of original step t0 in the rotated walk
-            tab[(size_t)e.slot * ns + t] = e.w;
+            tab[(size_t)e.slot * ns + t0] = e.w;
         }
         pairs.insert(pairs.end(), gp.begin(), gp.end());
         wtab.insert(wtab.end(), tab.begin(), tab.end());

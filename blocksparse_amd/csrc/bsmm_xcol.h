@@ -114,33 +114,17 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     };
     auto block = [&](const Frag32<DT>& wf, const unsigned char* slab, int half) {
         // all X fragments first, then the MFMAs with the two K-halves of one accumulator XC_RT instructions apart
-        // hipcc schedules this as read-2 / wait / 2 MFMAs.  Forcing all eight reads first (sched_barrier, -DBSMM_XC_BATCH)
+        // hipcc schedules this as read-2 / wait / 2 MFMAs.  Forcing all eight reads first (sched_barrier)
         // measured SLOWER (160 vs 122 us): the eight waves then hit the LDS in one burst and nobody has MFMA work meanwhile.
         Frag32<DT> xf[XC_RT];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int t = 0; t < XC_RT; ++t) xf[t].q[kk] = *reinterpret_cast<const uint4*>(slab + t * 4096 + xrd[half][kk]);
-#ifdef BSMM_XC_BATCH
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int t = 0; t < XC_RT; ++t) acc[t] = DT::mfma32(wf.q[kk], xf[t].q[kk], acc[t]);
-#ifdef BSMM_XC_BATCH
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef BSMM_XC_SGB
-        // software pipeline inside the block: BSMM_XC_SGB reads ahead, then one read per MFMA, then the remaining MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, BSMM_XC_SGB, 0);
-#pragma unroll
-        for (int i = 0; i < 2 * XC_RT - BSMM_XC_SGB; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, BSMM_XC_SGB, 0);
-#endif
     };
 
     // Phases of XC_PH steps, one barrier per phase, ring of 2*XC_PH slabs.  At the phase barrier both slabs of the phase have

@@ -73,7 +73,7 @@ int bst_nt(const void* a_, const void* b_, void* s_, const bst_args* a) {
                 const int ntiles = a->blocks * SUB * SUB;
                 auto staged = [&](auto ch_tag) {
                     constexpr int CH = decltype(ch_tag)::value;
-                    static const int il = [] { const char* e = getenv("BST_IL"); return e ? atoi(e) : 1; }();
+                    const int il = 1;     // heads of an XCD interleaved workgroup by workgroup: 2 / 4 / 8 made no difference
                     const int grid = xcd_head_grid((ntiles + NT_NB - 1) / NT_NB, a->heads, a->batch, il);
                     static const bool split = [] { const char* e = getenv("BST_NT_SPLIT"); return e ? atoi(e) != 0 : true; }();
                     if constexpr (!TA::is16) {
