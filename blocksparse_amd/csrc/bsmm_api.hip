@@ -219,7 +219,8 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
                      : launch_xprop_valu<DT, BS, AXIS, false>(X, W, Y, a, st);
     }
     // (xcol can gather the fprop operand transposed itself -- launch_xgroup32(..., transw = true), no workspace and no
-    //  pre-pass -- but that measured SLOWER than the 6 us transpose kernel + contiguous fragment loads: 145 vs 131 us.)
+    //  pre-pass -- but that measured SLOWER than the 6 us transpose kernel + contiguous fragment loads: 140 vs 127 us, also with
+    //  the kernel held at 128 VGPRs.)
     if constexpr (BS != 8) {
         const void* Wsel = W;
         if (fprop) {

@@ -41,8 +41,12 @@ constexpr int XC_LDS = (XC_RING * XC_SLAB > XC_STAGE) ? XC_RING * XC_SLAB : XC_S
 // TRANSW = true (fprop): Wsel is W in its natural [c-in-block][k-in-block] layout and each lane gathers its fragment
 // transposed (16 two-byte loads, stride 64 B, prefetched a step ahead) -- no transposed copy of W, no workspace.
 // Measured slower than the transpose pre-pass (fprop 145 vs 131 us), so the launcher passes TRANSW = false today.
+// launch_bounds(512, 4) = at most 128 VGPRs: with 64 KiB of LDS that is what lets TWO workgroups share a CU, and the kernel sits
+// exactly on that edge (128 registers, no spills).  Variants that need a few registers more (wave priority around the MFMAs:
+// 152; in-kernel transposed weight gather: 131; deeper read-ahead) drop to one workgroup per CU and from ~120 to ~160 us --
+// most "slower" results of this file's experiments were this cliff, not the idea itself.
 #ifndef BSMM_XC_OCC
-#define BSMM_XC_OCC 2
+#define BSMM_XC_OCC 4
 #endif
 #ifdef BSMM_XC_TRACE
 // cycle stamps of the first 8 workgroups: [wg][wave][phase][6] = before wait, after wait, after barrier, after DMA issue,
@@ -234,7 +238,7 @@ constexpr int XC0_PPR = XC0_ROWB / 16;             // 16-byte pieces per row
 constexpr int XC0_RPI = 1024 / XC0_ROWB;           // rows per DMA instruction
 
 template <class DT, bool TRANSW>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(512, BSMM_XC_OCC)
 xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
                  typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
     typedef typename DT::T T;
