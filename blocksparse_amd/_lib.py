@@ -24,7 +24,7 @@ class BsmmArgs(ctypes.Structure):
     _fields_ = [
         ("lut", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
         ("workspace_bytes", ctypes.c_size_t), ("plan", ctypes.c_void_p),
-        ("plan_items", ctypes.c_int32), ("flags", ctypes.c_int32),
+        ("plan_items", ctypes.c_int32), ("plan_aux", ctypes.c_int32), ("flags", ctypes.c_int32),
         ("blocks", ctypes.c_int32), ("bsize", ctypes.c_int32), ("segments", ctypes.c_int32),
         ("locks", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
         ("shared", ctypes.c_int32), ("pcount", ctypes.c_int32), ("axis", ctypes.c_int32),

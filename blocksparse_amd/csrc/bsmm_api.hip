@@ -10,6 +10,7 @@
 #include "bsmm_updat.h"
 #include "bsmm_updat_tr.h"
 #include "bsmm_updat_win.h"
+#include "bsmm_super8.h"
 #include "bsmm_xcol.h"
 #include "bsmm_xcol16.h"
 #include "bsmm_xprop.h"
@@ -210,6 +211,24 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     if (variant == 3 && a->plan != nullptr && !(AXIS == 0 && use_xcol() && (a->N % 8 != 0))) enough = true;   // test hook
     const bool use_group = !use_valu && (BS == 32 || (BS == 16 && DT::is16)) && a->plan != nullptr && (variant == 0 || variant == 3) && enough &&
                            a->gate == nullptr;   // gated calls take the per-segment kernels
+    if constexpr (BS == 8 && DT::is16) {
+        // bsize 8 on the matrix cores: expand W into the 32x32 super-blocks of the 'BSS8' plan and run the bsize-32 kernel
+        const bool shape_ok = a->C % 32 == 0 && a->K % 32 == 0 && !(AXIS == 0 && (a->N % 8 != 0));
+        if (a->plan != nullptr && a->plan_aux > 0 && a->gate == nullptr && vec_ok && shape_ok && (variant == 0 || variant == 3)) {
+            const bool fill = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
+            if (fill || variant == 3) {
+                const int ns = a->plan_aux;
+                const size_t need = (size_t)ns * 1024 * elem_size(a->dtype);
+                if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+                typedef typename DT::T T;
+                if (fprop) expand8_kernel<DT, true><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
+                else       expand8_kernel<DT, false><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
+                bsmm_args b = *a;
+                b.bsize = 32; b.blocks = ns; b.plan = a->plan + s8_off_nested(ns); b.plan_aux = 0;
+                return launch_xgroup32<DT, AXIS>(X, a->workspace, Y, &b, st, false);
+            }
+        }
+    }
     if (a->locks > 0 && !use_group) {   // several segments accumulate into the same output block: start from zero
         hipError_t e = hipMemsetAsync(Y, 0, (size_t)a->N * a->K * elem_size(a->dtype), st);
         if (e != hipSuccess) return (int)e;
@@ -268,6 +287,48 @@ int xprop(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a)
 // ---------------------------------------------------------------------------------------------
 // updat
 // ---------------------------------------------------------------------------------------------
+// Windowed bsize-32 kernels (bsmm_updat_win.h).  raw_sums: leave the fp32 sums of every block in a->workspace (zeroed
+// here) and apply no alpha / beta -- the bsize-8 super-block path finishes them itself; DW is not touched then.
+template <class DT, int AXIS>
+int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a, bool raw_sums) {
+    typedef typename DT::T T;
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const int N = a->N, nitems = a->plan_items;
+    if (nitems <= 0) return BSMM_ERR_ARG;
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        if constexpr (AXIS == 0)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a0_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UW0_LDS);
+        else
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
+        attr_set = true;
+    }
+    const int nchunks = AXIS == 0 ? (N + 63) / 64 : (N + UWN_CH - 1) / UWN_CH;
+    int split = 1;
+    while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;   // one workgroup per CU, >= 8 chunks each
+    const char* senv = getenv("BSMM_UPDAT_SPLIT");
+    if (senv) split = atoi(senv) > 0 ? atoi(senv) : split;
+    float* scratch = nullptr;
+    if (split > 1 || raw_sums) {
+        const size_t need = (size_t)a->blocks * 1024 * sizeof(float);
+        if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+        scratch = static_cast<float*>(a->workspace);
+        hipError_t e = hipMemsetAsync(scratch, 0, need, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if constexpr (AXIS == 0)
+        updat32_a0_win_kernel<DT><<<dim3(nitems, split), 512, UW0_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K, a->pcount,
+                                                                            a->alpha, a->beta);
+    else
+        updat32_a1_win_kernel<DT><<<dim3(nitems, split), 512, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K, a->pcount,
+                                                                            a->alpha, a->beta);
+    if (scratch && !raw_sums) {
+        const size_t n = (size_t)a->blocks * 1024;
+        updat_finalize_kernel<DT><<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), n, a->alpha, a->beta);
+    }
+    return (int)hipGetLastError();
+}
+
 template <class DT, int BS, int AXIS>
 int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a) {
     typedef typename DT::T T;
@@ -283,68 +344,35 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
     const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;   // gated dw: per-block kernels only
     const bool gated = ug != nullptr;
-    if constexpr (BS == 32 && AXIS == 0 && DT::is16) {
-        if (!use_valu && !gated && vec_ok && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed kernel, axis 0
-            static bool attr_set_w0 = false;
-            if (!attr_set_w0) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a0_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UW0_LDS);
-                attr_set_w0 = true;
-            }
-            const int nitems = a->plan_items;
-            const int nchunks = (N + 63) / 64;
-            int split = 1;
-            while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;
-            const char* senv = getenv("BSMM_UPDAT_SPLIT");
-            if (senv) split = atoi(senv) > 0 ? atoi(senv) : split;
-            float* scratch = nullptr;
-            if (split > 1) {
-                const size_t need = (size_t)a->blocks * 1024 * sizeof(float);
-                if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
-                scratch = static_cast<float*>(a->workspace);
-                hipError_t e = hipMemsetAsync(scratch, 0, need, st);
-                if (e != hipSuccess) return (int)e;
-            }
-            updat32_a0_win_kernel<DT><<<dim3(nitems, split), 512, UW0_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C,
-                                                                                a->K, a->pcount, a->alpha, a->beta);
-            if (split > 1) {
-                const size_t n = (size_t)a->blocks * 1024;
-                updat_finalize_kernel<DT><<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), n, a->alpha, a->beta);
-            }
+    if constexpr (BS == 8 && DT::is16) {
+        // bsize 8 on the matrix cores: fp32 sums of whole 32x32 super-blocks ('BSS8' plan) into the workspace, then the
+        // present 8x8 parts get alpha / beta and are rounded once
+        bool al = aligned16(DW) && a->C % 32 == 0 && a->K % 32 == 0 && !(AXIS == 0 && (N % 8 != 0));
+        for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
+        if (a->plan != nullptr && a->plan_aux > 0 && a->plan_items > 0 && !gated && al && (variant == 0 || variant == 3)) {
+            const int ns = a->plan_aux;
+            bsmm_args b = *a;
+            b.bsize = 32; b.blocks = ns; b.plan_aux = 0; b.flags = 0; b.gate = nullptr;
+            b.lut = a->plan + s8_off_lut32(ns);
+            b.plan = a->plan + s8_off_nested(ns);
+            const int rc = launch_updat32_win<DT, AXIS>(xs, es, nullptr, &b, true);
+            if (rc) return rc;
+            gather8_kernel<DT><<<ns, 256, 0, st>>>(static_cast<const float*>(a->workspace), a->plan, static_cast<T*>(DW), a->alpha, a->beta);
             return (int)hipGetLastError();
         }
+    }
+    if constexpr (BS == 32 && DT::is16) {
+        bool al = vec_ok;   // axis 0: 16-byte row pieces (checked above); axis 1: operand base pointers
+        if (AXIS == 1) {
+            al = aligned16(DW);
+            for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
+        }
+        if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0)   // windowed kernels (plan = bsmm_updat_plan_build)
+            return launch_updat32_win<DT, AXIS>(xs, es, DW, a, false);
     }
     if constexpr (BS == 32 && AXIS == 1 && DT::is16) {
         bool al = aligned16(DW);
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
-        if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr) {   // windowed kernel (plan = bsmm_updat_plan_build)
-            static bool attr_set_w = false;
-            if (!attr_set_w) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
-                attr_set_w = true;
-            }
-            const int nitems = a->plan_items;
-            if (nitems <= 0) return BSMM_ERR_ARG;
-            const int nchunks = (N + UWN_CH - 1) / UWN_CH;
-            int split = 1;
-            while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;   // one workgroup per CU, >= 8 chunks each
-            const char* senv = getenv("BSMM_UPDAT_SPLIT");
-            if (senv) split = atoi(senv) > 0 ? atoi(senv) : split;
-            float* scratch = nullptr;
-            if (split > 1) {
-                const size_t need = (size_t)a->blocks * 1024 * sizeof(float);
-                if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
-                scratch = static_cast<float*>(a->workspace);
-                hipError_t e = hipMemsetAsync(scratch, 0, need, st);
-                if (e != hipSuccess) return (int)e;
-            }
-            updat32_a1_win_kernel<DT><<<dim3(nitems, split), 512, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C,
-                                                                                a->K, a->pcount, a->alpha, a->beta);
-            if (split > 1) {
-                const size_t n = (size_t)a->blocks * 1024;
-                updat_finalize_kernel<DT><<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), n, a->alpha, a->beta);
-            }
-            return (int)hipGetLastError();
-        }
         if (!use_valu && !gated && al && variant != 1) {   // LDS-DMA + transposing-read kernel
             static bool attr_set = false;
             if (!attr_set) {
@@ -599,7 +627,9 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
 
 long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
                            int32_t dtype, int32_t axis) {
-    if ((bsize != 32 && bsize != 16) || (axis != 0 && axis != 1)) return 0;   // plan kernels: bsize 32 (any dtype) / 16 (16-bit)
+    if (axis != 0 && axis != 1) return 0;
+    if (bsize == 8) return dtype == BSMM_F32 ? 0 : build_super8_xprop_plan(host_lut, segments, blocks, n_out_blocks, nullptr);   // 'BSS8'
+    if (bsize != 32 && bsize != 16) return 0;   // plan kernels: bsize 32 (any dtype) / 16 and 8 (16-bit)
     if (dtype == BSMM_F32) return (bsize == 32 && use_xcol()) ? build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, nullptr) : 0;
     if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
     return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
@@ -608,6 +638,8 @@ long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t bl
 int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
                           int32_t dtype, int32_t axis, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
+    if (bsize == 8 && dtype != BSMM_F32 && (axis == 0 || axis == 1))
+        return build_super8_xprop_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     if ((bsize != 32 && bsize != 16) || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
     if (dtype == BSMM_F32) {
         if (bsize != 32 || !use_xcol()) return BSMM_ERR_UNSUPPORTED;
@@ -619,7 +651,9 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
 
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
                            int32_t axis) {
-    if ((bsize != 32 && bsize != 16) || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: bsize 32/16, 16-bit
+    if (dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: 16-bit types
+    if (bsize == 8) return build_super8_updat_plan(host_updat_lut, blocks, CB, KB, nullptr);   // 'BSS8'
+    if (bsize != 32 && bsize != 16) return 0;
     return bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, UW, UP_MAXB, nullptr)
                        : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, nullptr);
 }
@@ -627,6 +661,8 @@ long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_
 int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
                           int32_t axis, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
+    if (bsize == 8 && dtype != BSMM_F32 && (axis == 0 || axis == 1))
+        return build_super8_updat_plan(host_updat_lut, blocks, CB, KB, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     if ((bsize != 32 && bsize != 16) || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
     const long n = bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, UW, UP_MAXB, host_plan_out)
                                : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, host_plan_out);
@@ -635,6 +671,11 @@ int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t
 
 size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     if (!a) return 0;
+    if (a->bsize == 8) {   // 'BSS8' plans: the expanded W (xprop) / the fp32 sums of the super-blocks (updat)
+        if (!a->plan || a->plan_aux <= 0 || a->dtype == BSMM_F32) return 0;
+        const size_t blk = (size_t)a->plan_aux * 1024;
+        return op == BSMM_OP_UPDAT ? blk * sizeof(float) : blk * elem_size(a->dtype);
+    }
     if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32)
         return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float);   // fp32 partial sums of the split-minibatch path
     // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)

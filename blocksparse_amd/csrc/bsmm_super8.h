@@ -1,0 +1,64 @@
+// bsmm_super8.h -- bsize 8 on the matrix cores (16-bit types): the two small data-movement kernels around the bsize-32
+// kernels that do the work on the SUPER layout (plan 'BSS8', bsmm_plan.h).
+//   expand8:  W (8x8 blocks)  ->  Wsel (32x32 super-blocks in the [out feature][in feature] order the xcol kernels multiply),
+//             absent sub-blocks zero-filled.  ~2 KiB written per super-block, a few microseconds per pass.
+//   gather8:  fp32 sums of the 32x32 super-blocks ([c][k]) -> DW (the present 8x8 blocks): alpha, beta, ONE rounding.
+// Both: one workgroup of 256 threads per super-block, a thread moves 4 consecutive elements (8 bytes).
+#pragma once
+#include "bsmm_common.h"
+#include "bsmm_plan.h"
+
+namespace bsmm {
+
+// FROM_IN_OUT: the source blocks are stored [in][out] (fprop: W[w][c][k], in = c) and are transposed on the way;
+// otherwise they are stored [out][in] (bprop: out = c) and copied.
+template <class DT, bool FROM_IN_OUT>
+__global__ void __launch_bounds__(256)
+expand8_kernel(const typename DT::T* __restrict__ W8, const int32_t* __restrict__ plan, typename DT::T* __restrict__ W32) {
+    static_assert(DT::is16, "super8 path: 16-bit storage types");
+    const int s = blockIdx.x;
+    if (plan[0] != S8PLAN_MAGIC || plan[1] != S8PLAN_VERSION || s >= plan[2]) return;
+    const int32_t* sub = plan + plan[3] + 16 * s;
+    const int o32 = threadIdx.x >> 3, i0 = (threadIdx.x & 7) * 4;            // 4 consecutive in-features of one sub-block
+    const int w = sub[4 * (i0 >> 3) + (o32 >> 3)];
+    uint2 v = make_uint2(0u, 0u);
+    if (w >= 0) {
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(W8) + (size_t)w * 64;
+        if constexpr (FROM_IN_OUT) {
+            const uint16_t* p = src + (i0 & 7) * 8 + (o32 & 7);
+            v.x = (uint32_t)p[0] | ((uint32_t)p[8] << 16);
+            v.y = (uint32_t)p[16] | ((uint32_t)p[24] << 16);
+        } else {
+            v = *reinterpret_cast<const uint2*>(src + (o32 & 7) * 8 + (i0 & 7));
+        }
+    }
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(W32) + (size_t)s * 1024 + o32 * 32 + i0) = v;
+}
+
+template <class DT>
+__global__ void __launch_bounds__(256)
+gather8_kernel(const float* __restrict__ S32, const int32_t* __restrict__ plan, typename DT::T* __restrict__ DW8, float alpha, float beta) {
+    static_assert(DT::is16, "super8 path: 16-bit storage types");
+    const int s = blockIdx.x;
+    if (plan[0] != S8PLAN_MAGIC || plan[1] != S8PLAN_VERSION || s >= plan[2]) return;
+    const int32_t* sub = plan + plan[3] + 16 * s;
+    const int c32 = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * 4;
+    const int w = sub[4 * (c32 >> 3) + (k0 >> 3)];
+    if (w < 0) return;
+    const float4 v = *reinterpret_cast<const float4*>(S32 + (size_t)s * 1024 + c32 * 32 + k0);
+    float o[4] = {alpha * v.x, alpha * v.y, alpha * v.z, alpha * v.w};
+    uint16_t* dst = reinterpret_cast<uint16_t*>(DW8) + (size_t)w * 64 + (c32 & 7) * 8 + (k0 & 7);
+    if (beta != 0.f) {
+        const uint2 old = *reinterpret_cast<const uint2*>(dst);
+        o[0] += beta * DT::to_f32((typename DT::T)(old.x & 0xffffu));
+        o[1] += beta * DT::to_f32((typename DT::T)(old.x >> 16));
+        o[2] += beta * DT::to_f32((typename DT::T)(old.y & 0xffffu));
+        o[3] += beta * DT::to_f32((typename DT::T)(old.y >> 16));
+    }
+    uint2 r;
+    r.x = (uint32_t)DT::from_f32(o[0]) | ((uint32_t)DT::from_f32(o[1]) << 16);
+    r.y = (uint32_t)DT::from_f32(o[2]) | ((uint32_t)DT::from_f32(o[3]) << 16);
+    *reinterpret_cast<uint2*>(dst) = r;
+}
+
+}  // namespace bsmm

@@ -13,8 +13,9 @@
 //   Ring of UWN_D slots (slot = X slab + DY slab): the DMA of chunk q+UWN_D-1 is issued right after the barrier of
 //   chunk q; each wave issues a constant 2*UWN_NI DMA instructions per chunk (chunks past the end re-fetch the last
 //   rows), so a counted `vmcnt` = "my share of chunk q has landed".  One barrier per chunk, 512 threads, 1 WG per CU.
-//   Minibatch split: gridDim.y workgroups share an item; with gridDim.y > 1 partial tiles are added (fp32 atomics) into
-//   a zeroed fp32 scratch and a second kernel applies alpha/beta and rounds once; with gridDim.y == 1 the workgroup
+//   Minibatch split: gridDim.y workgroups share an item; with a scratch buffer (always when gridDim.y > 1; also the
+//   bsize-8 super-block path) partial tiles are added (fp32 atomics) into the zeroed fp32 scratch and a second kernel
+//   applies alpha/beta and rounds once; without one (gridDim.y == 1) the workgroup
 //   stores directly.
 #pragma once
 #include <type_traits>
@@ -173,7 +174,7 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
         for (int reg = 0; reg < 16; ++reg) {
             const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
             const size_t idx = base + ci * 32;
-            if (gridDim.y == 1) {
+            if (scratch == nullptr) {
                 float out = alpha * acc[j][reg];
                 if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
                 DW[idx] = DT::from_f32(out);
@@ -315,7 +316,7 @@ updat32_a0_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
         for (int reg = 0; reg < 16; ++reg) {
             const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
             const size_t idx = base + ci * 32;
-            if (gridDim.y == 1) {
+            if (scratch == nullptr) {
                 float out = alpha * acc[j][reg];
                 if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
                 DW[idx] = DT::from_f32(out);
@@ -489,7 +490,7 @@ updat16_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, fl
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const size_t idx = (size_t)wid[j] * 256 + (4 * q + reg) * 16 + f;
-            if (gridDim.y == 1) {
+            if (scratch == nullptr) {
                 float out = alpha * acc[j][reg];
                 if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
                 DW[idx] = DT::from_f32(out);

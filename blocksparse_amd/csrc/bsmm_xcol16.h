@@ -14,8 +14,21 @@
 
 namespace bsmm {
 
+// Register budget: the kernel takes 64 KB of LDS, so two workgroups fit a CU only when it stays within 128 VGPRs
+// (512 threads x 2 = 4 waves per SIMD).  Holding all 8 row-tile X fragments at once costs 156 VGPRs and halves the
+// occupancy (0.174 -> 0.129 ms on the 4096^2 10 % bprop); the compute loop therefore holds TH tiles at a time.
+// Measured best: TH = 2 on axis 1, TH = 1 on axis 0 (the transposed LDS reads are longer-latency there).
+#ifndef BSMM_XC16_OCC
+#define BSMM_XC16_OCC 4
+#endif
+#ifndef BSMM_XC16_TH_A1
+#define BSMM_XC16_TH_A1 2
+#endif
+#ifndef BSMM_XC16_TH_A0
+#define BSMM_XC16_TH_A0 1
+#endif
 template <class DT, int AXIS>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(512, BSMM_XC16_OCC)
 xcol16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
               typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
     typedef typename DT::T T;
@@ -146,15 +159,19 @@ xcol16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __rest
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         if (((act_c[0] | act_c[1]) >> ks) & 1) {
-                            uint4 xf[8];
+                            constexpr int TH = AXIS == 1 ? BSMM_XC16_TH_A1 : BSMM_XC16_TH_A0;      // row tiles whose X fragments are in registers at once
 #pragma unroll
-                            for (int tt = 0; tt < 8; ++tt) xf[tt] = xfrag(slab, tt, ks);
+                            for (int t0 = 0; t0 < 8; t0 += TH) {
+                                uint4 xf[TH];
 #pragma unroll
-                            for (int c = 0; c < 2; ++c)
-                                if ((act_c[c] >> ks) & 1) {
+                                for (int tt = 0; tt < TH; ++tt) xf[tt] = xfrag(slab, t0 + tt, ks);
 #pragma unroll
-                                    for (int tt = 0; tt < 8; ++tt) acc[c][tt] = DT::mfma16(wc[c][ks], xf[tt], acc[c][tt]);
-                                }
+                                for (int c = 0; c < 2; ++c)
+                                    if ((act_c[c] >> ks) & 1) {
+#pragma unroll
+                                        for (int tt = 0; tt < TH; ++tt) acc[c][t0 + tt] = DT::mfma16(wc[c][ks], xf[tt], acc[c][t0 + tt]);
+                                    }
+                            }
                         }
                     }
 #pragma unroll

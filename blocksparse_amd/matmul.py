@@ -99,7 +99,15 @@ class _DeviceTables(object):
         self.bprop_plan_f32 = up(bp32) if bp32 is not None else None
         upl = _host_updat_plan(tables["updat_lut"], B, CB, KB, bsize, _lib.BF16, axis)
         self.updat_plan = up(upl) if upl is not None else None
-        self.updat_items = int(upl[4]) if upl is not None else 0
+        # bsize 8: the plans are 'BSS8' composites (super-block count in word 2, the bsize-32 plan nested at word plan[5])
+        s8 = bsize == 8
+        self.fprop_aux = int(fp[2]) if (s8 and fp is not None) else 0
+        self.bprop_aux = int(bp[2]) if (s8 and bp is not None) else 0
+        self.updat_aux = int(upl[2]) if (s8 and upl is not None) else 0
+        if upl is None:
+            self.updat_items = 0
+        else:
+            self.updat_items = int(upl[int(upl[5]) + 4]) if s8 else int(upl[4])
 
 
 class BlocksparseMatMul(object):
@@ -229,6 +237,7 @@ class BlocksparseMatMul(object):
         y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
         a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype,
                        plan=tabs.fprop_plan_f32 if x.dtype == torch.float32 else tabs.fprop_plan)
+        a.plan_aux = tabs.fprop_aux if x.dtype != torch.float32 else 0
         a.gate = gate.data_ptr() if gate is not None else None
         need = lib.bsmm_workspace_bytes(_lib.OP_FPROP, ctypes.byref(a))
         ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device) if need else None
@@ -250,7 +259,12 @@ class BlocksparseMatMul(object):
         dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)
         a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype,
                        plan=tabs.bprop_plan_f32 if dy.dtype == torch.float32 else tabs.bprop_plan)
+        a.plan_aux = tabs.bprop_aux if dy.dtype != torch.float32 else 0
         a.gate = gate.data_ptr() if gate is not None else None
+        need = lib.bsmm_workspace_bytes(_lib.OP_BPROP, ctypes.byref(a))
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dy.device) if need else None
+        if ws is not None:
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
         return dx
 
@@ -287,6 +301,7 @@ class BlocksparseMatMul(object):
         a = self._args(tabs.updat, None, N, self.C, self.K, xs[0].dtype, pcount=len(xs), alpha=alpha, beta=beta,
                        plan=tabs.updat_plan if xs[0].dtype != torch.float32 else None)
         a.plan_items = tabs.updat_items
+        a.plan_aux = tabs.updat_aux if xs[0].dtype != torch.float32 else 0
         gate = self._check_gate(gate, dev)
         if gate is not None:
             a.gate, a.flags = gate.data_ptr(), _lib.FLAG_GATED_DW

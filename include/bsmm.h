@@ -66,7 +66,9 @@ typedef struct bsmm_args {
     const int32_t* plan;    /* optional device copy of the schedule built by bsmm_xprop_plan_build() (fprop/bprop) or
                                bsmm_updat_plan_build() (updat) for THIS lut (NULL = generic kernels).  Like the luts
                                it is a constant of the layout.                                                       */
-    int32_t plan_items;     /* updat only: header word [4] of the updat plan (number of work items = grid size)       */
+    int32_t plan_items;     /* updat only: header word [4] of the updat plan (number of work items = grid size); bsize 8:
+                               header word [4] of the plan nested at word plan[5]                                     */
+    int32_t plan_aux;       /* bsize 8 plans only: header word [2] (number of 32x32 super-blocks); otherwise 0        */
     int32_t flags;          /* BSMM_FLAG_* (0 = none)                                                                 */
     int32_t blocks;         /* nonzero blocks                                                                        */
     int32_t bsize;          /* 8, 16 or 32                                                                           */

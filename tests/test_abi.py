@@ -160,7 +160,7 @@ def test_plan_builder_covers_every_block_once(lib):
                                 assert (slot >> 2) < nob
                                 got16.add((ob0 + (slot >> 2), 4 * int(gq[tt]) + (slot & 3), w))
                 assert got16 == want
-    # no plan kernels for fp32 / bsize 8
+    # no plan kernels for fp32 at bsize 16, nor for bsize-8 grids that are not whole 32-feature blocks (tests/test_super8_plan.py)
     t = L.build_tables(np.ones((2, 2)))
     assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 16, lib.F32, 1) is None
     assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 8, lib.BF16, 1) is None
@@ -210,7 +210,8 @@ def test_updat_plan_covers_every_block_once(lib):
                 assert cnt == n
             assert seen == set(range(t["blocks"]))
     assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 32, lib.F32, 1) is None
-    assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 8, lib.BF16, 0) is None
+    assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 8, lib.F32, 0) is None
+    assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 8, lib.BF16, 0)[0] == 0x42535338   # 'BSS8' (tests/test_super8_plan.py)
 
 
 def test_host_class_surface():

@@ -119,6 +119,50 @@ def test_plan_kernels_forced_on_small_and_ragged_cases(env, axis, dtype, bs):
         L.bsmm_set_kernel_variant(0)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("axis", [0, 1])
+def test_bsize8_super_block_path(env, axis, dtype):
+    """bsize 8, 16-bit: the 'BSS8' plans run the bsize-32 matrix-core kernels on the 32x32 super-blocks (W expanded with
+    zeros, DW gathered back).  Forced on small / ragged / degenerate cases like the other plan kernels; a 7x9 grid has no
+    super plan (not a multiple of 4 blocks) and N % 8 != 0 on axis 0 must fall back to the V_FMA kernels, still correct."""
+    torch, BSMM, lib = env
+    L = lib.load()
+    holes = P.ba_layout(16, 2, seed=3)
+    holes[:, 5] = 0
+    holes[7, :] = 0
+    layouts = [P.ba_layout(40, 3, seed=1), holes, P.random_layout(8, 12, 0.5, seed=2), np.ones((4, 4), dtype=np.int32),
+               P.random_layout(20, 36, 0.1, seed=6), P.random_layout(7, 9, 0.5, seed=2)]
+    try:
+        L.bsmm_set_kernel_variant(3)
+        for li, layout in enumerate(layouts):
+            for N in (8, 72, 200) + ((100, 5) if li == 0 else ()):
+                res = P.run_case(torch, BSMM, layout, 8, axis, dtype, N, seed=li * 10 + N, segmented=(li == 4))
+                _check(res, dtype, "super8 layout%d a%d %s N%d" % (li, axis, dtype, N))
+    finally:
+        L.bsmm_set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_bsize8_super_block_updat_pairs_alpha_beta(env, axis):
+    torch, BSMM, lib = env
+    layout = P.random_layout(12, 8, 0.3, seed=8)
+    b = BSMM(layout, block_size=8, feature_axis=axis)
+    t = orc.build_layout_luts(layout, 8)
+    N = 328
+    Xs, Es = [], []
+    for p in range(3):
+        _, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "bf16", seed=60 + p)
+        Xs.append(X); Es.append(E)
+    dw0 = orc.round_bf16(np.random.RandomState(1).normal(size=b.w_shape).astype(np.float32) * 0.1)
+    ref = orc.updat(t, Xs, Es, axis, alpha=0.5, beta=2.0, dw_in=dw0)
+    dw = P.to_dev(dw0, "bf16", torch)
+    out = b.updat([P.to_dev(x, "bf16", torch) for x in Xs], [P.to_dev(e, "bf16", torch) for e in Es], alpha=0.5, beta=2.0, dw=dw)
+    torch.cuda.synchronize()
+    assert out.data_ptr() == dw.data_ptr()
+    l2, mx = P.errors(P.to_host(out), orc.round_bf16(ref))
+    assert l2 <= P.L2_BAR["bf16"], (l2, mx)     # fp32 sums -> alpha, beta -> ONE rounding, like the direct kernels
+
+
 @pytest.mark.parametrize("axis", [0, 1])
 def test_fp32_plan_kernels_forced(env, axis):
     """fp32 / bsize 32 has its own grouped kernel (xcol32f): same forced small / ragged cases, fp32 bar; N % 4 != 0 on
