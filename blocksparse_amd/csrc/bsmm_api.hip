@@ -90,26 +90,47 @@ int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args*
 }
 
 // grouped (xcol) kernels need args->plan built by bsmm_xprop_plan_build for args->lut
+#ifndef BSMM_XC_WIDE_PH
+#define BSMM_XC_WIDE_PH 4
+#endif
 inline bool use_xcol() { return true; }
+inline int xc16_group() {   // output blocks per workgroup of the bsize-16 xcol kernel: 16, or 32 ("wide")
+    static const int wide = [] { const char* e = getenv("BSMM_XC16_WIDE"); return e ? atoi(e) : 1; }();
+    return wide ? 32 : XC16_G;
+}
+// Output blocks per workgroup of the 16-bit bsize-32 xcol kernels: 16 (the wide <16, 4> variants, bsmm_xcol.h; measured
+// 5-10 % faster than <8, 2> from N = 3072 up, 8 % slower at N = 2048 where it fills only half the CUs).  The plan is
+// built for the same width; BSMM_XC_WIDE=0 (read once) selects the narrow kernels for A/B runs.
+inline int xc_group(int /*axis*/) {
+    static const int wide = [] { const char* e = getenv("BSMM_XC_WIDE"); return e ? atoi(e) : 1; }();
+    return wide ? 16 : XC_G;
+}
 
-template <class DT, int AXIS>
-int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+template <class DT, int AXIS, int NW, int PH>
+int launch_xcol16_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 16;
     XMap m;
     m.ntiles = (a->N + XC_R - 1) / XC_R;
-    m.segments = (n_out + XC16_G - 1) / XC16_G;
+    m.segments = (n_out + 2 * NW - 1) / (2 * NW);
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
+    constexpr int LDS = xc_lds_bytes(NW, PH);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol16_kernel<DT, AXIS>), hipFuncAttributeMaxDynamicSharedMemorySize, XC_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol16_kernel<DT, AXIS, NW, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    xcol16_kernel<DT, AXIS><<<m.grid(), 512, XC_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                           a->N, a->C, a->K);
+    xcol16_kernel<DT, AXIS, NW, PH><<<m.grid(), 64 * NW, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                   a->N, a->C, a->K);
     return (int)hipGetLastError();
+}
+
+template <class DT, int AXIS>
+int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    if (xc16_group() == 32) return launch_xcol16_g<DT, AXIS, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
+    return launch_xcol16_g<DT, AXIS, 8, XC_PH>(X, Wsel, Y, a, st);
 }
 
 template <int AXIS>
@@ -131,37 +152,56 @@ int launch_xcol32f(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     return (int)hipGetLastError();
 }
 
-template <class DT, bool TRANSW>
-void launch_xcol0(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+template <class DT, bool TRANSW, int G, int PH>
+void launch_xcol0_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
     XMap m;
     m.ntiles = (a->N + XC_R - 1) / XC_R;
-    m.segments = (n_out + XC_G - 1) / XC_G;
+    m.segments = (n_out + G - 1) / G;
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    xcol32_a0_kernel<DT, TRANSW><<<m.grid(), 512, XC0_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                         a->N, a->C, a->K);
+    constexpr int LDS = 2 * PH * XC0_SLAB;
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32_a0_kernel<DT, TRANSW, G, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    xcol32_a0_kernel<DT, TRANSW, G, PH><<<m.grid(), 64 * G, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                     a->N, a->C, a->K);
+}
+
+template <class DT, bool TRANSW>
+void launch_xcol0(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    if (xc_group(0) == 16) launch_xcol0_g<DT, TRANSW, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
+    else                   launch_xcol0_g<DT, TRANSW, XC_G, XC_PH>(X, Wsel, Y, a, st);
+}
+
+template <class DT, bool TRANSW, int G, int PH>
+void launch_xcol_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    typedef typename DT::T T;
+    const int n_out = a->K / 32;
+    XMap m;
+    m.ntiles = (a->N + XC_R - 1) / XC_R;
+    m.segments = (n_out + G - 1) / G;
+    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+    if (m.P > m.segments) m.P = m.segments;
+    m.SP = (m.segments + m.P - 1) / m.P;
+    constexpr int LDS = xc_lds_bytes(G, PH);
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32_a1_kernel<DT, TRANSW, G, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    xcol32_a1_kernel<DT, TRANSW, G, PH><<<m.grid(), 64 * G, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                     a->N, a->C, a->K);
 }
 
 template <class DT, bool TRANSW>
 void launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    typedef typename DT::T T;
-    const int n_out = a->K / 32;
-    XMap m;
-    m.ntiles = (a->N + XC_R - 1) / XC_R;
-    m.segments = (n_out + XC_G - 1) / XC_G;
-    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
-    if (m.P > m.segments) m.P = m.segments;
-    m.SP = (m.segments + m.P - 1) / m.P;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32_a1_kernel<DT, TRANSW>), hipFuncAttributeMaxDynamicSharedMemorySize, XC_LDS);
-        attr_set = true;
-    }
-    xcol32_a1_kernel<DT, TRANSW><<<m.grid(), 512, XC_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                        a->N, a->C, a->K);
+    if (xc_group(1) == 16) launch_xcol_g<DT, TRANSW, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
+    else                   launch_xcol_g<DT, TRANSW, XC_G, XC_PH>(X, Wsel, Y, a, st);
 }
 
 template <class DT, int AXIS>
@@ -628,25 +668,25 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
 long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
                            int32_t dtype, int32_t axis) {
     if (axis != 0 && axis != 1) return 0;
-    if (bsize == 8) return dtype == BSMM_F32 ? 0 : build_super8_xprop_plan(host_lut, segments, blocks, n_out_blocks, nullptr);   // 'BSS8'
+    if (bsize == 8) return dtype == BSMM_F32 ? 0 : build_super8_xprop_plan(host_lut, segments, blocks, n_out_blocks, nullptr, xc_group(axis));   // 'BSS8'
     if (bsize != 32 && bsize != 16) return 0;   // plan kernels: bsize 32 (any dtype) / 16 and 8 (16-bit)
     if (dtype == BSMM_F32) return (bsize == 32 && use_xcol()) ? build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, nullptr) : 0;
-    if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
-    return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
+    if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, nullptr, xc16_group());
+    return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr, xc_group(axis));
 }
 
 int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
                           int32_t dtype, int32_t axis, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
     if (bsize == 8 && dtype != BSMM_F32 && (axis == 0 || axis == 1))
-        return build_super8_xprop_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
+        return build_super8_xprop_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, xc_group(axis)) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     if ((bsize != 32 && bsize != 16) || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
     if (dtype == BSMM_F32) {
         if (bsize != 32 || !use_xcol()) return BSMM_ERR_UNSUPPORTED;
         return build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     }
-    if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
-    return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
+    if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, xc16_group()) > 0 ? BSMM_OK : BSMM_ERR_ARG;
+    return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, xc_group(axis)) > 0 ? BSMM_OK : BSMM_ERR_ARG;
 }
 
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,

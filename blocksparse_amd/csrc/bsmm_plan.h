@@ -114,9 +114,9 @@ constexpr int32_t XCPLAN_VERSION = 1;
 constexpr int XC_G = 8;
 constexpr int XC_HDR = 12;
 
-inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int G = XC_G) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
-    const int ngroups = (n_out_blocks + XC_G - 1) / XC_G;
+    const int ngroups = (n_out_blocks + G - 1) / G;
     struct E { int p, slot, w; };   // slot = 2*wave + half
     std::vector<std::vector<E>> per_group(ngroups);
     for (int s = 0; s < segments; ++s) {
@@ -125,7 +125,7 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
         for (int e = 0; e < cnt; ++e) {
             const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
             if (w < 0 || w >= blocks || c < 0) return -1;
-            per_group[ob / XC_G].push_back({c >> 1, 2 * (ob % XC_G) + (c & 1), w});
+            per_group[ob / G].push_back({c >> 1, 2 * (ob % G) + (c & 1), w});
         }
     }
     std::vector<int32_t> groups, pairs, wtab;
@@ -139,7 +139,7 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
         // (Starting every group at a different pair, to spread the L2 channels, measured slower: 373 vs 399 TF -- it destroys
         //  the L2 reuse between the groups of one row tile.)
         const std::vector<int32_t>& gp = gp0;
-        std::vector<int32_t> tab((size_t)2 * XC_G * ns, -1);
+        std::vector<int32_t> tab((size_t)2 * G * ns, -1);
         int t0 = -1, cur = -1;
         for (auto& e : v) {
             if (e.p != cur) { cur = e.p; ++t0; }
@@ -147,12 +147,12 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
         }
         pairs.insert(pairs.end(), gp.begin(), gp.end());
         wtab.insert(wtab.end(), tab.begin(), tab.end());
-        groups.insert(groups.end(), {step_off, ns, g * XC_G, std::min(XC_G, n_out_blocks - g * XC_G)});
+        groups.insert(groups.end(), {step_off, ns, g * G, std::min(G, n_out_blocks - g * G)});
     }
     const long total = XC_HDR + (long)groups.size() + (long)pairs.size() + (long)wtab.size();
     if (out) {
         const int off_groups = XC_HDR, off_pairs = off_groups + (int)groups.size(), off_wtab = off_pairs + (int)pairs.size();
-        const int32_t hdr[XC_HDR] = {XCPLAN_MAGIC, XCPLAN_VERSION, XC_G, ngroups, (int32_t)pairs.size(), off_groups, off_pairs, off_wtab,
+        const int32_t hdr[XC_HDR] = {XCPLAN_MAGIC, XCPLAN_VERSION, G, ngroups, (int32_t)pairs.size(), off_groups, off_pairs, off_wtab,
                                      n_out_blocks, 0, 0, 0};
         std::copy(hdr, hdr + XC_HDR, out);
         std::copy(groups.begin(), groups.end(), out + off_groups);
@@ -250,9 +250,9 @@ constexpr int32_t XC16PLAN_MAGIC = 0x42535836;
 constexpr int32_t XC16PLAN_VERSION = 1;
 constexpr int XC16_G = 16;
 
-inline long build_xcol16_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+inline long build_xcol16_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int G = XC16_G) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
-    const int ngroups = (n_out_blocks + XC16_G - 1) / XC16_G;
+    const int ngroups = (n_out_blocks + G - 1) / G;
     struct E { int p, slot, w; };
     std::vector<std::vector<E>> per_group(ngroups);
     for (int s = 0; s < segments; ++s) {
@@ -261,7 +261,7 @@ inline long build_xcol16_plan(const int32_t* lut, int segments, int blocks, int 
         for (int e = 0; e < cnt; ++e) {
             const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
             if (w < 0 || w >= blocks || c < 0) return -1;
-            per_group[ob / XC16_G].push_back({c >> 2, 4 * (ob % XC16_G) + (c & 3), w});
+            per_group[ob / G].push_back({c >> 2, 4 * (ob % G) + (c & 3), w});
         }
     }
     std::vector<int32_t> groups, quads, wtab;
@@ -272,7 +272,7 @@ inline long build_xcol16_plan(const int32_t* lut, int segments, int blocks, int 
         for (auto& e : v) if (gp.empty() || gp.back() != e.p) gp.push_back(e.p);
         const int ns = (int)gp.size();
         const int step_off = (int)quads.size();
-        std::vector<int32_t> tab((size_t)4 * XC16_G * ns, -1);
+        std::vector<int32_t> tab((size_t)4 * G * ns, -1);
         int t = -1, cur = -1;
         for (auto& e : v) {
             if (e.p != cur) { cur = e.p; ++t; }
@@ -280,12 +280,12 @@ inline long build_xcol16_plan(const int32_t* lut, int segments, int blocks, int 
         }
         quads.insert(quads.end(), gp.begin(), gp.end());
         wtab.insert(wtab.end(), tab.begin(), tab.end());
-        groups.insert(groups.end(), {step_off, ns, g * XC16_G, std::min(XC16_G, n_out_blocks - g * XC16_G)});
+        groups.insert(groups.end(), {step_off, ns, g * G, std::min(G, n_out_blocks - g * G)});
     }
     const long total = XC_HDR + (long)groups.size() + (long)quads.size() + (long)wtab.size();
     if (out) {
         const int off_groups = XC_HDR, off_quads = off_groups + (int)groups.size(), off_wtab = off_quads + (int)quads.size();
-        const int32_t hdr[XC_HDR] = {XC16PLAN_MAGIC, XC16PLAN_VERSION, XC16_G, ngroups, (int32_t)quads.size(), off_groups, off_quads,
+        const int32_t hdr[XC_HDR] = {XC16PLAN_MAGIC, XC16PLAN_VERSION, G, ngroups, (int32_t)quads.size(), off_groups, off_quads,
                                      off_wtab, n_out_blocks, 0, 0, 0};
         std::copy(hdr, hdr + XC_HDR, out);
         std::copy(groups.begin(), groups.end(), out + off_groups);
@@ -366,7 +366,7 @@ inline long s8_emit(const std::vector<S8Super>& supers, const std::vector<int32_
 }
 
 // xprop: lut = the bsize-8 segment table of the pass (headers (offset, count, out block, lock), then (in block, w) pairs)
-inline long build_super8_xprop_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+inline long build_super8_xprop_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int G = XC_G) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
     if (n_out_blocks % 4 != 0) return 0;                       // the super grid needs whole 32-feature blocks
     std::vector<int32_t> trip;
@@ -395,10 +395,10 @@ inline long build_super8_xprop_plan(const int32_t* lut, int segments, int blocks
         }
         lut32[4 * ob] = 2 * n_out32 + first; lut32[4 * ob + 1] = pos - first; lut32[4 * ob + 2] = ob; lut32[4 * ob + 3] = -1;
     }
-    const long nw = build_xcol_plan(lut32.data(), n_out32, ns, n_out32, nullptr);
+    const long nw = build_xcol_plan(lut32.data(), n_out32, ns, n_out32, nullptr, G);
     if (nw <= 0) return -1;
     std::vector<int32_t> nested((size_t)nw);
-    build_xcol_plan(lut32.data(), n_out32, ns, n_out32, nested.data());
+    build_xcol_plan(lut32.data(), n_out32, ns, n_out32, nested.data(), G);
     return s8_emit(supers, nested, 0, out);
 }
 

@@ -56,8 +56,13 @@ __device__ unsigned long long g_xc_trace[8 * 8 * 40 * 6];
 #else
 #define XC_STAMP(k) do { } while (0)
 #endif
-template <class DT, bool TRANSW>
-__global__ void __launch_bounds__(512, BSMM_XC_OCC)
+// G = output blocks (= waves) per workgroup, PH = steps per phase.  <8, 2>: 512 threads, 64 KiB, two workgroups per CU.
+// <16, 4> ("wide"): 1024 threads, one workgroup per CU with the same 16 resident waves, but ONE slab feeds 16 columns --
+// half the L2->LDS slab traffic per MFMA -- and the 128 KiB ring holds phases of four steps (half the barriers).
+constexpr int xc_lds_bytes(int g, int ph) { return (2 * ph * XC_SLAB > XC_R * g * 64) ? 2 * ph * XC_SLAB : XC_R * g * 64; }
+
+template <class DT, bool TRANSW, int G = XC_G, int PH = XC_PH>
+__global__ void __launch_bounds__(64 * G, BSMM_XC_OCC)
 xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
                  typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
     typedef typename DT::T T;
@@ -65,13 +70,17 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile, grp;
     if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
-    if (plan[0] != XCPLAN_MAGIC || plan[1] != XCPLAN_VERSION || plan[2] != XC_G) return;
+    if (plan[0] != XCPLAN_MAGIC || plan[1] != XCPLAN_VERSION || plan[2] != G) return;
     const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
     const int step_off = gh.x, nsteps = gh.y, ob0 = gh.z, nob = gh.w;
     const int32_t* pairs = plan + plan[6] + step_off;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int32_t* wt0 = plan + plan[7] + 2 * XC_G * step_off + (2 * wave) * nsteps;   // my column, even half
+    constexpr int NI = XC_SLAB / 1024 / G;      // DMA instructions per wave per slab
+    constexpr int RING = 2 * PH;
+    constexpr int ROWB = G * 64;                // bytes per row of the epilogue staging tile
+    static_assert(NI >= 1 && 64 % RING == 0, "slab split / ring must divide the 64-step table batch");
+    const int32_t* wt0 = plan + plan[7] + 2 * G * step_off + (2 * wave) * nsteps;   // my column, even half
     const int32_t* wt1 = wt0 + nsteps;                                                  // odd half
     const int r = lane & 31, h = lane >> 5;
     const int n_tile = tile * XC_R;
@@ -79,22 +88,22 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     // X DMA: slab = 32 instructions of 1 KiB (8 rows each); wave v issues instructions 4v .. 4v+3
     const uint32_t base_addr = lds_addr_of(smem);
     const int npairs_full = Cin / 64;
-    const T* xsrc[XC_NI];
+    const T* xsrc[NI];
     int oddsub[2];
 #pragma unroll
-    for (int i = 0; i < XC_NI; ++i) {
-        const int row = 8 * (XC_NI * wave + i) + (lane >> 3);
+    for (int i = 0; i < NI; ++i) {
+        const int row = 8 * (NI * wave + i) + (lane >> 3);
         const int xr = min(n_tile + row, N - 1);                     // rows past N are clamped (never stored)
         const int piece = (lane & 7) ^ ((row >> 1) & 7);
         xsrc[i] = X + (size_t)xr * Cin + piece * 8;
-        if (i < 2) oddsub[i] = (piece & 4) ? 32 : 0;                 // piece pattern repeats every 2 instructions (XC_NI even)
+        if (i < 2) oddsub[i] = (piece & 4) ? 32 : 0;                 // piece pattern repeats every 2 instructions
     }
     auto issue_x = [&](int p, int pos) {
         const bool full = p < npairs_full;
 #pragma unroll
-        for (int i = 0; i < XC_NI; ++i)
+        for (int i = 0; i < NI; ++i)
             glds16_asm(xsrc[i] + (p * 64 - (full ? 0 : oddsub[i & 1])),
-                       __builtin_amdgcn_readfirstlane(base_addr + pos * XC_SLAB + (XC_NI * wave + i) * 1024));
+                       __builtin_amdgcn_readfirstlane(base_addr + pos * XC_SLAB + (NI * wave + i) * 1024));
     };
     // fragment read offsets inside a 32-row band of the slab: piece = 4*half + 2*kk + h
     const int xsw = (r >> 1) & 7;
@@ -131,7 +140,7 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             for (int t = 0; t < XC_RT; ++t) acc[t] = DT::mfma32(wf.q[kk], xf[t].q[kk], acc[t]);
     };
 
-    // Phases of XC_PH steps, one barrier per phase, ring of 2*XC_PH slabs.  At the phase barrier both slabs of the phase have
+    // Phases of PH steps, one barrier per phase, ring of 2*PH slabs.  At the phase barrier both slabs of the phase have
     // landed (each wave waited for its DMA share, issued a whole phase earlier) and everyone has left the previous
     // phase, so the two slabs of the NEXT phase are requested right away (prefetch distance = one phase); a wave's W
     // fragments are still fetched one step ahead.  Half the barriers, and the per-step imbalance between waves
@@ -146,27 +155,27 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             const int idx = min(tb + lane, nsteps - 1);
             const int pv = pairs[idx];
             const int w0v = owner ? wt0[idx] : -1, w1v = owner ? wt1[idx] : -1;
-            const int tend = min(64, nsteps - tb);    // steps in this batch (64 % XC_RING == 0: slot = step % XC_RING)
+            const int tend = min(64, nsteps - tb);    // steps in this batch (64 % RING == 0: slot = step % RING)
             Frag32<DT> wc0, wc1, wn0, wn1;
             wc0.zero(); wc1.zero(); wn0.zero(); wn1.zero();
             int c0 = __builtin_amdgcn_readlane(w0v, 0), c1 = __builtin_amdgcn_readlane(w1v, 0);
             load_w(c0, wc0);
             load_w(c1, wc1);
 #pragma unroll
-            for (int u = 0; u < XC_PH; ++u)
+            for (int u = 0; u < PH; ++u)
                 if (u < tend) issue_x(__builtin_amdgcn_readlane(pv, u), u);
-            for (int s = 0; s < tend; s += XC_PH) {
+            for (int s = 0; s < tend; s += PH) {
                 XC_STAMP(0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my shares of this phase's slabs (+ my W fragments) landed
                 XC_STAMP(1);
                 __syncthreads();                                  // everyone's did; everyone left the previous phase
                 XC_STAMP(2);
 #pragma unroll
-                for (int u = 0; u < XC_PH; ++u)
-                    if (s + XC_PH + u < tend) issue_x(__builtin_amdgcn_readlane(pv, s + XC_PH + u), (s + XC_PH + u) % XC_RING);
+                for (int u = 0; u < PH; ++u)
+                    if (s + PH + u < tend) issue_x(__builtin_amdgcn_readlane(pv, s + PH + u), (s + PH + u) % RING);
                 XC_STAMP(3);
 #pragma unroll
-                for (int u = 0; u < XC_PH; ++u) {
+                for (int u = 0; u < PH; ++u) {
                     const int ss = s + u;
                     if (ss >= tend) break;
                     if (u >= 1) { XC_STAMP(4); }
@@ -178,7 +187,7 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
                         load_w(n0, wn0);
                         load_w(n1, wn1);
                     }
-                    const unsigned char* slab = smem + (ss % XC_RING) * XC_SLAB;
+                    const unsigned char* slab = smem + (ss % RING) * XC_SLAB;
                     if (c0 >= 0) block(wc0, slab, 0);
                     if (c1 >= 0) block(wc1, slab, 1);
                     wc0 = wn0; wc1 = wn1; c0 = n0; c1 = n1;
@@ -195,7 +204,7 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     // 512 B per instruction (direct 8-byte stores at an 8 KiB stride cost ~22 us for the 67 MB; this costs ~13).
     // staging image: [XC_R rows][512 B], 16-byte pieces of row n XOR-swizzled with (n & 31) (bank-conflict free both
     // ways: writers walk n across lanes, readers walk pieces across lanes).
-    static_assert(XC_STAGE <= XC_LDS, "staging tile must fit");
+    static_assert(XC_R * ROWB <= xc_lds_bytes(G, PH), "staging tile must fit");
     __syncthreads();   // everyone is done with the slabs
     if (owner) {
 #pragma unroll
@@ -206,7 +215,7 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
                 uint32_t lo = (uint32_t)DT::from_f32(acc[t][4 * q + 0]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 1]) << 16);
                 uint32_t hi = (uint32_t)DT::from_f32(acc[t][4 * q + 2]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 3]) << 16);
                 const int piece = wave * 4 + q;                     // 16-byte piece inside the 512-byte row: o = 8q + 4h + ...
-                *reinterpret_cast<uint2*>(smem + n * 512 + ((piece ^ (n & 31)) << 4) + 8 * h) = make_uint2(lo, hi);
+                *reinterpret_cast<uint2*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4) + 8 * h) = make_uint2(lo, hi);
             }
         }
     }
@@ -214,10 +223,11 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     {
         const int rowbytes = nob * 64;                              // partial last group: fewer valid columns
         T* ybase = Y + (size_t)ob0 * 32;
-        for (int i = threadIdx.x; i < XC_R * 32; i += 512) {        // 32 pieces per row
-            const int n = i >> 5, piece = i & 31;
+        constexpr int PPR = ROWB / 16;                              // 16-byte pieces per row
+        for (int i = threadIdx.x; i < XC_R * PPR; i += 64 * G) {
+            const int n = i / PPR, piece = i % PPR;
             if (n_tile + n < N && piece * 16 < rowbytes) {
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + n * 512 + ((piece ^ (n & 31)) << 4));
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4));
                 *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)(n_tile + n) * Kout) + piece * 16) = v;
             }
         }
@@ -237,8 +247,8 @@ constexpr int XC0_NI = XC0_SLAB / 1024 / XC_G;     // DMA instructions per wave 
 constexpr int XC0_PPR = XC0_ROWB / 16;             // 16-byte pieces per row
 constexpr int XC0_RPI = 1024 / XC0_ROWB;           // rows per DMA instruction
 
-template <class DT, bool TRANSW>
-__global__ void __launch_bounds__(512, BSMM_XC_OCC)
+template <class DT, bool TRANSW, int G = XC_G, int PH = XC_PH>      // <8, 2> or the wide <16, 4> (see xcol32_a1_kernel)
+__global__ void __launch_bounds__(64 * G, BSMM_XC_OCC)
 xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
                  typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
     typedef typename DT::T T;
@@ -246,32 +256,35 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile, grp;
     if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
-    if (plan[0] != XCPLAN_MAGIC || plan[1] != XCPLAN_VERSION || plan[2] != XC_G) return;
+    if (plan[0] != XCPLAN_MAGIC || plan[1] != XCPLAN_VERSION || plan[2] != G) return;
     const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
     const int step_off = gh.x, nsteps = gh.y, ob0 = gh.z, nob = gh.w;
     const int32_t* pairs = plan + plan[6] + step_off;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int32_t* wt0 = plan + plan[7] + 2 * XC_G * step_off + (2 * wave) * nsteps;
+    constexpr int NI = XC0_SLAB / 1024 / G;     // DMA instructions per wave per slab
+    constexpr int RING = 2 * PH;
+    static_assert(NI >= 1 && 64 % RING == 0, "slab split / ring must divide the 64-step table batch");
+    const int32_t* wt0 = plan + plan[7] + 2 * G * step_off + (2 * wave) * nsteps;
     const int32_t* wt1 = wt0 + nsteps;
     const int r = lane & 31, h = lane >> 5;
     const int n_tile = tile * XC_R;
 
     const uint32_t base_addr = lds_addr_of(smem);
     // DMA: instruction i covers rows XC0_RPI*i ..; lane -> (row + lane / PPR, stored piece lane % PPR)
-    int drow[XC0_NI], dcol[XC0_NI];
+    int drow[NI], dcol[NI];
 #pragma unroll
-    for (int i = 0; i < XC0_NI; ++i) {
-        const int row = XC0_RPI * (XC0_NI * wave + i) + lane / XC0_PPR;
+    for (int i = 0; i < NI; ++i) {
+        const int row = XC0_RPI * (NI * wave + i) + lane / XC0_PPR;
         const int piece = (lane % XC0_PPR) ^ (4 * (row & 3));
         drow[i] = row;
         dcol[i] = min(n_tile + piece * 8, N - 8);          // columns past N are clamped re-reads (never stored)
     }
     auto issue_x = [&](int p, int pos) {
 #pragma unroll
-        for (int i = 0; i < XC0_NI; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int frow = min(p * 64 + drow[i], Cin - 1);   // an odd half that does not exist re-reads the last row
-            glds16_asm(X + (size_t)frow * N + dcol[i], __builtin_amdgcn_readfirstlane(base_addr + pos * XC0_SLAB + (XC0_NI * wave + i) * 1024));
+            glds16_asm(X + (size_t)frow * N + dcol[i], __builtin_amdgcn_readfirstlane(base_addr + pos * XC0_SLAB + (NI * wave + i) * 1024));
         }
     };
     // transposing-read addressing: 16-lane group g16 -> minibatch columns 16*(g16&1) .. +15 of a 32-column tile, K half
@@ -312,7 +325,7 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     };
 
     const bool owner = wave < nob;
-    if (nsteps > 0) {   // phases of XC_PH steps, one barrier per phase (see xcol32_a1_kernel)
+    if (nsteps > 0) {   // phases of PH steps, one barrier per phase (see xcol32_a1_kernel)
         for (int tb = 0; tb < nsteps; tb += 64) {
             const int idx = min(tb + lane, nsteps - 1);
             const int pv = pairs[idx];
@@ -324,16 +337,16 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             load_w(c0, wc0);
             load_w(c1, wc1);
 #pragma unroll
-            for (int u = 0; u < XC_PH; ++u)
+            for (int u = 0; u < PH; ++u)
                 if (u < tend) issue_x(__builtin_amdgcn_readlane(pv, u), u);
-            for (int s = 0; s < tend; s += XC_PH) {
+            for (int s = 0; s < tend; s += PH) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
 #pragma unroll
-                for (int u = 0; u < XC_PH; ++u)
-                    if (s + XC_PH + u < tend) issue_x(__builtin_amdgcn_readlane(pv, s + XC_PH + u), (s + XC_PH + u) % XC_RING);
+                for (int u = 0; u < PH; ++u)
+                    if (s + PH + u < tend) issue_x(__builtin_amdgcn_readlane(pv, s + PH + u), (s + PH + u) % RING);
 #pragma unroll
-                for (int u = 0; u < XC_PH; ++u) {
+                for (int u = 0; u < PH; ++u) {
                     const int ss = s + u;
                     if (ss >= tend) break;
                     if (u >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -344,7 +357,7 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
                         load_w(n0, wn0);
                         load_w(n1, wn1);
                     }
-                    const unsigned char* slab = smem + (ss % XC_RING) * XC0_SLAB;
+                    const unsigned char* slab = smem + (ss % RING) * XC0_SLAB;
                     if (c0 >= 0) block(wc0, slab, 0);
                     if (c1 >= 0) block(wc1, slab, 1);
                     wc0 = wn0; wc1 = wn1; c0 = n0; c1 = n1;

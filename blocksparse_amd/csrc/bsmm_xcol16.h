@@ -27,8 +27,10 @@ namespace bsmm {
 #ifndef BSMM_XC16_TH_A0
 #define BSMM_XC16_TH_A0 1
 #endif
-template <class DT, int AXIS>
-__global__ void __launch_bounds__(512, BSMM_XC16_OCC)
+// NW = waves per workgroup (each owns 2 output blocks), PH = steps per phase.  <8, 2>: 512 threads, 64 KiB, two workgroups
+// per CU; <16, 4> ("wide", see xcol32_a1_kernel): 1024 threads, 32 output blocks share a slab, phases of four steps.
+template <class DT, int AXIS, int NW = 8, int PH = XC_PH>
+__global__ void __launch_bounds__(64 * NW, BSMM_XC16_OCC)
 xcol16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
               typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
     typedef typename DT::T T;
@@ -37,26 +39,31 @@ xcol16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile, grp;
     if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
-    if (plan[0] != XC16PLAN_MAGIC || plan[1] != XC16PLAN_VERSION || plan[2] != XC16_G) return;
+    if (plan[0] != XC16PLAN_MAGIC || plan[1] != XC16PLAN_VERSION || plan[2] != 2 * NW) return;
     const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
     const int step_off = gh.x, nsteps = gh.y, ob0 = gh.z, nob = gh.w;
     const int32_t* quads = plan + plan[6] + step_off;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int32_t* wt = plan + plan[7] + 4 * XC16_G * step_off + (size_t)(8 * wave) * nsteps;   // my 8 slots: (col, sub)
+    constexpr int G16 = 2 * NW;                       // output blocks per workgroup
+    constexpr int NI1 = XC_SLAB / 1024 / NW, NI0 = XC0_SLAB / 1024 / NW;   // DMA instructions per wave per slab (axis 1 / 0)
+    constexpr int RING = 2 * PH;
+    constexpr int ROWB = G16 * 32;                    // bytes per row of the axis-1 epilogue staging tile
+    static_assert(NI1 >= 1 && NI0 >= 1 && 64 % RING == 0 && XC_R * ROWB <= xc_lds_bytes(NW, PH), "geometry");
+    const int32_t* wt = plan + plan[7] + 4 * G16 * step_off + (size_t)(8 * wave) * nsteps;   // my 8 slots: (col, sub)
     const int o16 = lane & 15, q = lane >> 4;
     const int n_tile = tile * XC_R;
     const uint32_t base_addr = lds_addr_of(smem);
 
     // ---- X DMA: identical to xcol32 (a quad of 16-blocks = the 64 features of a bsize-32 pair) ----
     const int nquads_full = Cin / 64;
-    const T* xsrc[XC_NI];
+    const T* xsrc[NI1];
     int oddsub[2];
-    int drow[XC0_NI], dcol[XC0_NI];
+    int drow[NI0], dcol[NI0];
     if constexpr (AXIS == 1) {
 #pragma unroll
-        for (int i = 0; i < XC_NI; ++i) {
-            const int row = 8 * (XC_NI * wave + i) + (lane >> 3);
+        for (int i = 0; i < NI1; ++i) {
+            const int row = 8 * (NI1 * wave + i) + (lane >> 3);
             const int xr = min(n_tile + row, N - 1);
             const int piece = (lane & 7) ^ ((row >> 1) & 7);
             xsrc[i] = X + (size_t)xr * Cin + piece * 8;
@@ -64,8 +71,8 @@ xcol16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __rest
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < XC0_NI; ++i) {
-            const int row = XC0_RPI * (XC0_NI * wave + i) + lane / XC0_PPR;
+        for (int i = 0; i < NI0; ++i) {
+            const int row = XC0_RPI * (NI0 * wave + i) + lane / XC0_PPR;
             const int piece = (lane % XC0_PPR) ^ (4 * (row & 3));
             drow[i] = row;
             dcol[i] = min(n_tile + piece * 8, N - 8);
@@ -75,15 +82,15 @@ xcol16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __rest
         if constexpr (AXIS == 1) {
             // a trailing quad may lack some blocks (Cin % 64 != 0): pieces past the row end re-read the row's last 16 bytes
 #pragma unroll
-            for (int i = 0; i < XC_NI; ++i) {
+            for (int i = 0; i < NI1; ++i) {
                 const int over = (p < nquads_full) ? 0 : max(0, p * 64 + oddsub[i & 1] + 8 - Cin);
-                glds16_asm(xsrc[i] + (p * 64 - over), __builtin_amdgcn_readfirstlane(base_addr + pos * XC_SLAB + (XC_NI * wave + i) * 1024));
+                glds16_asm(xsrc[i] + (p * 64 - over), __builtin_amdgcn_readfirstlane(base_addr + pos * XC_SLAB + (NI1 * wave + i) * 1024));
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < XC0_NI; ++i) {
+            for (int i = 0; i < NI0; ++i) {
                 const int frow = min(p * 64 + drow[i], Cin - 1);
-                glds16_asm(X + (size_t)frow * N + dcol[i], __builtin_amdgcn_readfirstlane(base_addr + pos * XC0_SLAB + (XC0_NI * wave + i) * 1024));
+                glds16_asm(X + (size_t)frow * N + dcol[i], __builtin_amdgcn_readfirstlane(base_addr + pos * XC0_SLAB + (NI0 * wave + i) * 1024));
             }
         }
     };
@@ -140,22 +147,22 @@ xcol16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __rest
             };
             fetch(0, wc, act_c);
 #pragma unroll
-            for (int u = 0; u < XC_PH; ++u)
+            for (int u = 0; u < PH; ++u)
                 if (u < tend) issue_x(__builtin_amdgcn_readlane(pv, u), u);
-            for (int s = 0; s < tend; s += XC_PH) {
+            for (int s = 0; s < tend; s += PH) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
 #pragma unroll
-                for (int u = 0; u < XC_PH; ++u)
-                    if (s + XC_PH + u < tend) issue_x(__builtin_amdgcn_readlane(pv, s + XC_PH + u), (s + XC_PH + u) % XC_RING);
+                for (int u = 0; u < PH; ++u)
+                    if (s + PH + u < tend) issue_x(__builtin_amdgcn_readlane(pv, s + PH + u), (s + PH + u) % RING);
 #pragma unroll
-                for (int u = 0; u < XC_PH; ++u) {
+                for (int u = 0; u < PH; ++u) {
                     const int ss = s + u;
                     if (ss >= tend) break;
                     if (u >= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     act_n[0] = act_n[1] = 0;
                     if (ss + 1 < tend) fetch(ss + 1, wn, act_n);
-                    const unsigned char* slab = smem + (ss % XC_RING) * XC_SLAB;
+                    const unsigned char* slab = smem + (ss % RING) * XC_SLAB;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         if (((act_c[0] | act_c[1]) >> ks) & 1) {
@@ -188,7 +195,7 @@ xcol16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __rest
 
     // D[o][n]: col = n = lane & 15 (row of tile tt), rows o = 4q + reg
     if constexpr (AXIS == 1) {
-        // staged through LDS and stored as full 512-byte rows (see xcol32_a1_kernel)
+        // staged through LDS and stored as full rows (see xcol32_a1_kernel)
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -199,16 +206,17 @@ xcol16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __rest
                 const uint32_t lo = (uint32_t)DT::from_f32(acc[c][tt][0]) | ((uint32_t)DT::from_f32(acc[c][tt][1]) << 16);
                 const uint32_t hi = (uint32_t)DT::from_f32(acc[c][tt][2]) | ((uint32_t)DT::from_f32(acc[c][tt][3]) << 16);
                 const int piece = (2 * wave + c) * 2 + (q >> 1);          // 16 features x 2 B = 2 pieces per block
-                *reinterpret_cast<uint2*>(smem + n * 512 + ((piece ^ (n & 31)) << 4) + 8 * (q & 1)) = make_uint2(lo, hi);
+                *reinterpret_cast<uint2*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4) + 8 * (q & 1)) = make_uint2(lo, hi);
             }
         }
         __syncthreads();
         const int rowbytes = nob * 32;
         T* ybase = Y + (size_t)ob0 * 16;
-        for (int i = threadIdx.x; i < XC_R * 32; i += 512) {
-            const int n = i >> 5, piece = i & 31;
+        constexpr int PPR = ROWB / 16;
+        for (int i = threadIdx.x; i < XC_R * PPR; i += 64 * NW) {
+            const int n = i / PPR, piece = i % PPR;
             if (n_tile + n < N && piece * 16 < rowbytes) {
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + n * 512 + ((piece ^ (n & 31)) << 4));
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4));
                 *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)(n_tile + n) * Kout) + piece * 16) = v;
             }
         }
