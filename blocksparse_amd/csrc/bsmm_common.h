@@ -253,6 +253,17 @@ __device__ __forceinline__ void glds16_asm(const void* gsrc, uint32_t lds_byte_a
                  : "v"(gsrc), "s"(lds_byte_addr)
                  : "memory");
 }
+// Same with only the lanes of `mask` active (the LDS slot of a lane is still lane * 16; inactive lanes move nothing).
+// The caller must be in wave-uniform control flow with ALL lanes active: EXEC is set to -1 afterwards.  (An `if` around
+// glds16_asm costs a saveexec / branch / restore sequence per instruction, measurably more than this.)
+__device__ __forceinline__ void glds16_asm_masked(const void* gsrc, uint32_t lds_byte_addr, uint64_t mask) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr), "s"(mask)
+                 : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }

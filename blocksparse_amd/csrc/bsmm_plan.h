@@ -22,14 +22,16 @@
 //
 // Layout (int32):  [0] magic 'BSUP'  [1] version  [2] UW  [3] UP_MAXB  [4] nitems (multiple of 8)  [5] nblocks
 //                  [6] off_items  [7] UP_WAVES
-//   item: UP_ITEM = 4 + UP_WAVES*UP_MAXB*2 words = (c0_block, k0_block, nblocks_in_item, nslots) then for wave v, slot j:
-//         (nslots = slots every wave of the item walks = max blocks owned by one wave; empty slots have meta = 0)
+//   item: UP_ITEM = 4 + UP_WAVES*UP_MAXB*2 words = (c0_block, k0_block, nblocks_in_item | cmask << 16, nslots | kmask << 16)
+//         then for wave v, slot j:
+//         (nslots = slots every wave of the item walks = max blocks owned by one wave; empty slots have meta = 0;
+//          cmask / kmask = window rows / columns that hold a block of the item: the kernels stage only those slab parts)
 //         (meta, w)   meta = cidx | kidx << 4 | 1 << 8 (valid) | sameX << 9     (cidx/kidx = block offset inside the window)
 // =================================================================================================
 namespace bsmm {
 
 constexpr int32_t UPLAN_MAGIC = 0x42535550;
-constexpr int32_t UPLAN_VERSION = 4;
+constexpr int32_t UPLAN_VERSION = 5;
 constexpr int UW = 8;          // bsize 32: 8x8-block windows, 4 slots per wave
 constexpr int UP_WAVES = 8;
 constexpr int UP_MAXB = 4;
@@ -68,14 +70,19 @@ inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int K
                 std::vector<int32_t> it(UP_ITEM, 0);
                 const int per = (n + UP_WAVES - 1) / UP_WAVES;
                 it[0] = wi * UW; it[1] = wj * UW; it[2] = n; it[3] = per;   // contiguous runs per wave keep equal-c blocks together
+                uint32_t cmask = 0, kmask = 0;                              // window rows / columns this item touches
                 for (int e = 0; e < n; ++e) {
                     const int wave = e / per, slot = e % per;
                     const Ent& en = v[beg + e];
+                    cmask |= 1u << (en.c - wi * UW);
+                    kmask |= 1u << (en.k - wj * UW);
                     const bool same = slot > 0 && v[beg + e - 1].c == en.c;
                     int32_t* p = &it[4 + (wave * UP_MAXB + slot) * 2];
                     p[0] = (en.c - wi * UW) | ((en.k - wj * UW) << 4) | (1 << 8) | (same ? (1 << 9) : 0);
                     p[1] = en.w;
                 }
+                it[2] |= (int32_t)(cmask << 16);
+                it[3] |= (int32_t)(kmask << 16);
                 per_xcd[xcd].insert(per_xcd[xcd].end(), it.begin(), it.end());
             }
         }

@@ -47,6 +47,9 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = item[0], k0 = item[1];
     if (item[2] == 0) return;   // padding item
+    // (The plan's row / column use masks, item[2] >> 16 and item[3] >> 16, are NOT applied here: skipping unused 64-byte
+    //  blocks inside the 512-byte rows saves bytes but no 128-byte lines, and measured 2-5 % slower.  The axis-0 kernels,
+    //  where an unused block is 32 whole slab rows, do use them.)
     int meta[UP_MAXB], wid[UP_MAXB];
 #pragma unroll
     for (int j = 0; j < UP_MAXB; ++j) {
@@ -88,7 +91,7 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
     // Every wave of the item walks the same number of slots (item[3]); a wave with fewer blocks computes its empty
     // slots on block (0,0) of the window into accumulators that are never stored.  No per-slot branches: the chunk body
     // is straight-line code, specialised on the slot count, so all transposing reads of a chunk are issued up-front.
-    const int nslots = item[3];
+    const int nslots = item[3] & 0xffff;
     int aoff[UP_MAXB], boff[UP_MAXB];   // per-slot byte offset of this lane's piece inside a slab row band
 #pragma unroll
     for (int j = 0; j < UP_MAXB; ++j) {
@@ -210,7 +213,10 @@ updat32_a0_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = item[0], k0 = item[1];
     if (item[2] == 0) return;   // padding item
-    const int nslots = item[3];
+    const int nslots = item[3] & 0xffff;
+    // wave v stages exactly block v of both slabs (UW0_NI instructions = 32 feature rows): skipped when the item has no block there
+    static_assert(8 * UW0_NI == 32, "a wave's DMA share is one 32-row block");
+    const bool xon = ((uint32_t)item[2] >> (16 + wave)) & 1, eon = ((uint32_t)item[3] >> (16 + wave)) & 1;
     int meta[UP_MAXB], wid[UP_MAXB];
 #pragma unroll
     for (int j = 0; j < UP_MAXB; ++j) {
@@ -258,8 +264,8 @@ updat32_a0_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
                 for (int i = 0; i < UW0_NI; ++i) {
                     const int col = min(n0 + dpiece[i], N - 8);   // pieces past N are clamped re-reads (masked below)
                     const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (UW0_NI * wave + i) * 1024);
-                    glds16_asm(X + xrow[i] + col, dst);
-                    glds16_asm(E + erow[i] + col, dst + UW0_SLAB);
+                    if (xon) glds16_asm(X + xrow[i] + col, dst);
+                    if (eon) glds16_asm(E + erow[i] + col, dst + UW0_SLAB);
                 }
             };
             if (q_beg >= q_end) break;
@@ -348,7 +354,8 @@ updat16_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, fl
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = item[0], k0 = item[1];   // window origin in 16-feature blocks
     if (item[2] == 0) return;
-    const int nslots = item[3];
+    const int nslots = item[3] & 0xffff;
+    const uint32_t cmask = (uint32_t)item[2] >> 16, kmask = (uint32_t)item[3] >> 16;   // 16-feature blocks of the window in use
     int meta[UP16_MAXB], wid[UP16_MAXB];
 #pragma unroll
     for (int j = 0; j < UP16_MAXB; ++j) {
@@ -365,6 +372,7 @@ updat16_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, fl
     constexpr int NI = (AXIS == 1) ? UWN_NI : UW0_NI;
     int xcol[NI], ecol[NI];           // axis 1: source element column; axis 0: piece offset (elements) inside the row
     size_t xrow[NI], erow[NI];        // axis 0: element offset of the source row
+    uint64_t xon[NI], eon[NI];        // lanes of the instruction whose part belongs to a block the item uses (others are not staged)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         if constexpr (AXIS == 1) {
@@ -374,11 +382,14 @@ updat16_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, fl
             xcol[i] = min(c0 * 16 + piece * 8, Cf - 8);
             ecol[i] = min(k0 * 16 + piece * 8, Kf - 8);
             xrow[i] = erow[i] = 0;
+            xon[i] = eon[i] = ~0ull;      // (partial 512-byte rows save no cache lines: everything is staged, see the bsize-32 kernel)
         } else {
             const int row = 8 * (NI * wave + i) + (lane >> 3);
             xcol[i] = ecol[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
             xrow[i] = (size_t)min(c0 * 16 + row, Cf - 1) * N;
             erow[i] = (size_t)min(k0 * 16 + row, Kf - 1) * N;
+            xon[i] = __ballot((cmask >> (row >> 4)) & 1);
+            eon[i] = __ballot((kmask >> (row >> 4)) & 1);
         }
     }
     // ---- fragment addressing ----
@@ -419,8 +430,8 @@ updat16_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, fl
                         glds16_asm(E + (size_t)row * Kf + ecol[i], dst + UWN_SLAB);
                     } else {
                         const int col = min(n0 + xcol[i], N - 8);
-                        glds16_asm(X + xrow[i] + col, dst);
-                        glds16_asm(E + erow[i] + col, dst + UW0_SLAB);
+                        glds16_asm_masked(X + xrow[i] + col, dst, xon[i]);
+                        glds16_asm_masked(E + erow[i] + col, dst + UW0_SLAB, eon[i]);
                     }
                 }
             };

@@ -20,5 +20,6 @@ for axis in (0, 1):
     x = (torch.randn(b.i_shape(N), device="cuda") * 0.1).bfloat16()
     dy = (torch.randn(b.o_shape(N), device="cuda") * 0.1).bfloat16()
     fl = 2.0 * b.blocks * 256 * N
-    tf, tb = timeit(lambda: b.fprop(x, w)), timeit(lambda: b.bprop(dy, w))
-    print("%s bs16 a%d fprop %.3f ms %6.1f TF | bprop %.3f ms %6.1f TF" % (os.environ.get("TAG", ""), axis, tf, fl/tf/1e9, tb, fl/tb/1e9), flush=True)
+    tf, tb, tu = timeit(lambda: b.fprop(x, w)), timeit(lambda: b.bprop(dy, w)), timeit(lambda: b.updat(x, dy))
+    print("%s bs16 a%d fprop %.3f ms %6.1f TF | bprop %.3f ms %6.1f TF | updat %.3f ms %6.1f TF" % (
+        os.environ.get("TAG", ""), axis, tf, fl/tf/1e9, tb, fl/tb/1e9, tu, fl/tu/1e9), flush=True)

@@ -52,3 +52,5 @@ row("configs[2] bs16", 4096, 16, 0.1, 0, "bf16", 8192)
 row("configs[2] bs16 axis 1", 4096, 16, 0.1, 1, "bf16", 8192)
 row("configs[3] per-GPU shard", 8192, 32, 0.05, 1, "bf16", 512)
 row("bs 8", 4096, 8, 0.1, 0, "bf16", 8192)
+row("bs 8 axis 1", 4096, 8, 0.1, 1, "bf16", 8192)
+row("bs 8, 3 %", 4096, 8, 0.03, 0, "bf16", 8192)

@@ -186,7 +186,10 @@ def test_updat_plan_covers_every_block_once(lib):
             items = plan[plan[6]:].reshape(nitems, isz)
             seen = set()
             for it in items:
-                c0, k0, n, nslots = (int(v) for v in it[:4])
+                c0, k0 = int(it[0]), int(it[1])
+                n, nslots = int(it[2]) & 0xffff, int(it[3]) & 0xffff
+                cmask, kmask = (int(it[2]) >> 16) & 0xffff, (int(it[3]) >> 16) & 0xffff
+                want_c, want_k = 0, 0
                 slots = it[4:].reshape(waves, MAXB, 2)
                 cnt = 0
                 for v in range(waves):
@@ -197,6 +200,8 @@ def test_updat_plan_covers_every_block_once(lib):
                             c, k = c0 + (meta & 15), k0 + ((meta >> 4) & 15)
                             assert (meta & 15) < UW and ((meta >> 4) & 15) < UW
                             assert tuple(t["updat_lut"][w]) == (c, k)
+                            want_c |= 1 << (meta & 15)
+                            want_k |= 1 << ((meta >> 4) & 15)
                             assert w not in seen
                             seen.add(w)
                             cnt += 1
@@ -208,6 +213,7 @@ def test_updat_plan_covers_every_block_once(lib):
                             assert meta == 0
                     assert per_wave <= nslots
                 assert cnt == n
+                assert (cmask, kmask) == (want_c, want_k)      # the window rows / columns the kernels stage
             assert seen == set(range(t["blocks"]))
     assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 32, lib.F32, 1) is None
     assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 8, lib.F32, 0) is None
