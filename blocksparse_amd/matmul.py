@@ -19,7 +19,8 @@ Differences from the reference that a user can observe:
     reference-policy tables; output blocks shared by several segments are then accumulated with atomics
     in the storage type, like the reference's locked path.  The public attributes ``fprop_lut`` etc.
     always hold the reference-policy tables (bit-identical to the reference builder).
-  * gating (``gate=``) is not implemented yet and raises NotImplementedError.
+  * ``gate=`` / ``gate_grad`` / ``dw_gated`` follow the reference (matmul.py:455-527); gated calls run the per-segment /
+    per-block kernels (the plan kernels do not take gates).
 """
 import ctypes
 

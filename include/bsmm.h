@@ -89,7 +89,8 @@ typedef struct bsmm_args {
 /* Y = fprop(X, W).  args->lut = fprop_lut.  Needs workspace (a transposed copy of W). */
 int bsmm_fprop(const void* X, const void* W, void* Y, const bsmm_args* args);
 
-/* DX = bprop(DY, W).  args->lut = bprop_lut, args->C/K swapped by the caller.  No workspace. */
+/* DX = bprop(DY, W).  args->lut = bprop_lut, args->C/K swapped by the caller.  Workspace only for bsize 8 with a plan
+ * (the expanded W): ask bsmm_workspace_bytes(BSMM_OP_BPROP, args). */
 int bsmm_bprop(const void* DY, const void* W, void* DX, const bsmm_args* args);
 
 /* DW = alpha * sum_{p<pcount} updat(X[p], DY[p]) + beta * DW.  args->lut = updat_lut.
@@ -135,7 +136,10 @@ int bsmm_sparse_mul_grad(void* dx, void* dy, const void* dz, const void* x, cons
  * memory (the luts are constants of the layout: the reference builds them in NumPy, blocksparse/matmul.py:137-138).
  * n_out_blocks = K / bsize of the pass the lut belongs to; axis = feature axis the plan will be used with.  bsmm_xprop_plan_words returns the number of int32 words
  * (0 if this (bsize, dtype, axis) has no grouped kernel, <0 on malformed input); bsmm_xprop_plan_build fills host_plan_out
- * (that many words).  The caller uploads the words to the device and passes the pointer as bsmm_args.plan. */
+ * (that many words).  The caller uploads the words to the device and passes the pointer as bsmm_args.plan.
+ * bsize 8 (16-bit types, n_out_blocks % 4 == 0): the result is a composite 'BSS8' plan -- the 8x8 blocks grouped into 32x32
+ * super-blocks, the bsize-32 plan of that super layout nested at word [5]; word [2] (the number of super-blocks) goes to
+ * bsmm_args.plan_aux, and fprop / bprop then need workspace (bsmm_workspace_bytes). */
 long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks,
                            int32_t bsize, int32_t dtype, int32_t axis);
 int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks,
@@ -143,7 +147,9 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
 
 /* Host-only: work items of the windowed weight-gradient kernel for an updat lut in HOST memory (CB/KB = block rows /
  * columns of the layout).  Same conventions as the xprop plan; word [4] of the result goes to bsmm_args.plan_items.
- * With a plan, bsmm_updat may need workspace (fp32 partial sums): ask bsmm_workspace_bytes(BSMM_OP_UPDAT, args). */
+ * With a plan, bsmm_updat may need workspace (fp32 partial sums): ask bsmm_workspace_bytes(BSMM_OP_UPDAT, args).
+ * bsize 8 (16-bit types, CB % 4 == 0 and KB % 4 == 0): composite 'BSS8' plan as above; word [2] goes to
+ * bsmm_args.plan_aux and word [4] of the NESTED plan (it starts at word plan[5]) to bsmm_args.plan_items. */
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize,
                            int32_t dtype, int32_t axis);
 int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize,
@@ -152,8 +158,8 @@ int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t
 /* Bytes of device scratch the given op (BSMM_OP_*) needs for these args. */
 size_t bsmm_workspace_bytes(int op, const bsmm_args* args);
 
-/* Test hook: 0 = production kernels (grouped MFMA kernel when a plan is given, else per-segment MFMA kernels for
- *                bsize 16/32, VALU for 8);
+/* Test hook: 0 = production kernels (grouped MFMA kernel when a plan is given and the problem fills the chip, else
+ *                per-segment MFMA kernels for bsize 16/32, VALU for 8);
  *            1 = force the plain VALU kernels for every bsize (independent second implementation);
  *            2 = ignore bsmm_args.plan (per-segment / per-block MFMA kernels);
  *            3 = use the plan kernels whenever a plan is given, regardless of the problem-size heuristic. */
