@@ -11,6 +11,7 @@
 #include "bsmm_updat_tr.h"
 #include "bsmm_updat_win.h"
 #include "bsmm_super8.h"
+#include "bsmm_xcols.h"
 #include "bsmm_xcol.h"
 #include "bsmm_xcol16.h"
 #include "bsmm_xprop.h"
@@ -94,6 +95,12 @@ int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args*
 #define BSMM_XC_WIDE_PH 4
 #endif
 inline bool use_xcol() { return true; }
+// fp32, bsize 32, axis 1: the exact three-piece bf16 kernel (bsmm_xcols.h) instead of the fp32-MFMA kernel xcol32f
+// (BSMM_F32_SPLIT=0, read once, selects the latter for A/B runs).  Decides the plan format too ('BSXC' G = 16 / 'BSXF').
+inline bool f32_split(int axis) {
+    static const int on = [] { const char* e = getenv("BSMM_F32_SPLIT"); return e ? atoi(e) : 1; }();
+    return axis == 1 && on;
+}
 inline int xc16_group() {   // output blocks per workgroup of the bsize-16 xcol kernel: 16, or 32 ("wide")
     static const int wide = [] { const char* e = getenv("BSMM_XC16_WIDE"); return e ? atoi(e) : 1; }();
     return wide ? 32 : XC16_G;
@@ -149,6 +156,35 @@ int launch_xcol32f(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     }
     xcol32f_kernel<AXIS><<<m.grid(), 512, XF_LDS, st>>>(static_cast<const float*>(X), static_cast<const float*>(Wsel), static_cast<float*>(Y),
                                                         a->plan, m, a->N, a->C, a->K);
+    return (int)hipGetLastError();
+}
+
+// fp32 on the bf16 matrix cores: split pre-passes into the workspace ([3][N*C] activation pieces, then [3][blocks*1024]
+// weight pieces), then the wide xcol kernel with three slabs per step.
+inline size_t xcols_workspace_bytes(const bsmm_args* a) {
+    return 6 * ((size_t)a->N * a->C + (size_t)a->blocks * 1024);
+}
+inline int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a, hipStream_t st) {
+    const size_t nx = (size_t)a->N * a->C;
+    if (!a->workspace || a->workspace_bytes < xcols_workspace_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+    uint16_t* xp = static_cast<uint16_t*>(a->workspace);
+    uint16_t* wp = xp + 3 * nx;
+    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X), xp, nx);
+    if (fprop) split3_w_kernel<true><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), wp, a->blocks);
+    else       split3_w_kernel<false><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), wp, a->blocks);
+    const int n_out = a->K / 32;
+    XMap m;
+    m.ntiles = (a->N + XC_R - 1) / XC_R;
+    m.segments = (n_out + XS_G - 1) / XS_G;
+    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+    if (m.P > m.segments) m.P = m.segments;
+    m.SP = (m.segments + m.P - 1) / m.P;
+    static bool attr_set = false;   // benign race: idempotent
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32s_a1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS);
+        attr_set = true;
+    }
+    xcol32s_a1_kernel<<<m.grid(), 64 * XS_G, XS_LDS, st>>>(xp, wp, static_cast<float*>(Y), a->plan, m, a->N, a->C, a->K, a->blocks);
     return (int)hipGetLastError();
 }
 
@@ -280,6 +316,9 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     // (xcol can gather the fprop operand transposed itself -- launch_xgroup32(..., transw = true), no workspace and no
     //  pre-pass -- but that measured SLOWER than the 6 us transpose kernel + contiguous fragment loads: 140 vs 127 us, also with
     //  the kernel held at 128 VGPRs.)
+    if constexpr (BS == 32 && !DT::is16 && AXIS == 1) {
+        if (use_group && f32_split(1) && a->C % 32 == 0) return launch_xcol32s(fprop, X, W, Y, a, st);
+    }
     if constexpr (BS != 8) {
         const void* Wsel = W;
         if (fprop) {
@@ -670,7 +709,11 @@ long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t bl
     if (axis != 0 && axis != 1) return 0;
     if (bsize == 8) return dtype == BSMM_F32 ? 0 : build_super8_xprop_plan(host_lut, segments, blocks, n_out_blocks, nullptr, xc_group(axis));   // 'BSS8'
     if (bsize != 32 && bsize != 16) return 0;   // plan kernels: bsize 32 (any dtype) / 16 and 8 (16-bit)
-    if (dtype == BSMM_F32) return (bsize == 32 && use_xcol()) ? build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, nullptr) : 0;
+    if (dtype == BSMM_F32) {
+        if (bsize != 32 || !use_xcol()) return 0;
+        return f32_split(axis) ? build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr, XS_G)
+                               : build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
+    }
     if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, nullptr, xc16_group());
     return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr, xc_group(axis));
 }
@@ -683,6 +726,7 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
     if ((bsize != 32 && bsize != 16) || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
     if (dtype == BSMM_F32) {
         if (bsize != 32 || !use_xcol()) return BSMM_ERR_UNSUPPORTED;
+        if (f32_split(axis)) return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, XS_G) > 0 ? BSMM_OK : BSMM_ERR_ARG;
         return build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     }
     if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, xc16_group()) > 0 ? BSMM_OK : BSMM_ERR_ARG;
@@ -718,6 +762,8 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     }
     if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32)
         return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float);   // fp32 partial sums of the split-minibatch path
+    if ((op == BSMM_OP_FPROP || op == BSMM_OP_BPROP) && a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && f32_split(a->axis))
+        return xcols_workspace_bytes(a);   // bf16 pieces of the activations and the weights (bsmm_xcols.h)
     // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)
     if (op == BSMM_OP_FPROP && a->bsize != 8) return (size_t)a->blocks * a->bsize * a->bsize * elem_size(a->dtype);
     return 0;

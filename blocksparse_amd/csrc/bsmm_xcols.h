@@ -1,0 +1,237 @@
+// bsmm_xcols.h -- fp32 xprop (bsize 32, feature_axis = 1, BASELINE configs[1]) on the 16-bit matrix cores, EXACTLY.
+//
+// v_mfma_f32_32x32x2_f32 needs 1024 cycles per (block, 32-row tile); the bf16 instruction v_mfma_f32_32x32x16_bf16 does the
+// same K = 32 in 64.  Every fp32 value is the exact sum of three bf16 pieces (x = b1 + b2 + b3: 8 + 8 + 8 significand bits,
+// the two subtractions are exact in fp32), a bf16 x bf16 product is exact in fp32, and the accumulation stays fp32, so
+//     x * w  =  b1c1 + (b1c2 + b2c1) + (b1c3 + b2c2 + b3c1)  +  O(2^-26 |x w|)
+// with six MFMAs (384 cycles) -- the three dropped terms are below a quarter of an fp32 ulp of the product.  The result
+// differs from the fp32-MFMA kernel (xcol32f) only in the order of fp32 additions.  (Same device as the fp32 attention
+// kernels, bst_kernels.h.)  Inf / NaN inputs give NaN (inf - inf in the split), like any 0 * inf.
+//
+// Two pre-passes write the pieces as bf16 arrays into the caller's workspace: split3_x_kernel (activations, [3][N][C])
+// and split3_w_kernel (weights, [3][blocks][32][32], transposed per block for fprop).  The main kernel is the WIDE xcol
+// kernel (bsmm_xcol.h: 16 waves, wave v owns output block v of the group for all 128 rows, 'BSXC' plan with G = 16) with
+// three slabs per pair step: ring of 2 steps x 3 x 16 KiB = 96 KiB, one barrier per step (a step now carries 6x the MFMA
+// work of the bf16 kernel's).  Weight pieces (24 VGPRs) are requested right after the last use of the previous ones --
+// from inline asm, with the waits placed by hand, because hipcc's own vmcnt for an ordinary load would also drain the
+// LDS-DMA of the next slab that was issued in between.
+#pragma once
+#include "bsmm_common.h"
+#include "bsmm_plan.h"
+#include "bsmm_xcol.h"
+
+namespace bsmm {
+
+__device__ __forceinline__ void split3(float x, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
+    const uint16_t p1 = DTbf16::from_f32(x);
+    const float r1 = x - DTbf16::to_f32(p1);
+    const uint16_t p2 = DTbf16::from_f32(r1);
+    const float r2 = r1 - DTbf16::to_f32(p2);
+    b1 = p1; b2 = p2; b3 = DTbf16::from_f32(r2);
+}
+
+// P[q][i] = piece q of X[i], i < n (n % 8 == 0); 8 elements per thread
+__global__ void __launch_bounds__(256)
+split3_x_kernel(const float* __restrict__ X, uint16_t* __restrict__ P, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const float4 a = *reinterpret_cast<const float4*>(X + i), b = *reinterpret_cast<const float4*>(X + i + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t p[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(v[j], p[0][j], p[1][j], p[2][j]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        *reinterpret_cast<uint4*>(P + q * n + i) = make_uint4(p[q][0] | (p[q][1] << 16), p[q][2] | (p[q][3] << 16),
+                                                              p[q][4] | (p[q][5] << 16), p[q][6] | (p[q][7] << 16));
+}
+
+// P[q][w][o][i] = piece q of (TRANS ? W[w][i][o] : W[w][o][i]); one workgroup per 32x32 block, 4 elements per thread
+template <bool TRANS>
+__global__ void __launch_bounds__(256)
+split3_w_kernel(const float* __restrict__ W, uint16_t* __restrict__ P, int blocks) {
+    const int w = blockIdx.x;
+    const int o = threadIdx.x >> 3, i0 = (threadIdx.x & 7) * 4;
+    const float* src = W + (size_t)w * 1024;
+    float v[4];
+    if constexpr (TRANS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = src[(i0 + j) * 32 + o];
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(src + o * 32 + i0);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    }
+    uint32_t p[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split3(v[j], p[0][j], p[1][j], p[2][j]);
+    const size_t stride = (size_t)blocks * 1024;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        *reinterpret_cast<uint2*>(P + q * stride + (size_t)w * 1024 + o * 32 + i0) = make_uint2(p[q][0] | (p[q][1] << 16), p[q][2] | (p[q][3] << 16));
+}
+
+constexpr int XS_G = 16;                    // waves = output blocks per workgroup (the wide 'BSXC' plan)
+constexpr int XS_SLOT = 3 * XC_SLAB;        // the three piece slabs of one pair step: 48 KiB
+constexpr int XS_LDS = 2 * XS_SLOT;         // ring of two steps; also holds the 64 KiB epilogue staging tile
+constexpr int XS_ROWB = XS_G * 128;         // bytes per staged output row (16 blocks x 32 fp32)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte global load from inline asm (not tracked by hipcc's waitcnt insertion; see the file comment)
+__device__ __forceinline__ void gload16_asm(u32x4& dst, const void* src) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+__device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(64 * XS_G, 4)
+xcol32s_a1_kernel(const uint16_t* __restrict__ Xp, const uint16_t* __restrict__ Wp, float* __restrict__ Y,
+                  const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout, int blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile, grp;
+    if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
+    if (plan[0] != XCPLAN_MAGIC || plan[1] != XCPLAN_VERSION || plan[2] != XS_G) return;
+    const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
+    const int step_off = gh.x, nsteps = gh.y, ob0 = gh.z, nob = gh.w;
+    const int32_t* pairs = plan + plan[6] + step_off;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t* wt0 = plan + plan[7] + 2 * XS_G * step_off + (2 * wave) * nsteps;   // my column, even half of the pair
+    const int32_t* wt1 = wt0 + nsteps;                                                  // odd half
+    const int r = lane & 31, h = lane >> 5;
+    const int n_tile = tile * XC_R;
+    const uint32_t base_addr = lds_addr_of(smem);
+    const int npairs_full = Cin / 64;
+    const size_t pstride = (size_t)N * Cin, wstride = (size_t)blocks * 1024;
+
+    // X DMA: a slab is 16 instructions of 1 KiB (8 rows each), wave v issues instruction v of each of the three slabs
+    const int drow = 8 * wave + (lane >> 3);
+    const int dpiece = (lane & 7) ^ ((drow >> 1) & 7);
+    const uint16_t* xsrc = Xp + (size_t)min(n_tile + drow, N - 1) * Cin + dpiece * 8;     // rows past N are clamped (never stored)
+    const int oddsub = (dpiece & 4) ? 32 : 0;                                              // trailing pair without its odd block
+    auto issue_x = [&](int p, int pos) {
+        const uint16_t* src = xsrc + (p * 64 - (p < npairs_full ? 0 : oddsub));
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            glds16_asm(src + q * pstride, __builtin_amdgcn_readfirstlane(base_addr + pos * XS_SLOT + q * XC_SLAB + wave * 1024));
+    };
+    const int xsw = (r >> 1) & 7;
+    int xrd[2][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xrd[half][kk] = r * 128 + (((4 * half + 2 * kk + h) ^ xsw) << 4);
+
+    f32x16 acc[XC_RT];
+#pragma unroll
+    for (int t = 0; t < XC_RT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    u32x4 wq[3][2];      // weight pieces of the entry this wave handles next: [piece][K half]
+#pragma unroll
+    for (int q = 0; q < 3; ++q) wq[q][0] = wq[q][1] = u32x4{0u, 0u, 0u, 0u};
+    auto request_w = [&](int w) {
+        const uint16_t* row = Wp + (size_t)w * 1024 + r * 32 + 8 * h;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            gload16_asm(wq[q][0], row + q * wstride);
+            gload16_asm(wq[q][1], row + q * wstride + 16);
+        }
+    };
+    auto wait_all = [&]() {      // everything this wave requested has landed; ties the weight registers to the wait
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(wq[0][0]), "+v"(wq[0][1]), "+v"(wq[1][0]), "+v"(wq[1][1]), "+v"(wq[2][0]), "+v"(wq[2][1])
+                     :
+                     : "memory");
+    };
+    auto block = [&](const unsigned char* slot, int half) {
+#pragma unroll
+        for (int t = 0; t < XC_RT; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned char* p = slot + t * 4096 + xrd[half][kk];
+                const uint4 x0 = *reinterpret_cast<const uint4*>(p), x1 = *reinterpret_cast<const uint4*>(p + XC_SLAB),
+                            x2 = *reinterpret_cast<const uint4*>(p + 2 * XC_SLAB);
+                // smallest terms first
+                acc[t] = mfma32_bf16(wq[2][kk], x0, acc[t]);
+                acc[t] = mfma32_bf16(wq[1][kk], x1, acc[t]);
+                acc[t] = mfma32_bf16(wq[0][kk], x2, acc[t]);
+                acc[t] = mfma32_bf16(wq[1][kk], x0, acc[t]);
+                acc[t] = mfma32_bf16(wq[0][kk], x1, acc[t]);
+                acc[t] = mfma32_bf16(wq[0][kk], x0, acc[t]);
+            }
+    };
+
+    const bool owner = wave < nob;
+    if (nsteps > 0) {
+        for (int tb = 0; tb < nsteps; tb += 64) {     // lane-indexed tables for steps [tb, tb+64)
+            const int idx = min(tb + lane, nsteps - 1);
+            const int pv = pairs[idx];
+            const int tend = min(64, nsteps - tb);
+            const int w0v = (owner && lane < tend) ? wt0[idx] : -1, w1v = (owner && lane < tend) ? wt1[idx] : -1;
+            const uint64_t m0 = __ballot(w0v >= 0), m1 = __ballot(w1v >= 0);     // bit s: this wave has a block in half 0 / 1 of step s
+            // entries of this wave in walk order: e = 2 * step + half
+            auto next_entry = [&](int e) -> int {      // first entry >= e, or 128
+                const int s = e >> 1;
+                if (s >= 64) return 128;
+                uint64_t a = m0 >> s;
+                const uint64_t b = m1 >> s;
+                if (e & 1) a &= ~1ull;
+                const int ea = a ? 2 * (s + __builtin_ctzll(a)) : 128;
+                const int eb = b ? 2 * (s + __builtin_ctzll(b)) + 1 : 128;
+                return min(ea, eb);
+            };
+            auto entry_block = [&](int e) -> int {
+                const int s = e >> 1;
+                return (e & 1) ? __builtin_amdgcn_readlane(w1v, s) : __builtin_amdgcn_readlane(w0v, s);
+            };
+            int ne = __builtin_amdgcn_readfirstlane(next_entry(0));
+            if (ne < 128) request_w(entry_block(ne));
+            issue_x(__builtin_amdgcn_readlane(pv, 0), 0);
+            for (int s = 0; s < tend; ++s) {
+                wait_all();            // my share of this step's slabs and my next weight pieces have landed
+                __syncthreads();       // everyone's did; everyone has left step s - 1, whose slot is refilled now
+                if (s + 1 < tend) issue_x(__builtin_amdgcn_readlane(pv, s + 1), (s + 1) & 1);
+                const unsigned char* slot = smem + (s & 1) * XS_SLOT;
+                while ((ne >> 1) == s) {
+                    block(slot, ne & 1);
+                    ne = __builtin_amdgcn_readfirstlane(next_entry(ne + 1));
+                    if (ne < 128) request_w(entry_block(ne));      // into the registers just used (the MFMAs have read them)
+                    if ((ne >> 1) == s) wait_all();                // second block of the same step: needed right away
+                }
+            }
+            wait_all();
+            __syncthreads();   // the next batch re-primes slot 0
+        }
+    }
+
+    // Epilogue.  D[o][n]: col = n = r, rows o = (reg & 3) + 8 * (reg >> 2) + 4h: 4 consecutive o = one 16-byte piece.
+    // 32 rows at a time are staged as [32][2 KiB] (pieces XOR-swizzled with n) and stored as full rows.
+    const int rowbytes = nob * 128;
+    float* ybase = Y + (size_t)ob0 * 32;
+#pragma unroll
+    for (int t = 0; t < XC_RT; ++t) {
+        __syncthreads();
+        if (owner) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int piece = wave * 8 + 2 * g + h;
+                *reinterpret_cast<float4*>(smem + r * XS_ROWB + ((piece ^ r) << 4)) =
+                    make_float4(acc[t][4 * g + 0], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+            }
+        }
+        __syncthreads();
+        constexpr int PPR = XS_ROWB / 16;      // 128 pieces per row
+        for (int i = threadIdx.x; i < 32 * PPR; i += 64 * XS_G) {
+            const int nn = i / PPR, piece = i % PPR, row = n_tile + 32 * t + nn;
+            if (row < N && piece * 16 < rowbytes) {
+                const float4 v = *reinterpret_cast<const float4*>(smem + nn * XS_ROWB + ((piece ^ nn) << 4));
+                *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)row * Kout) + piece * 16) = v;
+            }
+        }
+    }
+}
+
+}  // namespace bsmm

@@ -165,8 +165,9 @@ def test_bsize8_super_block_updat_pairs_alpha_beta(env, axis):
 
 @pytest.mark.parametrize("axis", [0, 1])
 def test_fp32_plan_kernels_forced(env, axis):
-    """fp32 / bsize 32 has its own grouped kernel (xcol32f): same forced small / ragged cases, fp32 bar; N % 4 != 0 on
-    axis 0 falls back to the generic kernel."""
+    """fp32 / bsize 32 has its own grouped kernels (axis 0: xcol32f on the fp32 matrix-core instruction; axis 1: the exact
+    three-piece bf16 kernel of bsmm_xcols.h): same forced small / ragged cases, fp32 bar; N % 4 != 0 on axis 0 falls back
+    to the generic kernel."""
     torch, BSMM, lib = env
     L = lib.load()
     holes = P.ba_layout(16, 2, seed=3)
@@ -181,6 +182,36 @@ def test_fp32_plan_kernels_forced(env, axis):
                 _check(res, "f32", "forced-plan f32 layout%d a%d N%d" % (li, axis, N))
     finally:
         L.bsmm_set_kernel_variant(0)
+
+
+def test_fp32_split_kernel_is_exact_over_a_wide_exponent_range(env):
+    """The axis-1 fp32 path multiplies bf16 PIECES (x = b1 + b2 + b3 exactly) on the 16-bit matrix cores.  Operands whose
+    magnitudes span 2^-12 .. 2^12 element by element (so the pieces have very different scales) must still meet the fp32
+    bar against the float64 oracle, in both passes, and agree with the fp32-MFMA per-segment kernels (variant 2)."""
+    torch, BSMM, lib = env
+    L = lib.load()
+    layout = P.random_layout(12, 20, 0.4, seed=11)
+    b = BSMM(layout, block_size=32, feature_axis=1)
+    t = orc.build_layout_luts(layout, 32)
+    N = 264
+    rng = np.random.RandomState(5)
+    def wide(shape, scale):
+        return (rng.normal(size=shape) * scale * np.exp2(rng.randint(-12, 13, size=shape))).astype(np.float32)
+    W, X, E = wide(b.w_shape, 0.01), wide(b.i_shape(N), 0.1), wide(b.o_shape(N), 0.1)
+    w, x, e = (torch.from_numpy(a).cuda() for a in (W, X, E))
+    try:
+        L.bsmm_set_kernel_variant(3)
+        y, dx = b.fprop(x, w), b.bprop(e, w)
+        L.bsmm_set_kernel_variant(2)
+        y2, dx2 = b.fprop(x, w), b.bprop(e, w)
+        torch.cuda.synchronize()
+    finally:
+        L.bsmm_set_kernel_variant(0)
+    for got, got2, ref, nm in ((y, y2, orc.fprop(t, X, W, 1), "Y"), (dx, dx2, orc.bprop(t, E, W, 1), "DX")):
+        l2, mx = P.errors(P.to_host(got), ref)
+        l2b, _ = P.errors(P.to_host(got2), ref)
+        assert l2 <= P.L2_BAR["f32"], (nm, l2, mx)
+        assert l2 <= 2 * l2b + 1e-8, (nm, l2, l2b)       # no worse than the fp32 matrix-core instruction
 
 
 @pytest.mark.parametrize("axis", [0, 1])
