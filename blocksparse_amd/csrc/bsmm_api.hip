@@ -1,5 +1,7 @@
 // bsmm_api.hip -- C-ABI entry points (include/bsmm.h) and kernel dispatch for gfx950.
+#include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -266,7 +268,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
     const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
     // grouped kernels need enough (row tile x group) workgroups to fill 256 CUs; below that the per-segment kernel,
-    // which has segments x tiles workgroups, is faster (measured: N = 512 -> 136 vs 70 TF; N = 2048 -> 189 vs 257 TF)
+    // which has segments x tiles workgroups, is faster
     bool enough = false;
     if (BS == 16 && a->plan != nullptr && DT::is16) {
         enough = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 16 + XC16_G - 1) / XC16_G) >= 224;
@@ -279,9 +281,18 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         if (AXIS == 0 && (a->N % 4 != 0)) enough = false;
     }
     if (BS == 32 && a->plan != nullptr && DT::is16) {
-        const int rows = XC_R;
-        const int g = XC_G;
-        enough = (long)((a->N + rows - 1) / rows) * ((a->K / 32 + g - 1) / g) >= 224;
+        // Cost model fitted to the measurements in profiles/r01_sweeps.md (4096^2 / 20 % and 8192^2 / 5 %, N = 512 .. 8192):
+        // the grouped kernel pays ~0.48 us per pair step of a group plus ~0.045 us per block, once per round of 256
+        // workgroups, whatever the density; the per-segment kernel pays ~1.04e-5 us per (block, minibatch row).
+        const int G = xc_group(AXIS);
+        const double CB = a->C / 32.0, KB = a->K / 32.0;
+        const double ngroups = (double)((a->K / 32 + G - 1) / G), ntiles = (double)((a->N + XC_R - 1) / XC_R);
+        const double rounds = std::max(1.0, std::ceil(ntiles * ngroups / 256.0));
+        const double dens = std::min(1.0, a->blocks / std::max(1.0, CB * KB));
+        const double steps = std::ceil(CB / 2.0) * (1.0 - std::pow(1.0 - dens, 2.0 * G));
+        const double t_group = rounds * (0.48 * steps + 0.045 * a->blocks / ngroups) + 8.0;
+        const double t_segment = 17.0 + 1.04e-5 * (double)a->blocks * a->N;
+        enough = t_group < t_segment;
         if (AXIS == 0 && use_xcol() && (a->N % 8 != 0)) enough = false;   // axis-0 xcol needs 16-byte aligned row pieces
     }
     if (variant == 3 && a->plan != nullptr && !(AXIS == 0 && use_xcol() && (a->N % 8 != 0))) enough = true;   // test hook
@@ -446,8 +457,22 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             al = aligned16(DW);
             for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
         }
-        if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0)   // windowed kernels (plan = bsmm_updat_plan_build)
-            return launch_updat32_win<DT, AXIS>(xs, es, DW, a, false);
+        if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed kernels (plan = bsmm_updat_plan_build)
+            // Sparse layouts at small minibatch (BASELINE configs[3]'s per-GPU shard: 8192^2, 5 %, N = 512): a window holds ~3
+            // blocks, so the windowed kernel streams 64 KiB per chunk for almost nothing, while the per-block transposing-read
+            // kernel moves 128 bytes per (block, row).  Fitted to measurements (us): windowed 8 + rounds * chunks * 0.9;
+            // per block 10 + 9.7e-6 * blocks * N * pcount, 2.2x that once its traffic (128 B per block and row) leaves the caches.
+            bool windowed = true;
+            if (AXIS == 1 && variant == 0) {
+                const double chunks = std::ceil(N / 64.0) * a->pcount;
+                const double rounds = std::max(1.0, std::ceil(a->plan_items / 256.0));
+                const double t_win = 8.0 + rounds * chunks * 0.9;
+                const double work = (double)a->blocks * N * a->pcount;
+                const double t_blk = 10.0 + 9.7e-6 * work * (work * 128.0 > 1.0e9 ? 2.2 : 1.0);
+                windowed = t_win <= t_blk;
+            }
+            if (windowed) return launch_updat32_win<DT, AXIS>(xs, es, DW, a, false);
+        }
     }
     if constexpr (BS == 32 && AXIS == 1 && DT::is16) {
         bool al = aligned16(DW);
