@@ -389,11 +389,14 @@ int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const b
     if (!attr_set) {
         if constexpr (AXIS == 0)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a0_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UW0_LDS);
-        else
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
+        else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
+        }
         attr_set = true;
     }
-    const int nchunks = AXIS == 0 ? (N + 63) / 64 : (N + UWN_CH - 1) / UWN_CH;
+    const bool wide_win = AXIS == 1 && a->plan_aux == 16;     // plan built with 16x16 windows (sparse layouts): 32-row chunks
+    const int nchunks = wide_win ? (N + 31) / 32 : (N + 63) / 64;
     int split = 1;
     while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;   // one workgroup per CU, >= 8 chunks each
     const char* senv = getenv("BSMM_UPDAT_SPLIT");
@@ -409,9 +412,12 @@ int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const b
     if constexpr (AXIS == 0)
         updat32_a0_win_kernel<DT><<<dim3(nitems, split), 512, UW0_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K, a->pcount,
                                                                             a->alpha, a->beta);
+    else if (wide_win)
+        updat32_a1_win_kernel<DT, 16><<<dim3(nitems, split), 512, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K,
+                                                                                a->pcount, a->alpha, a->beta);
     else
-        updat32_a1_win_kernel<DT><<<dim3(nitems, split), 512, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K, a->pcount,
-                                                                            a->alpha, a->beta);
+        updat32_a1_win_kernel<DT, 8><<<dim3(nitems, split), 512, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K, a->pcount,
+                                                                               a->alpha, a->beta);
     if (scratch && !raw_sums) {
         const size_t n = (size_t)a->blocks * 1024;
         updat_finalize_kernel<DT><<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), n, a->alpha, a->beta);
@@ -460,15 +466,19 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed kernels (plan = bsmm_updat_plan_build)
             // Sparse layouts at small minibatch (BASELINE configs[3]'s per-GPU shard: 8192^2, 5 %, N = 512): a window holds ~3
             // blocks, so the windowed kernel streams 64 KiB per chunk for almost nothing, while the per-block transposing-read
-            // kernel moves 128 bytes per (block, row).  Fitted to measurements (us): windowed 8 + rounds * chunks * 0.9;
-            // per block 10 + 9.7e-6 * blocks * N * pcount, 2.2x that once its traffic (128 B per block and row) leaves the caches.
+            // kernel moves 128 bytes per (block, row).  Fitted to measurements (us): windowed 8 + rounds * chunks * 0.9 (1.8x that
+            // per chunk with 16x16 windows); per block 8 + rounds of 512 blocks * N * 0.0065 .. 0.0105.
             bool windowed = true;
             if (AXIS == 1 && variant == 0) {
-                const double chunks = std::ceil(N / 64.0) * a->pcount;
-                const double rounds = std::max(1.0, std::ceil(a->plan_items / 256.0));
-                const double t_win = 8.0 + rounds * chunks * 0.9;
-                const double work = (double)a->blocks * N * a->pcount;
-                const double t_blk = 10.0 + 9.7e-6 * work * (work * 128.0 > 1.0e9 ? 2.2 : 1.0);
+                const bool w16 = a->plan_aux == 16;
+                const double chunks = std::ceil(N / 64.0) * a->pcount;                 // 64-row units per window
+                int split = 1;                                                          // as launch_updat32_win chooses it
+                while (a->plan_items * split < 256 && split * 2 <= (w16 ? (N + 31) / 32 : (N + 63) / 64) / 8 && split < 8) split *= 2;
+                const double rounds = std::max(1.0, std::ceil(a->plan_items * (double)split / 256.0));
+                const double t_win = 8.0 + rounds * (chunks / split) * 0.9 * (w16 ? 1.8 : 1.0) + (split > 1 ? 6.0 : 0.0);
+                // per-block kernel: two workgroups per CU, each walks the whole minibatch for ONE block
+                const double rounds_b = std::max(1.0, std::ceil(a->blocks / 512.0));
+                const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * (N > 1024 ? 0.0105 : 0.0065);
                 windowed = t_win <= t_blk;
             }
             if (windowed) return launch_updat32_win<DT, AXIS>(xs, es, DW, a, false);
@@ -758,12 +768,21 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
     return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, xc_group(axis)) > 0 ? BSMM_OK : BSMM_ERR_ARG;
 }
 
+// bsize 32, axis 1: 16x16-block windows when they hold <= 16 blocks on average (sparse layouts), else 8x8 (bsmm_updat_win.h)
+static int updat_window(int32_t blocks, int32_t CB, int32_t KB, int32_t axis) {
+    static const int force = [] { const char* e = getenv("BSMM_UPDAT_WINDOW"); return e ? atoi(e) : 0; }();   // A/B runs: 8 or 16
+    if (axis != 1) return UW;
+    if (force == 8 || force == 16) return force;
+    const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);
+    return blocks <= 16.0 * windows ? 16 : UW;     // <= 2 block slots per wave on average (measured: 13 per window 2.1x faster, 26 per window 20 % slower)
+}
+
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
                            int32_t axis) {
     if (dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: 16-bit types
     if (bsize == 8) return build_super8_updat_plan(host_updat_lut, blocks, CB, KB, nullptr);   // 'BSS8'
     if (bsize != 32 && bsize != 16) return 0;
-    return bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, UW, UP_MAXB, nullptr)
+    return bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, updat_window(blocks, CB, KB, axis), UP_MAXB, nullptr)
                        : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, nullptr);
 }
 
@@ -773,7 +792,7 @@ int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t
     if (bsize == 8 && dtype != BSMM_F32 && (axis == 0 || axis == 1))
         return build_super8_updat_plan(host_updat_lut, blocks, CB, KB, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     if ((bsize != 32 && bsize != 16) || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
-    const long n = bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, UW, UP_MAXB, host_plan_out)
+    const long n = bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, updat_window(blocks, CB, KB, axis), UP_MAXB, host_plan_out)
                                : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, host_plan_out);
     return n > 0 ? BSMM_OK : BSMM_ERR_ARG;
 }

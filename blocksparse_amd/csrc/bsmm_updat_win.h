@@ -34,14 +34,23 @@ constexpr int UWN_NI = UWN_SLAB / 1024 / UP_WAVES;   // DMA instructions per wav
 constexpr int UWN_SLOT = 2 * UWN_SLAB;
 constexpr int UWN_LDS = UWN_D * UWN_SLOT;
 
-template <class DT>
+// WU = window side in blocks.  8: 8x8 windows, 64-row chunks.  16: 16x16 windows, 32-row chunks (the slabs are 32 KiB either
+// way) for SPARSE layouts: with <= ~28 blocks per 16x16 window an item still fits the 32 block slots, and every slab byte
+// staged feeds twice as many blocks (at 10 % density an 8x8 window holds 6 blocks, at 5 % three).
+template <class DT, int WU = UW>
 __global__ void __launch_bounds__(512, 2)
 updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
                       const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
     typedef typename DT::T T;
     static_assert(DT::is16, "windowed updat: 16-bit storage types");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (plan[0] != UPLAN_MAGIC || plan[1] != UPLAN_VERSION || plan[2] != UW || plan[3] != UP_MAXB || plan[7] != UP_WAVES) return;
+    if (plan[0] != UPLAN_MAGIC || plan[1] != UPLAN_VERSION || plan[2] != WU || plan[3] != UP_MAXB || plan[7] != UP_WAVES) return;
+    constexpr int CH = 512 / WU;                 // minibatch rows per chunk
+    constexpr int ROWB = WU * 64;                // bytes per slab row (WU blocks x 64 B)
+    constexpr int SLAB = CH * ROWB;              // 32 KiB
+    constexpr int NI = SLAB / 1024 / UP_WAVES;   // DMA instructions per wave per slab
+    constexpr int SLOT = 2 * SLAB;
+    static_assert(SLAB == UWN_SLAB && (WU == 8 || WU == 16), "slab geometry");
     const int32_t* item = plan + plan[6] + (size_t)blockIdx.x * UP_ITEM;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -57,21 +66,21 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
         wid[j] = item[4 + (wave * UP_MAXB + j) * 2 + 1];
     }
 
-    // rows handled by this workgroup: chunks [q_beg, q_end) of UWN_CH rows
-    const int nchunks = (N + UWN_CH - 1) / UWN_CH;
+    // rows handled by this workgroup: chunks [q_beg, q_end) of CH rows
+    const int nchunks = (N + CH - 1) / CH;
     const int per = (nchunks + gridDim.y - 1) / gridDim.y;
     const int q_beg = blockIdx.y * per, q_end = min(nchunks, q_beg + per);
 
     const uint32_t base_addr = lds_addr_of(smem);
-    // DMA: a slab is UWN_SLAB/1024 instructions of 1 KiB (RPI = 1024/UWN_ROWB rows each); wave v issues instructions
-    // UWN_NI*v .. UWN_NI*v + UWN_NI-1 of both slabs.  lane L -> row RPI*i + L / PPR, stored piece L % PPR,
+    // DMA: a slab is SLAB/1024 instructions of 1 KiB (RPI = 1024/ROWB rows each); wave v issues instructions
+    // NI*v .. NI*v + NI-1 of both slabs.  lane L -> row RPI*i + L / PPR, stored piece L % PPR,
     // source piece (L % PPR) ^ (4 * (row & 3))
-    constexpr int PPR = UWN_ROWB / 16, RPI = 1024 / UWN_ROWB;
+    constexpr int PPR = ROWB / 16, RPI = 1024 / ROWB;
     const int drow_in = lane / PPR, dpiece = lane % PPR;
-    int xcol[UWN_NI], ecol[UWN_NI];   // source element column of this lane for instruction UWN_NI*wave + i (clamped inside the row)
+    int xcol[NI], ecol[NI];   // source element column of this lane for instruction NI*wave + i (clamped inside the row)
 #pragma unroll
-    for (int i = 0; i < UWN_NI; ++i) {
-        const int row = RPI * (UWN_NI * wave + i) + drow_in;
+    for (int i = 0; i < NI; ++i) {
+        const int row = RPI * (NI * wave + i) + drow_in;
         const int piece = dpiece ^ (4 * (row & 3));
         xcol[i] = min(c0 * 32 + piece * 8, Cf - 8);
         ecol[i] = min(k0 * 32 + piece * 8, Kf - 8);
@@ -96,8 +105,8 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
 #pragma unroll
     for (int j = 0; j < UP_MAXB; ++j) {
         const int cidx = meta[j] & 15, kidx = (meta[j] >> 4) & 15;
-        aoff[j] = trow * UWN_ROWB + ((cidx ^ trow) << 6) + tsub;
-        boff[j] = UWN_SLAB + trow * UWN_ROWB + ((kidx ^ trow) << 6) + tsub;
+        aoff[j] = trow * ROWB + ((cidx ^ trow) << 6) + tsub;
+        boff[j] = SLAB + trow * ROWB + ((kidx ^ trow) << 6) + tsub;
     }
     auto run = [&](auto ns_tag) {
         constexpr int NS = decltype(ns_tag)::value;
@@ -105,14 +114,14 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
             const T* X = static_cast<const T*>(Xs.p[p]);
             const T* E = static_cast<const T*>(Es.p[p]);
             auto issue = [&](int q, int pos) {
-                const int n0 = min(q, q_end - 1) * UWN_CH;   // chunks past the end re-fetch the last one (never read)
-                const uint32_t slot = base_addr + pos * UWN_SLOT;
+                const int n0 = min(q, q_end - 1) * CH;   // chunks past the end re-fetch the last one (never read)
+                const uint32_t slot = base_addr + pos * SLOT;
 #pragma unroll
-                for (int i = 0; i < UWN_NI; ++i) {
-                    const int row = min(n0 + RPI * (UWN_NI * wave + i) + drow_in, N - 1);   // clamped rows are masked below
-                    const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (UWN_NI * wave + i) * 1024);
+                for (int i = 0; i < NI; ++i) {
+                    const int row = min(n0 + RPI * (NI * wave + i) + drow_in, N - 1);   // clamped rows are masked below
+                    const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (NI * wave + i) * 1024);
                     glds16_asm(X + (size_t)row * Cf + xcol[i], dst);
-                    glds16_asm(E + (size_t)row * Kf + ecol[i], dst + UWN_SLAB);
+                    glds16_asm(E + (size_t)row * Kf + ecol[i], dst + SLAB);
                 }
             };
             if (q_beg >= q_end) break;
@@ -120,24 +129,24 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
             for (int d = 0; d < UWN_D - 1; ++d) issue(q_beg + d, d);
             int pos = 0, wpos = UWN_D - 1;
             for (int q = q_beg; q < q_end; ++q) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UWN_NI * (UWN_D - 2)) : "memory");   // my share of chunk q landed
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI * (UWN_D - 2)) : "memory");   // my share of chunk q landed
                 __syncthreads();                                  // everyone's did; everyone finished chunk q-1
                 issue(q + UWN_D - 1, wpos);                       // refills the slot chunk q-1 used
-                const unsigned char* slot = smem + pos * UWN_SLOT;
+                const unsigned char* slot = smem + pos * SLOT;
                 pos = (pos + 1) & (UWN_D - 1);
                 wpos = (wpos + 1) & (UWN_D - 1);
-                const int n0 = q * UWN_CH;
-                constexpr int NK = UWN_CH / 16;     // 16 minibatch rows per MFMA
-                const bool tail = n0 + UWN_CH > N;  // ragged tail: rows >= N were clamped re-reads -> zero them (X side suffices)
+                const int n0 = q * CH;
+                constexpr int NK = CH / 16;     // 16 minibatch rows per MFMA
+                const bool tail = n0 + CH > N;  // ragged tail: rows >= N were clamped re-reads -> zero them (X side suffices)
 #pragma unroll
                 for (int kk = 0; kk < NK; ++kk) {   // fragments of one K sub-step for all slots, then their MFMAs
                     uint4 a[NS], b[NS];
 #pragma unroll
                     for (int j = 0; j < NS; ++j) {
-                        const unsigned char* sa = slot + (16 * kk + 8 * h) * UWN_ROWB + aoff[j];
-                        const unsigned char* sb = slot + (16 * kk + 8 * h) * UWN_ROWB + boff[j];
-                        const uint2 a0 = ds_tr16(sa), a1 = ds_tr16(sa + 4 * UWN_ROWB);
-                        const uint2 b0 = ds_tr16(sb), b1 = ds_tr16(sb + 4 * UWN_ROWB);
+                        const unsigned char* sa = slot + (16 * kk + 8 * h) * ROWB + aoff[j];
+                        const unsigned char* sb = slot + (16 * kk + 8 * h) * ROWB + boff[j];
+                        const uint2 a0 = ds_tr16(sa), a1 = ds_tr16(sa + 4 * ROWB);
+                        const uint2 b0 = ds_tr16(sb), b1 = ds_tr16(sb + 4 * ROWB);
                         a[j] = make_uint4(a0.x, a0.y, a1.x, a1.y);
                         b[j] = make_uint4(b0.x, b0.y, b1.x, b1.y);
                     }

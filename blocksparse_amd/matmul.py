@@ -104,7 +104,8 @@ class _DeviceTables(object):
         s8 = bsize == 8
         self.fprop_aux = int(fp[2]) if (s8 and fp is not None) else 0
         self.bprop_aux = int(bp[2]) if (s8 and bp is not None) else 0
-        self.updat_aux = int(upl[2]) if (s8 and upl is not None) else 0
+        # updat: word 2 is the super-block count (bsize 8) or the window side the plan was built for (bsize 32: 8 or 16)
+        self.updat_aux = int(upl[2]) if (upl is not None and (s8 or bsize == 32)) else 0
         if upl is None:
             self.updat_items = 0
         else:

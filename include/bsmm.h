@@ -68,7 +68,8 @@ typedef struct bsmm_args {
                                it is a constant of the layout.                                                       */
     int32_t plan_items;     /* updat only: header word [4] of the updat plan (number of work items = grid size); bsize 8:
                                header word [4] of the plan nested at word plan[5]                                     */
-    int32_t plan_aux;       /* bsize 8 plans only: header word [2] (number of 32x32 super-blocks); otherwise 0        */
+    int32_t plan_aux;       /* header word [2] of the plan for bsize 8 (number of 32x32 super-blocks) and for bsize-32
+                               updat (window side, 8 or 16; 0 is read as 8); otherwise 0                                */
     int32_t flags;          /* BSMM_FLAG_* (0 = none)                                                                 */
     int32_t blocks;         /* nonzero blocks                                                                        */
     int32_t bsize;          /* 8, 16 or 32                                                                           */

@@ -192,7 +192,11 @@ def test_updat_plan_covers_every_block_once(lib):
         t = L.build_tables(lay)
         for bsize in (32, 16):
             plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, bsize, lib.BF16, 1)
-            assert plan[0] == 0x42535550 and plan[5] == t["blocks"] and plan[2] == 256 // bsize
+            # window side: 256 features, or 512 (16 blocks of 32) for sparse bsize-32 layouts on axis 1
+            assert plan[0] == 0x42535550 and plan[5] == t["blocks"] and plan[2] in ((8, 16) if bsize == 32 else (16,))
+            if bsize == 32:
+                assert (int(plan[2]) == 16) == (t["blocks"] <= 16 * (-(-CB // 16)) * (-(-KB // 16)))
+                assert _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 0)[2] == 8      # axis 0: always 8x8
             UW, MAXB, nitems, waves = int(plan[2]), int(plan[3]), int(plan[4]), int(plan[7])
             assert nitems % 8 == 0
             isz = 4 + waves * MAXB * 2
