@@ -392,10 +392,12 @@ int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const b
         else {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
         }
         attr_set = true;
     }
-    const bool wide_win = AXIS == 1 && a->plan_aux == 16;     // plan built with 16x16 windows (sparse layouts): 32-row chunks
+    // plan_aux = window side of the plan (+ 256 when it was built for 16 waves per workgroup): 16x16 windows use 32-row chunks
+    const bool wide_win = AXIS == 1 && (a->plan_aux & 255) == 16, waves16 = wide_win && (a->plan_aux & 256);
     const int nchunks = wide_win ? (N + 31) / 32 : (N + 63) / 64;
     int split = 1;
     while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;   // one workgroup per CU, >= 8 chunks each
@@ -412,6 +414,9 @@ int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const b
     if constexpr (AXIS == 0)
         updat32_a0_win_kernel<DT><<<dim3(nitems, split), 512, UW0_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K, a->pcount,
                                                                             a->alpha, a->beta);
+    else if (waves16)
+        updat32_a1_win_kernel<DT, 16, 16><<<dim3(nitems, split), 1024, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K,
+                                                                                     a->pcount, a->alpha, a->beta);
     else if (wide_win)
         updat32_a1_win_kernel<DT, 16><<<dim3(nitems, split), 512, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K,
                                                                                 a->pcount, a->alpha, a->beta);
@@ -470,7 +475,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             // per chunk with 16x16 windows); per block 8 + rounds of 512 blocks * N * 0.0065 .. 0.0105.
             bool windowed = true;
             if (AXIS == 1 && variant == 0) {
-                const bool w16 = a->plan_aux == 16;
+                const bool w16 = (a->plan_aux & 255) == 16;
                 const double chunks = std::ceil(N / 64.0) * a->pcount;                 // 64-row units per window
                 int split = 1;                                                          // as launch_updat32_win chooses it
                 while (a->plan_items * split < 256 && split * 2 <= (w16 ? (N + 31) / 32 : (N + 63) / 64) / 8 && split < 8) split *= 2;
@@ -769,12 +774,16 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
 }
 
 // bsize 32, axis 1: 16x16-block windows when they hold <= 16 blocks on average (sparse layouts), else 8x8 (bsmm_updat_win.h)
-static int updat_window(int32_t blocks, int32_t CB, int32_t KB, int32_t axis) {
-    static const int force = [] { const char* e = getenv("BSMM_UPDAT_WINDOW"); return e ? atoi(e) : 0; }();   // A/B runs: 8 or 16
+static int updat_window(int32_t blocks, int32_t CB, int32_t KB, int32_t axis) {   // 8, 16, or 1616 (16x16 windows, 16 waves)
+    static const int force = [] { const char* e = getenv("BSMM_UPDAT_WINDOW"); return e ? atoi(e) : 0; }();   // A/B runs
     if (axis != 1) return UW;
-    if (force == 8 || force == 16) return force;
+    if (force == 8 || force == 16 || force == 1616) return force;
     const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);
     return blocks <= 16.0 * windows ? 16 : UW;     // <= 2 block slots per wave on average (measured: 13 per window 2.1x faster, 26 per window 20 % slower)
+}
+static long updat32_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t KB, int32_t axis, int32_t* out) {
+    const int w = updat_window(blocks, CB, KB, axis);
+    return build_updat_plan(lut, blocks, CB, KB, w == 8 ? 8 : 16, UP_MAXB, out, w == 1616 ? 16 : 8);
 }
 
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
@@ -782,7 +791,7 @@ long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_
     if (dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: 16-bit types
     if (bsize == 8) return build_super8_updat_plan(host_updat_lut, blocks, CB, KB, nullptr);   // 'BSS8'
     if (bsize != 32 && bsize != 16) return 0;
-    return bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, updat_window(blocks, CB, KB, axis), UP_MAXB, nullptr)
+    return bsize == 32 ? updat32_plan(host_updat_lut, blocks, CB, KB, axis, nullptr)
                        : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, nullptr);
 }
 
@@ -792,7 +801,7 @@ int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t
     if (bsize == 8 && dtype != BSMM_F32 && (axis == 0 || axis == 1))
         return build_super8_updat_plan(host_updat_lut, blocks, CB, KB, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
     if ((bsize != 32 && bsize != 16) || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
-    const long n = bsize == 32 ? build_updat_plan(host_updat_lut, blocks, CB, KB, updat_window(blocks, CB, KB, axis), UP_MAXB, host_plan_out)
+    const long n = bsize == 32 ? updat32_plan(host_updat_lut, blocks, CB, KB, axis, host_plan_out)
                                : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, host_plan_out);
     return n > 0 ? BSMM_OK : BSMM_ERR_ARG;
 }

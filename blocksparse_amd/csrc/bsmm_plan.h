@@ -42,9 +42,9 @@ constexpr int UP16_MAXB = 8;
 constexpr int UP16_ITEM = 4 + UP_WAVES * UP16_MAXB * 2;
 
 // uw = window side in blocks (256 / bsize), maxb = slots per wave (4 for bsize 32, 8 for bsize 16)
-inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int uw, int maxb, int32_t* out) {
-    if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || uw < 1 || uw > 16 || maxb < 1) return -1;
-    const int UW = uw, UP_MAXB = maxb, UP_ITEM = 4 + UP_WAVES * maxb * 2;
+inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int uw, int maxb, int32_t* out, int waves = 8) {
+    if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || uw < 1 || uw > 16 || maxb < 1 || waves < 1) return -1;
+    const int UW = uw, UP_MAXB = maxb, UP_WAVES = waves, UP_ITEM = 4 + waves * maxb * 2;
     const int wc = (CB + UW - 1) / UW, wk = (KB + UW - 1) / UW;
     struct Ent { int c, k, w; };
     std::vector<std::vector<Ent>> win((size_t)wc * wk);

@@ -37,21 +37,24 @@ constexpr int UWN_LDS = UWN_D * UWN_SLOT;
 // WU = window side in blocks.  8: 8x8 windows, 64-row chunks.  16: 16x16 windows, 32-row chunks (the slabs are 32 KiB either
 // way) for SPARSE layouts: with <= ~28 blocks per 16x16 window an item still fits the 32 block slots, and every slab byte
 // staged feeds twice as many blocks (at 10 % density an 8x8 window holds 6 blocks, at 5 % three).
-template <class DT, int WU = UW>
-__global__ void __launch_bounds__(512, 2)
+// NW = waves per workgroup, each with up to 4 block slots: <16, 16> (1024 threads, 64 slots) lets a 16x16 window of a DENSER
+// layout (20 %: ~51 blocks) stay one item, so the slab traffic per block halves there too; it runs at <= 128 VGPRs, with the
+// fragments of two slots in registers at a time.
+template <class DT, int WU = UW, int NW = UP_WAVES>
+__global__ void __launch_bounds__(64 * NW, NW == 16 ? 4 : 2)
 updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
                       const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
     typedef typename DT::T T;
     static_assert(DT::is16, "windowed updat: 16-bit storage types");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (plan[0] != UPLAN_MAGIC || plan[1] != UPLAN_VERSION || plan[2] != WU || plan[3] != UP_MAXB || plan[7] != UP_WAVES) return;
+    if (plan[0] != UPLAN_MAGIC || plan[1] != UPLAN_VERSION || plan[2] != WU || plan[3] != UP_MAXB || plan[7] != NW) return;
     constexpr int CH = 512 / WU;                 // minibatch rows per chunk
     constexpr int ROWB = WU * 64;                // bytes per slab row (WU blocks x 64 B)
     constexpr int SLAB = CH * ROWB;              // 32 KiB
-    constexpr int NI = SLAB / 1024 / UP_WAVES;   // DMA instructions per wave per slab
+    constexpr int NI = SLAB / 1024 / NW;         // DMA instructions per wave per slab
     constexpr int SLOT = 2 * SLAB;
     static_assert(SLAB == UWN_SLAB && (WU == 8 || WU == 16), "slab geometry");
-    const int32_t* item = plan + plan[6] + (size_t)blockIdx.x * UP_ITEM;
+    const int32_t* item = plan + plan[6] + (size_t)blockIdx.x * (4 + NW * UP_MAXB * 2);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = item[0], k0 = item[1];
@@ -139,31 +142,37 @@ updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW,
                 constexpr int NK = CH / 16;     // 16 minibatch rows per MFMA
                 const bool tail = n0 + CH > N;  // ragged tail: rows >= N were clamped re-reads -> zero them (X side suffices)
 #pragma unroll
-                for (int kk = 0; kk < NK; ++kk) {   // fragments of one K sub-step for all slots, then their MFMAs
-                    uint4 a[NS], b[NS];
+                for (int kk = 0; kk < NK; ++kk) {   // fragments of one K sub-step for FB slots at a time, then their MFMAs
+                    constexpr int FB = (NW == 16 && NS > 2) ? 2 : NS;      // 16 waves: stay within 128 VGPRs
 #pragma unroll
-                    for (int j = 0; j < NS; ++j) {
-                        const unsigned char* sa = slot + (16 * kk + 8 * h) * ROWB + aoff[j];
-                        const unsigned char* sb = slot + (16 * kk + 8 * h) * ROWB + boff[j];
-                        const uint2 a0 = ds_tr16(sa), a1 = ds_tr16(sa + 4 * ROWB);
-                        const uint2 b0 = ds_tr16(sb), b1 = ds_tr16(sb + 4 * ROWB);
-                        a[j] = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                        b[j] = make_uint4(b0.x, b0.y, b1.x, b1.y);
-                    }
-                    if (tail) {
-                        const int nb = n0 + 16 * kk + 8 * h;
+                    for (int j0 = 0; j0 < NS; j0 += FB) {
+                        uint4 a[FB], b[FB];
 #pragma unroll
-                        for (int j = 0; j < NS; ++j) {
-                            uint32_t* u = reinterpret_cast<uint32_t*>(&a[j]);
+                        for (int jj = 0; jj < FB; ++jj) {
+                            const int j = (j0 + jj < NS) ? j0 + jj : NS - 1;
+                            const unsigned char* sa = slot + (16 * kk + 8 * h) * ROWB + aoff[j];
+                            const unsigned char* sb = slot + (16 * kk + 8 * h) * ROWB + boff[j];
+                            const uint2 a0 = ds_tr16(sa), a1 = ds_tr16(sa + 4 * ROWB);
+                            const uint2 b0 = ds_tr16(sb), b1 = ds_tr16(sb + 4 * ROWB);
+                            a[jj] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                            b[jj] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                        }
+                        if (tail) {
+                            const int nb = n0 + 16 * kk + 8 * h;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
-                                u[e] &= (lo | hi);
+                            for (int jj = 0; jj < FB; ++jj) {
+                                uint32_t* u = reinterpret_cast<uint32_t*>(&a[jj]);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
+                                    u[e] &= (lo | hi);
+                                }
                             }
                         }
-                    }
 #pragma unroll
-                    for (int j = 0; j < NS; ++j) acc[j] = DT::mfma32(a[j], b[j], acc[j]);
+                        for (int jj = 0; jj < FB; ++jj)
+                            if (j0 + jj < NS) acc[j0 + jj] = DT::mfma32(a[jj], b[jj], acc[j0 + jj]);
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

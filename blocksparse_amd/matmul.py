@@ -106,6 +106,8 @@ class _DeviceTables(object):
         self.bprop_aux = int(bp[2]) if (s8 and bp is not None) else 0
         # updat: word 2 is the super-block count (bsize 8) or the window side the plan was built for (bsize 32: 8 or 16)
         self.updat_aux = int(upl[2]) if (upl is not None and (s8 or bsize == 32)) else 0
+        if upl is not None and bsize == 32 and int(upl[7]) == 16:
+            self.updat_aux += 256          # plan built for 16 waves per workgroup
         if upl is None:
             self.updat_items = 0
         else:

@@ -69,7 +69,7 @@ typedef struct bsmm_args {
     int32_t plan_items;     /* updat only: header word [4] of the updat plan (number of work items = grid size); bsize 8:
                                header word [4] of the plan nested at word plan[5]                                     */
     int32_t plan_aux;       /* header word [2] of the plan for bsize 8 (number of 32x32 super-blocks) and for bsize-32
-                               updat (window side, 8 or 16; 0 is read as 8); otherwise 0                                */
+                               updat (window side, 8 or 16, + 256 if header word [7] is 16; 0 is read as 8); otherwise 0 */
     int32_t flags;          /* BSMM_FLAG_* (0 = none)                                                                 */
     int32_t blocks;         /* nonzero blocks                                                                        */
     int32_t bsize;          /* 8, 16 or 32                                                                           */
