@@ -304,11 +304,34 @@ def main():
                    "blocks": int(b.blocks), "global_minibatch": N * world,
                    "parallelism": "dp%d (minibatch sharded, dw all-reduce over RCCL)" % world if world > 1 else "single GPU"},
         "gbps_algorithmic": round(bytes_step / (ms_step * 1e-3) / 1e9, 1),
+        # what a dense GEMM of the same shapes would have to sustain to take the same time (reported alongside,
+        # never the headline)
+        "dense_equivalent_tflops": round(3 * 2.0 * a.hidden * a.hidden * N * world * a.steps / el / 1e12, 1),
         "pass_ms": {"fprop": round(f_ms, 4), "bprop": round(b_ms, 4), "updat": round(u_ms, 4)},
         "pass_tflops": {"fprop": round(flops_pass / f_ms / 1e9, 2), "bprop": round(flops_pass / b_ms / 1e9, 2),
                         "updat": round(flops_pass / u_ms / 1e9, 2)},
         "roofline": roof,
     }
+    if use_dist:
+        # the dw all-reduce on its own (it overlaps with bprop inside the step): time alone, and how much of it the step hides
+        red = DwAllReduce(accumulate_fp32=False)
+        dw_t = torch.zeros(b.w_shape, dtype=td, device="cuda")
+        for _ in range(5):
+            red.start(dw_t); red.wait()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t_ar = time.perf_counter()
+        for _ in range(20):
+            red.start(dw_t); red.wait()
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t_ar) / 20 * 1e3
+        tt = torch.tensor([ar_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ar_ms = float(tt.item())
+        compute_ms = f_ms + u_ms + b_ms
+        out["allreduce"] = {"bytes": int(dw_t.numel() * dw_t.element_size()), "ms_alone": round(ar_ms, 4),
+                            "compute_ms": round(compute_ms, 4),
+                            "exposed_ms": round(max(0.0, ms_step - compute_ms), 4),
+                            "hidden_frac": round(max(0.0, min(1.0, 1.0 - max(0.0, ms_step - compute_ms) / max(ar_ms, 1e-9))), 3)}
     # BASELINE.json configs[1]: same layout, fp32, feature_axis=1, fprop only.  Priced against the fp32 matrix-core peak
     # (157.3 TF; AI 195 > ridge 20) although the kernel computes the fp32 result exactly from bf16 pieces on the 16-bit
     # matrix cores (six MFMAs per product, bsmm_xcols.h), whose ceiling for this formulation is 2500 / 6 = 417 TF.
@@ -351,10 +374,19 @@ def main():
         out["cpu_baseline"] = cpu_baseline(layout, a.bsize, a.axis, a.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the LAST thing on stdout: RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer
+        # and would otherwise be flushed after Python's own buffer at exit
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

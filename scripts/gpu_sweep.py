@@ -16,9 +16,12 @@ def timeit(fn, reps=100):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
-def row(tag, hidden, bs, dens, axis, dt, N):
+def row(tag, hidden, bs, dens, axis, dt, N, layout=None):
     td = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[dt]
-    b = BlocksparseMatMul(P.random_layout(hidden // bs, hidden // bs, dens, seed=1234), block_size=bs, feature_axis=axis)
+    if layout is None:
+        layout = P.random_layout(hidden // bs, hidden // bs, dens, seed=1234)
+    dens = float(layout.sum()) / layout.size
+    b = BlocksparseMatMul(layout, block_size=bs, feature_axis=axis)
     w = (torch.randn(b.w_shape, device="cuda") * 0.01).to(td)
     x = (torch.randn(b.i_shape(N), device="cuda") * 0.1).to(td)
     dy = (torch.randn(b.o_shape(N), device="cuda") * 0.1).to(td)
@@ -54,3 +57,7 @@ row("configs[3] per-GPU shard", 8192, 32, 0.05, 1, "bf16", 512)
 row("bs 8", 4096, 8, 0.1, 0, "bf16", 8192)
 row("bs 8 axis 1", 4096, 8, 0.1, 1, "bf16", 8192)
 row("bs 8, 3 %", 4096, 8, 0.03, 0, "bf16", 8192)
+# skewed layout of about the headline's block count: Barabasi-Albert graph (hubs = block rows / columns with many blocks) + I
+# (the reference's own bench layout, test/blocksparse_matmul_bench.py:66-68)
+row("headline shape, BA(128, 14) + I layout", 4096, 32, 0.2, 1, "bf16", 8192, layout=P.ba_layout(128, 14, seed=1))
+row("same, axis 0", 4096, 32, 0.2, 0, "bf16", 8192, layout=P.ba_layout(128, 14, seed=1))
