@@ -3,12 +3,12 @@
 // Lesson from the grouped kernels (profiles/): when every wave carries all G accumulators of a group, each
 // 32x32 block costs a dispatch decision, two LDS fragment reads and their latency for only 2 MFMAs -- the control
 // skeleton, not a bandwidth, bounds the kernel (~15% of the MFMA rate).  Here the ownership is transposed:
-//   workgroup = XC_G (8) consecutive output blocks x XC_R (256) minibatch rows, 8 waves;
-//   wave v owns output block v for ALL 256 rows: 8 row tiles x 16 accumulator registers, statically addressed.
-// Per step (one PAIR of input blocks = one 128-byte line per row) the X slab [256 rows x 128 B] is DMA'd once into a
-// 2-deep LDS ring and shared by all waves; a wave whose column has a block in either half of the pair loads that
-// block's fragment straight from global memory (prefetched one step ahead) and issues 16 MFMAs with it; waves without
-// a block skip to the barrier.  One decision per step per wave, ~10 LDS reads per 16 MFMAs.
+//   workgroup = G (16; narrow variant 8) consecutive output blocks x XC_R (128) minibatch rows, G waves;
+//   wave v owns output block v for ALL 128 rows: 4 row tiles x 16 accumulator registers, statically addressed.
+// Per step (one PAIR of input blocks = one 128-byte line per row) the X slab [128 rows x 128 B] is DMA'd once into an
+// LDS ring and shared by all waves; a wave whose column has a block in either half of the pair loads that
+// block's fragment straight from global memory (prefetched one step ahead) and issues 8 MFMAs with it; waves without
+// a block skip to the barrier (one per PHASE of PH steps).  One decision per step per wave, ~8 LDS reads per 8 MFMAs.
 //   slab image: rows of 128 B, the eight 16-byte pieces of row r XOR-swizzled with (r >> 1) & 7 (conflict-free b128).
 //
 // Measured (4096^2, 20%, N = 8192, bf16; kernel-trace ablation, profiles/): 133 us total; with the X DMA removed 114,
@@ -32,11 +32,8 @@ namespace bsmm {
 constexpr int XC_RT = BSMM_XC_RT;         // 32-row tiles per wave
 constexpr int XC_PH = BSMM_XC_PH;         // steps per phase (one barrier per phase); ring = 2*XC_PH slabs
 constexpr int XC_R = 32 * XC_RT;          // minibatch rows per workgroup
-constexpr int XC_SLAB = XC_R * 128;
-constexpr int XC_NI = XC_SLAB / 1024 / XC_G;   // DMA instructions per wave per slab
-constexpr int XC_STAGE = XC_R * 512;         // epilogue staging tile (XC_G column blocks x 64 B per row)
+constexpr int XC_SLAB = XC_R * 128;       // one pair step of 16-bit activations: 128 rows x 128 B = 16 KiB
 constexpr int XC_RING = 2 * XC_PH;
-constexpr int XC_LDS = (XC_RING * XC_SLAB > XC_STAGE) ? XC_RING * XC_SLAB : XC_STAGE;   // slab ring / staging tile
 
 // TRANSW = true (fprop): Wsel is W in its natural [c-in-block][k-in-block] layout and each lane gathers its fragment
 // transposed (16 two-byte loads, stride 64 B, prefetched a step ahead) -- no transposed copy of W, no workspace.
@@ -242,8 +239,6 @@ xcol32_a1_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int XC0_ROWB = XC_R * 2;                 // bytes per slab row
 constexpr int XC0_SLAB = 64 * XC0_ROWB;            // 16 KiB
-constexpr int XC0_LDS = XC_RING * XC0_SLAB;
-constexpr int XC0_NI = XC0_SLAB / 1024 / XC_G;     // DMA instructions per wave per slab
 constexpr int XC0_PPR = XC0_ROWB / 16;             // 16-byte pieces per row
 constexpr int XC0_RPI = 1024 / XC0_ROWB;           // rows per DMA instruction
 
