@@ -97,11 +97,11 @@ int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args*
 #define BSMM_XC_WIDE_PH 4
 #endif
 inline bool use_xcol() { return true; }
-// fp32, bsize 32, axis 1: the exact three-piece bf16 kernel (bsmm_xcols.h) instead of the fp32-MFMA kernel xcol32f
+// fp32, bsize 32: the exact three-piece bf16 kernel (bsmm_xcols.h) instead of the fp32-MFMA kernel xcol32f
 // (BSMM_F32_SPLIT=0, read once, selects the latter for A/B runs).  Decides the plan format too ('BSXC' G = 16 / 'BSXF').
 inline bool f32_split(int axis) {
     static const int on = [] { const char* e = getenv("BSMM_F32_SPLIT"); return e ? atoi(e) : 1; }();
-    return axis == 1 && on;
+    return (axis == 0 || axis == 1) && on;
 }
 inline int xc16_group() {   // output blocks per workgroup of the bsize-16 xcol kernel: 16, or 32 ("wide")
     static const int wide = [] { const char* e = getenv("BSMM_XC16_WIDE"); return e ? atoi(e) : 1; }();
@@ -166,7 +166,8 @@ int launch_xcol32f(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
 inline size_t xcols_workspace_bytes(const bsmm_args* a) {
     return 6 * ((size_t)a->N * a->C + (size_t)a->blocks * 1024);
 }
-inline int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a, hipStream_t st) {
+template <int AXIS>
+int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a, hipStream_t st) {
     const size_t nx = (size_t)a->N * a->C;
     if (!a->workspace || a->workspace_bytes < xcols_workspace_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
     uint16_t* xp = static_cast<uint16_t*>(a->workspace);
@@ -183,10 +184,10 @@ inline int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, con
     m.SP = (m.segments + m.P - 1) / m.P;
     static bool attr_set = false;   // benign race: idempotent
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32s_a1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32s_kernel<AXIS>), hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS);
         attr_set = true;
     }
-    xcol32s_a1_kernel<<<m.grid(), 64 * XS_G, XS_LDS, st>>>(xp, wp, static_cast<float*>(Y), a->plan, m, a->N, a->C, a->K, a->blocks);
+    xcol32s_kernel<AXIS><<<m.grid(), 64 * XS_G, XS_LDS, st>>>(xp, wp, static_cast<float*>(Y), a->plan, m, a->N, a->C, a->K, a->blocks);
     return (int)hipGetLastError();
 }
 
@@ -327,8 +328,9 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     // (xcol can gather the fprop operand transposed itself -- launch_xgroup32(..., transw = true), no workspace and no
     //  pre-pass -- but that measured SLOWER than the 6 us transpose kernel + contiguous fragment loads: 140 vs 127 us, also with
     //  the kernel held at 128 VGPRs.)
-    if constexpr (BS == 32 && !DT::is16 && AXIS == 1) {
-        if (use_group && f32_split(1) && a->C % 32 == 0) return launch_xcol32s(fprop, X, W, Y, a, st);
+    if constexpr (BS == 32 && !DT::is16) {
+        // (axis 0 needs 16-byte aligned bf16 row pieces: N % 8 == 0; otherwise the per-segment kernel below)
+        if (use_group && f32_split(AXIS) && a->C % 32 == 0 && !(AXIS == 0 && a->N % 8 != 0)) return launch_xcol32s<AXIS>(fprop, X, W, Y, a, st);
     }
     if constexpr (BS != 8) {
         const void* Wsel = W;
@@ -346,7 +348,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
             if (use_group) return launch_xcol16<DT, AXIS>(X, Wsel, Y, a, st);
         }
         if constexpr (BS == 32 && !DT::is16) {
-            if (use_group) return launch_xcol32f<AXIS>(X, Wsel, Y, a, st);
+            if (use_group && !f32_split(AXIS)) return launch_xcol32f<AXIS>(X, Wsel, Y, a, st);     // plan is 'BSXF' only then
         }
         return launch_xprop_mfma<DT, BS, AXIS>(X, Wsel, Y, a, st);
     }

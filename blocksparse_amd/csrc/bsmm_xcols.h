@@ -1,4 +1,4 @@
-// bsmm_xcols.h -- fp32 xprop (bsize 32, feature_axis = 1, BASELINE configs[1]) on the 16-bit matrix cores, EXACTLY.
+// bsmm_xcols.h -- fp32 xprop (bsize 32, both feature axes; BASELINE configs[1]) on the 16-bit matrix cores, EXACTLY.
 //
 // v_mfma_f32_32x32x2_f32 needs 1024 cycles per (block, 32-row tile); the bf16 instruction v_mfma_f32_32x32x16_bf16 does the
 // same K = 32 in 64.  Every fp32 value is the exact sum of three bf16 pieces (x = b1 + b2 + b3: 8 + 8 + 8 significand bits,
@@ -8,7 +8,7 @@
 // differs from the fp32-MFMA kernel (xcol32f) only in the order of fp32 additions.  (Same device as the fp32 attention
 // kernels, bst_kernels.h.)  Inf / NaN inputs give NaN (inf - inf in the split), like any 0 * inf.
 //
-// Two pre-passes write the pieces as bf16 arrays into the caller's workspace: split3_x_kernel (activations, [3][N][C])
+// Two pre-passes write the pieces as bf16 arrays into the caller's workspace: split3_x_kernel (activations, [3] x the input layout)
 // and split3_w_kernel (weights, [3][blocks][32][32], transposed per block for fprop).  The main kernel is the WIDE xcol
 // kernel (bsmm_xcol.h: 16 waves, wave v owns output block v of the group for all 128 rows, 'BSXC' plan with G = 16) with
 // three slabs per pair step: ring of 2 steps x 3 x 16 KiB = 96 KiB, one barrier per step (a step now carries 6x the MFMA
@@ -85,8 +85,11 @@ __device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// AXIS = 1: activations (N, C), slab rows are minibatch rows (xcol32_a1_kernel).  AXIS = 0: activations (C, N), slab rows are
+// features, B-operand fragments by transposing reads, direct stores (xcol32_a0_kernel; needs N % 8 == 0).
+template <int AXIS>
 __global__ void __launch_bounds__(64 * XS_G, 4)
-xcol32s_a1_kernel(const uint16_t* __restrict__ Xp, const uint16_t* __restrict__ Wp, float* __restrict__ Y,
+xcol32s_kernel(const uint16_t* __restrict__ Xp, const uint16_t* __restrict__ Wp, float* __restrict__ Y,
                   const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout, int blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile, grp;
@@ -105,13 +108,18 @@ xcol32s_a1_kernel(const uint16_t* __restrict__ Xp, const uint16_t* __restrict__ 
     const int npairs_full = Cin / 64;
     const size_t pstride = (size_t)N * Cin, wstride = (size_t)blocks * 1024;
 
-    // X DMA: a slab is 16 instructions of 1 KiB (8 rows each), wave v issues instruction v of each of the three slabs
-    const int drow = 8 * wave + (lane >> 3);
-    const int dpiece = (lane & 7) ^ ((drow >> 1) & 7);
-    const uint16_t* xsrc = Xp + (size_t)min(n_tile + drow, N - 1) * Cin + dpiece * 8;     // rows past N are clamped (never stored)
-    const int oddsub = (dpiece & 4) ? 32 : 0;                                              // trailing pair without its odd block
+    // X DMA: a slab is 16 instructions of 1 KiB, wave v issues instruction v of each of the three slabs.
+    //   axis 1: 8 minibatch rows x 128 B per instruction; axis 0: 4 feature rows x 256 B (XC0_* geometry of bsmm_xcol.h)
+    static_assert(XC0_SLAB == XC_SLAB, "both slab shapes are 16 KiB");
+    const int drow = AXIS == 1 ? 8 * wave + (lane >> 3) : XC0_RPI * wave + lane / XC0_PPR;
+    const int dpiece = AXIS == 1 ? (lane & 7) ^ ((drow >> 1) & 7) : (lane % XC0_PPR) ^ (4 * (drow & 3));
+    // axis 1: rows past N are clamped (never stored); axis 0: columns past N are clamped re-reads (never stored)
+    const uint16_t* xsrc = AXIS == 1 ? Xp + (size_t)min(n_tile + drow, N - 1) * Cin + dpiece * 8 : Xp + min(n_tile + dpiece * 8, N - 8);
+    const int oddsub = (dpiece & 4) ? 32 : 0;                                              // axis 1: trailing pair without its odd block
     auto issue_x = [&](int p, int pos) {
-        const uint16_t* src = xsrc + (p * 64 - (p < npairs_full ? 0 : oddsub));
+        const uint16_t* src;
+        if constexpr (AXIS == 1) src = xsrc + (p * 64 - (p < npairs_full ? 0 : oddsub));
+        else                     src = xsrc + (size_t)min(p * 64 + drow, Cin - 1) * N;     // a missing odd half re-reads the last row
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             glds16_asm(src + q * pstride, __builtin_amdgcn_readfirstlane(base_addr + pos * XS_SLOT + q * XC_SLAB + wave * 1024));
@@ -122,6 +130,10 @@ xcol32s_a1_kernel(const uint16_t* __restrict__ Xp, const uint16_t* __restrict__ 
     for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) xrd[half][kk] = r * 128 + (((4 * half + 2 * kk + h) ^ xsw) << 4);
+    // axis 0, transposing reads: 16-lane group g16 -> minibatch columns 16*(g16&1) .. +15 of a 32-column tile, K half g16 >> 1;
+    // lane t16 points at row (t16 >> 2) of a 4-row band, 8 bytes at column 4*(t16 & 3)
+    const int g16 = lane >> 4, t16 = lane & 15, trow = t16 >> 2;
+    const int tcolb = (16 * (g16 & 1) + 4 * (t16 & 3)) * 2;
 
     f32x16 acc[XC_RT];
 #pragma unroll
@@ -151,9 +163,23 @@ xcol32s_a1_kernel(const uint16_t* __restrict__ Xp, const uint16_t* __restrict__ 
         for (int t = 0; t < XC_RT; ++t)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const unsigned char* p = slot + t * 4096 + xrd[half][kk];
-                const uint4 x0 = *reinterpret_cast<const uint4*>(p), x1 = *reinterpret_cast<const uint4*>(p + XC_SLAB),
-                            x2 = *reinterpret_cast<const uint4*>(p + 2 * XC_SLAB);
+                uint4 x0, x1, x2;
+                if constexpr (AXIS == 1) {
+                    const unsigned char* p = slot + t * 4096 + xrd[half][kk];
+                    x0 = *reinterpret_cast<const uint4*>(p);
+                    x1 = *reinterpret_cast<const uint4*>(p + XC_SLAB);
+                    x2 = *reinterpret_cast<const uint4*>(p + 2 * XC_SLAB);
+                } else {
+                    // rows (features) 32*half + 16*kk + 8*(g16>>1) + {0..3 | 4..7}; row & 3 == trow for both bands
+                    const int row0 = 32 * half + 16 * kk + 8 * (g16 >> 1) + trow;
+                    const int byte = 64 * t + tcolb;
+                    const unsigned char* p = slot + row0 * XC0_ROWB + ((((byte >> 4) ^ (4 * trow)) << 4) | (byte & 15));
+                    auto tr = [&](const unsigned char* q) {
+                        const uint2 lo = ds_tr16(q), hi = ds_tr16(q + 4 * XC0_ROWB);
+                        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    };
+                    x0 = tr(p); x1 = tr(p + XC_SLAB); x2 = tr(p + 2 * XC_SLAB);
+                }
                 // smallest terms first
                 acc[t] = mfma32_bf16(wq[2][kk], x0, acc[t]);
                 acc[t] = mfma32_bf16(wq[1][kk], x1, acc[t]);
@@ -207,6 +233,20 @@ xcol32s_a1_kernel(const uint16_t* __restrict__ Xp, const uint16_t* __restrict__ 
         }
     }
 
+    if constexpr (AXIS == 0) {
+        // D[o][n]: col = n = r, rows o = (reg & 3) + 8 * (reg >> 2) + 4h  ->  Y[(ob*32 + o) * N + n]: 128 contiguous bytes per half wave
+        if (!owner) return;
+#pragma unroll
+        for (int t = 0; t < XC_RT; ++t) {
+            const int n = n_tile + t * 32 + r;
+            if (n >= N) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int o = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                Y[(size_t)((ob0 + wave) * 32 + o) * N + n] = acc[t][reg];
+            }
+        }
+    } else {
     // Epilogue.  D[o][n]: col = n = r, rows o = (reg & 3) + 8 * (reg >> 2) + 4h: 4 consecutive o = one 16-byte piece.
     // 32 rows at a time are staged as [32][2 KiB] (pieces XOR-swizzled with n) and stored as full rows.
     const int rowbytes = nob * 128;
@@ -231,6 +271,7 @@ xcol32s_a1_kernel(const uint16_t* __restrict__ Xp, const uint16_t* __restrict__ 
                 *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)row * Kout) + piece * 16) = v;
             }
         }
+    }
     }
 }
 

@@ -88,11 +88,11 @@ typedef struct bsmm_args {
 } bsmm_args;
 
 /* Y = fprop(X, W).  args->lut = fprop_lut.  Needs workspace: a transposed copy of W; bsize 8 with a plan: the expanded W;
- * fp32 / bsize 32 / axis 1 with a plan: the bf16 pieces of X and W (6 bytes per element) -- ask bsmm_workspace_bytes(). */
+ * fp32 / bsize 32 with a plan: the bf16 pieces of X and W (6 bytes per element) -- ask bsmm_workspace_bytes(). */
 int bsmm_fprop(const void* X, const void* W, void* Y, const bsmm_args* args);
 
 /* DX = bprop(DY, W).  args->lut = bprop_lut, args->C/K swapped by the caller.  Workspace only for bsize 8 with a plan
- * (the expanded W) and fp32 / bsize 32 / axis 1 with a plan (bf16 pieces): ask bsmm_workspace_bytes(BSMM_OP_BPROP, args). */
+ * (the expanded W) and fp32 / bsize 32 with a plan (bf16 pieces): ask bsmm_workspace_bytes(BSMM_OP_BPROP, args). */
 int bsmm_bprop(const void* DY, const void* W, void* DX, const bsmm_args* args);
 
 /* DW = alpha * sum_{p<pcount} updat(X[p], DY[p]) + beta * DW.  args->lut = updat_lut.

@@ -80,8 +80,10 @@ def test_argument_validation_without_gpu(lib):
     assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * (100 * 64 + 10 * 1024)
     assert L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == 6 * (100 * 64 + 10 * 1024)
     a.axis = 0
-    assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 10 * 32 * 32 * 4
-    a.axis, a.plan, a.dtype = 1, None, lib.BF16
+    assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * (100 * 64 + 10 * 1024)
+    a.plan = None
+    assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 10 * 32 * 32 * 4      # no plan: the transposed copy of W
+    a.axis, a.dtype = 1, lib.BF16
     assert L.bsmm_gate_grad(one, None, one, one, one, 4, 32, lib.F32, None) == -1
     assert L.bsmm_gate_grad(one, one, one, one, one, 4, 64, lib.F32, None) == -2
 
@@ -131,28 +133,11 @@ def test_plan_builder_covers_every_block_once(lib):
                     for c, w in col:
                         want.add((ob, c, w))
                 assert got == want
+                # fp32 (bsize 32): the split kernel (bsmm_xcols.h) walks the 16-wide 'BSXC' format of the 16-bit kernels, both axes
+                # (the 'BSXF' format of the fp32-MFMA kernel xcol32f is only built with BSMM_F32_SPLIT=0)
                 pf = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.F32, axis)
-                if axis == 1:
-                    # fp32 (bsize 32), axis 1: the split kernel (bsmm_xcols.h) walks the 16-wide 'BSXC' format of the 16-bit kernels
-                    assert pf[0] == 0x42535843 and int(pf[2]) == 16
-                    assert _check_xcol_plan(pf, f, t, n_out) == want
-                else:
-                    # axis 0 (xcol32f): same groups / pairs, compacted entry lists per wave class with four sentinels each
-                    assert pf[0] == 0x42535846 and pf[8] == n_out
-                    gf = pf[pf[5]:pf[6]].reshape(-1, 8)
-                    pairs_f = pf[pf[6]:pf[6] + pf[4]]
-                    ents = pf[pf[7]:pf[7] + 2 * pf[9]].reshape(-1, 2)
-                    gotf = set()
-                    for g, (so, ns, ob0, nob, o0, c0, o1, c1) in enumerate(gf):
-                        for cls, (o, cnt) in enumerate(((o0, c0), (o1, c1))):
-                            last = -1
-                            for w, code in ents[o:o + cnt]:
-                                st, j, half = int(code) >> 3, (int(code) >> 1) & 3, int(code) & 1
-                                assert 0 <= st < ns and st >= last and 4 * cls + j < nob
-                                last = st
-                                gotf.add((ob0 + 4 * cls + j, 2 * int(pairs_f[so + st]) + half, int(w)))
-                            assert all(int(x) == -1 and int(y) == 0x7fffffff for x, y in ents[o + cnt:o + cnt + 4])
-                    assert gotf == want
+                assert pf[0] == 0x42535843 and int(pf[2]) == 16
+                assert _check_xcol_plan(pf, f, t, n_out) == want
                 # bsize 16: quads of input blocks, 16 output blocks per group, slot = 4*member + (c & 3)
                 p16 = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis)
                 assert p16[0] == 0x42535836 and p16[8] == n_out

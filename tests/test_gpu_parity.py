@@ -165,9 +165,8 @@ def test_bsize8_super_block_updat_pairs_alpha_beta(env, axis):
 
 @pytest.mark.parametrize("axis", [0, 1])
 def test_fp32_plan_kernels_forced(env, axis):
-    """fp32 / bsize 32 has its own grouped kernels (axis 0: xcol32f on the fp32 matrix-core instruction; axis 1: the exact
-    three-piece bf16 kernel of bsmm_xcols.h): same forced small / ragged cases, fp32 bar; N % 4 != 0 on axis 0 falls back
-    to the generic kernel."""
+    """fp32 / bsize 32 has its own grouped kernel (the exact three-piece bf16 kernel of bsmm_xcols.h, both axes): same forced
+    small / ragged cases, fp32 bar; N % 8 != 0 on axis 0 falls back to the generic kernel."""
     torch, BSMM, lib = env
     L = lib.load()
     holes = P.ba_layout(16, 2, seed=3)
