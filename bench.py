@@ -374,18 +374,24 @@ def main():
         out["cpu_baseline"] = cpu_baseline(layout, a.bsize, a.axis, a.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        # the JSON line must be the LAST thing on stdout: RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer
-        # and would otherwise be flushed after Python's own buffer at exit
-        import ctypes
+    # The JSON line must be the LAST thing on stdout.  RCCL's version banner (NCCL_DEBUG=VERSION) sits in every rank's C stdio
+    # buffer and would otherwise be flushed at process exit, after Python's own output: push it out on ALL ranks first, meet at
+    # a barrier, and only then let rank 0 print.
+    import ctypes
+
+    def flush_c_stdio():
         try:
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
         sys.stdout.flush()
+
+    flush_c_stdio()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
 
 
