@@ -1,18 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- block-sparse matmul hot path on MI355X: effective TFLOP/s (+ GB/s, roofline, CPU baseline).
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W] [--config headline|cfg3]
 
-Workload (BASELINE.json metric: bsmm 4096x4096 bs=32 @ 20% density): one STEP = fprop + bprop + updat of
-one minibatch of N_LOCAL columns on every rank, bf16 storage / fp32 accumulate, synthetic data resident in
-HBM before the timed region.  Multi-GPU = data parallel: tables and W replicated, minibatch sharded
-(weak scaling: N_LOCAL fixed per GPU), one RCCL all-reduce of dw per step overlapped with bprop.
+`--gpus N` with N > 1 spawns the N ranks itself (re-exec under torch.distributed.run, one process per GPU, rendezvous on
+127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set), so both `python bench.py --gpus 8` and the driver's
+`python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` give the same 8-rank run.
+
+Workloads
+  headline (BASELINE.json metric): bsmm 4096x4096 bs=32 @ {10, 20, 50} % density, bf16 storage / fp32 accumulate, one STEP =
+      fprop + bprop + updat of a minibatch of 8192 rows per GPU (weak scaling).  `value` is the 20 % figure; the three
+      densities sit side by side in "densities".
+  cfg3 (BASELINE configs[3]): 8192x8192 bs=32 @ 5 %, GLOBAL minibatch 4096 sharded over the ranks (strong scaling; the
+      N = 1 line is the whole minibatch on one GPU).
+Multi-GPU = data parallel: tables and W replicated, minibatch sharded, ONE all-reduce of dw per step over RCCL/xGMI,
+overlapped with bprop.  Synthetic inputs are resident in HBM before the timed region.
 Effective FLOPs per pass = 2 * blocks * bs^2 * N (nonzero blocks only; the reference's own definition,
 src/gpu_types.cc:48, src/blocksparse_matmul_op.cc:102,182).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                                            # GB/s (spec)
+PROFILE_ROUND = "r02"
 
 
 def random_layout(CB, KB, density, seed):
@@ -41,20 +51,33 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--config", default="headline", choices=["headline", "cfg3"])
     p.add_argument("--prewarm-seconds", type=float, default=0.5,
                    help="untimed steps run for this long before the warmup steps: the GPU needs a few hundred ms of sustained load "
-                        "to reach its boost clock (20 steps measure 0.41 ms/step, 400 steps 0.34 ms/step on the same box)")
-    p.add_argument("--hidden", type=int, default=4096)
+                        "to reach its boost clock")
+    p.add_argument("--hidden", type=int, default=None)
     p.add_argument("--bsize", type=int, default=32)
-    p.add_argument("--density", type=float, default=0.2)
+    p.add_argument("--density", type=float, default=None, help="headline density (default 0.2; cfg3: 0.05)")
     p.add_argument("--axis", type=int, default=1)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    p.add_argument("--n-local", type=int, default=8192, help="minibatch columns per GPU")
+    p.add_argument("--n-local", type=int, default=None, help="minibatch rows per GPU (headline; default 8192)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-attention", action="store_true", help="skip the BASELINE configs[4] (block-sparse attention) extra")
-    p.add_argument("--sweep", action="store_true", help="also time 10%% and 50%% density (extra JSON fields)")
+    p.add_argument("--no-densities", action="store_true", help="skip the 10 % / 50 % runs of the headline metric")
+    p.add_argument("--no-extras", action="store_true", help="headline line only (no fp32 / attention / other densities / CPU baseline)")
+    p.add_argument("--master-port", type=int, default=29533)
     return p.parse_args()
+
+
+def respawn_under_launcher(a):
+    """`python bench.py --gpus N` outside a launcher: become N ranks (one per GPU) of one node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(a.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def alg_bytes_xprop(b, N, s):
@@ -64,6 +87,21 @@ def alg_bytes_xprop(b, N, s):
 
 def alg_bytes_updat(b, N, s):
     return s * (b.C * N + b.K * N) + s * b.blocks * b.bsize ** 2 + 8 * b.blocks
+
+
+def roofline_of(dom, d_ms, d_flops, d_bytes, dtype):
+    ai = d_flops / d_bytes
+    ridge = PEAK_MFMA[dtype] * 1e12 / (PEAK_HBM * 1e9)
+    if ai >= ridge:
+        roof = {"bound": "mfma", "achieved": round(d_flops / (d_ms * 1e-3) / 1e12, 2), "peak": PEAK_MFMA[dtype], "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": round(d_bytes / (d_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof["traffic"] = None
+    roof["kernel"] = dom
+    roof["kernel_ms"] = round(d_ms, 4)
+    roof["arithmetic_intensity"] = round(ai, 1)
+    return roof
 
 
 def attention_extra(a):
@@ -111,10 +149,9 @@ def attention_extra(a):
            ("nn", lambda: bst._xn(p, v, False), flops, 2 * abytes + sbytes),
            ("tn", lambda: bst._xn(p, q, True), flops, 2 * abytes + sbytes),
            ("softmax_grad", lambda: bst._softmax_bwd(dp, p, scale), 0.0, 3 * sbytes)]
-    res, total = {}, 0.0
+    res = {}
     for name, fn, fl, by in ops:
         ms = timeit(fn)
-        total += ms
         bound = max(fl / (PEAK_MFMA["f32"] * 1e12), by / (PEAK_HBM * 1e9)) * 1e3
         res[name] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "gbps": round(by / ms / 1e6, 1),
                      "bound": "mfma" if fl / (PEAK_MFMA["f32"] * 1e12) > by / (PEAK_HBM * 1e9) else "hbm",
@@ -147,40 +184,115 @@ def attention_extra(a):
     return out
 
 
-def cpu_baseline(layout, bs, axis, seconds):
-    """The oracle's batched-BLAS port (fp32) of the same three passes on the host cores, bounded sample."""
-    from oracle import bsmm_oracle as orc
-    t = orc.build_layout_luts(layout, bs)
-    N = 1024
-    rng = np.random.default_rng(0)
-    CB, KB = layout.shape
-    W = rng.normal(0, 0.01, (t["blocks"], bs, bs)).astype(np.float32)
-    X = rng.normal(0, 0.1, (N, CB * bs) if axis else (CB * bs, N)).astype(np.float32)
-    E = rng.normal(0, 0.1, (N, KB * bs) if axis else (KB * bs, N)).astype(np.float32)
-    flops_step = 3 * 2.0 * t["blocks"] * bs * bs * N
-    orc.fprop_fast(t, X, W, axis)                       # warm up BLAS threads
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        orc.fprop_fast(t, X, W, axis)
-        orc.bprop_fast(t, E, W, axis)
-        orc.updat_fast(t, X, E, axis)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or steps >= 50:
-            break
+def blas_threads():
     try:
         from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count()])
+        info = threadpool_info()
+        return int(max([i.get("num_threads", 1) for i in info] or [os.cpu_count()])), ",".join(sorted(set(i.get("internal_api", "?") for i in info)))
     except Exception:
-        cores = os.cpu_count()
-    return {"value": round(flops_step * steps / el / 1e12, 4), "unit": "TFLOP/s", "cores": int(cores), "kind": "port",
-            "sample": "oracle batched-BLAS fp32 port (oracle/bsmm_oracle.py *_fast), same layout, minibatch %d, "
-                      "%d steps of fprop+bprop+updat in %.1f s" % (N, steps, el)}
+        return int(os.cpu_count() or 1), "?"
+
+
+def cpu_baseline(layout, bs, axis, N, seconds):
+    """The CPU baseline north_star names: NumPy fp32 DENSE-EQUIVALENT of the three passes on the host cores -- fprop X @ Wd,
+    bprop DY @ Wd^T, updat X^T @ DY (dense, then block gather) with Wd = to_dense(W) -- at the headline minibatch, all BLAS
+    threads, bounded to `seconds`.  `value` counts only the nonzero-block FLOPs (the same definition as the GPU line), the
+    dense rate is given next to it; the oracle's gathered-block port (work-efficient, batched small GEMMs) is a second field."""
+    from oracle import bsmm_oracle as orc
+    t = orc.build_layout_luts(layout, bs)
+    rng = np.random.default_rng(0)
+    CB, KB = layout.shape
+    C, K = CB * bs, KB * bs
+    W = rng.normal(0, 0.01, (t["blocks"], bs, bs)).astype(np.float32)
+    X = rng.normal(0, 0.1, (N, C) if axis else (C, N)).astype(np.float32)
+    E = rng.normal(0, 0.1, (N, K) if axis else (K, N)).astype(np.float32)
+    Wd = np.ascontiguousarray(orc.to_dense(t, W).astype(np.float32))
+    ul = t["updat_lut"]
+
+    def dense_step():
+        if axis:
+            y = X @ Wd
+            dx = E @ Wd.T
+            dwd = X.T @ E
+        else:
+            y = Wd.T @ X
+            dx = Wd @ E
+            dwd = X @ E.T
+        dw = dwd.reshape(CB, bs, KB, bs).transpose(0, 2, 1, 3)[ul[:, 0], ul[:, 1]]
+        return y, dx, dw
+
+    dense_step()                                        # warm up BLAS threads
+    t0 = time.perf_counter()
+    steps, times = 0, []
+    while True:
+        t1 = time.perf_counter()
+        dense_step()
+        times.append(time.perf_counter() - t1)
+        steps += 1
+        if time.perf_counter() - t0 >= seconds * 0.75 or steps >= 30:
+            break
+    med = float(np.median(times))
+    dense_flops = 3 * 2.0 * C * K * N
+    eff_flops = 3 * 2.0 * t["blocks"] * bs * bs * N
+    threads, api = blas_threads()
+    out = {"value": round(eff_flops / med / 1e12, 4), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+           "sample": "NumPy fp32 dense-equivalent (X @ to_dense(W), DY @ Wd^T, X^T @ DY + block gather), same layout, minibatch %d, "
+                     "median of %d steps of fprop+bprop+updat (%.2f s each), %d BLAS threads (%s) on %d host cores"
+                     % (N, steps, med, threads, api, os.cpu_count() or 0),
+           "dense_tflops": round(dense_flops / med / 1e12, 4), "host_cores": int(os.cpu_count() or 0)}
+    # second figure: the oracle's gathered-block port (only nonzero blocks are multiplied), smaller minibatch sample
+    Ns = min(N, 1024)
+    Xs, Es = (X[:Ns], E[:Ns]) if axis else (X[:, :Ns], E[:, :Ns])
+    Xs, Es = np.ascontiguousarray(Xs), np.ascontiguousarray(Es)
+    orc.fprop_fast(t, Xs, W, axis)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        orc.fprop_fast(t, Xs, W, axis)
+        orc.bprop_fast(t, Es, W, axis)
+        orc.updat_fast(t, Xs, Es, axis)
+        reps += 1
+        if time.perf_counter() - t0 >= seconds * 0.25 or reps >= 20:
+            break
+    el = time.perf_counter() - t0
+    out["gathered_blocks_port"] = {"value": round(3 * 2.0 * t["blocks"] * bs * bs * Ns * reps / el / 1e12, 4), "unit": "TFLOP/s",
+                                   "sample": "oracle *_fast (batched BLAS over gathered blocks), minibatch %d, %d steps in %.1f s" % (Ns, reps, el)}
+    return out
+
+
+def parity_check(torch, b, layout, w, x, dy, dtype):
+    """One sampled-block check of what was just timed, against the float64 oracle (tests/ hold the full parity suite)."""
+    from oracle import bsmm_oracle as orc
+    t = orc.build_layout_luts(layout, b.bsize)
+    bs, axis = b.bsize, b.axis
+    W, X, E = (v.float().cpu().numpy() for v in (w, x, dy))
+    y, dx, dw = (v.float().cpu().numpy() for v in (b.fprop(x, w), b.bprop(dy, w), b.updat(x, dy)))
+    worst = 0.0
+
+    def blk(a, i):
+        return a[:, i * bs:(i + 1) * bs] if axis else a[i * bs:(i + 1) * bs, :]
+
+    def l2(got, ref):
+        ref = orc.round_to(ref, dtype)
+        return float(np.linalg.norm(got.astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30))
+    ks = [0, b.KB // 3 + 1, b.KB - 1]
+    for k, ref in orc.fprop_cols(t, X, W, axis, ks).items():
+        worst = max(worst, l2(blk(y, k), ref))
+    cs = [1, b.CB // 2, b.CB - 2]
+    for c, ref in orc.bprop_rows(t, E, W, axis, cs).items():
+        worst = max(worst, l2(blk(dx, c), ref))
+    ws = list(range(0, b.blocks, max(1, b.blocks // 16)))[:16]
+    for i, ref in orc.updat_blocks(t, X, E, axis, ws).items():
+        worst = max(worst, l2(dw[i], ref))
+    bar = 2e-6 if dtype == "f32" else 1e-3
+    return {"parity_checked": bool(worst <= bar), "parity_worst_l2": float("%.3e" % worst), "parity_bar": bar,
+            "parity_sample": "fprop 3 block columns, bprop 3 block rows, updat 16 blocks vs oracle/bsmm_oracle.py (float64)"}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_launcher(a)
     import torch
     import torch.distributed as dist
     from blocksparse_amd import BlocksparseMatMul, _lib
@@ -190,27 +302,42 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    if a.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get("BSMM_FORCE_DIST") == "1"   # the env forces the RCCL path at world_size 1 (self-test)
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     _lib.load()
 
+    cfg3 = a.config == "cfg3"
+    hidden = a.hidden or (8192 if cfg3 else 4096)
+    density = a.density if a.density is not None else (0.05 if cfg3 else 0.2)
+    if cfg3:
+        n_global = 4096
+        assert n_global % world == 0, "cfg3: the 4096-row minibatch must divide over the ranks"
+        n_local = n_global // world
+    else:
+        n_local = a.n_local or 8192
+        n_global = n_local * world
+    if a.no_extras:
+        a.no_densities = a.no_attention = a.no_cpu_baseline = True
     td = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     s = 4 if a.dtype == "f32" else 2
-    CB = a.hidden // a.bsize
+    CB = hidden // a.bsize
 
-    def setup(density):
-        layout = random_layout(CB, CB, density, seed=1234)
+    def setup(dens):
+        layout = random_layout(CB, CB, dens, seed=1234)
         b = BlocksparseMatMul(layout, block_size=a.bsize, feature_axis=a.axis)
         g = torch.Generator(device="cuda").manual_seed(1 + rank)
         w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.01).to(td)
-        x = (torch.randn(b.i_shape(a.n_local), device="cuda", generator=g) * 0.1).to(td)
-        dy = (torch.randn(b.o_shape(a.n_local), device="cuda", generator=g) * 0.1).to(td)
+        x = (torch.randn(b.i_shape(n_local), device="cuda", generator=g) * 0.1).to(td)
+        dy = (torch.randn(b.o_shape(n_local), device="cuda", generator=g) * 0.1).to(td)
         return layout, b, w, x, dy
 
-    def run(b, w, x, dy, steps, warmup, timed_events):
-        red = DwAllReduce(accumulate_fp32=False)
+    def run(b, w, x, dy, steps, warmup):
+        """(seconds for `steps` steps [max over ranks], mean ms of fprop / updat / bprop from HIP events on the launch stream)"""
+        red = DwAllReduce(accumulate_fp32=True)
         dw = torch.empty(b.w_shape, dtype=td, device="cuda")
 
         def step(ev=None):
@@ -233,14 +360,14 @@ def main():
                 torch.cuda.synchronize()
         for _ in range(warmup):
             step()
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)] if timed_events else None
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(evs[i] if evs else None)
+            step(evs[i])
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -250,71 +377,62 @@ def main():
             t = torch.tensor([el], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        per = None
-        if evs:
-            per = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i in range(3)]   # ms: fprop, updat, bprop
+        per = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i in range(3)]   # ms: fprop, updat, bprop
         return el, per
 
-    layout, b, w, x, dy = setup(a.density)
-    el, per = run(b, w, x, dy, a.steps, a.warmup, timed_events=True)
-    N = a.n_local
-    workload_name = ("bsmm fprop+bprop+updat %dx%d block_size=%d density=%.0f%% feature_axis=%d, minibatch %d per GPU, "
-                     "layout default_rng(1234)" % (a.hidden, a.hidden, a.bsize, a.density * 100, a.axis, N))
-    flops_pass = 2.0 * b.blocks * a.bsize ** 2 * N
-    total_flops = 3 * flops_pass * world * a.steps
-    ms_step = el / a.steps * 1e3
-    value = total_flops / el / 1e12
-    bytes_step = 2 * alg_bytes_xprop(b, N, s) + alg_bytes_updat(b, N, s)
-    f_ms, u_ms, b_ms = per
+    def summarize(b, el, per, steps):
+        """metrics of one density: whole-job TFLOP/s, per-pass times, roofline of the dominant kernel"""
+        N = n_local
+        flops_pass = 2.0 * b.blocks * a.bsize ** 2 * N
+        f_ms, u_ms, b_ms = per
+        # bprop is ONE launch of the xprop kernel (fprop = the same kernel + a small weight-transpose launch); updat is one
+        # launch of the updat kernel (+ a finalize launch when the minibatch is split).  HIP events on the launch stream.
+        cand = {"bsmm_xprop(bprop)": (b_ms, flops_pass, alg_bytes_xprop(b, N, s)), "bsmm_updat": (u_ms, flops_pass, alg_bytes_updat(b, N, s))}
+        dom = max(cand, key=lambda k: cand[k][0])
+        roof = roofline_of(dom, *cand[dom], a.dtype)
+        return {"blocks": int(b.blocks), "value": round(3 * flops_pass * world * steps / el / 1e12, 3), "ms_per_step": round(el / steps * 1e3, 4),
+                "pass_ms": {"fprop": round(f_ms, 4), "bprop": round(b_ms, 4), "updat": round(u_ms, 4)},
+                "pass_tflops": {"fprop": round(flops_pass / f_ms / 1e9, 2), "bprop": round(flops_pass / b_ms / 1e9, 2),
+                                "updat": round(flops_pass / u_ms / 1e9, 2)},
+                "gbps_algorithmic": round((2 * alg_bytes_xprop(b, N, s) + alg_bytes_updat(b, N, s)) / (el / steps) / 1e9, 1),
+                "roofline": roof}
 
-    # roofline of the dominant kernel.  bprop is ONE launch of the xprop kernel (fprop = the same kernel + a
-    # small weight-transpose launch); updat is one launch of the updat kernel.  HIP events on the launch stream.
-    cand = {
-        "bsmm_xprop(bprop)": (b_ms, flops_pass, alg_bytes_xprop(b, N, s)),
-        "bsmm_updat": (u_ms, flops_pass, alg_bytes_updat(b, N, s)),
-    }
-    dom = max(cand, key=lambda k: cand[k][0])
-    d_ms, d_flops, d_bytes = cand[dom]
-    ai = d_flops / d_bytes
-    ridge = PEAK_MFMA[a.dtype] * 1e12 / (PEAK_HBM * 1e9)
-    if ai >= ridge:
-        roof = {"bound": "mfma", "achieved": round(d_flops / (d_ms * 1e-3) / 1e12, 2), "peak": PEAK_MFMA[a.dtype], "unit": "TFLOP/s"}
-    else:
-        roof = {"bound": "hbm", "achieved": round(d_bytes / (d_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s"}
-    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    layout, b, w, x, dy = setup(density)
+    el, per = run(b, w, x, dy, a.steps, a.warmup)
+    head = summarize(b, el, per, a.steps)
+    dname = "d%d" % round(density * 100)
+    workload_name = ("bsmm fprop+bprop+updat %dx%d block_size=%d density=%.0f%% feature_axis=%d, minibatch %d per GPU, "
+                     "layout default_rng(1234)" % (hidden, hidden, a.bsize, density * 100, a.axis, n_local))
+    roof = head["roofline"]
     # HBM bytes per launch of that kernel, from the committed rocprofv3 PMC passes (separate runs; gfx950-corrected):
     # only quoted when the profile was taken on exactly this workload
-    roof["traffic"] = None
+    traffic = {}
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tr.get("workload") == workload_name and dom in tr and world == 1:
-            roof["traffic"] = tr[dom]["hbm_bytes"]
+        traffic = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")))
+        if traffic.get("workload") == workload_name and roof["kernel"] in traffic and world == 1:
+            roof["traffic"] = traffic[roof["kernel"]]["hbm_bytes"]
     except Exception:
-        pass
-    roof["kernel"] = dom
-    roof["kernel_ms"] = round(d_ms, 4)
-    roof["arithmetic_intensity"] = round(ai, 1)
+        traffic = {}
 
     out = {
-        "metric": "bsmm_effective_tflops_%dx%d_bs%d_d%d" % (a.hidden, a.hidden, a.bsize, round(a.density * 100)),
-        "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "bsmm_effective_tflops_%dx%d_bs%d_%s" % (hidden, hidden, a.bsize, dname),
+        "value": head["value"], "unit": "TFLOP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if cfg3 else "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": workload_name,
-                   "blocks": int(b.blocks), "global_minibatch": N * world,
-                   "parallelism": "dp%d (minibatch sharded, dw all-reduce over RCCL)" % world if world > 1 else "single GPU"},
-        "gbps_algorithmic": round(bytes_step / (ms_step * 1e-3) / 1e9, 1),
+        "config": {"workload": workload_name, "blocks": int(b.blocks), "global_minibatch": n_global,
+                   "parallelism": "dp%d (minibatch sharded, dw all-reduce over RCCL, fp32 accumulation)" % world if world > 1 else "single GPU"},
+        "gbps_algorithmic": head["gbps_algorithmic"],
         # what a dense GEMM of the same shapes would have to sustain to take the same time (SURVEY 8d: reported alongside,
         # never the headline)
-        "dense_equivalent_tflops": round(3 * 2.0 * a.hidden * a.hidden * N * world * a.steps / el / 1e12, 1),
-        "pass_ms": {"fprop": round(f_ms, 4), "bprop": round(b_ms, 4), "updat": round(u_ms, 4)},
-        "pass_tflops": {"fprop": round(flops_pass / f_ms / 1e9, 2), "bprop": round(flops_pass / b_ms / 1e9, 2),
-                        "updat": round(flops_pass / u_ms / 1e9, 2)},
+        "dense_equivalent_tflops": round(3 * 2.0 * hidden * hidden * n_global * a.steps / el / 1e12, 1),
+        "pass_ms": head["pass_ms"], "pass_tflops": head["pass_tflops"],
         "roofline": roof,
     }
+    if rank == 0:
+        out.update(parity_check(torch, b, layout, w, x, dy, a.dtype))
     if use_dist:
         # the dw all-reduce on its own (it overlaps with bprop inside the step): time alone, and how much of it the step hides
-        red = DwAllReduce(accumulate_fp32=False)
+        red = DwAllReduce(accumulate_fp32=True)
         dw_t = torch.zeros(b.w_shape, dtype=td, device="cuda")
         for _ in range(5):
             red.start(dw_t); red.wait()
@@ -327,15 +445,36 @@ def main():
         tt = torch.tensor([ar_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ar_ms = float(tt.item())
-        compute_ms = f_ms + u_ms + b_ms
-        out["allreduce"] = {"bytes": int(dw_t.numel() * dw_t.element_size()), "ms_alone": round(ar_ms, 4),
+        compute_ms = sum(per)
+        ms_step = head["ms_per_step"]
+        out["allreduce"] = {"bytes": int(dw_t.numel() * 4), "dtype": "f32", "ms_alone": round(ar_ms, 4),
                             "compute_ms": round(compute_ms, 4),
                             "exposed_ms": round(max(0.0, ms_step - compute_ms), 4),
                             "hidden_frac": round(max(0.0, min(1.0, 1.0 - max(0.0, ms_step - compute_ms) / max(ar_ms, 1e-9))), 3)}
+    # the other densities of the BASELINE metric (10 % and 50 %; the headline run above is the 20 % one), same shape and minibatch
+    if not cfg3 and not a.no_densities:
+        dens = {dname: {k: head[k] for k in ("blocks", "value", "ms_per_step", "pass_ms", "pass_tflops", "roofline")}}
+        dens[dname]["roofline"] = dict(roof)
+        for d in (0.1, 0.5):
+            if abs(d - density) < 1e-9:
+                continue
+            _, b2, w2, x2, dy2 = setup(d)
+            st2 = max(10, a.steps // 2)
+            el2, per2 = run(b2, w2, x2, dy2, st2, max(3, a.warmup // 2))
+            r = summarize(b2, el2, per2, st2)
+            key = "d%d" % round(d * 100)
+            dens[key] = {k: r[k] for k in ("blocks", "value", "ms_per_step", "pass_ms", "pass_tflops", "roofline")}
+            wl2 = workload_name.replace("density=%.0f%%" % (density * 100), "density=%.0f%%" % (d * 100))
+            tr = traffic.get("densities", {}).get(key, {})
+            if tr.get("workload") == wl2 and world == 1 and r["roofline"]["kernel"] in tr:
+                dens[key]["roofline"]["traffic"] = tr[r["roofline"]["kernel"]]["hbm_bytes"]
+            del b2, w2, x2, dy2
+        out["densities"] = dens
     # BASELINE.json configs[1]: same layout, fp32, feature_axis=1, fprop only.  Priced against the fp32 matrix-core peak
     # (157.3 TF; AI 195 > ridge 20) although the kernel computes the fp32 result exactly from bf16 pieces on the 16-bit
     # matrix cores (six MFMAs per product, bsmm_xcols.h), whose ceiling for this formulation is 2500 / 6 = 417 TF.
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not cfg3 and not a.no_extras:
+        N = n_local
         b32 = BlocksparseMatMul(layout, block_size=a.bsize, feature_axis=1)
         g32 = torch.Generator(device="cuda").manual_seed(7)
         w32 = torch.randn(b32.w_shape, device="cuda", generator=g32) * 0.01
@@ -352,26 +491,17 @@ def main():
         ms32 = e0.elapsed_time(e1) / 50
         tf32 = 2.0 * b32.blocks * a.bsize ** 2 * N / ms32 / 1e9
         out["fp32_fprop_axis1"] = {"workload": "BASELINE configs[1]: %dx%d bs%d d%.0f%% fp32 feature_axis=1 fprop, minibatch %d" %
-                                               (a.hidden, a.hidden, a.bsize, a.density * 100, N),
+                                               (hidden, hidden, a.bsize, density * 100, N),
                                    "kernel": "exact three-piece bf16 split on v_mfma_f32_32x32x16_bf16 (incl. the split pre-passes)",
                                    "ms": round(ms32, 4), "tflops": round(tf32, 2), "peak": PEAK_MFMA["f32"],
                                    "frac": round(tf32 / PEAK_MFMA["f32"], 4),
                                    "peak_bf16_six_products": round(PEAK_MFMA["bf16"] / 6, 1),
                                    "frac_bf16_six_products": round(tf32 / (PEAK_MFMA["bf16"] / 6), 4)}
         del b32, w32, x32
-    if rank == 0 and world == 1 and not a.no_attention:
+    if rank == 0 and world == 1 and not cfg3 and not a.no_attention:
         out["attention"] = attention_extra(a)
-    if a.sweep:
-        sw = {}
-        for d in (0.1, 0.5):
-            _, b2, w2, x2, dy2 = setup(d)
-            el2, per2 = run(b2, w2, x2, dy2, max(3, a.steps // 2), 5, timed_events=True)
-            fp = 2.0 * b2.blocks * a.bsize ** 2 * N
-            sw["d%d" % round(d * 100)] = {"tflops": round(3 * fp * world * max(3, a.steps // 2) / el2 / 1e12, 2),
-                                          "pass_ms": {"fprop": round(per2[0], 4), "updat": round(per2[1], 4), "bprop": round(per2[2], 4)}, "blocks": int(b2.blocks)}
-        out["density_sweep"] = sw
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(layout, a.bsize, a.axis, a.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(layout, a.bsize, a.axis, min(n_local, 8192), a.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
     # The JSON line must be the LAST thing on stdout.  RCCL's version banner (NCCL_DEBUG=VERSION) sits in every rank's C stdio

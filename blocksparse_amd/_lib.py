@@ -11,11 +11,16 @@ LIB_PATH = os.path.join(_HERE, "libbsmm_hip.so")
 
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
-FLAG_GATED_DW = 1
+FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN = 1, 2, 4, 8
+# bsmm_args.trace codes (include/bsmm.h BSMM_K_*)
+K_XPROP_VALU, K_XPROP_SEGMENT, K_XCOL32, K_XCOL16, K_XCOL32_F32SPLIT, K_XCOL32_F32MFMA, K_XPROP_SUPER8 = 1, 2, 3, 4, 5, 6, 7
+K_UPDAT_VALU, K_UPDAT_BLOCK, K_UPDAT_BLOCK_TR, K_UPDAT_WIN, K_UPDAT16_WIN, K_UPDAT_SUPER8 = 16, 17, 18, 19, 20, 21
+# plan-builder options (BSMM_PLAN_*)
+PLAN_XCOL_NARROW, PLAN_F32_MFMA, PLAN_WINDOW_8, PLAN_WINDOW_16, PLAN_WINDOW_16W = 1, 2, 0x10, 0x20, 0x30
 
 SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_sparse_op", "bsmm_sparse_mul_grad", "bsmm_workspace_bytes",
            "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
-           "bsmm_set_kernel_variant", "bsmm_get_kernel_variant", "bsmm_error_string", "bsmm_version")
+           "bsmm_plan_attach", "bsmm_error_string", "bsmm_version")
 BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask")
 
 
@@ -24,12 +29,13 @@ class BsmmArgs(ctypes.Structure):
     _fields_ = [
         ("lut", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
         ("workspace_bytes", ctypes.c_size_t), ("plan", ctypes.c_void_p),
-        ("plan_items", ctypes.c_int32), ("plan_aux", ctypes.c_int32), ("flags", ctypes.c_int32),
+        ("plan_magic", ctypes.c_int32), ("plan_width", ctypes.c_int32), ("plan_waves", ctypes.c_int32),
+        ("plan_items", ctypes.c_int32), ("plan_inner", ctypes.c_int32), ("flags", ctypes.c_int32), ("split", ctypes.c_int32),
         ("blocks", ctypes.c_int32), ("bsize", ctypes.c_int32), ("segments", ctypes.c_int32),
         ("locks", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
         ("shared", ctypes.c_int32), ("pcount", ctypes.c_int32), ("axis", ctypes.c_int32),
         ("dtype", ctypes.c_int32), ("alpha", ctypes.c_float), ("beta", ctypes.c_float),
-        ("stream", ctypes.c_void_p),
+        ("stream", ctypes.c_void_p), ("trace", ctypes.POINTER(ctypes.c_int32)),
     ]
 
 
@@ -44,6 +50,26 @@ class BstArgs(ctypes.Structure):
 
 
 _lib = None
+
+# Test hook (host side only -- the library itself keeps no switches): flags OR-ed into every call the host classes make.
+#   0 production dispatch, 1 = FLAG_FORCE_VALU, 2 = FLAG_NO_PLAN, 3 = FLAG_FORCE_PLAN
+_VARIANT_FLAGS = {0: 0, 1: FLAG_FORCE_VALU, 2: FLAG_NO_PLAN, 3: FLAG_FORCE_PLAN}
+_call_flags = 0
+_last_kernel = ctypes.c_int32(0)
+
+
+def set_kernel_variant(variant):
+    global _call_flags
+    _call_flags = _VARIANT_FLAGS.get(int(variant), 0)
+
+
+def call_flags():
+    return _call_flags
+
+
+def last_kernel():
+    """BSMM_K_* code of the kernel family the most recent fprop / bprop / updat call of the host classes dispatched to."""
+    return int(_last_kernel.value)
 
 
 class BsmmError(RuntimeError):
@@ -86,18 +112,16 @@ def load():
     lib.bsmm_workspace_bytes.argtypes = [ctypes.c_int, pargs]
     lib.bsmm_workspace_bytes.restype = ctypes.c_size_t
     ip = ctypes.POINTER(ctypes.c_int32)
-    lib.bsmm_xprop_plan_words.argtypes = [ip, i32, i32, i32, i32, i32, i32]
+    lib.bsmm_xprop_plan_words.argtypes = [ip, i32, i32, i32, i32, i32, i32, i32]
     lib.bsmm_xprop_plan_words.restype = ctypes.c_long
-    lib.bsmm_xprop_plan_build.argtypes = [ip, i32, i32, i32, i32, i32, i32, ip]
+    lib.bsmm_xprop_plan_build.argtypes = [ip, i32, i32, i32, i32, i32, i32, i32, ip]
     lib.bsmm_xprop_plan_build.restype = ctypes.c_int
-    lib.bsmm_updat_plan_words.argtypes = [ip, i32, i32, i32, i32, i32, i32]
+    lib.bsmm_updat_plan_words.argtypes = [ip, i32, i32, i32, i32, i32, i32, i32]
     lib.bsmm_updat_plan_words.restype = ctypes.c_long
-    lib.bsmm_updat_plan_build.argtypes = [ip, i32, i32, i32, i32, i32, i32, ip]
+    lib.bsmm_updat_plan_build.argtypes = [ip, i32, i32, i32, i32, i32, i32, i32, ip]
     lib.bsmm_updat_plan_build.restype = ctypes.c_int
-    lib.bsmm_set_kernel_variant.argtypes = [ctypes.c_int]
-    lib.bsmm_set_kernel_variant.restype = None
-    lib.bsmm_get_kernel_variant.argtypes = []
-    lib.bsmm_get_kernel_variant.restype = ctypes.c_int
+    lib.bsmm_plan_attach.argtypes = [pargs, ip, ctypes.c_long, vp]
+    lib.bsmm_plan_attach.restype = ctypes.c_int
     lib.bsmm_error_string.argtypes = [ctypes.c_int]
     lib.bsmm_error_string.restype = ctypes.c_char_p
     lib.bsmm_version.argtypes = []

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 
 #include "bsmm.h"
 #include "bsmm_plan.h"
@@ -22,7 +23,30 @@ using namespace bsmm;
 
 namespace {
 
-std::atomic<int> g_variant{0};
+// kernel-choice overrides come with the call (bsmm_args.flags), never from process state:
+//   0 production dispatch, 1 = BSMM_FLAG_FORCE_VALU, 2 = BSMM_FLAG_NO_PLAN, 3 = BSMM_FLAG_FORCE_PLAN
+inline int call_variant(const bsmm_args* a) {
+    if (a->flags & BSMM_FLAG_FORCE_VALU) return 1;
+    if (a->flags & BSMM_FLAG_NO_PLAN) return 2;
+    if (a->flags & BSMM_FLAG_FORCE_PLAN) return 3;
+    return 0;
+}
+inline void trace(const bsmm_args* a, int k) { if (a->trace) *a->trace = k; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); the result is checked.  The latch is a cache of an
+// idempotent driver call, not a switch: it never changes what a later call computes.
+template <class F>
+inline int ensure_lds(F* func, int bytes) {
+    static std::atomic<uint64_t> done{0};          // one instantiation (and one latch) per kernel
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(func), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 inline size_t elem_size(int dtype) { return dtype == BSMM_F32 ? 4 : 2; }
 
@@ -39,22 +63,37 @@ int check_common(const bsmm_args* a) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// A plan must be one this library built for THIS kind of call (the descriptor comes from bsmm_plan_attach): anything else
+// is refused here, on the host, instead of reaching a kernel that would not recognise it.
+int check_plan(bool updat, const bsmm_args* a) {
+    if (!a->plan) return BSMM_OK;
+    if (reinterpret_cast<uintptr_t>(a->plan) & 15) return BSMM_ERR_ARG;
+    const int32_t m = a->plan_magic;
+    if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
+    if (updat) return (m == UPLAN_MAGIC && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
+    if (a->bsize == 16) return (m == XC16PLAN_MAGIC && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
+    if (a->dtype == BSMM_F32) return ((m == XCPLAN_MAGIC && a->plan_width == XS_G) || m == XFPLAN_MAGIC) ? BSMM_OK : BSMM_ERR_ARG;
+    return m == XCPLAN_MAGIC ? BSMM_OK : BSMM_ERR_ARG;
+}
+
 // ---------------------------------------------------------------------------------------------
 // xprop
 // ---------------------------------------------------------------------------------------------
 template <class DT, int BS, int AXIS, bool FPROP>
-int launch_xprop_valu(const void* X, const void* W, void* Y, const bsmm_args* a, hipStream_t st) {
+int launch_xprop_valu(const void* X, const void* W, void* Y, const bsmm_args* a, hipStream_t st, float* yacc) {
     typedef typename DT::T T;
-    dim3 grid((a->N + 255) / 256, a->segments);
+    dim3 grid(a->segments, (a->N + 255) / 256);    // segments on x: no 65535 limit
+    trace(a, BSMM_K_XPROP_VALU);
     xprop_valu_kernel<DT, BS, AXIS, FPROP><<<grid, 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(W),
-                                                                 static_cast<T*>(Y), a->lut, a->N, a->C, a->K, a->gate);
+                                                                 static_cast<T*>(Y), a->lut, a->N, a->C, a->K, a->gate, yacc);
     return (int)hipGetLastError();
 }
 
 template <class DT, int BS, int AXIS>
-int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, float* yacc) {
     typedef typename DT::T T;
     const int N = a->N;
+    trace(a, BSMM_K_XPROP_SEGMENT);
     auto go = [&](auto nsub_tag) {
         constexpr int NSUB = decltype(nsub_tag)::value;
         constexpr int NT = 4 * BS * NSUB;
@@ -67,18 +106,18 @@ int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args*
         if (a->gate) {
             if constexpr (BS == 32)
                 xprop32_kernel<DT, AXIS, NSUB, true><<<m.grid(), 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
-                                                                               static_cast<T*>(Y), a->lut, m, N, a->C, a->K, a->gate);
+                                                                               static_cast<T*>(Y), a->lut, m, N, a->C, a->K, a->gate, yacc);
             else
                 xprop16_kernel<DT, AXIS, NSUB, true><<<m.grid(), 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
-                                                                               static_cast<T*>(Y), a->lut, m, N, a->C, a->K, a->gate);
+                                                                               static_cast<T*>(Y), a->lut, m, N, a->C, a->K, a->gate, yacc);
             return;
         }
         if constexpr (BS == 32)
             xprop32_kernel<DT, AXIS, NSUB><<<m.grid(), 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
-                                                                     static_cast<T*>(Y), a->lut, m, N, a->C, a->K);
+                                                                     static_cast<T*>(Y), a->lut, m, N, a->C, a->K, nullptr, yacc);
         else
             xprop16_kernel<DT, AXIS, NSUB><<<m.grid(), 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel),
-                                                                     static_cast<T*>(Y), a->lut, m, N, a->C, a->K);
+                                                                     static_cast<T*>(Y), a->lut, m, N, a->C, a->K, nullptr, yacc);
     };
     // per-wave minibatch extent: BS*NSUB columns; use the wide tile only when it still fills the chip
     if constexpr (BS == 32) {
@@ -97,23 +136,6 @@ int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args*
 #define BSMM_XC_WIDE_PH 4
 #endif
 inline bool use_xcol() { return true; }
-// fp32, bsize 32: the exact three-piece bf16 kernel (bsmm_xcols.h) instead of the fp32-MFMA kernel xcol32f
-// (BSMM_F32_SPLIT=0, read once, selects the latter for A/B runs).  Decides the plan format too ('BSXC' G = 16 / 'BSXF').
-inline bool f32_split(int axis) {
-    static const int on = [] { const char* e = getenv("BSMM_F32_SPLIT"); return e ? atoi(e) : 1; }();
-    return (axis == 0 || axis == 1) && on;
-}
-inline int xc16_group() {   // output blocks per workgroup of the bsize-16 xcol kernel: 16, or 32 ("wide")
-    static const int wide = [] { const char* e = getenv("BSMM_XC16_WIDE"); return e ? atoi(e) : 1; }();
-    return wide ? 32 : XC16_G;
-}
-// Output blocks per workgroup of the 16-bit bsize-32 xcol kernels: 16 (the wide <16, 4> variants, bsmm_xcol.h; measured
-// 5-10 % faster than <8, 2> from N = 3072 up, 8 % slower at N = 2048 where it fills only half the CUs).  The plan is
-// built for the same width; BSMM_XC_WIDE=0 (read once) selects the narrow kernels for A/B runs.
-inline int xc_group(int /*axis*/) {
-    static const int wide = [] { const char* e = getenv("BSMM_XC_WIDE"); return e ? atoi(e) : 1; }();
-    return wide ? 16 : XC_G;
-}
 
 template <class DT, int AXIS, int NW, int PH>
 int launch_xcol16_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
@@ -126,11 +148,8 @@ int launch_xcol16_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
     constexpr int LDS = xc_lds_bytes(NW, PH);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol16_kernel<DT, AXIS, NW, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    if (int rc = ensure_lds(&xcol16_kernel<DT, AXIS, NW, PH>, LDS)) return rc;
+    trace(a, BSMM_K_XCOL16);
     xcol16_kernel<DT, AXIS, NW, PH><<<m.grid(), 64 * NW, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                    a->N, a->C, a->K);
     return (int)hipGetLastError();
@@ -138,8 +157,10 @@ int launch_xcol16_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a
 
 template <class DT, int AXIS>
 int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    if (xc16_group() == 32) return launch_xcol16_g<DT, AXIS, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
-    return launch_xcol16_g<DT, AXIS, 8, XC_PH>(X, Wsel, Y, a, st);
+    if (a->plan_magic != XC16PLAN_MAGIC) return BSMM_ERR_ARG;
+    if (a->plan_width == 32) return launch_xcol16_g<DT, AXIS, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
+    if (a->plan_width == XC16_G) return launch_xcol16_g<DT, AXIS, 8, XC_PH>(X, Wsel, Y, a, st);
+    return BSMM_ERR_ARG;
 }
 
 template <int AXIS>
@@ -151,11 +172,9 @@ int launch_xcol32f(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32f_kernel<AXIS>), hipFuncAttributeMaxDynamicSharedMemorySize, XF_LDS);
-        attr_set = true;
-    }
+    if (a->plan_magic != XFPLAN_MAGIC || a->plan_width != XC_G) return BSMM_ERR_ARG;
+    if (int rc = ensure_lds(&xcol32f_kernel<AXIS>, XF_LDS)) return rc;
+    trace(a, BSMM_K_XCOL32_F32MFMA);
     xcol32f_kernel<AXIS><<<m.grid(), 512, XF_LDS, st>>>(static_cast<const float*>(X), static_cast<const float*>(Wsel), static_cast<float*>(Y),
                                                         a->plan, m, a->N, a->C, a->K);
     return (int)hipGetLastError();
@@ -169,6 +188,7 @@ inline size_t xcols_workspace_bytes(const bsmm_args* a) {
 template <int AXIS>
 int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a, hipStream_t st) {
     const size_t nx = (size_t)a->N * a->C;
+    if (a->plan_magic != XCPLAN_MAGIC || a->plan_width != XS_G) return BSMM_ERR_ARG;
     if (!a->workspace || a->workspace_bytes < xcols_workspace_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
     uint16_t* xp = static_cast<uint16_t*>(a->workspace);
     uint16_t* wp = xp + 3 * nx;
@@ -182,17 +202,14 @@ int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32s_kernel<AXIS>), hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS);
-        attr_set = true;
-    }
+    if (int rc = ensure_lds(&xcol32s_kernel<AXIS>, XS_LDS)) return rc;
+    trace(a, BSMM_K_XCOL32_F32SPLIT);
     xcol32s_kernel<AXIS><<<m.grid(), 64 * XS_G, XS_LDS, st>>>(xp, wp, static_cast<float*>(Y), a->plan, m, a->N, a->C, a->K, a->blocks);
     return (int)hipGetLastError();
 }
 
 template <class DT, bool TRANSW, int G, int PH>
-void launch_xcol0_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+int launch_xcol0_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
     XMap m;
@@ -202,23 +219,22 @@ void launch_xcol0_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
     constexpr int LDS = 2 * PH * XC0_SLAB;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32_a0_kernel<DT, TRANSW, G, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    if (int rc = ensure_lds(&xcol32_a0_kernel<DT, TRANSW, G, PH>, LDS)) return rc;
+    trace(a, BSMM_K_XCOL32);
     xcol32_a0_kernel<DT, TRANSW, G, PH><<<m.grid(), 64 * G, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                      a->N, a->C, a->K);
+    return (int)hipGetLastError();
 }
 
 template <class DT, bool TRANSW>
-void launch_xcol0(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    if (xc_group(0) == 16) launch_xcol0_g<DT, TRANSW, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
-    else                   launch_xcol0_g<DT, TRANSW, XC_G, XC_PH>(X, Wsel, Y, a, st);
+int launch_xcol0(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    if (a->plan_width == 16)   return launch_xcol0_g<DT, TRANSW, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
+    if (a->plan_width == XC_G) return launch_xcol0_g<DT, TRANSW, XC_G, XC_PH>(X, Wsel, Y, a, st);
+    return BSMM_ERR_ARG;
 }
 
 template <class DT, bool TRANSW, int G, int PH>
-void launch_xcol_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+int launch_xcol_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
     XMap m;
@@ -228,31 +244,25 @@ void launch_xcol_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
     constexpr int LDS = xc_lds_bytes(G, PH);
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xcol32_a1_kernel<DT, TRANSW, G, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    if (int rc = ensure_lds(&xcol32_a1_kernel<DT, TRANSW, G, PH>, LDS)) return rc;
+    trace(a, BSMM_K_XCOL32);
     xcol32_a1_kernel<DT, TRANSW, G, PH><<<m.grid(), 64 * G, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                      a->N, a->C, a->K);
+    return (int)hipGetLastError();
 }
 
 template <class DT, bool TRANSW>
-void launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    if (xc_group(1) == 16) launch_xcol_g<DT, TRANSW, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
-    else                   launch_xcol_g<DT, TRANSW, XC_G, XC_PH>(X, Wsel, Y, a, st);
+int launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    if (a->plan_width == 16)   return launch_xcol_g<DT, TRANSW, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
+    if (a->plan_width == XC_G) return launch_xcol_g<DT, TRANSW, XC_G, XC_PH>(X, Wsel, Y, a, st);
+    return BSMM_ERR_ARG;
 }
 
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
-    if constexpr (AXIS == 1) {
-        if (transw) launch_xcol<DT, true>(X, Wsel, Y, a, st);
-        else        launch_xcol<DT, false>(X, Wsel, Y, a, st);
-    } else {
-        if (transw) launch_xcol0<DT, true>(X, Wsel, Y, a, st);
-        else        launch_xcol0<DT, false>(X, Wsel, Y, a, st);
-    }
-    return (int)hipGetLastError();
+    if (a->plan_magic != XCPLAN_MAGIC) return BSMM_ERR_ARG;
+    if constexpr (AXIS == 1) return transw ? launch_xcol<DT, true>(X, Wsel, Y, a, st) : launch_xcol<DT, false>(X, Wsel, Y, a, st);
+    else                     return transw ? launch_xcol0<DT, true>(X, Wsel, Y, a, st) : launch_xcol0<DT, false>(X, Wsel, Y, a, st);
 }
 
 template <class DT, int BS>
@@ -262,30 +272,61 @@ int launch_transpose(const void* W, void* Wt, int blocks, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// Workspace layout of an xprop call (both parts 16-byte aligned): [0, wt) the transposed / expanded / split weights of
+// the kernel that runs, then [wt, wt + N*K*4) the fp32 accumulators of LOCKED output blocks when the reference-policy
+// table is walked by the per-segment kernels with a 16-bit storage type (lut segments that share an output block are
+// summed in fp32 and rounded ONCE by lock_finalize_kernel -- the reference rounds every partial sum to 16 bit with
+// red.add.f16x2, src/blocksparse_hgemm_cn_64_op_gpu.cu:211-240).
+inline size_t round16(size_t b) { return (b + 15) & ~(size_t)15; }
+inline size_t wt_bytes(const bsmm_args* a) { return round16((size_t)a->blocks * a->bsize * a->bsize * elem_size(a->dtype)); }
+inline size_t lock_acc_bytes(const bsmm_args* a) {
+    return (a->locks > 0 && a->dtype != BSMM_F32) ? (size_t)a->N * a->K * sizeof(float) : 0;
+}
+
+enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_F32MFMA, XP_SUPER8 };
+
+// ONE decision, used for the workspace layout, the zero-fill of locked outputs and the launch (the three used to be
+// derived separately and could disagree).
 template <class DT, int BS, int AXIS>
-int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
-    hipStream_t st = static_cast<hipStream_t>(a->stream);
-    const int variant = g_variant.load(std::memory_order_relaxed);
+XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a) {
+    const int variant = call_variant(a);
     const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
-    const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
+    const bool plan_ok = a->plan != nullptr && a->gate == nullptr && vec_ok && (variant == 0 || variant == 3);   // gated calls: per-segment kernels
+    const bool force = variant == 3;
+    if constexpr (BS == 8) {
+        if constexpr (DT::is16) {
+            // bsize 8 on the matrix cores: expand W into the 32x32 super-blocks of the 'BSS8' plan and run the bsize-32 kernel
+            const bool shape_ok = a->C % 32 == 0 && a->K % 32 == 0 && !(AXIS == 0 && (a->N % 8 != 0));
+            const bool fill = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
+            if (plan_ok && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && shape_ok && (fill || force)) return XP_SUPER8;
+        }
+        return XP_VALU;
+    }
+    if (variant == 1 || !vec_ok) return XP_VALU;
+    if (!plan_ok) return XP_SEGMENT;
     // grouped kernels need enough (row tile x group) workgroups to fill 256 CUs; below that the per-segment kernel,
     // which has segments x tiles workgroups, is faster
-    bool enough = false;
-    if (BS == 16 && a->plan != nullptr && DT::is16) {
-        enough = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 16 + XC16_G - 1) / XC16_G) >= 224;
-        if (AXIS == 0 && (a->N % 8 != 0)) enough = false;
-        if (variant == 3 && !(AXIS == 0 && (a->N % 8 != 0))) enough = true;
+    if constexpr (BS == 16) {
+        if constexpr (!DT::is16) return XP_SEGMENT;
+        if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // 16-byte aligned row pieces
+        const bool enough = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 16 + XC16_G - 1) / XC16_G) >= 224;
+        return (enough || force) ? XP_XCOL16 : XP_SEGMENT;
     }
-    if (BS == 32 && a->plan != nullptr && !DT::is16) {   // fp32: xcol32f (axis 0 needs 16-byte aligned row pieces: N % 4 == 0)
-        enough = use_xcol() && (long)((a->N + XF_R - 1) / XF_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
-        if (variant == 3 && use_xcol()) enough = true;
-        if (AXIS == 0 && (a->N % 4 != 0)) enough = false;
+    if constexpr (BS == 32 && !DT::is16) {
+        const bool split = a->plan_magic == XCPLAN_MAGIC;               // 'BSXC' (G = 16): exact bf16 split; 'BSXF': fp32 MFMA
+        if (AXIS == 0 && (a->N % (split ? 8 : 4) != 0)) return XP_SEGMENT;
+        if (split && a->C % 32 != 0) return XP_SEGMENT;
+        const bool enough = (long)((a->N + XF_R - 1) / XF_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
+        if (!(enough || force)) return XP_SEGMENT;
+        return split ? XP_F32SPLIT : XP_F32MFMA;
     }
-    if (BS == 32 && a->plan != nullptr && DT::is16) {
+    if constexpr (BS == 32 && DT::is16) {
+        if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // axis-0 xcol needs 16-byte aligned row pieces
+        if (force) return XP_XCOL32;
         // Cost model fitted to the measurements in profiles/r01_sweeps.md (4096^2 / 20 % and 8192^2 / 5 %, N = 512 .. 8192):
         // the grouped kernel pays ~0.48 us per pair step of a group plus ~0.045 us per block, once per round of 256
         // workgroups, whatever the density; the per-segment kernel pays ~1.04e-5 us per (block, minibatch row).
-        const int G = xc_group(AXIS);
+        const int G = a->plan_width > 0 ? a->plan_width : 16;
         const double CB = a->C / 32.0, KB = a->K / 32.0;
         const double ngroups = (double)((a->K / 32 + G - 1) / G), ntiles = (double)((a->N + XC_R - 1) / XC_R);
         const double rounds = std::max(1.0, std::ceil(ntiles * ngroups / 256.0));
@@ -293,66 +334,85 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         const double steps = std::ceil(CB / 2.0) * (1.0 - std::pow(1.0 - dens, 2.0 * G));
         const double t_group = rounds * (0.48 * steps + 0.045 * a->blocks / ngroups) + 8.0;
         const double t_segment = 17.0 + 1.04e-5 * (double)a->blocks * a->N;
-        enough = t_group < t_segment;
-        if (AXIS == 0 && use_xcol() && (a->N % 8 != 0)) enough = false;   // axis-0 xcol needs 16-byte aligned row pieces
+        return t_group < t_segment ? XP_XCOL32 : XP_SEGMENT;
     }
-    if (variant == 3 && a->plan != nullptr && !(AXIS == 0 && use_xcol() && (a->N % 8 != 0))) enough = true;   // test hook
-    const bool use_group = !use_valu && (BS == 32 || (BS == 16 && DT::is16)) && a->plan != nullptr && (variant == 0 || variant == 3) && enough &&
-                           a->gate == nullptr;   // gated calls take the per-segment kernels
-    if constexpr (BS == 8 && DT::is16) {
-        // bsize 8 on the matrix cores: expand W into the 32x32 super-blocks of the 'BSS8' plan and run the bsize-32 kernel
-        const bool shape_ok = a->C % 32 == 0 && a->K % 32 == 0 && !(AXIS == 0 && (a->N % 8 != 0));
-        if (a->plan != nullptr && a->plan_aux > 0 && a->gate == nullptr && vec_ok && shape_ok && (variant == 0 || variant == 3)) {
-            const bool fill = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
-            if (fill || variant == 3) {
-                const int ns = a->plan_aux;
-                const size_t need = (size_t)ns * 1024 * elem_size(a->dtype);
-                if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
-                typedef typename DT::T T;
-                if (fprop) expand8_kernel<DT, true><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
-                else       expand8_kernel<DT, false><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
-                bsmm_args b = *a;
-                b.bsize = 32; b.blocks = ns; b.plan = a->plan + s8_off_nested(ns); b.plan_aux = 0;
-                return launch_xgroup32<DT, AXIS>(X, a->workspace, Y, &b, st, false);
-            }
+    return XP_SEGMENT;
+}
+
+template <class DT, int BS, int AXIS>
+int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
+    typedef typename DT::T T;
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const XPath path = xprop_path<DT, BS, AXIS>(X, W, Y, a);
+    if (path == XP_SUPER8) {
+        if constexpr (BS == 8 && DT::is16) {
+            const int ns = a->plan_width;
+            const size_t need = (size_t)ns * 1024 * elem_size(a->dtype);
+            if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+            if (fprop) expand8_kernel<DT, true><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
+            else       expand8_kernel<DT, false><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
+            bsmm_args b = *a;
+            b.bsize = 32; b.blocks = ns; b.plan = a->plan + s8_off_nested(ns);
+            b.plan_magic = XCPLAN_MAGIC; b.plan_width = a->plan_inner; b.plan_inner = 0;
+            const int rc = launch_xgroup32<DT, AXIS>(X, a->workspace, Y, &b, st, false);
+            trace(a, BSMM_K_XPROP_SUPER8);
+            return rc;
         }
     }
-    if (a->locks > 0 && !use_group) {   // several segments accumulate into the same output block: start from zero
-        hipError_t e = hipMemsetAsync(Y, 0, (size_t)a->N * a->K * elem_size(a->dtype), st);
-        if (e != hipSuccess) return (int)e;
+    if (path == XP_F32SPLIT) {
+        if constexpr (BS == 32 && !DT::is16) return launch_xcol32s<AXIS>(fprop, X, W, Y, a, st);
     }
-    if (use_valu) {
-        return fprop ? launch_xprop_valu<DT, BS, AXIS, true>(X, W, Y, a, st)
-                     : launch_xprop_valu<DT, BS, AXIS, false>(X, W, Y, a, st);
-    }
-    // (xcol can gather the fprop operand transposed itself -- launch_xgroup32(..., transw = true), no workspace and no
-    //  pre-pass -- but that measured SLOWER than the 6 us transpose kernel + contiguous fragment loads: 140 vs 127 us, also with
-    //  the kernel held at 128 VGPRs.)
-    if constexpr (BS == 32 && !DT::is16) {
-        // (axis 0 needs 16-byte aligned bf16 row pieces: N % 8 == 0; otherwise the per-segment kernel below)
-        if (use_group && f32_split(AXIS) && a->C % 32 == 0 && !(AXIS == 0 && a->N % 8 != 0)) return launch_xcol32s<AXIS>(fprop, X, W, Y, a, st);
-    }
-    if constexpr (BS != 8) {
-        const void* Wsel = W;
-        if (fprop) {
-            const size_t need = (size_t)a->blocks * BS * BS * elem_size(a->dtype);
-            if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
-            int rc = launch_transpose<DT, BS>(W, a->workspace, a->blocks, st);
+    // the remaining kernels read the weights with the contraction index contiguous: fprop needs the transposed copy
+    const bool generic = path == XP_VALU || path == XP_SEGMENT;
+    float* yacc = nullptr;
+    size_t off = 0;
+    const void* Wsel = W;
+    if (fprop && path != XP_VALU) {
+        if constexpr (BS != 8) {
+            if (!a->workspace || a->workspace_bytes < wt_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+            const int rc = launch_transpose<DT, BS>(W, a->workspace, a->blocks, st);
             if (rc) return rc;
             Wsel = a->workspace;
+            off = wt_bytes(a);
         }
-        if constexpr (BS == 32 && DT::is16) {
-            if (use_group) return launch_xgroup32<DT, AXIS>(X, Wsel, Y, a, st, false);
-        }
-        if constexpr (BS == 16 && DT::is16) {
-            if (use_group) return launch_xcol16<DT, AXIS>(X, Wsel, Y, a, st);
-        }
-        if constexpr (BS == 32 && !DT::is16) {
-            if (use_group && !f32_split(AXIS)) return launch_xcol32f<AXIS>(X, Wsel, Y, a, st);     // plan is 'BSXF' only then
-        }
-        return launch_xprop_mfma<DT, BS, AXIS>(X, Wsel, Y, a, st);
     }
-    return BSMM_ERR_UNSUPPORTED;
+    if (generic && a->locks > 0) {   // several segments accumulate into the same output block: start from zero
+        if (DT::is16) {
+            const size_t need = off + lock_acc_bytes(a);
+            if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+            yacc = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + off);
+            hipError_t e = hipMemsetAsync(yacc, 0, lock_acc_bytes(a), st);
+            if (e != hipSuccess) return (int)e;
+        } else {
+            hipError_t e = hipMemsetAsync(Y, 0, (size_t)a->N * a->K * elem_size(a->dtype), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    int rc = BSMM_ERR_UNSUPPORTED;
+    switch (path) {
+        case XP_VALU:
+            rc = fprop ? launch_xprop_valu<DT, BS, AXIS, true>(X, W, Y, a, st, yacc) : launch_xprop_valu<DT, BS, AXIS, false>(X, W, Y, a, st, yacc);
+            break;
+        case XP_SEGMENT:
+            if constexpr (BS != 8) rc = launch_xprop_mfma<DT, BS, AXIS>(X, Wsel, Y, a, st, yacc);
+            break;
+        case XP_XCOL32:
+            if constexpr (BS == 32 && DT::is16) rc = launch_xgroup32<DT, AXIS>(X, Wsel, Y, a, st, false);
+            break;
+        case XP_XCOL16:
+            if constexpr (BS == 16 && DT::is16) rc = launch_xcol16<DT, AXIS>(X, Wsel, Y, a, st);
+            break;
+        case XP_F32MFMA:
+            if constexpr (BS == 32 && !DT::is16) rc = launch_xcol32f<AXIS>(X, Wsel, Y, a, st);
+            break;
+        default: break;
+    }
+    if (rc == 0 && yacc) {
+        dim3 grid(a->segments, (a->N + 255) / 256);
+        lock_finalize_kernel<DT, BS, AXIS><<<grid, 256, 0, st>>>(yacc, static_cast<T*>(Y), a->lut, a->N, a->K);
+        rc = (int)hipGetLastError();
+    }
+    return rc;
 }
 
 template <class DT>
@@ -368,6 +428,7 @@ int xprop(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a)
     int rc = check_common(a);
     if (rc) return rc;
     if (!X || !W || !Y || a->segments <= 0) return BSMM_ERR_ARG;
+    if ((rc = check_plan(false, a))) return rc;
     switch (a->dtype) {
         case BSMM_F32:  return xprop_dt<DTf32>(fprop, X, W, Y, a);
         case BSMM_F16:  return xprop_dt<DTf16>(fprop, X, W, Y, a);
@@ -379,6 +440,15 @@ int xprop(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a)
 // ---------------------------------------------------------------------------------------------
 // updat
 // ---------------------------------------------------------------------------------------------
+// workgroups per work item of the windowed kernels (each takes a slice of the minibatch): the caller's choice
+// (bsmm_args.split), else enough to give every CU a workgroup while each keeps >= 8 chunks
+inline int updat_split(const bsmm_args* a, int nitems, int nchunks) {
+    if (a->split > 0) return std::min(a->split, std::max(1, nchunks));
+    int split = 1;
+    while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;
+    return split;
+}
+
 // Windowed bsize-32 kernels (bsmm_updat_win.h).  raw_sums: leave the fp32 sums of every block in a->workspace (zeroed
 // here) and apply no alpha / beta -- the bsize-8 super-block path finishes them itself; DW is not touched then.
 template <class DT, int AXIS>
@@ -386,25 +456,19 @@ int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const b
     typedef typename DT::T T;
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     const int N = a->N, nitems = a->plan_items;
-    if (nitems <= 0) return BSMM_ERR_ARG;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        if constexpr (AXIS == 0)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a0_win_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UW0_LDS);
-        else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_win_kernel<DT, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, UWN_LDS);
-        }
-        attr_set = true;
-    }
-    // plan_aux = window side of the plan (+ 256 when it was built for 16 waves per workgroup): 16x16 windows use 32-row chunks
-    const bool wide_win = AXIS == 1 && (a->plan_aux & 255) == 16, waves16 = wide_win && (a->plan_aux & 256);
+    if (nitems <= 0 || a->plan_magic != UPLAN_MAGIC) return BSMM_ERR_ARG;
+    // the descriptor names the window side and the waves per workgroup the plan was dealt for: 16x16 windows use 32-row chunks
+    const bool wide_win = a->plan_width == 16, waves16 = a->plan_waves == 16;
+    if (!((a->plan_width == 8 && a->plan_waves == 8) || (AXIS == 1 && wide_win && (a->plan_waves == 8 || waves16)))) return BSMM_ERR_ARG;
+    int rc_attr = 0;
+    if constexpr (AXIS == 0) rc_attr = ensure_lds(&updat32_a0_win_kernel<DT>, UW0_LDS);
+    else if (waves16)        rc_attr = ensure_lds(&updat32_a1_win_kernel<DT, 16, 16>, UWN_LDS);
+    else if (wide_win)       rc_attr = ensure_lds(&updat32_a1_win_kernel<DT, 16>, UWN_LDS);
+    else                     rc_attr = ensure_lds(&updat32_a1_win_kernel<DT, 8>, UWN_LDS);
+    if (rc_attr) return rc_attr;
     const int nchunks = wide_win ? (N + 31) / 32 : (N + 63) / 64;
-    int split = 1;
-    while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;   // one workgroup per CU, >= 8 chunks each
-    const char* senv = getenv("BSMM_UPDAT_SPLIT");
-    if (senv) split = atoi(senv) > 0 ? atoi(senv) : split;
+    const int split = updat_split(a, nitems, nchunks);
+    trace(a, BSMM_K_UPDAT_WIN);
     float* scratch = nullptr;
     if (split > 1 || raw_sums) {
         const size_t need = (size_t)a->blocks * 1024 * sizeof(float);
@@ -443,7 +507,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         vec_ok = vec_ok && (N % (DT::is16 ? 8 : 4) == 0);
         for (int p = 0; p < a->pcount; ++p) vec_ok = vec_ok && aligned16(xs.p[p]) && aligned16(es.p[p]);
     }
-    const int variant = g_variant.load(std::memory_order_relaxed);
+    const int variant = call_variant(a);
     const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
     const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;   // gated dw: per-block kernels only
     const bool gated = ug != nullptr;
@@ -452,14 +516,16 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         // present 8x8 parts get alpha / beta and are rounded once
         bool al = aligned16(DW) && a->C % 32 == 0 && a->K % 32 == 0 && !(AXIS == 0 && (N % 8 != 0));
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
-        if (a->plan != nullptr && a->plan_aux > 0 && a->plan_items > 0 && !gated && al && (variant == 0 || variant == 3)) {
-            const int ns = a->plan_aux;
+        if (a->plan != nullptr && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && a->plan_items > 0 && !gated && al && (variant == 0 || variant == 3)) {
+            const int ns = a->plan_width;
             bsmm_args b = *a;
-            b.bsize = 32; b.blocks = ns; b.plan_aux = 0; b.flags = 0; b.gate = nullptr;
+            b.bsize = 32; b.blocks = ns; b.flags = 0; b.gate = nullptr; b.trace = nullptr;
             b.lut = a->plan + s8_off_lut32(ns);
             b.plan = a->plan + s8_off_nested(ns);
+            b.plan_magic = UPLAN_MAGIC; b.plan_width = a->plan_inner; b.plan_inner = 0;
             const int rc = launch_updat32_win<DT, AXIS>(xs, es, nullptr, &b, true);
             if (rc) return rc;
+            trace(a, BSMM_K_UPDAT_SUPER8);
             gather8_kernel<DT><<<ns, 256, 0, st>>>(static_cast<const float*>(a->workspace), a->plan, static_cast<T*>(DW), a->alpha, a->beta);
             return (int)hipGetLastError();
         }
@@ -477,10 +543,9 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             // per chunk with 16x16 windows); per block 8 + rounds of 512 blocks * N * 0.0065 .. 0.0105.
             bool windowed = true;
             if (AXIS == 1 && variant == 0) {
-                const bool w16 = (a->plan_aux & 255) == 16;
+                const bool w16 = a->plan_width == 16;
                 const double chunks = std::ceil(N / 64.0) * a->pcount;                 // 64-row units per window
-                int split = 1;                                                          // as launch_updat32_win chooses it
-                while (a->plan_items * split < 256 && split * 2 <= (w16 ? (N + 31) / 32 : (N + 63) / 64) / 8 && split < 8) split *= 2;
+                const int split = updat_split(a, a->plan_items, w16 ? (N + 31) / 32 : (N + 63) / 64);   // as launch_updat32_win chooses it
                 const double rounds = std::max(1.0, std::ceil(a->plan_items * (double)split / 256.0));
                 const double t_win = 8.0 + rounds * (chunks / split) * 0.9 * (w16 ? 1.8 : 1.0) + (split > 1 ? 6.0 : 0.0);
                 // per-block kernel: two workgroups per CU, each walks the whole minibatch for ONE block
@@ -495,11 +560,8 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         bool al = aligned16(DW);
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
         if (!use_valu && !gated && al && variant != 1) {   // LDS-DMA + transposing-read kernel
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat32_a1_tr_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UT_LDS);
-                attr_set = true;
-            }
+            if (int rc = ensure_lds(&updat32_a1_tr_kernel<DT>, UT_LDS)) return rc;
+            trace(a, BSMM_K_UPDAT_BLOCK_TR);
             const int grid = 8 * ((a->blocks + 7) / 8);
             updat32_a1_tr_kernel<DT><<<grid, 256, UT_LDS, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K, a->pcount,
                                                               a->alpha, a->beta);
@@ -510,17 +572,12 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         bool al16 = aligned16(DW) && (AXIS == 1 || N % 8 == 0);
         for (int p = 0; p < a->pcount; ++p) al16 = al16 && aligned16(xs.p[p]) && aligned16(es.p[p]);
         if (!use_valu && !gated && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed, 16x16 blocks
-            static bool attr_set_w16 = false;
-            if (!attr_set_w16) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat16_win_kernel<DT, AXIS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * UWN_SLOT);
-                attr_set_w16 = true;
-            }
+            if (a->plan_magic != UPLAN_MAGIC || a->plan_width != UW16 || a->plan_waves != UP_WAVES) return BSMM_ERR_ARG;
+            if (int rc = ensure_lds(&updat16_win_kernel<DT, AXIS>, 2 * UWN_SLOT)) return rc;
+            trace(a, BSMM_K_UPDAT16_WIN);
             const int nitems = a->plan_items;
             const int nchunks = (N + 63) / 64;
-            int split = 1;
-            while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;
-            const char* senv = getenv("BSMM_UPDAT_SPLIT");
-            if (senv) split = atoi(senv) > 0 ? atoi(senv) : split;
+            const int split = updat_split(a, nitems, nchunks);
             float* scratch = nullptr;
             const size_t nel = (size_t)a->blocks * 256;
             if (split > 1) {
@@ -540,17 +597,15 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         bool al = aligned16(DW);
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
         if (!use_valu && !gated && al && variant != 1) {   // LDS-DMA + transposing-read kernel, 16x16 blocks
-            static bool attr_set16 = false;
-            if (!attr_set16) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&updat16_a1_tr_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, UT16_LDS);
-                attr_set16 = true;
-            }
+            if (int rc = ensure_lds(&updat16_a1_tr_kernel<DT>, UT16_LDS)) return rc;
+            trace(a, BSMM_K_UPDAT_BLOCK_TR);
             const int grid = 8 * ((a->blocks + 7) / 8);
             updat16_a1_tr_kernel<DT><<<grid, 256, UT16_LDS, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K, a->pcount,
                                                                 a->alpha, a->beta);
             return (int)hipGetLastError();
         }
     }
+    trace(a, use_valu ? BSMM_K_UPDAT_VALU : BSMM_K_UPDAT_BLOCK);
     if (use_valu) {
         updat_valu_kernel<DT, BS, AXIS><<<a->blocks, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C,
                                                                    a->K, a->pcount, a->alpha, a->beta, ug);
@@ -612,6 +667,7 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
     if (rc) return rc;
     if (!X || !DY || !DW) return BSMM_ERR_ARG;
     if (a->pcount < 1 || a->pcount > 8) return BSMM_ERR_ARG;
+    if ((rc = check_plan(true, a))) return rc;
     PtrList8 xs, es;
     for (int p = 0; p < 8; ++p) {
         xs.p[p] = p < a->pcount ? X[p] : nullptr;
@@ -667,7 +723,7 @@ int bsmm_sparse_op(void* z, const void* x, const void* y, const int32_t* lut, in
         hipError_t e = hipMemcpyAsync(z, x, (size_t)rows_z * N * esz, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid(std::min((N + 255) / 256, 64), K);
+    dim3 grid(K, std::min((N + 255) / 256, 64));
     auto go = [&](auto t) {
         typedef decltype(t) DT;
         typedef typename DT::T T;
@@ -694,7 +750,7 @@ int bsmm_sparse_mul_grad(void* dx, void* dy, const void* dz, const void* x, cons
         hipError_t e = hipMemcpyAsync(dx, dz, (size_t)rows_x * N * esz, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid(std::min((N + 255) / 256, 64), K);
+    dim3 grid(K, std::min((N + 255) / 256, 64));
     auto go = [&](auto t) {
         typedef decltype(t) DT;
         typedef typename DT::T T;
@@ -746,86 +802,124 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
     return (int)hipGetLastError();
 }
 
-long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
-                           int32_t dtype, int32_t axis) {
+// widths the plan options select (defaults: the wide shapes)
+static inline int opt_xc_group(int32_t options) { return (options & BSMM_PLAN_XCOL_NARROW) ? XC_G : 16; }
+static inline int opt_xc16_group(int32_t options) { return (options & BSMM_PLAN_XCOL_NARROW) ? XC16_G : 32; }
+
+static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int32_t n_out, int32_t bsize, int32_t dtype, int32_t axis,
+                       int32_t options, int32_t* out) {
     if (axis != 0 && axis != 1) return 0;
-    if (bsize == 8) return dtype == BSMM_F32 ? 0 : build_super8_xprop_plan(host_lut, segments, blocks, n_out_blocks, nullptr, xc_group(axis));   // 'BSS8'
+    if (bsize == 8) return dtype == BSMM_F32 ? 0 : build_super8_xprop_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));   // 'BSS8'
     if (bsize != 32 && bsize != 16) return 0;   // plan kernels: bsize 32 (any dtype) / 16 and 8 (16-bit)
     if (dtype == BSMM_F32) {
-        if (bsize != 32 || !use_xcol()) return 0;
-        return f32_split(axis) ? build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr, XS_G)
-                               : build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, nullptr);
+        if (bsize != 32) return 0;
+        return (options & BSMM_PLAN_F32_MFMA) ? build_xcolf_plan(lut, segments, blocks, n_out, out)
+                                              : build_xcol_plan(lut, segments, blocks, n_out, out, XS_G);
     }
-    if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, nullptr, xc16_group());
-    return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, nullptr, xc_group(axis));
+    if (bsize == 16) return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
+    return build_xcol_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));
+}
+
+long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
+                           int32_t dtype, int32_t axis, int32_t options) {
+    return xprop_plan(host_lut, segments, blocks, n_out_blocks, bsize, dtype, axis, options, nullptr);
 }
 
 int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks, int32_t bsize,
-                          int32_t dtype, int32_t axis, int32_t* host_plan_out) {
+                          int32_t dtype, int32_t axis, int32_t options, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
-    if (bsize == 8 && dtype != BSMM_F32 && (axis == 0 || axis == 1))
-        return build_super8_xprop_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, xc_group(axis)) > 0 ? BSMM_OK : BSMM_ERR_ARG;
-    if ((bsize != 32 && bsize != 16) || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
-    if (dtype == BSMM_F32) {
-        if (bsize != 32 || !use_xcol()) return BSMM_ERR_UNSUPPORTED;
-        if (f32_split(axis)) return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, XS_G) > 0 ? BSMM_OK : BSMM_ERR_ARG;
-        return build_xcolf_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
-    }
-    if (bsize == 16) return build_xcol16_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, xc16_group()) > 0 ? BSMM_OK : BSMM_ERR_ARG;
-    return build_xcol_plan(host_lut, segments, blocks, n_out_blocks, host_plan_out, xc_group(axis)) > 0 ? BSMM_OK : BSMM_ERR_ARG;
+    const long n = xprop_plan(host_lut, segments, blocks, n_out_blocks, bsize, dtype, axis, options, host_plan_out);
+    return n > 0 ? BSMM_OK : (n == 0 ? BSMM_ERR_UNSUPPORTED : BSMM_ERR_ARG);
 }
 
-// bsize 32, axis 1: 16x16-block windows when they hold <= 16 blocks on average (sparse layouts), else 8x8 (bsmm_updat_win.h)
-static int updat_window(int32_t blocks, int32_t CB, int32_t KB, int32_t axis) {   // 8, 16, or 1616 (16x16 windows, 16 waves)
-    static const int force = [] { const char* e = getenv("BSMM_UPDAT_WINDOW"); return e ? atoi(e) : 0; }();   // A/B runs
+// bsize 32, axis 1: 16x16-block windows when they hold <= 16 blocks on average (sparse layouts), else 8x8 (bsmm_updat_win.h);
+// the caller can name the shape (BSMM_PLAN_WINDOW_*)
+static int updat_window(int32_t blocks, int32_t CB, int32_t KB, int32_t axis, int32_t options) {   // 8, 16, or 1616 (16x16 windows, 16 waves)
+    const int force = options & BSMM_PLAN_WINDOW_MASK;
     if (axis != 1) return UW;
-    if (force == 8 || force == 16 || force == 1616) return force;
+    if (force == BSMM_PLAN_WINDOW_8) return 8;
+    if (force == BSMM_PLAN_WINDOW_16) return 16;
+    if (force == BSMM_PLAN_WINDOW_16W) return 1616;
     const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);
     return blocks <= 16.0 * windows ? 16 : UW;     // <= 2 block slots per wave on average (measured: 13 per window 2.1x faster, 26 per window 20 % slower)
 }
-static long updat32_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t KB, int32_t axis, int32_t* out) {
-    const int w = updat_window(blocks, CB, KB, axis);
+static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype, int32_t axis, int32_t options,
+                       int32_t* out) {
+    if (dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: 16-bit types
+    if (bsize == 8) return build_super8_updat_plan(lut, blocks, CB, KB, out);   // 'BSS8'
+    if (bsize == 16) return build_updat_plan(lut, blocks, CB, KB, UW16, UP16_MAXB, out);
+    if (bsize != 32) return 0;
+    const int w = updat_window(blocks, CB, KB, axis, options);
     return build_updat_plan(lut, blocks, CB, KB, w == 8 ? 8 : 16, UP_MAXB, out, w == 1616 ? 16 : 8);
 }
 
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
-                           int32_t axis) {
-    if (dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: 16-bit types
-    if (bsize == 8) return build_super8_updat_plan(host_updat_lut, blocks, CB, KB, nullptr);   // 'BSS8'
-    if (bsize != 32 && bsize != 16) return 0;
-    return bsize == 32 ? updat32_plan(host_updat_lut, blocks, CB, KB, axis, nullptr)
-                       : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, nullptr);
+                           int32_t axis, int32_t options) {
+    return updat_plan(host_updat_lut, blocks, CB, KB, bsize, dtype, axis, options, nullptr);
 }
 
 int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
-                          int32_t axis, int32_t* host_plan_out) {
+                          int32_t axis, int32_t options, int32_t* host_plan_out) {
     if (!host_plan_out) return BSMM_ERR_ARG;
-    if (bsize == 8 && dtype != BSMM_F32 && (axis == 0 || axis == 1))
-        return build_super8_updat_plan(host_updat_lut, blocks, CB, KB, host_plan_out) > 0 ? BSMM_OK : BSMM_ERR_ARG;
-    if ((bsize != 32 && bsize != 16) || dtype == BSMM_F32 || (axis != 0 && axis != 1)) return BSMM_ERR_UNSUPPORTED;
-    const long n = bsize == 32 ? updat32_plan(host_updat_lut, blocks, CB, KB, axis, host_plan_out)
-                               : build_updat_plan(host_updat_lut, blocks, CB, KB, UW16, UP16_MAXB, host_plan_out);
-    return n > 0 ? BSMM_OK : BSMM_ERR_ARG;
+    const long n = updat_plan(host_updat_lut, blocks, CB, KB, bsize, dtype, axis, options, host_plan_out);
+    return n > 0 ? BSMM_OK : (n == 0 ? BSMM_ERR_UNSUPPORTED : BSMM_ERR_ARG);
+}
+
+// descriptor of a flat (non-composite) plan: (magic, width, waves, items)
+static bool describe_flat(const int32_t* p, long words, int32_t d[4]) {
+    if (words < 8) return false;
+    switch (p[0]) {
+        case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
+        case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
+        case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;
+        case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;
+        default: return false;
+    }
+    d[0] = p[0];
+    return true;
+}
+
+int bsmm_plan_attach(bsmm_args* a, const int32_t* host_plan, long words, const int32_t* device_plan) {
+    if (!a) return BSMM_ERR_ARG;
+    a->plan = nullptr;
+    a->plan_magic = a->plan_width = a->plan_waves = a->plan_items = a->plan_inner = 0;
+    if (!device_plan) return BSMM_OK;
+    if (!host_plan || words < 8 || (reinterpret_cast<uintptr_t>(device_plan) & 15)) return BSMM_ERR_ARG;
+    int32_t d[4];
+    if (host_plan[0] == S8PLAN_MAGIC) {
+        if (host_plan[1] != S8PLAN_VERSION || host_plan[2] <= 0 || host_plan[6] != words) return BSMM_ERR_ARG;
+        const int32_t off = host_plan[5];
+        if (off < S8_HDR || off >= words || !describe_flat(host_plan + off, words - off, d)) return BSMM_ERR_ARG;
+        if (d[0] != (host_plan[7] ? UPLAN_MAGIC : XCPLAN_MAGIC)) return BSMM_ERR_ARG;     // word [7]: 0 = xprop, 1 = updat
+        a->plan_magic = S8PLAN_MAGIC; a->plan_width = host_plan[2]; a->plan_waves = d[2]; a->plan_items = d[3]; a->plan_inner = d[1];
+    } else {
+        if (!describe_flat(host_plan, words, d)) return BSMM_ERR_ARG;
+        a->plan_magic = d[0]; a->plan_width = d[1]; a->plan_waves = d[2]; a->plan_items = d[3];
+    }
+    a->plan = device_plan;
+    return BSMM_OK;
 }
 
 size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     if (!a) return 0;
+    const bool xprop_op = op == BSMM_OP_FPROP || op == BSMM_OP_BPROP;
+    // locked reference-policy tables on the per-segment kernels with a 16-bit type: fp32 image of the output (see xprop_typed);
+    // asked for whenever the call COULD take that path (no plan, a gate, or the size heuristic)
+    const size_t lock = xprop_op ? lock_acc_bytes(a) : 0;
     if (a->bsize == 8) {   // 'BSS8' plans: the expanded W (xprop) / the fp32 sums of the super-blocks (updat)
-        if (!a->plan || a->plan_aux <= 0 || a->dtype == BSMM_F32) return 0;
-        const size_t blk = (size_t)a->plan_aux * 1024;
-        return op == BSMM_OP_UPDAT ? blk * sizeof(float) : blk * elem_size(a->dtype);
+        if (!a->plan || a->plan_magic != S8PLAN_MAGIC || a->plan_width <= 0 || a->dtype == BSMM_F32) return lock;
+        const size_t blk = (size_t)a->plan_width * 1024;
+        return op == BSMM_OP_UPDAT ? blk * sizeof(float) : std::max(blk * elem_size(a->dtype), lock);
     }
     if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32)
         return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float);   // fp32 partial sums of the split-minibatch path
-    if ((op == BSMM_OP_FPROP || op == BSMM_OP_BPROP) && a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && f32_split(a->axis))
+    if (xprop_op && a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && a->plan_magic == XCPLAN_MAGIC)
         return xcols_workspace_bytes(a);   // bf16 pieces of the activations and the weights (bsmm_xcols.h)
     // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)
-    if (op == BSMM_OP_FPROP && a->bsize != 8) return (size_t)a->blocks * a->bsize * a->bsize * elem_size(a->dtype);
+    if (op == BSMM_OP_FPROP) return wt_bytes(a) + lock;
+    if (op == BSMM_OP_BPROP) return lock;
     return 0;
 }
-
-void bsmm_set_kernel_variant(int variant) { g_variant.store((variant >= 1 && variant <= 3) ? variant : 0); }
-int bsmm_get_kernel_variant(void) { return g_variant.load(); }
 
 const char* bsmm_error_string(int code) {
     switch (code) {

@@ -17,9 +17,9 @@ template <class DT, int OP>
 __global__ void __launch_bounds__(256)
 sparse_proj_kernel(typename DT::T* __restrict__ Z, const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Y,
                    const int32_t* __restrict__ lut, int K, int N) {
-    const int k = blockIdx.y;
+    const int k = blockIdx.x;            // rows on grid.x (no 65535 limit), minibatch strips on grid.y
     const int src = lut[k];
-    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+    for (int n = blockIdx.y * 256 + threadIdx.x; n < N; n += gridDim.y * 256) {
         if constexpr (OP == SP_GAT) {
             Z[(size_t)k * N + n] = X[(size_t)src * N + n];
         } else if constexpr (OP == SP_SCT) {
@@ -38,9 +38,9 @@ __global__ void __launch_bounds__(256)
 sparse_mul_grad_kernel(typename DT::T* __restrict__ DX, typename DT::T* __restrict__ DY, const typename DT::T* __restrict__ DZ,
                        const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut,
                        int K, int N) {
-    const int k = blockIdx.y;
+    const int k = blockIdx.x;            // rows on grid.x (no 65535 limit), minibatch strips on grid.y
     const int xk = lut[k];
-    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+    for (int n = blockIdx.y * 256 + threadIdx.x; n < N; n += gridDim.y * 256) {
         const float dz = DT::to_f32(DZ[(size_t)xk * N + n]);
         const float x = DT::to_f32(X[(size_t)xk * N + n]), y = DT::to_f32(Y[(size_t)k * N + n]);
         DX[(size_t)xk * N + n] = DT::from_f32(dz * y);

@@ -31,6 +31,34 @@ __device__ __forceinline__ bool xmap_decode(const XMap& m, int b, int& tile, int
     return tile < m.ntiles && seg < m.segments;
 }
 
+// Locked segments (several lut segments write one output block): 16-bit storage types sum into the fp32 accumulator image
+// Yacc (same indexing as Y, zeroed by the launcher) and lock_finalize_kernel rounds every locked block ONCE; fp32 adds
+// straight into the zeroed Y.  (Yacc == nullptr with a 16-bit type keeps the storage-type CAS accumulation.)
+template <class DT>
+__device__ __forceinline__ void lock_accumulate(typename DT::T* Y, float* Yacc, size_t idx, float v) {
+    if constexpr (DT::is16) {
+        if (Yacc) { __hip_atomic_fetch_add(Yacc + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    }
+    atomic_accumulate<DT>(Y + idx, v);
+}
+
+// grid (segments, ceil(N / 256)): every segment with a lock id converts its output block (segments that share a block write
+// identical values).
+template <class DT, int BS, int AXIS>
+__global__ void __launch_bounds__(256)
+lock_finalize_kernel(const float* __restrict__ Yacc, typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, int N, int Kout) {
+    const int4 hdr = *reinterpret_cast<const int4*>(lut + 4 * blockIdx.x);
+    if (hdr.w == 0) return;
+    const int ob = hdr.z;
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= N) return;
+#pragma unroll
+    for (int o = 0; o < BS; ++o) {
+        const size_t idx = (AXIS == 1) ? ((size_t)n * Kout + ob * BS + o) : ((size_t)(ob * BS + o) * N + n);
+        Y[idx] = DT::from_f32(Yacc[idx]);
+    }
+}
+
 // =================================================================================================
 // bsize 32, MFMA 32x32.  256 threads = 4 waves; wave w owns minibatch columns [tile*NT + w*32*NSUB, +32*NSUB).
 // MFMA roles: A = Wop (M = o), B = XT (N = n)  ->  D[o][n]; every lane ends up with 4 consecutive o per
@@ -43,7 +71,7 @@ template <class DT, int AXIS, int NSUB, bool GATED = false>
 __global__ void __launch_bounds__(256)
 xprop32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
                typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, XMap map, int N, int Cin, int Kout,
-               const float* __restrict__ gate = nullptr) {
+               const float* __restrict__ gate = nullptr, float* __restrict__ Yacc = nullptr) {
     typedef typename DT::T T;
     constexpr int NT = 4 * 32 * NSUB;
     int tile, seg;
@@ -124,8 +152,8 @@ xprop32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int o = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                T* p = (AXIS == 1) ? (Y + (size_t)n * Kout + ob * 32 + o) : (Y + (size_t)(ob * 32 + o) * N + n);
-                atomic_accumulate<DT>(p, acc[s][reg]);
+                const size_t idx = (AXIS == 1) ? ((size_t)n * Kout + ob * 32 + o) : ((size_t)(ob * 32 + o) * N + n);
+                lock_accumulate<DT>(Y, Yacc, idx, acc[s][reg]);
             }
         }
     }
@@ -144,7 +172,7 @@ template <class DT, int AXIS, int NSUB, bool GATED = false>
 __global__ void __launch_bounds__(256)
 xprop16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
                typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, XMap map, int N, int Cin, int Kout,
-               const float* __restrict__ gate = nullptr) {
+               const float* __restrict__ gate = nullptr, float* __restrict__ Yacc = nullptr) {
     typedef typename DT::T T;
     constexpr int NT = 4 * 16 * NSUB;
     int tile, seg;
@@ -255,8 +283,8 @@ xprop16_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int o = 4 * q + reg;
-                T* p = (AXIS == 1) ? (Y + (size_t)n * Kout + ob * 16 + o) : (Y + (size_t)(ob * 16 + o) * N + n);
-                atomic_accumulate<DT>(p, acc[s][reg]);
+                const size_t idx = (AXIS == 1) ? ((size_t)n * Kout + ob * 16 + o) : ((size_t)(ob * 16 + o) * N + n);
+                lock_accumulate<DT>(Y, Yacc, idx, acc[s][reg]);
             }
         }
     }
@@ -272,11 +300,11 @@ template <class DT, int BS, int AXIS, bool FPROP>
 __global__ void __launch_bounds__(256)
 xprop_valu_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ W,
                   typename DT::T* __restrict__ Y, const int32_t* __restrict__ lut, int N, int Cin, int Kout,
-                  const float* __restrict__ gate = nullptr) {
+                  const float* __restrict__ gate = nullptr, float* __restrict__ Yacc = nullptr) {
     typedef typename DT::T T;
     __shared__ float Wl[BS * BS];
-    const int seg = blockIdx.y;
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int seg = blockIdx.x;
+    const int n = blockIdx.y * 256 + threadIdx.x;
     const int4 hdr = *reinterpret_cast<const int4*>(lut + 4 * seg);
     const int2* ent = reinterpret_cast<const int2*>(lut) + hdr.x;
     const int cnt = hdr.y, ob = hdr.z, lock = hdr.w;
@@ -315,9 +343,9 @@ xprop_valu_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __
     if (n >= N) return;
 #pragma unroll
     for (int o = 0; o < BS; ++o) {
-        T* p = (AXIS == 1) ? (Y + (size_t)n * Kout + ob * BS + o) : (Y + (size_t)(ob * BS + o) * N + n);
-        if (lock == 0) *p = DT::from_f32(acc[o]);
-        else atomic_accumulate<DT>(p, acc[o]);
+        const size_t idx = (AXIS == 1) ? ((size_t)n * Kout + ob * BS + o) : ((size_t)(ob * BS + o) * N + n);
+        if (lock == 0) Y[idx] = DT::from_f32(acc[o]);
+        else lock_accumulate<DT>(Y, Yacc, idx, acc[o]);
     }
 }
 

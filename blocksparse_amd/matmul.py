@@ -45,84 +45,88 @@ def _dtype_code(dt):
     raise TypeError("blocksparse_amd: unsupported dtype %s (float32, float16, bfloat16)" % dt)
 
 
-def _host_plan(lut, segments, blocks, n_out_blocks, bsize, dtype_code, axis):
+def _host_plan(lut, segments, blocks, n_out_blocks, bsize, dtype_code, axis, options=0):
     """Grouped-kernel schedule for one xprop lut (host call into the library: bsmm_xprop_plan_build)."""
     lib = _lib.load()
     lut = np.ascontiguousarray(lut, dtype=np.int32)
     ip = ctypes.POINTER(ctypes.c_int32)
-    words = lib.bsmm_xprop_plan_words(lut.ctypes.data_as(ip), segments, blocks, n_out_blocks, bsize, dtype_code, axis)
+    words = lib.bsmm_xprop_plan_words(lut.ctypes.data_as(ip), segments, blocks, n_out_blocks, bsize, dtype_code, axis, options)
     if words < 0:
         raise RuntimeError("bsmm_xprop_plan_words rejected the lookup table")
     if words == 0:
         return None
     out = np.empty(words, dtype=np.int32)
-    _lib.check(lib.bsmm_xprop_plan_build(lut.ctypes.data_as(ip), segments, blocks, n_out_blocks, bsize, dtype_code, axis,
+    _lib.check(lib.bsmm_xprop_plan_build(lut.ctypes.data_as(ip), segments, blocks, n_out_blocks, bsize, dtype_code, axis, options,
                                          out.ctypes.data_as(ip)), "bsmm_xprop_plan_build")
     return out
 
 
-def _host_updat_plan(updat_lut, blocks, CB, KB, bsize, dtype_code, axis):
+def _host_updat_plan(updat_lut, blocks, CB, KB, bsize, dtype_code, axis, options=0):
     """Work items of the windowed updat kernel (host call into the library: bsmm_updat_plan_build)."""
     lib = _lib.load()
     lut = np.ascontiguousarray(updat_lut, dtype=np.int32)
     ip = ctypes.POINTER(ctypes.c_int32)
-    words = lib.bsmm_updat_plan_words(lut.ctypes.data_as(ip), blocks, CB, KB, bsize, dtype_code, axis)
+    words = lib.bsmm_updat_plan_words(lut.ctypes.data_as(ip), blocks, CB, KB, bsize, dtype_code, axis, options)
     if words < 0:
         raise RuntimeError("bsmm_updat_plan_words rejected the lookup table")
     if words == 0:
         return None
     out = np.empty(words, dtype=np.int32)
-    _lib.check(lib.bsmm_updat_plan_build(lut.ctypes.data_as(ip), blocks, CB, KB, bsize, dtype_code, axis,
+    _lib.check(lib.bsmm_updat_plan_build(lut.ctypes.data_as(ip), blocks, CB, KB, bsize, dtype_code, axis, options,
                                          out.ctypes.data_as(ip)), "bsmm_updat_plan_build")
     return out
+
+
+class _Plan(object):
+    """A schedule of the library: the host words (the library reads its descriptor from them, bsmm_plan_attach) and the
+    device copy the kernels walk."""
+
+    def __init__(self, host, device):
+        self.host = np.ascontiguousarray(host, dtype=np.int32)
+        self.dev = torch.from_numpy(self.host).to(device)
+
+    def attach(self, args):
+        ip = ctypes.POINTER(ctypes.c_int32)
+        _lib.check(_lib.load().bsmm_plan_attach(ctypes.byref(args), self.host.ctypes.data_as(ip), self.host.size, self.dev.data_ptr()),
+                   "bsmm_plan_attach")
 
 
 class _DeviceTables(object):
     """int32 lookup tables resident on one device (the reference keeps them as TF variables, matmul.py:33-53),
     plus the derived schedules ("plans") of the grouped kernels."""
 
-    def __init__(self, tables, device, bsize, axis):
+    def __init__(self, tables, device, bsize, axis, plan_options=0):
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+        def plan(words):
+            return _Plan(words, device) if words is not None else None
         self.fprop = up(tables["fprop"]["lut"])
         self.bprop = up(tables["bprop"]["lut"])
         self.updat = up(tables["updat_lut"])
         CB, KB, B = tables["CB"], tables["KB"], tables["blocks"]
-        # plans exist only for 16-bit types (they do not depend on which of the two)
-        fp = _host_plan(tables["fprop"]["lut"], tables["fprop"]["segments"], B, KB, bsize, _lib.BF16, axis)
-        bp = _host_plan(tables["bprop"]["lut"], tables["bprop"]["segments"], B, CB, bsize, _lib.BF16, axis)
-        self.fprop_plan = up(fp) if fp is not None else None
-        self.bprop_plan = up(bp) if bp is not None else None
-        # fp32 has its own (xprop-only) plan kernels for bsize 32; the schedule format is the library's business
-        fp32 = _host_plan(tables["fprop"]["lut"], tables["fprop"]["segments"], B, KB, bsize, _lib.F32, axis)
-        bp32 = _host_plan(tables["bprop"]["lut"], tables["bprop"]["segments"], B, CB, bsize, _lib.F32, axis)
-        self.fprop_plan_f32 = up(fp32) if fp32 is not None else None
-        self.bprop_plan_f32 = up(bp32) if bp32 is not None else None
-        upl = _host_updat_plan(tables["updat_lut"], B, CB, KB, bsize, _lib.BF16, axis)
-        self.updat_plan = up(upl) if upl is not None else None
-        # bsize 8: the plans are 'BSS8' composites (super-block count in word 2, the bsize-32 plan nested at word plan[5])
-        s8 = bsize == 8
-        self.fprop_aux = int(fp[2]) if (s8 and fp is not None) else 0
-        self.bprop_aux = int(bp[2]) if (s8 and bp is not None) else 0
-        # updat: word 2 is the super-block count (bsize 8) or the window side the plan was built for (bsize 32: 8 or 16)
-        self.updat_aux = int(upl[2]) if (upl is not None and (s8 or bsize == 32)) else 0
-        if upl is not None and bsize == 32 and int(upl[7]) == 16:
-            self.updat_aux += 256          # plan built for 16 waves per workgroup
-        if upl is None:
-            self.updat_items = 0
-        else:
-            self.updat_items = int(upl[int(upl[5]) + 4]) if s8 else int(upl[4])
+        f, b = tables["fprop"], tables["bprop"]
+        # plans exist only for 16-bit types (they do not depend on which of the two) ...
+        self.fprop_plan = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.BF16, axis, plan_options))
+        self.bprop_plan = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.BF16, axis, plan_options))
+        # ... and fp32 has its own (xprop-only) plan kernels for bsize 32; the schedule format is the library's business
+        self.fprop_plan_f32 = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.F32, axis, plan_options))
+        self.bprop_plan_f32 = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.F32, axis, plan_options))
+        self.updat_plan = plan(_host_updat_plan(tables["updat_lut"], B, CB, KB, bsize, _lib.BF16, axis, plan_options))
 
 
 class BlocksparseMatMul(object):
 
     def __getstate__(self):
-        return (self.layout, self.bsize, self.axis, self.z_order, self.name, self.segmented)
+        return (self.layout, self.bsize, self.axis, self.z_order, self.name, self.segmented, self.plan_options, self.updat_split)
 
     def __setstate__(self, state):
         self.__init__(*state)
 
-    def __init__(self, layout, block_size=32, feature_axis=0, z_order=True, name=None, segmented=False):
+    def __init__(self, layout, block_size=32, feature_axis=0, z_order=True, name=None, segmented=False, plan_options=0,
+                 updat_split=0):
+        """``plan_options``: BSMM_PLAN_* bits for the library's schedule builders (0 = its defaults); ``updat_split``: minibatch
+        split of the windowed updat kernels (0 = the library chooses).  Both are tuning / test knobs, not semantics."""
         if feature_axis not in (0, 1) or block_size not in (8, 16, 32):
             raise ValueError("Unsupported block size with this feature axis")
         layout = np.asarray(layout)
@@ -131,6 +135,8 @@ class BlocksparseMatMul(object):
         self.bsize = block_size
         self.z_order = bool(z_order)
         self.segmented = bool(segmented)
+        self.plan_options = int(plan_options)
+        self.updat_split = int(updat_split)
         self.name = name if name is not None else "BlocksparseMatMul"
 
         ref = _lut.build_tables(layout, z_order=z_order, segmented=True)      # reference-policy tables
@@ -158,6 +164,7 @@ class BlocksparseMatMul(object):
         self.sparsity = round(float(blocks) / float(CB * KB), 3)
         self.layout = ref["layout"]
         self._device_cache = {}
+        self._workspaces = {}
 
     # ---- shapes ----------------------------------------------------------------------------------
     def i_shape(self, N):
@@ -174,7 +181,7 @@ class BlocksparseMatMul(object):
         key = (device.type, device.index)
         t = self._device_cache.get(key)
         if t is None:
-            t = _DeviceTables(self._dev_tables, device, self.bsize, self.axis)
+            t = _DeviceTables(self._dev_tables, device, self.bsize, self.axis, self.plan_options)
             self._device_cache[key] = t
         return t
 
@@ -193,13 +200,16 @@ class BlocksparseMatMul(object):
             raise ValueError("expected %d features on the last axis, got shape %s" % (feat, tuple(x.shape)))
         return int(x.numel() // feat)
 
-    def _args(self, lut_t, side, N, Cin, Kout, dtype, pcount=1, alpha=1.0, beta=0.0, workspace=None, plan=None):
+    def _args(self, lut_t, side, N, Cin, Kout, dtype, pcount=1, alpha=1.0, beta=0.0, plan=None):
         a = _lib.BsmmArgs()
         a.lut = lut_t.data_ptr()
-        a.plan = plan.data_ptr() if plan is not None else None
+        if plan is not None:
+            plan.attach(a)
         a.gate = None
-        a.workspace = workspace.data_ptr() if workspace is not None else None
-        a.workspace_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+        a.workspace, a.workspace_bytes = None, 0
+        a.flags = _lib.call_flags()
+        a.split = self.updat_split
+        a.trace = ctypes.pointer(_lib._last_kernel)
         a.blocks, a.bsize = self.blocks, self.bsize
         if side is not None:
             a.segments, a.locks, a.shared = side["segments"], side["locks"], side["shared"]
@@ -208,6 +218,20 @@ class BlocksparseMatMul(object):
         a.alpha, a.beta = alpha, beta
         a.stream = torch.cuda.current_stream(lut_t.device).cuda_stream
         return a
+
+    def _workspace(self, a, op, device):
+        """Device scratch for one call, kept per (device, stream, op) and grown on demand: the entry points never allocate, and
+        consecutive calls on a stream reuse the same bytes in stream order (nothing inside the timed region of a step)."""
+        need = _lib.load().bsmm_workspace_bytes(op, ctypes.byref(a))
+        if not need:
+            return None
+        key = (device.index, a.stream, op)
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+            self._workspaces[key] = ws
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        return ws
 
     def _out_shape(self, x, feat_out):
         shp = list(x.shape)
@@ -241,12 +265,8 @@ class BlocksparseMatMul(object):
         y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
         a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype,
                        plan=tabs.fprop_plan_f32 if x.dtype == torch.float32 else tabs.fprop_plan)
-        a.plan_aux = tabs.fprop_aux if x.dtype != torch.float32 else 0
         a.gate = gate.data_ptr() if gate is not None else None
-        need = lib.bsmm_workspace_bytes(_lib.OP_FPROP, ctypes.byref(a))
-        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device) if need else None
-        if ws is not None:
-            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        self._workspace(a, _lib.OP_FPROP, x.device)
         _lib.check(lib.bsmm_fprop(x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(a)), "bsmm_fprop")
         return y
 
@@ -263,12 +283,8 @@ class BlocksparseMatMul(object):
         dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)
         a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype,
                        plan=tabs.bprop_plan_f32 if dy.dtype == torch.float32 else tabs.bprop_plan)
-        a.plan_aux = tabs.bprop_aux if dy.dtype != torch.float32 else 0
         a.gate = gate.data_ptr() if gate is not None else None
-        need = lib.bsmm_workspace_bytes(_lib.OP_BPROP, ctypes.byref(a))
-        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dy.device) if need else None
-        if ws is not None:
-            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        self._workspace(a, _lib.OP_BPROP, dy.device)
         _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
         return dx
 
@@ -304,15 +320,10 @@ class BlocksparseMatMul(object):
                 raise ValueError("dw must be a contiguous %s tensor of dtype %s" % (self.w_shape, xs[0].dtype))
         a = self._args(tabs.updat, None, N, self.C, self.K, xs[0].dtype, pcount=len(xs), alpha=alpha, beta=beta,
                        plan=tabs.updat_plan if xs[0].dtype != torch.float32 else None)
-        a.plan_items = tabs.updat_items
-        a.plan_aux = tabs.updat_aux if xs[0].dtype != torch.float32 else 0
         gate = self._check_gate(gate, dev)
         if gate is not None:
-            a.gate, a.flags = gate.data_ptr(), _lib.FLAG_GATED_DW
-        need = lib.bsmm_workspace_bytes(_lib.OP_UPDAT, ctypes.byref(a))
-        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev) if need else None
-        if ws is not None:
-            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            a.gate, a.flags = gate.data_ptr(), a.flags | _lib.FLAG_GATED_DW
+        self._workspace(a, _lib.OP_UPDAT, dev)
         arr = ctypes.c_void_p * len(xs)
         xp = arr(*[t.data_ptr() for t in xs])
         ep = arr(*[t.data_ptr() for t in dys])
@@ -428,14 +439,20 @@ class BlocksparseMatMul(object):
     def prune(self, param, gate):
         """Drop the blocks whose gate is 0: returns (new_param, new_gate) and clears those blocks in ``self.layout``
         (blocksparse/matmul.py:272-290; as there, build a new BlocksparseMatMul from the pruned layout afterwards)."""
-        gate = np.asarray(gate)
-        keep = gate != 0.0
+        is_t = torch is not None and isinstance(gate, torch.Tensor)
+        gate_np = gate.detach().cpu().numpy() if is_t else np.asarray(gate)
+        keep = gate_np != 0.0
         if int(keep.sum()) != self.blocks:
             for w_id, (c, k) in enumerate(self.updat_list):
                 if not keep[w_id]:
                     self.layout[c, k] = 0
-            param = np.asarray(param)[keep]
-        return param, np.ones((int(keep.sum()),), dtype=gate.dtype)
+            if torch is not None and isinstance(param, torch.Tensor):     # device tensors stay on their device
+                param = param[torch.from_numpy(keep).to(param.device)]
+            else:
+                param = np.asarray(param)[keep]
+        n = int(keep.sum())
+        new_gate = torch.ones(n, dtype=gate.dtype, device=gate.device) if is_t else np.ones((n,), dtype=gate_np.dtype)
+        return param, new_gate
 
     def matmul(self, I, W, gate=None, gate_grad=False, dw_gated=False, name=None, bench=0):
         return self.__call__(I, W, gate=gate, gate_grad=gate_grad, dw_gated=dw_gated, name=name, bench=bench)

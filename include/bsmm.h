@@ -21,7 +21,9 @@
  *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees device memory;
  *   - every call only enqueues work on `stream` (a hipStream_t) and returns immediately; no host sync;
  *   - return value: 0 = ok; >0 = a hipError_t from the launch; <0 = BSMM_ERR_* (bad arguments); nothing throws;
- *   - no global mutable state on the data path: concurrent calls on distinct streams are safe.
+ *   - no global mutable state: the library reads no environment variables and keeps no process-wide switches; kernel
+ *     choice is a function of the arguments only (bsmm_args.flags, the plan descriptor fields, the problem size), so
+ *     concurrent calls on distinct streams are safe.
  *
  * Tensor layouts:
  *   W  [blocks][bsize][bsize]  W[w][ci][ki] = Wdense[c*bsize+ci][k*bsize+ki] with (c,k) = updat_lut[w]
@@ -44,11 +46,35 @@ extern "C" {
 #define BSMM_VERSION 100 /* 0.1.0 */
 
 enum { BSMM_F32 = 0, BSMM_F16 = 1, BSMM_BF16 = 2 };
-enum { BSMM_FLAG_GATED_DW = 1 };   /* updat: scale dw by the gate (op attr gated_dw, src/blocksparse_matmul_op.cc:363,403) */
+enum {
+    BSMM_FLAG_GATED_DW = 1,     /* updat: scale dw by the gate (op attr gated_dw, src/blocksparse_matmul_op.cc:363,403)  */
+    BSMM_FLAG_FORCE_VALU = 2,   /* per call: plain V_FMA kernels for every bsize (independent second implementation)      */
+    BSMM_FLAG_NO_PLAN = 4,      /* per call: ignore bsmm_args.plan (per-segment / per-block matrix-core kernels)          */
+    BSMM_FLAG_FORCE_PLAN = 8    /* per call: take the plan kernels whenever a plan is given, whatever the size heuristic   */
+};
+
+/* bsmm_args.trace: which kernel family a call dispatched to (tests assert that the intended kernel ran) */
+enum {
+    BSMM_K_NONE = 0,
+    BSMM_K_XPROP_VALU = 1, BSMM_K_XPROP_SEGMENT = 2, BSMM_K_XCOL32 = 3, BSMM_K_XCOL16 = 4, BSMM_K_XCOL32_F32SPLIT = 5,
+    BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7,
+    BSMM_K_UPDAT_VALU = 16, BSMM_K_UPDAT_BLOCK = 17, BSMM_K_UPDAT_BLOCK_TR = 18, BSMM_K_UPDAT_WIN = 19, BSMM_K_UPDAT16_WIN = 20,
+    BSMM_K_UPDAT_SUPER8 = 21
+};
+
+/* options of the plan builders (0 = the library's default for the layout) */
+enum {
+    BSMM_PLAN_XCOL_NARROW = 1,      /* xprop bsize 32 / 16: 8 (16) output blocks per workgroup instead of 16 (32)            */
+    BSMM_PLAN_F32_MFMA = 2,         /* xprop fp32 bsize 32: schedule for the fp32 matrix-core kernel instead of the bf16 split */
+    BSMM_PLAN_WINDOW_8 = 0x10,      /* updat bsize 32: 8x8-block windows, 8 waves                                           */
+    BSMM_PLAN_WINDOW_16 = 0x20,     /*                 16x16-block windows, 8 waves (sparse layouts)                        */
+    BSMM_PLAN_WINDOW_16W = 0x30,    /*                 16x16-block windows, 16 waves                                        */
+    BSMM_PLAN_WINDOW_MASK = 0xf0
+};
 
 enum {
     BSMM_OK = 0,
-    BSMM_ERR_ARG = -1,         /* NULL pointer / non-positive size / pcount out of 1..8            */
+    BSMM_ERR_ARG = -1,         /* NULL pointer / non-positive size / pcount out of 1..8 / plan descriptor mismatch */
     BSMM_ERR_UNSUPPORTED = -2, /* bsize not in {8,16,32}, axis not in {0,1}, unknown dtype, gating */
     BSMM_ERR_WORKSPACE = -3    /* workspace pointer NULL or smaller than bsmm_workspace_bytes()     */
 };
@@ -66,11 +92,15 @@ typedef struct bsmm_args {
     const int32_t* plan;    /* optional device copy of the schedule built by bsmm_xprop_plan_build() (fprop/bprop) or
                                bsmm_updat_plan_build() (updat) for THIS lut (NULL = generic kernels).  Like the luts
                                it is a constant of the layout.                                                       */
-    int32_t plan_items;     /* updat only: header word [4] of the updat plan (number of work items = grid size); bsize 8:
-                               header word [4] of the plan nested at word plan[5]                                     */
-    int32_t plan_aux;       /* header word [2] of the plan for bsize 8 (number of 32x32 super-blocks) and for bsize-32
-                               updat (window side, 8 or 16, + 256 if header word [7] is 16; 0 is read as 8); otherwise 0 */
+    int32_t plan_magic;     /* plan descriptor, filled by bsmm_plan_attach() from the HOST copy of the plan: format tag    */
+    int32_t plan_width;     /*   output blocks per workgroup (xprop) / window side (updat); bsize 8: number of super-blocks */
+    int32_t plan_waves;     /*   waves per workgroup the schedule was dealt for                                          */
+    int32_t plan_items;     /*   updat: number of work items (= grid size)                                               */
+    int32_t plan_inner;     /*   bsize 8: width / window side of the nested bsize-32 plan                                */
+                            /* The launchers check the descriptor against the kernel they are about to launch and return
+                               BSMM_ERR_ARG on a mismatch (a plan built with other options, or for another pass).        */
     int32_t flags;          /* BSMM_FLAG_* (0 = none)                                                                 */
+    int32_t split;          /* updat with a plan: minibatch split factor (workgroups per work item); 0 = library chooses */
     int32_t blocks;         /* nonzero blocks                                                                        */
     int32_t bsize;          /* 8, 16 or 32                                                                           */
     int32_t segments;       /* xprop: number of lut headers (incl. empty output blocks)                              */
@@ -85,6 +115,7 @@ typedef struct bsmm_args {
     float alpha;            /* updat: DW = alpha * sum_p X_p DY_p^T + beta * DW                                      */
     float beta;
     void* stream;           /* hipStream_t                                                                           */
+    int32_t* trace;         /* optional HOST pointer: receives the BSMM_K_* code of the kernel this call dispatched to  */
 } bsmm_args;
 
 /* Y = fprop(X, W).  args->lut = fprop_lut.  Needs workspace: a transposed copy of W; bsize 8 with a plan: the expanded W;
@@ -138,35 +169,33 @@ int bsmm_sparse_mul_grad(void* dx, void* dy, const void* dz, const void* x, cons
  * memory (the luts are constants of the layout: the reference builds them in NumPy, blocksparse/matmul.py:137-138).
  * n_out_blocks = K / bsize of the pass the lut belongs to; axis = feature axis the plan will be used with.  bsmm_xprop_plan_words returns the number of int32 words
  * (0 if this (bsize, dtype, axis) has no grouped kernel, <0 on malformed input); bsmm_xprop_plan_build fills host_plan_out
- * (that many words).  The caller uploads the words to the device and passes the pointer as bsmm_args.plan.
+ * (that many words).  The caller uploads the words to the device and attaches both copies with bsmm_plan_attach().
+ * options: BSMM_PLAN_* (0 = default).
  * bsize 8 (16-bit types, n_out_blocks % 4 == 0): the result is a composite 'BSS8' plan -- the 8x8 blocks grouped into 32x32
- * super-blocks, the bsize-32 plan of that super layout nested at word [5]; word [2] (the number of super-blocks) goes to
- * bsmm_args.plan_aux, and fprop / bprop then need workspace (bsmm_workspace_bytes). */
+ * super-blocks, the bsize-32 plan of that super layout nested at word [5]; fprop / bprop then need workspace
+ * (bsmm_workspace_bytes). */
 long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks,
-                           int32_t bsize, int32_t dtype, int32_t axis);
+                           int32_t bsize, int32_t dtype, int32_t axis, int32_t options);
 int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks,
-                          int32_t bsize, int32_t dtype, int32_t axis, int32_t* host_plan_out);
+                          int32_t bsize, int32_t dtype, int32_t axis, int32_t options, int32_t* host_plan_out);
 
 /* Host-only: work items of the windowed weight-gradient kernel for an updat lut in HOST memory (CB/KB = block rows /
- * columns of the layout).  Same conventions as the xprop plan; word [4] of the result goes to bsmm_args.plan_items.
+ * columns of the layout).  Same conventions as the xprop plan (options: BSMM_PLAN_WINDOW_* or 0).
  * With a plan, bsmm_updat may need workspace (fp32 partial sums): ask bsmm_workspace_bytes(BSMM_OP_UPDAT, args).
- * bsize 8 (16-bit types, CB % 4 == 0 and KB % 4 == 0): composite 'BSS8' plan as above; word [2] goes to
- * bsmm_args.plan_aux and word [4] of the NESTED plan (it starts at word plan[5]) to bsmm_args.plan_items. */
+ * bsize 8 (16-bit types, CB % 4 == 0 and KB % 4 == 0): composite 'BSS8' plan as above. */
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize,
-                           int32_t dtype, int32_t axis);
+                           int32_t dtype, int32_t axis, int32_t options);
 int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize,
-                          int32_t dtype, int32_t axis, int32_t* host_plan_out);
+                          int32_t dtype, int32_t axis, int32_t options, int32_t* host_plan_out);
+
+/* Host-only: point args at a plan.  host_plan = the words produced by one of the builders above (host memory, `words` of
+ * them), device_plan = the caller's device copy of the same words.  Fills args->plan and the descriptor fields
+ * (plan_magic, plan_width, plan_waves, plan_items, plan_inner); BSMM_ERR_ARG if the words are not a plan of this library
+ * version.  device_plan == NULL detaches (generic kernels). */
+int bsmm_plan_attach(bsmm_args* args, const int32_t* host_plan, long words, const int32_t* device_plan);
 
 /* Bytes of device scratch the given op (BSMM_OP_*) needs for these args. */
 size_t bsmm_workspace_bytes(int op, const bsmm_args* args);
-
-/* Test hook: 0 = production kernels (grouped MFMA kernel when a plan is given and the problem fills the chip, else
- *                per-segment MFMA kernels for bsize 16/32, VALU for 8);
- *            1 = force the plain VALU kernels for every bsize (independent second implementation);
- *            2 = ignore bsmm_args.plan (per-segment / per-block MFMA kernels);
- *            3 = use the plan kernels whenever a plan is given, regardless of the problem-size heuristic. */
-void bsmm_set_kernel_variant(int variant);
-int bsmm_get_kernel_variant(void);
 
 const char* bsmm_error_string(int code);
 int bsmm_version(void);

@@ -419,3 +419,62 @@ def updat_fast(t, I, E, axis, dtype=np.float32):
         X = I.reshape(CB, bs, -1)
         D = E.reshape(KB, bs, -1)
     return np.matmul(X[ul[:, 0]], np.transpose(D[ul[:, 1]], (0, 2, 1)))
+
+
+# ----------------------------------------------------------------------------------------------
+# sampled variants for BASELINE-size parity tests: the same sums as fprop / bprop / updat, in float64, restricted to a
+# chosen set of output block columns / rows / weight blocks (the full float64 product of a 4096^2 layout at minibatch
+# 8192 would take minutes; a sample of every workgroup class takes seconds)
+# ----------------------------------------------------------------------------------------------
+
+def fprop_cols(t, I, W, axis, ks):
+    """{k: output block column k of fprop(I, W)} (axis 1: (n, bs) arrays, axis 0: (bs, n))  -- blocksparse/matmul.py:353-375."""
+    bs = t["bsize"]
+    cols = dict(t["fprop_list"])
+    I = np.asarray(I)
+    out = {}
+    for k in ks:
+        n = I.shape[0] if axis else I.shape[1]
+        ref = np.zeros((n, bs) if axis else (bs, n), dtype=np.float64)
+        for c, w in cols[k]:
+            Wb = np.asarray(W[w], dtype=np.float64)
+            if axis:
+                ref += I[:, c * bs:(c + 1) * bs].astype(np.float64) @ Wb
+            else:
+                ref += Wb.T @ I[c * bs:(c + 1) * bs, :].astype(np.float64)
+        out[k] = ref
+    return out
+
+
+def bprop_rows(t, E, W, axis, cs):
+    """{c: input block c of bprop(E, W)}  -- blocksparse/matmul.py:377-399."""
+    bs = t["bsize"]
+    rows = dict(t["bprop_list"])
+    E = np.asarray(E)
+    out = {}
+    for c in cs:
+        n = E.shape[0] if axis else E.shape[1]
+        ref = np.zeros((n, bs) if axis else (bs, n), dtype=np.float64)
+        for k, w in rows[c]:
+            Wb = np.asarray(W[w], dtype=np.float64)
+            if axis:
+                ref += E[:, k * bs:(k + 1) * bs].astype(np.float64) @ Wb.T
+            else:
+                ref += Wb @ E[k * bs:(k + 1) * bs, :].astype(np.float64)
+        out[c] = ref
+    return out
+
+
+def updat_blocks(t, I, E, axis, ws):
+    """{w: weight-gradient block w of updat(I, E)}  -- blocksparse/matmul.py:401-419."""
+    bs = t["bsize"]
+    ul = t["updat_lut"]
+    I = np.asarray(I); E = np.asarray(E)
+    out = {}
+    for w in ws:
+        c, k = int(ul[w][0]), int(ul[w][1])
+        if axis:
+            out[w] = I[:, c * bs:(c + 1) * bs].astype(np.float64).T @ E[:, k * bs:(k + 1) * bs].astype(np.float64)
+        else:
+            out[w] = I[c * bs:(c + 1) * bs, :].astype(np.float64) @ E[k * bs:(k + 1) * bs, :].astype(np.float64).T
+    return out

@@ -46,7 +46,7 @@ def test_struct_layout_matches_header(lib):
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = [re.search(r"(\w+)\s*;", ln).group(1) for ln in body.splitlines() if ";" in ln]
     assert names == [f[0] for f in lib.BsmmArgs._fields_]
-    assert ctypes.sizeof(lib.BsmmArgs) == 5 * 8 + 13 * 4 + 2 * 4 + 4 + 8   # 4 ptr + size_t, 13 int32, 2 float, pad, ptr
+    assert ctypes.sizeof(lib.BsmmArgs) == 5 * 8 + 18 * 4 + 2 * 4 + 2 * 8   # 4 ptr + size_t, 18 int32, 2 float, 2 ptr
 
 
 def test_argument_validation_without_gpu(lib):
@@ -76,7 +76,7 @@ def test_argument_validation_without_gpu(lib):
     a.bsize = 8
     assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 0
     # fp32, bsize 32, axis 1 with a plan: bf16 pieces of the activations and the weights (6 bytes per element)
-    a.bsize, a.dtype, a.axis, a.N, a.C, a.plan = 32, lib.F32, 1, 100, 64, 256
+    a.bsize, a.dtype, a.axis, a.N, a.C, a.plan, a.plan_magic = 32, lib.F32, 1, 100, 64, 256, 0x42535843
     assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * (100 * 64 + 10 * 1024)
     assert L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == 6 * (100 * 64 + 10 * 1024)
     a.axis = 0
@@ -134,7 +134,7 @@ def test_plan_builder_covers_every_block_once(lib):
                         want.add((ob, c, w))
                 assert got == want
                 # fp32 (bsize 32): the split kernel (bsmm_xcols.h) walks the 16-wide 'BSXC' format of the 16-bit kernels, both axes
-                # (the 'BSXF' format of the fp32-MFMA kernel xcol32f is only built with BSMM_F32_SPLIT=0)
+                # (the 'BSXF' format of the fp32-MFMA kernel xcol32f is only built with BSMM_PLAN_F32_MFMA)
                 pf = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.F32, axis)
                 assert pf[0] == 0x42535843 and int(pf[2]) == 16
                 assert _check_xcol_plan(pf, f, t, n_out) == want
@@ -257,3 +257,74 @@ def test_cpu_tensors_are_rejected_loudly():
     b = BlocksparseMatMul(np.ones((2, 2)), block_size=8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         b.fprop(torch.zeros(b.i_shape(4)), torch.zeros(b.w_shape))
+
+
+def test_plan_attach_descriptor_and_host_side_rejection(lib):
+    """bsmm_plan_attach reads the descriptor from the HOST words; a call whose plan does not belong to it is refused on the
+    host (BSMM_ERR_ARG) before anything is launched -- no GPU needed to see that."""
+    import numpy as np
+    from blocksparse_amd import lut as LT
+    from blocksparse_amd.matmul import _host_plan, _host_updat_plan
+    L = lib.load()
+    ip = ctypes.POINTER(ctypes.c_int32)
+    lay = np.random.default_rng(1).random((24, 40)) < 0.3
+    lay[0, :] = True
+    t = LT.build_tables(lay)
+    f = t["bprop"]
+    dev = ctypes.c_void_p(4096)                     # stand-in for the device copy: never dereferenced on the host
+
+    def attach(words):
+        a = lib.BsmmArgs()
+        assert L.bsmm_plan_attach(ctypes.byref(a), words.ctypes.data_as(ip), words.size, dev) == 0
+        return a
+    xp = _host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1)
+    a = attach(xp)
+    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items, a.plan_inner) == (0x42535843, 16, 16, 0, 0) and a.plan == 4096
+    a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_NARROW))
+    assert (a.plan_width, a.plan_waves) == (8, 8)
+    a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.F32, 1, lib.PLAN_F32_MFMA))
+    assert a.plan_magic == 0x42535846
+    up = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 32, lib.BF16, 1, lib.PLAN_WINDOW_16W)
+    a = attach(up)
+    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items) == (0x42535550, 16, 16, int(up[4]))
+    a = attach(_host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 32, lib.BF16, 1, lib.PLAN_WINDOW_8))
+    assert (a.plan_width, a.plan_waves) == (8, 8)
+    s8 = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 8, lib.BF16, 0)
+    a = attach(s8)
+    assert (a.plan_magic, a.plan_width, a.plan_inner, a.plan_waves) == (0x42535338, int(s8[2]), 8, 8) and a.plan_items > 0
+    # garbage / truncated / foreign-version words are not a plan
+    bad = xp.copy(); bad[1] += 1
+    b = lib.BsmmArgs()
+    assert L.bsmm_plan_attach(ctypes.byref(b), bad.ctypes.data_as(ip), bad.size, dev) == -1 and not b.plan
+    assert L.bsmm_plan_attach(ctypes.byref(b), xp.ctypes.data_as(ip), 4, dev) == -1
+    assert L.bsmm_plan_attach(ctypes.byref(b), xp.ctypes.data_as(ip), xp.size, None) == 0 and not b.plan     # detach
+
+    # a call with a plan of the wrong kind is refused before any launch (bprop: no pre-pass, so the check is the first thing)
+    one = ctypes.c_void_p(256)
+    a = attach(up)                                   # updat plan ...
+    a.lut = 256
+    a.blocks, a.N, a.C, a.K, a.segments, a.bsize, a.axis, a.dtype = t["blocks"], 256, 40 * 32, 24 * 32, 24, 32, 1, lib.BF16
+    a.flags = lib.FLAG_FORCE_PLAN
+    assert L.bsmm_bprop(one, one, one, ctypes.byref(a)) == -1          # ... handed to bprop
+    a = attach(xp)
+    a.lut = 256
+    a.blocks, a.N, a.C, a.K, a.segments, a.bsize, a.axis, a.dtype = t["blocks"], 256, 40 * 32, 24 * 32, 24, 32, 1, lib.BF16
+    a.flags = lib.FLAG_FORCE_PLAN
+    a.plan_width = 5                                 # descriptor of a width no kernel has
+    assert L.bsmm_bprop(one, one, one, ctypes.byref(a)) == -1
+    a.plan_width, a.bsize, a.C, a.K = 16, 16, 40 * 16, 24 * 16      # bsize-32 plan on a bsize-16 call
+    assert L.bsmm_bprop(one, one, one, ctypes.byref(a)) == -1
+    a = attach(xp)
+    a.lut, a.pcount = 256, 1
+    a.blocks, a.N, a.C, a.K, a.bsize, a.axis, a.dtype = t["blocks"], 256, 24 * 32, 40 * 32, 32, 1, lib.BF16
+    arr = (ctypes.c_void_p * 1)(256)
+    assert L.bsmm_updat(arr, arr, one, ctypes.byref(a)) == -1          # xprop plan handed to updat
+
+
+def test_library_reads_no_environment_and_keeps_no_switches(lib):
+    """include/bsmm.h promises a stateless library: no getenv, no process-wide kernel switch in the sources."""
+    src = ""
+    for f in ("bsmm_api.hip",):
+        src += open(os.path.join(ROOT, "blocksparse_amd", "csrc", f)).read()
+    assert "getenv" not in src and "g_variant" not in src and "static bool attr_set" not in src
+    assert not hasattr(ctypes.CDLL(lib.LIB_PATH), "bsmm_set_kernel_variant")

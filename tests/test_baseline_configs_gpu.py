@@ -1,0 +1,253 @@
+"""GPU parity at the BASELINE.json configurations themselves (not scaled-down stand-ins), production dispatch
+(no kernel-choice flags unless a case says so), against the float64 oracle on sampled output blocks; every case asserts
+through bsmm_args.trace WHICH kernel family ran, so a silent fall-back to a generic kernel fails the test.
+
+  (a) the bench shape: 4096^2, bsize 32, bf16, minibatch 8192, density 10 / 20 / 50 % (feature axis 1; 20 % on axis 0 too)
+  (b) BASELINE configs[3]: 8192^2, 5 %, bf16, the per-GPU shard N = 512 and the whole minibatch N = 4096, all three passes
+  (c) the 16-wave 16x16-window updat variant (BSMM_PLAN_WINDOW_16W) and forced 16x16 / 8x8 windows
+  (d) small forced-plan layouts whose 16x16 windows hold several blocks (multi-block windows, shared fragments, split items)
+  (e) the reference's own test matrix at its own size: Barabasi-Albert(160, 5) + I, N in {256,128,64,32,16,8},
+      bsize 32/16/8 (test/blocksparse_matmul_test.py:276-328), here on both feature axes
+  (f) BASELINE configs[2]: 4096^2, bsize 16, 10 %, bf16, axis 0, minibatch 8192
+"""
+import numpy as np
+import pytest
+
+import _parity as P
+from oracle import bsmm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from blocksparse_amd import BlocksparseMatMul, _lib
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    _lib.load()
+    return torch, BlocksparseMatMul, _lib
+
+
+def _inputs(torch, b, N, dtype, seed):
+    """W ~ N(0, .01), X, E ~ N(0, .1) generated on the device, rounded to the storage type; host copies are exact."""
+    td = getattr(torch, P.TORCH_DT[dtype])
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.01).to(td)
+    x = (torch.randn(b.i_shape(N), device="cuda", generator=g) * 0.1).to(td)
+    e = (torch.randn(b.o_shape(N), device="cuda", generator=g) * 0.1).to(td)
+    return w, x, e
+
+
+def _spread(n, count):
+    """`count` indices spread over range(n), hitting different residues mod 16 (= different waves of a workgroup)."""
+    if n <= count:
+        return list(range(n))
+    step = n / float(count)
+    return sorted(set(min(n - 1, int(i * step) + (i % 16 if int(i * step) + (i % 16) < n else 0)) for i in range(count)) | {0, n - 1})
+
+
+def _check_sampled(torch, lib, b, layout, N, dtype, seed, expect, ctx, n_cols=12, n_blocks=96, passes=("Y", "DX", "DW")):
+    """fprop / bprop / updat on the device; sampled output block columns / rows / weight blocks vs the float64 oracle."""
+    bs, axis = b.bsize, b.axis
+    t = orc.build_layout_luts(layout, bs)
+    w, x, e = _inputs(torch, b, N, dtype, seed)
+    W, X, E = P.to_host(w), P.to_host(x), P.to_host(e)
+    bar = P.L2_BAR[dtype]
+
+    def blk(a, i):
+        return a[:, i * bs:(i + 1) * bs] if axis else a[i * bs:(i + 1) * bs, :]
+
+    if "Y" in passes:
+        y = P.to_host(b.fprop(x, w))
+        if expect.get("xprop") is not None:
+            assert lib.last_kernel() == expect["xprop"], "%s fprop ran kernel %d" % (ctx, lib.last_kernel())
+        assert np.isfinite(y).all()
+        for k, ref in orc.fprop_cols(t, X, W, axis, _spread(b.KB, n_cols)).items():
+            l2, mx = P.errors(blk(y, k), orc.round_to(ref, dtype))
+            assert l2 <= bar, "%s Y col %d L2 %.3e" % (ctx, k, l2)
+    if "DX" in passes:
+        dx = P.to_host(b.bprop(e, w))
+        if expect.get("xprop") is not None:
+            assert lib.last_kernel() == expect["xprop"], "%s bprop ran kernel %d" % (ctx, lib.last_kernel())
+        assert np.isfinite(dx).all()
+        for c, ref in orc.bprop_rows(t, E, W, axis, _spread(b.CB, n_cols)).items():
+            l2, mx = P.errors(blk(dx, c), orc.round_to(ref, dtype))
+            assert l2 <= bar, "%s DX row %d L2 %.3e" % (ctx, c, l2)
+    if "DW" in passes:
+        dw = P.to_host(b.updat(x, e))
+        if expect.get("updat") is not None:
+            assert lib.last_kernel() == expect["updat"], "%s updat ran kernel %d" % (ctx, lib.last_kernel())
+        assert np.isfinite(dw).all()
+        ws = _spread(b.blocks, n_blocks)
+        ref = orc.updat_blocks(t, X, E, axis, ws)
+        got = np.stack([dw[i] for i in ws])
+        want = np.stack([orc.round_to(ref[i], dtype) for i in ws])
+        l2, mx = P.errors(got, want)
+        assert l2 <= bar, "%s DW sampled L2 %.3e" % (ctx, l2)
+        worst = max(P.errors(dw[i], orc.round_to(ref[i], dtype))[0] for i in ws)
+        assert worst <= 4 * bar, "%s DW worst block L2 %.3e" % (ctx, worst)
+        # every block was written (an item the plan forgot would leave torch.empty garbage or zeros): column sums of |dw|
+        assert (np.abs(dw).reshape(b.blocks, -1).sum(axis=1) > 0).all(), ctx
+
+
+# ---- (a) the bench shape ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("density,axis", [(0.1, 1), (0.2, 1), (0.5, 1), (0.2, 0)])
+def test_bench_shape_against_oracle(env, density, axis):
+    torch, BSMM, lib = env
+    layout = P.random_layout(128, 128, density, seed=1234)          # bench.py's layout
+    b = BSMM(layout, block_size=32, feature_axis=axis)
+    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=11, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_WIN},
+                   ctx="bench d%d a%d" % (round(density * 100), axis))
+
+
+def test_bench_shape_fp16_and_ragged_minibatch(env):
+    """fp16 storage and a minibatch that is not a multiple of the row tile (8192 - 24): last row tile / last chunk partial."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(128, 128, 0.2, seed=1234)
+    b = BSMM(layout, block_size=32, feature_axis=1)
+    _check_sampled(torch, lib, b, layout, 8192 - 24, "f16", seed=12, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_WIN}, ctx="bench f16 ragged")
+
+
+def test_bench_shape_skewed_layout(env):
+    """Barabasi-Albert + I layout of the bench size (hub rows / columns with ~100 blocks, most windows nearly empty): the
+    reference's own bench layout (test/blocksparse_matmul_bench.py:66-68)."""
+    torch, BSMM, lib = env
+    layout = P.ba_layout(128, 14, seed=1)
+    b = BSMM(layout, block_size=32, feature_axis=1)
+    _check_sampled(torch, lib, b, layout, 4096, "bf16", seed=13, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_WIN}, ctx="bench BA")
+
+
+# ---- (b) BASELINE configs[3] -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("axis,N,force", [(1, 512, False), (1, 512, True), (1, 4096, False), (0, 512, True), (0, 4096, False)])
+def test_cfg3_8192_5pct(env, axis, N, force):
+    """8192^2, 5 %: the plan builder picks 16x16 windows (~13 blocks each) on axis 1.  N = 512 is one GPU's shard of the
+    4096 minibatch: the cost models may prefer the per-segment / per-block kernels there, so the plan kernels are ALSO run
+    forced (BSMM_FLAG_FORCE_PLAN)."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(256, 256, 0.05, seed=1234)
+    b = BSMM(layout, block_size=32, feature_axis=axis)
+    expect = {"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_WIN} if (force or N >= 4096) else {}
+    try:
+        lib.set_kernel_variant(3 if force else 0)
+        _check_sampled(torch, lib, b, layout, N, "bf16", seed=21, expect=expect, ctx="cfg3 a%d N%d force%d" % (axis, N, force))
+    finally:
+        lib.set_kernel_variant(0)
+
+
+# ---- (c) window variants ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opt", ["PLAN_WINDOW_8", "PLAN_WINDOW_16", "PLAN_WINDOW_16W"])
+@pytest.mark.parametrize("density", [0.05, 0.2])
+def test_updat_window_variants(env, opt, density):
+    torch, BSMM, lib = env
+    layout = P.random_layout(128, 128, density, seed=77)
+    b = BSMM(layout, block_size=32, feature_axis=1, plan_options=getattr(lib, opt))
+    _check_sampled(torch, lib, b, layout, 2048, "bf16", seed=31, expect={"updat": lib.K_UPDAT_WIN}, ctx="%s d%.2f" % (opt, density), passes=("DW",))
+
+
+# ---- (d) small forced-plan layouts with several blocks per 16x16 window -----------------------------------------------
+@pytest.mark.parametrize("opt", [0, "PLAN_WINDOW_16", "PLAN_WINDOW_16W"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_small_layouts_multi_block_windows(env, opt, dtype):
+    torch, BSMM, lib = env
+    cases = [(P.random_layout(40, 40, 0.04, seed=1), (72, 200)),        # 64 blocks / 9 windows: default plan = 16x16 windows
+             (P.random_layout(40, 40, 0.15, seed=2), (392,)),           # ~27 per window: several items per window when forced
+             (P.random_layout(33, 17, 0.3, seed=3), (100, 8)),          # partial windows on both edges
+             (P.ba_layout(40, 3, seed=1), (264,))]                      # hub rows: one wave's slots share the X fragment
+    try:
+        lib.set_kernel_variant(3)
+        for li, (layout, Ns) in enumerate(cases):
+            b = BSMM(layout, block_size=32, feature_axis=1, plan_options=getattr(lib, opt) if opt else 0)
+            t = orc.build_layout_luts(layout, 32)
+            for N in Ns:
+                W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=li * 7 + N)
+                x, e = P.to_dev(X, dtype, torch), P.to_dev(E, dtype, torch)
+                got = P.to_host(b.updat(x, e))
+                assert lib.last_kernel() == lib.K_UPDAT_WIN
+                l2, mx = P.errors(got, orc.round_to(orc.updat(t, X, E, 1), dtype))
+                assert l2 <= P.L2_BAR[dtype], (opt, li, N, l2)
+    finally:
+        lib.set_kernel_variant(0)
+
+
+# ---- (e) the reference's own test matrix ------------------------------------------------------------------------------
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("bs", [32, 16, 8])
+def test_reference_matrix_ba160(env, bs, axis):
+    """BA(n=160, m=5) + I with a dense 5x5 corner, N in {256,128,64,32,16,8}, fp32 (the reference's dtype for this test) and
+    bf16 at the two ends; the whole output against the oracle (test/blocksparse_matmul_test.py:276-328)."""
+    torch, BSMM, lib = env
+    layout = P.ba_layout(160, 5, seed=1)
+    for N in (256, 128, 64, 32, 16, 8):
+        for dtype in ("f32",) + (("bf16",) if N in (256, 8) else ()):
+            res = P.run_case(torch, BSMM, layout, bs, axis, dtype, N, seed=N + bs, fast_oracle=True)
+            for name, (l2, mx) in res.items():
+                assert l2 <= P.L2_BAR[dtype], ("ba160", bs, axis, dtype, N, name, l2)
+    # and through the reference-policy (segmented, locked) tables, as a reference-side binding without a plan would pass them
+    b = BSMM(layout, block_size=bs, feature_axis=axis, segmented=True)
+    assert b.fprop_locks > 0
+    res = P.run_case(torch, BSMM, layout, bs, axis, "bf16", 64, seed=5, segmented=True, passes=("Y", "DX"), fast_oracle=True)
+    for name, (l2, mx) in res.items():
+        assert l2 <= P.L2_BAR["bf16"], ("ba160 locked", bs, axis, name, l2)
+
+
+# ---- (f) BASELINE configs[2] ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("axis", [0, 1])
+def test_cfg2_bsize16_10pct(env, axis):
+    torch, BSMM, lib = env
+    layout = P.random_layout(256, 256, 0.1, seed=1234)
+    b = BSMM(layout, block_size=16, feature_axis=axis)
+    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=41, expect={"xprop": lib.K_XCOL16, "updat": lib.K_UPDAT16_WIN}, ctx="cfg2 a%d" % axis)
+
+
+def test_cfg1_fp32_axis1(env):
+    """BASELINE configs[1]: 4096^2, bsize 32, 20 %, fp32, feature axis 1, fprop (the exact bf16-split kernel), N = 8192."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(128, 128, 0.2, seed=1234)
+    b = BSMM(layout, block_size=32, feature_axis=1)
+    _check_sampled(torch, lib, b, layout, 8192, "f32", seed=51, expect={"xprop": lib.K_XCOL32_F32SPLIT}, ctx="cfg1", passes=("Y", "DX"))
+
+
+# ---- boundary: a plan that does not belong to the call is refused, not silently ignored -------------------------------
+def test_mismatched_plan_is_rejected(env):
+    import ctypes
+    torch, BSMM, lib = env
+    layout = P.random_layout(16, 16, 0.3, seed=4)
+    b = BSMM(layout, block_size=32, feature_axis=1)
+    N = 256
+    w, x, e = _inputs(torch, b, N, "bf16", 1)
+    tabs = b._tables_on(x.device)
+    L = lib.load()
+    y = torch.full(b.o_shape(N), 7.0, dtype=torch.bfloat16, device="cuda")
+
+    def args(plan, lut, side):
+        a = b._args(lut, side, N, b.K, b.C, torch.bfloat16, plan=plan)
+        a.flags = lib.FLAG_FORCE_PLAN
+        return a
+    # an updat plan handed to bprop
+    a = args(tabs.updat_plan, tabs.bprop, b._dev_tables["bprop"])
+    assert L.bsmm_bprop(e.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(a)) == -1
+    # the right format with a descriptor of another width (a plan built with other options than the caller claims)
+    a = args(tabs.bprop_plan, tabs.bprop, b._dev_tables["bprop"])
+    a.plan_width = 5
+    assert L.bsmm_bprop(e.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(a)) == -1
+    # an xprop plan handed to updat
+    a = b._args(tabs.updat, None, N, b.C, b.K, torch.bfloat16, plan=tabs.fprop_plan)
+    a.flags = lib.FLAG_FORCE_PLAN
+    dw = torch.empty(b.w_shape, dtype=torch.bfloat16, device="cuda")
+    arr = (ctypes.c_void_p * 1)
+    assert L.bsmm_updat(arr(x.data_ptr()), arr(e.data_ptr()), dw.data_ptr(), ctypes.byref(a)) == -1
+    torch.cuda.synchronize()
+    assert (y.float() == 7.0).all()            # the refused calls launched nothing
+
+
+def test_locked_tables_fp32_axis0_unaligned_minibatch(env):
+    """Regression (round-1 advisor finding): fp32, bsize 32, feature axis 0, reference-policy (locked) tables, a minibatch
+    with N % 8 == 4 large enough for the grouped-kernel heuristic.  The split kernel needs N % 8 == 0 on axis 0, so the call
+    must take the per-segment kernel AND zero-fill the locked output blocks first (the two decisions used to disagree)."""
+    torch, BSMM, lib = env
+    layout = P.ba_layout(128, 6, seed=3)
+    b = BSMM(layout, block_size=32, feature_axis=0, segmented=True)
+    assert b.fprop_locks > 0 and b.bprop_locks > 0
+    for N in (2052, 2056):
+        expect = {"xprop": lib.K_XPROP_SEGMENT if N % 8 else lib.K_XCOL32_F32SPLIT}
+        _check_sampled(torch, lib, b, layout, N, "f32", seed=61, expect=expect, ctx="locked f32 a0 N%d" % N, passes=("Y", "DX"))

@@ -66,15 +66,15 @@ def test_empty_rows_cols_and_single_block(env, bs, axis):
 @pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("bs", [32, 16, 8])
 def test_segmented_luts_with_locks(env, bs, axis, dtype):
-    """Reference-policy tables (segments + lock ids) fed to the device: shared output blocks accumulate atomically."""
+    """Reference-policy tables (segments + lock ids) fed to the device: shared output blocks accumulate atomically (fp32)."""
     torch, BSMM, _ = env
     layout = P.ba_layout(64, 3, seed=5)
     b = BSMM(layout, block_size=bs, feature_axis=axis, segmented=True)
     assert b.fprop_locks > 0 and b.bprop_locks > 0
     res = P.run_case(torch, BSMM, layout, bs, axis, dtype, 48, seed=9, segmented=True, passes=("Y", "DX"))
-    bar = {"f32": (1e-5, 1e-4), "f16": (3e-3, 2e-2), "bf16": (2e-2, 1e-1)}[dtype]   # per-segment rounding in 16 bit
-    for name, (l2, mx) in res.items():
-        assert l2 <= bar[0] and mx <= bar[1], (name, l2, mx)
+    # shared output blocks are summed in fp32 (workspace image) and rounded once: the north-star bar holds for the
+    # reference-format locked tables too (the reference itself rounds every partial sum to 16 bit)
+    _check(res, dtype, "locked luts bs%d a%d" % (bs, axis))
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -85,10 +85,10 @@ def test_mfma_and_valu_kernels_agree(env, bs, axis, dtype):
     layout = P.random_layout(10, 12, 0.35, seed=11)
     L = lib.load()
     try:
-        L.bsmm_set_kernel_variant(1)
+        lib.set_kernel_variant(1)
         a = P.run_case(torch, BSMM, layout, bs, axis, dtype, 72, seed=2)
     finally:
-        L.bsmm_set_kernel_variant(0)
+        lib.set_kernel_variant(0)
     b = P.run_case(torch, BSMM, layout, bs, axis, dtype, 72, seed=2)
     _check(a, dtype, "valu")
     _check(b, dtype, "mfma")
@@ -99,7 +99,7 @@ def test_mfma_and_valu_kernels_agree(env, bs, axis, dtype):
 @pytest.mark.parametrize("axis", [0, 1])
 def test_plan_kernels_forced_on_small_and_ragged_cases(env, axis, dtype, bs):
     """The grouped (xcol) / windowed kernels normally run only when the problem fills the chip; force them
-    (bsmm_set_kernel_variant(3)) on small, ragged and degenerate cases: BA layout with hubs, empty rows/columns, odd
+    (BSMM_FLAG_FORCE_PLAN on every call: lib.set_kernel_variant(3)) on small, ragged and degenerate cases: BA layout with hubs, empty rows/columns, odd
     block counts (partial groups, a trailing input pair without its odd block), single block, N not a multiple of the
     row tile, and N % 8 != 0 on axis 0 (must fall back to the generic kernel, still correct)."""
     torch, BSMM, lib = env
@@ -110,13 +110,13 @@ def test_plan_kernels_forced_on_small_and_ragged_cases(env, axis, dtype, bs):
     layouts = [P.ba_layout(40, 3, seed=1), holes, P.random_layout(7, 9, 0.5, seed=2), np.ones((1, 1), dtype=np.int32),
                P.random_layout(17, 33, 0.3, seed=6)]
     try:
-        L.bsmm_set_kernel_variant(3)
+        lib.set_kernel_variant(3)
         for li, layout in enumerate(layouts):
             for N in (8, 72, 200, 392) + ((100, 5) if li == 0 else ()):
                 res = P.run_case(torch, BSMM, layout, bs, axis, dtype, N, seed=li * 10 + N)
                 _check(res, dtype, "forced-plan bs%d layout%d a%d %s N%d" % (bs, li, axis, dtype, N))
     finally:
-        L.bsmm_set_kernel_variant(0)
+        lib.set_kernel_variant(0)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -133,13 +133,13 @@ def test_bsize8_super_block_path(env, axis, dtype):
     layouts = [P.ba_layout(40, 3, seed=1), holes, P.random_layout(8, 12, 0.5, seed=2), np.ones((4, 4), dtype=np.int32),
                P.random_layout(20, 36, 0.1, seed=6), P.random_layout(7, 9, 0.5, seed=2)]
     try:
-        L.bsmm_set_kernel_variant(3)
+        lib.set_kernel_variant(3)
         for li, layout in enumerate(layouts):
             for N in (8, 72, 200) + ((100, 5) if li == 0 else ()):
                 res = P.run_case(torch, BSMM, layout, 8, axis, dtype, N, seed=li * 10 + N, segmented=(li == 4))
                 _check(res, dtype, "super8 layout%d a%d %s N%d" % (li, axis, dtype, N))
     finally:
-        L.bsmm_set_kernel_variant(0)
+        lib.set_kernel_variant(0)
 
 
 @pytest.mark.parametrize("axis", [0, 1])
@@ -174,13 +174,13 @@ def test_fp32_plan_kernels_forced(env, axis):
     holes[7, :] = 0
     layouts = [P.ba_layout(40, 3, seed=1), holes, P.random_layout(7, 9, 0.5, seed=2), np.ones((1, 1), dtype=np.int32)]
     try:
-        L.bsmm_set_kernel_variant(3)
+        lib.set_kernel_variant(3)
         for li, layout in enumerate(layouts):
             for N in (4, 72, 200, 392) + ((100, 5, 130) if li == 0 else ()):
                 res = P.run_case(torch, BSMM, layout, 32, axis, "f32", N, seed=li * 10 + N)
                 _check(res, "f32", "forced-plan f32 layout%d a%d N%d" % (li, axis, N))
     finally:
-        L.bsmm_set_kernel_variant(0)
+        lib.set_kernel_variant(0)
 
 
 def test_fp32_split_kernel_is_exact_over_a_wide_exponent_range(env):
@@ -199,13 +199,13 @@ def test_fp32_split_kernel_is_exact_over_a_wide_exponent_range(env):
     W, X, E = wide(b.w_shape, 0.01), wide(b.i_shape(N), 0.1), wide(b.o_shape(N), 0.1)
     w, x, e = (torch.from_numpy(a).cuda() for a in (W, X, E))
     try:
-        L.bsmm_set_kernel_variant(3)
+        lib.set_kernel_variant(3)
         y, dx = b.fprop(x, w), b.bprop(e, w)
-        L.bsmm_set_kernel_variant(2)
+        lib.set_kernel_variant(2)
         y2, dx2 = b.fprop(x, w), b.bprop(e, w)
         torch.cuda.synchronize()
     finally:
-        L.bsmm_set_kernel_variant(0)
+        lib.set_kernel_variant(0)
     for got, got2, ref, nm in ((y, y2, orc.fprop(t, X, W, 1), "Y"), (dx, dx2, orc.bprop(t, E, W, 1), "DX")):
         l2, mx = P.errors(P.to_host(got), ref)
         l2b, _ = P.errors(P.to_host(got2), ref)
@@ -228,11 +228,11 @@ def test_plan_and_generic_kernels_agree_at_scale(env, axis):
     dy = (torch.randn(b.o_shape(N), device="cuda", generator=g) * 0.1).bfloat16()
     outs = {}
     for v in (0, 2):
-        L.bsmm_set_kernel_variant(v)
+        lib.set_kernel_variant(v)
         try:
             outs[v] = (b.fprop(x, w).float(), b.bprop(dy, w).float(), b.updat(x, dy).float())
         finally:
-            L.bsmm_set_kernel_variant(0)
+            lib.set_kernel_variant(0)
     for name, p, q in zip(("Y", "DX", "DW"), outs[0], outs[2]):
         l2 = ((p - q).double().norm() / q.double().norm()).item()
         assert l2 < 2e-3, (name, l2)        # both are bf16-rounded results of fp32 sums in different orders
@@ -242,11 +242,11 @@ def test_plan_and_generic_kernels_agree_at_scale(env, axis):
 @pytest.mark.parametrize("axis", [0, 1])
 def test_windowed_updat_pairs_alpha_beta_and_minibatch_split(env, axis, split):
     """Windowed updat (bf16): 3 (x,dy) pairs, alpha/beta with DW accumulated in place (DWA form), and the
-    split-minibatch path (fp32 atomics into the workspace + finalize kernel) forced via BSMM_UPDAT_SPLIT."""
+    split-minibatch path (fp32 atomics into the workspace + finalize kernel) forced via bsmm_args.split."""
     torch, BSMM, lib = env
     L = lib.load()
     layout = P.random_layout(12, 20, 0.4, seed=4)
-    b = BSMM(layout, block_size=32, feature_axis=axis)
+    b = BSMM(layout, block_size=32, feature_axis=axis, updat_split=int(split))
     t = orc.build_layout_luts(layout, 32)
     N = 328
     Xs, Es = [], []
@@ -256,19 +256,14 @@ def test_windowed_updat_pairs_alpha_beta_and_minibatch_split(env, axis, split):
     dw0 = orc.round_bf16(np.random.RandomState(1).normal(size=b.w_shape).astype(np.float32) * 0.1)
     ref = orc.updat(t, Xs, Es, axis, alpha=0.5, beta=2.0, dw_in=dw0)
     dw = P.to_dev(dw0, "bf16", torch)
-    old = os.environ.get("BSMM_UPDAT_SPLIT")
-    os.environ["BSMM_UPDAT_SPLIT"] = split
     try:
-        L.bsmm_set_kernel_variant(3)
+        lib.set_kernel_variant(3)
         out = b.updat([P.to_dev(x, "bf16", torch) for x in Xs], [P.to_dev(e, "bf16", torch) for e in Es],
                       alpha=0.5, beta=2.0, dw=dw)
         torch.cuda.synchronize()
     finally:
-        L.bsmm_set_kernel_variant(0)
-        if old is None:
-            del os.environ["BSMM_UPDAT_SPLIT"]
-        else:
-            os.environ["BSMM_UPDAT_SPLIT"] = old
+        lib.set_kernel_variant(0)
+    assert lib.last_kernel() == lib.K_UPDAT_WIN
     assert out.data_ptr() == dw.data_ptr()
     l2, mx = P.errors(P.to_host(out), orc.round_bf16(ref))
     assert l2 <= P.L2_BAR["bf16"], (l2, mx)

@@ -119,3 +119,24 @@ def test_identity_init_rule():
     for w, (c, k) in enumerate(t["updat_list"]):
         want = 2.0 * np.eye(8) if (c % 5) == (k % 3) else np.zeros((8, 8))
         np.testing.assert_array_equal(W[w], want)
+
+
+def test_sampled_oracle_matches_the_full_oracle():
+    """oracle.fprop_cols / bprop_rows / updat_blocks (used at BASELINE sizes) are the same sums as fprop / bprop / updat."""
+    import _parity as P
+    lay = P.random_layout(6, 9, 0.4, seed=3)
+    for bs in (8, 32):
+        t = orc.build_layout_luts(lay, bs)
+        for axis in (0, 1):
+            rng = np.random.default_rng(bs + axis)
+            N = 20
+            W = rng.normal(size=(t["blocks"], bs, bs))
+            X = rng.normal(size=(N, 6 * bs) if axis else (6 * bs, N))
+            E = rng.normal(size=(N, 9 * bs) if axis else (9 * bs, N))
+            Y, DX, DW = orc.fprop(t, X, W, axis), orc.bprop(t, E, W, axis), orc.updat(t, X, E, axis)
+            for k, v in orc.fprop_cols(t, X, W, axis, range(9)).items():
+                np.testing.assert_allclose(Y[:, k * bs:(k + 1) * bs] if axis else Y[k * bs:(k + 1) * bs], v, atol=1e-12)
+            for c, v in orc.bprop_rows(t, E, W, axis, range(6)).items():
+                np.testing.assert_allclose(DX[:, c * bs:(c + 1) * bs] if axis else DX[c * bs:(c + 1) * bs], v, atol=1e-12)
+            for w, v in orc.updat_blocks(t, X, E, axis, range(t["blocks"])).items():
+                np.testing.assert_allclose(DW[w], v, atol=1e-12)
