@@ -7,7 +7,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 OUT = os.path.join(_HERE, "libbsmm_hip.so")
 SOURCES = ["bsmm_api.hip", "bst_api.hip"]
-HEADERS = ["bsmm_common.h", "bsmm_xprop.h", "bsmm_updat.h", "bsmm_plan.h", "bsmm_updat_tr.h", "bsmm_updat_win.h", "bsmm_xcol.h", "bsmm_xcol16.h", "bsmm_super8.h", "bsmm_xcols.h", "bst_kernels.h", "bsmm_l2norm.h", "bsmm_sparse_proj.h"]
+HEADERS = ["bsmm_common.h", "bsmm_xprop.h", "bsmm_updat.h", "bsmm_plan.h", "bsmm_updat_tr.h", "bsmm_updat_win.h", "bsmm_updat_v2.h", "bsmm_xcol.h", "bsmm_xcol16.h", "bsmm_super8.h", "bsmm_xcols.h", "bst_kernels.h", "bsmm_l2norm.h", "bsmm_sparse_proj.h"]
 
 
 def _stale():

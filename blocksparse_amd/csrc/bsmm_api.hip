@@ -13,6 +13,7 @@
 #include "bsmm_updat.h"
 #include "bsmm_updat_tr.h"
 #include "bsmm_updat_win.h"
+#include "bsmm_updat_v2.h"
 #include "bsmm_super8.h"
 #include "bsmm_xcols.h"
 #include "bsmm_xcol.h"
@@ -70,7 +71,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (reinterpret_cast<uintptr_t>(a->plan) & 15) return BSMM_ERR_ARG;
     const int32_t m = a->plan_magic;
     if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
-    if (updat) return (m == UPLAN_MAGIC && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
+    if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32 && a->axis == 1)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 16) return (m == XC16PLAN_MAGIC && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return ((m == XCPLAN_MAGIC && a->plan_width == XS_G) || m == XFPLAN_MAGIC) ? BSMM_OK : BSMM_ERR_ARG;
     return m == XCPLAN_MAGIC ? BSMM_OK : BSMM_ERR_ARG;
@@ -496,6 +497,58 @@ int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const b
     return (int)hipGetLastError();
 }
 
+inline int device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+}
+
+// Streaming kernel (bsmm_updat_v2.h, 'BSU2' plans).  Grid: a fixed number of workgroups over the flattened (item, chunk)
+// sequence -- one per CU, or `split` per item when the caller says so; one workgroup per item (split == 1, or so many items
+// that the tail does not matter) stores directly, otherwise partial sums meet in the fp32 workspace.
+struct U2Launch { int grid; bool scratch; };
+inline U2Launch updat2_shape(const bsmm_args* a, bool gated) {
+    const long nchunks = (a->N + U2_CH - 1) / U2_CH;
+    const long T = (long)a->plan_items * a->pcount * nchunks;
+    const int cus = device_cus();
+    U2Launch L;
+    if (a->split == 1 && !gated) { L.grid = a->plan_items; L.scratch = false; return L; }
+    if (a->split > 1) { L.grid = (int)std::min<long>((long)a->plan_items * a->split, std::max<long>(1, T)); L.scratch = true; return L; }
+    if (a->plan_items >= 4 * cus && !gated) { L.grid = a->plan_items; L.scratch = false; return L; }
+    L.grid = (int)std::max<long>(1, std::min<long>(cus, T / 4));     // >= 4 chunks per workgroup
+    L.scratch = true;
+    return L;
+}
+
+template <class DT>
+int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a, const float* gate) {
+    typedef typename DT::T T;
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    if (a->plan_magic != U2PLAN_MAGIC || a->plan_waves != U2_WAVES || a->plan_items <= 0 || (a->plan_width != 16 && a->plan_width != 8)) return BSMM_ERR_ARG;
+    const U2Launch L = updat2_shape(a, gate != nullptr);
+    float* scratch = nullptr;
+    const size_t nel = (size_t)a->blocks * 1024;
+    if (L.scratch) {
+        if (!a->workspace || a->workspace_bytes < nel * sizeof(float) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+        scratch = static_cast<float*>(a->workspace);
+        hipError_t e = hipMemsetAsync(scratch, 0, nel * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    trace(a, BSMM_K_UPDAT_STREAM);
+    if (a->plan_width == 16) {
+        if (int rc = ensure_lds(&updat32_a1_v2_kernel<DT, 16>, u2_lds_bytes(16))) return rc;
+        updat32_a1_v2_kernel<DT, 16><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(16), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
+                                                                                     a->pcount, a->alpha, a->beta);
+    } else {
+        if (int rc = ensure_lds(&updat32_a1_v2_kernel<DT, 8>, u2_lds_bytes(8))) return rc;
+        updat32_a1_v2_kernel<DT, 8><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(8), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
+                                                                                   a->pcount, a->alpha, a->beta);
+    }
+    if (scratch)
+        updat_finalize_gated_kernel<DT><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), nel, 1024, a->alpha, a->beta, gate);
+    return (int)hipGetLastError();
+}
+
 template <class DT, int BS, int AXIS>
 int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a) {
     typedef typename DT::T T;
@@ -536,7 +589,25 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             al = aligned16(DW);
             for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
         }
-        if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed kernels (plan = bsmm_updat_plan_build)
+        if constexpr (AXIS == 1) {
+            // streaming kernel ('BSU2' plan): 32-bit element offsets inside an operand
+            if (!use_valu && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_magic == U2PLAN_MAGIC &&
+                (long)N * std::max(a->C, a->K) < (1L << 30)) {
+                bool stream = true;
+                if (variant == 0) {
+                    // ~0.3 us per 16-row chunk of a workgroup's range (L2 -> LDS bound), + zero-fill / finalize of the scratch;
+                    // per-block kernel as fitted in round 1
+                    const U2Launch L = updat2_shape(a, gated);
+                    const double chunks = (double)a->plan_items * a->pcount * ((N + U2_CH - 1) / U2_CH);
+                    const double t_stream = 10.0 + std::ceil(chunks / L.grid) * 0.30 + (L.scratch ? 8.0 : 0.0);
+                    const double rounds_b = std::max(1.0, std::ceil(a->blocks / 512.0));
+                    const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * (N > 1024 ? 0.0105 : 0.0065);
+                    stream = t_stream <= t_blk && !(gated && false);
+                }
+                if (stream) return launch_updat2<DT>(xs, es, DW, a, ug);
+            }
+        }
+        if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_magic == UPLAN_MAGIC && a->plan_items > 0) {   // windowed kernels (plan = bsmm_updat_plan_build)
             // Sparse layouts at small minibatch (BASELINE configs[3]'s per-GPU shard: 8192^2, 5 %, N = 512): a window holds ~3
             // blocks, so the windowed kernel streams 64 KiB per chunk for almost nothing, while the per-block transposing-read
             // kernel moves 128 bytes per (block, row).  Fitted to measurements (us): windowed 8 + rounds * chunks * 0.9 (1.8x that
@@ -849,6 +920,14 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
     if (bsize == 8) return build_super8_updat_plan(lut, blocks, CB, KB, out);   // 'BSS8'
     if (bsize == 16) return build_updat_plan(lut, blocks, CB, KB, UW16, UP16_MAXB, out);
     if (bsize != 32) return 0;
+    const int force = options & BSMM_PLAN_WINDOW_MASK;
+    if (axis == 1 && (force == 0 || force == BSMM_PLAN_STREAM_16 || force == BSMM_PLAN_STREAM_8)) {
+        // streaming kernel: 16x16 windows while a window's blocks fit the 64 accumulator slots of a workgroup (with some
+        // slack for the rows that do not pack: <= 56 on average), 8x8 windows for denser layouts
+        const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);
+        const int ws = force == BSMM_PLAN_STREAM_16 ? 16 : (force == BSMM_PLAN_STREAM_8 ? 8 : (blocks <= 56.0 * windows ? 16 : 8));
+        return build_updat2_plan(lut, blocks, CB, KB, ws, out);
+    }
     const int w = updat_window(blocks, CB, KB, axis, options);
     return build_updat_plan(lut, blocks, CB, KB, w == 8 ? 8 : 16, UP_MAXB, out, w == 1616 ? 16 : 8);
 }
@@ -873,6 +952,7 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[4]) {
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;
+        case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR) return false;   d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;
         default: return false;
     }
     d[0] = p[0];

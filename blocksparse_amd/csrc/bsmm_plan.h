@@ -432,3 +432,142 @@ inline long build_super8_updat_plan(const int32_t* updat_lut, int blocks, int CB
 }
 
 }  // namespace bsmm
+
+// =================================================================================================
+// updat v2 plan ('BSU2'): work items of the streaming weight-gradient kernel (bsmm_updat_v2.h), bsize 32, feature axis 1,
+// 16-bit types.  The block grid is cut into WS x WS windows (WS = 16 for layouts up to ~22 % density: a window then holds
+// up to 64 blocks = 16 waves x 4 accumulator slots; WS = 8 above).  Inside an item every wave owns up to U2_SLOTS blocks
+// taken from at most TWO block rows of the window: the X^T fragment of a row is read from LDS once and reused by all of the
+// wave's blocks in that row (row pieces are packed first-fit-decreasing so that most waves hold a single row).  A window
+// with more blocks than slots, or whose rows cannot be packed that way, is cut into several items.
+// The kernel walks the flattened sequence (item, 16-row minibatch chunk) with a FIXED number of workgroups, each taking a
+// contiguous range of it, so any number of items fills the chip evenly; partial sums meet in an fp32 scratch (atomics).
+// Item order: workgroup u runs on XCD u % 8 (observed; speed only) and, at the bench shape, covers a quarter of the
+// minibatch of item u / 4 -- even list positions hold the windows of the upper half of the block rows, odd positions those
+// of the lower half, so an XCD's L2 sees one minibatch quarter of HALF of X and all of DY (1.5x the compulsory traffic
+// instead of 3x with a window patch per XCD).
+// Layout (int32): [0] magic 'BSU2' [1] version [2] WS [3] U2_SLOTS [4] nitems [5] nblocks [6] off_items [7] U2_WAVES
+//   item: U2_ITEM = 4 + U2_WAVES * 5 words = (c0_block, k0_block, nblocks_in_item, 0) then per wave
+//         word 0 = n0 | n1 << 4 | cidx0 << 8 | cidx1 << 12 | kidx[0] << 16 | kidx[1] << 20 | kidx[2] << 24 | kidx[3] << 28
+//                  slots [0, n0) are blocks (cidx0, kidx[j]), slots [n0, n0 + n1) blocks (cidx1, kidx[j]) of the window
+//         words 1..4 = weight block id of slot j (-1 = empty)
+// =================================================================================================
+namespace bsmm {
+
+constexpr int32_t U2PLAN_MAGIC = 0x42535532;
+constexpr int32_t U2PLAN_VERSION = 1;
+constexpr int U2_WAVES = 16;
+constexpr int U2_SLOTS = 4;
+constexpr int U2_WWORDS = 5;
+constexpr int U2_ITEM = 4 + U2_WAVES * U2_WWORDS;
+constexpr int U2_HDR = 8;
+
+inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out) {
+    if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || (ws != 8 && ws != 16)) return -1;
+    const int WS = ws;
+    const int wc = (CB + WS - 1) / WS, wk = (KB + WS - 1) / WS;
+    struct Ent { int c, k, w; };
+    std::vector<std::vector<Ent>> win((size_t)wc * wk);
+    for (int w = 0; w < blocks; ++w) {
+        const int c = updat_lut[2 * w], k = updat_lut[2 * w + 1];
+        if (c < 0 || c >= CB || k < 0 || k >= KB) return -1;
+        win[(size_t)(c / WS) * wk + (k / WS)].push_back({c, k, w});
+    }
+    struct Piece { int row; std::vector<Ent> e; };            // <= U2_SLOTS blocks of one window row
+    struct Wave { std::vector<Piece> p; int n = 0; };
+    std::vector<std::vector<int32_t>> half_items[2];           // items of the upper / lower half of the window rows
+    auto emit = [&](int wi, int wj, const std::vector<Wave>& waves) {
+        std::vector<int32_t> it(U2_ITEM, 0);
+        int n = 0;
+        for (int v = 0; v < U2_WAVES; ++v) {
+            int32_t* wd = &it[4 + v * U2_WWORDS];
+            wd[1] = wd[2] = wd[3] = wd[4] = -1;
+            if (v >= (int)waves.size() || waves[v].p.empty()) continue;
+            const Wave& W = waves[v];
+            const int n0 = (int)W.p[0].e.size(), n1 = W.p.size() > 1 ? (int)W.p[1].e.size() : 0;
+            uint32_t m = (uint32_t)n0 | ((uint32_t)n1 << 4) | ((uint32_t)(W.p[0].row - wi * WS) << 8);
+            if (n1) m |= (uint32_t)(W.p[1].row - wi * WS) << 12;
+            int j = 0;
+            for (const Piece& pc : W.p)
+                for (const Ent& e : pc.e) {
+                    m |= (uint32_t)(e.k - wj * WS) << (16 + 4 * j);
+                    wd[1 + j] = e.w;
+                    ++j; ++n;
+                }
+            wd[0] = (int32_t)m;
+        }
+        it[0] = wi * WS; it[1] = wj * WS; it[2] = n;
+        half_items[(2 * wi >= wc) ? 1 : 0].push_back(std::move(it));
+    };
+    for (int wj = 0; wj < wk; ++wj)                 // column-major over the windows: consecutive items share their DY panel
+        for (int wi = 0; wi < wc; ++wi) {
+            auto& v = win[(size_t)wi * wk + wj];
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end(), [](const Ent& a, const Ent& b) { return a.c != b.c ? a.c < b.c : a.k < b.k; });
+            // row pieces: whole groups of U2_SLOTS first, then the remainder of each row
+            std::vector<Piece> full, part;
+            for (size_t i = 0; i < v.size();) {
+                size_t j = i;
+                while (j < v.size() && v[j].c == v[i].c) ++j;
+                for (size_t b = i; b < j; b += U2_SLOTS) {
+                    Piece pc{v[i].c, std::vector<Ent>(v.begin() + b, v.begin() + std::min(j, b + U2_SLOTS))};
+                    ((int)pc.e.size() == U2_SLOTS ? full : part).push_back(std::move(pc));
+                }
+                i = j;
+            }
+            std::sort(part.begin(), part.end(), [](const Piece& a, const Piece& b) { return a.e.size() > b.e.size(); });
+            // pack: a wave holds one full piece, or one / two partial pieces with <= U2_SLOTS blocks.  Loose first (every
+            // piece its own wave while the item has waves left: one row per wave, even matrix-pipe load), tight (best fit
+            // decreasing) when that needs more than U2_WAVES waves.
+            auto pack = [&](bool tight) {
+                std::vector<Wave> ws;
+                for (auto& pc : full) { Wave w; w.n = U2_SLOTS; w.p.push_back(pc); ws.push_back(std::move(w)); }
+                for (auto& pc : part) {
+                    const int sz = (int)pc.e.size();
+                    Wave* best = nullptr;
+                    for (auto& w : ws)
+                        if (w.p.size() == 1 && w.n + sz <= U2_SLOTS && (!best || w.n > best->n)) best = &w;
+                    if (best && (tight || ws.size() >= (size_t)U2_WAVES)) { best->p.push_back(pc); best->n += sz; }
+                    else { Wave w; w.n = sz; w.p.push_back(pc); ws.push_back(std::move(w)); }
+                }
+                return ws;
+            };
+            std::vector<Wave> waves = pack(false);
+            if (waves.size() > (size_t)U2_WAVES) waves = pack(true);
+            // more than U2_WAVES waves: the window becomes several items of about equal size (each streams the slabs once)
+            const size_t nit = (waves.size() + U2_WAVES - 1) / U2_WAVES;
+            const size_t per_item = (waves.size() + nit - 1) / nit;
+            // spread the load over the four SIMDs: waves v, v+4, v+8, v+12 share a matrix pipe -> deal waves sorted by load
+            std::sort(waves.begin(), waves.end(), [](const Wave& a, const Wave& b) { return a.n > b.n; });
+            for (size_t beg = 0; beg < waves.size(); beg += per_item) {
+                const size_t cnt = std::min<size_t>(per_item, waves.size() - beg);
+                std::vector<Wave> dealt(U2_WAVES);
+                int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+                for (size_t i = 0; i < cnt; ++i) {
+                    int s = -1;
+                    for (int q = 0; q < 4; ++q)
+                        if (used[q] < 4 && (s < 0 || load[q] < load[s])) s = q;
+                    dealt[s + 4 * used[s]] = waves[beg + i];
+                    load[s] += waves[beg + i].n; ++used[s];
+                }
+                emit(wi, wj, dealt);
+            }
+        }
+    // interleave the two halves: even positions upper half, odd positions lower half (shorter list: the rest in sequence)
+    std::vector<int32_t> items;
+    size_t ia = 0, ib = 0;
+    while (ia < half_items[0].size() || ib < half_items[1].size()) {
+        if (ia < half_items[0].size()) { items.insert(items.end(), half_items[0][ia].begin(), half_items[0][ia].end()); ++ia; }
+        if (ib < half_items[1].size()) { items.insert(items.end(), half_items[1][ib].begin(), half_items[1][ib].end()); ++ib; }
+    }
+    const long nitems = (long)(items.size() / U2_ITEM);
+    const long total = U2_HDR + (long)items.size();
+    if (out) {
+        const int32_t hdr[U2_HDR] = {U2PLAN_MAGIC, U2PLAN_VERSION, WS, U2_SLOTS, (int32_t)nitems, blocks, U2_HDR, U2_WAVES};
+        std::copy(hdr, hdr + U2_HDR, out);
+        std::copy(items.begin(), items.end(), out + U2_HDR);
+    }
+    return total;
+}
+
+}  // namespace bsmm

@@ -59,17 +59,19 @@ enum {
     BSMM_K_XPROP_VALU = 1, BSMM_K_XPROP_SEGMENT = 2, BSMM_K_XCOL32 = 3, BSMM_K_XCOL16 = 4, BSMM_K_XCOL32_F32SPLIT = 5,
     BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7,
     BSMM_K_UPDAT_VALU = 16, BSMM_K_UPDAT_BLOCK = 17, BSMM_K_UPDAT_BLOCK_TR = 18, BSMM_K_UPDAT_WIN = 19, BSMM_K_UPDAT16_WIN = 20,
-    BSMM_K_UPDAT_SUPER8 = 21
+    BSMM_K_UPDAT_SUPER8 = 21, BSMM_K_UPDAT_STREAM = 22
 };
 
 /* options of the plan builders (0 = the library's default for the layout) */
 enum {
     BSMM_PLAN_XCOL_NARROW = 1,      /* xprop bsize 32 / 16: 8 (16) output blocks per workgroup instead of 16 (32)            */
     BSMM_PLAN_F32_MFMA = 2,         /* xprop fp32 bsize 32: schedule for the fp32 matrix-core kernel instead of the bf16 split */
-    BSMM_PLAN_WINDOW_8 = 0x10,      /* updat bsize 32: 8x8-block windows, 8 waves                                           */
-    BSMM_PLAN_WINDOW_16 = 0x20,     /*                 16x16-block windows, 8 waves (sparse layouts)                        */
-    BSMM_PLAN_WINDOW_16W = 0x30,    /*                 16x16-block windows, 16 waves                                        */
-    BSMM_PLAN_WINDOW_MASK = 0xf0
+    BSMM_PLAN_WINDOW_8 = 0x10,      /* updat bsize 32: round-1 windowed kernel, 8x8-block windows, 8 waves                  */
+    BSMM_PLAN_WINDOW_16 = 0x20,     /*                 round-1 windowed kernel, 16x16-block windows, 8 waves                */
+    BSMM_PLAN_WINDOW_16W = 0x30,    /*                 round-1 windowed kernel, 16x16-block windows, 16 waves               */
+    BSMM_PLAN_STREAM_16 = 0x40,     /*                 streaming kernel (bsmm_updat_v2.h, axis 1), 16x16-block windows      */
+    BSMM_PLAN_STREAM_8 = 0x50,      /*                 streaming kernel, 8x8-block windows (dense layouts)                  */
+    BSMM_PLAN_WINDOW_MASK = 0xf0    /* (0: axis 1 -> streaming kernel, window side by density; axis 0 -> 8x8 windows)       */
 };
 
 enum {
@@ -100,7 +102,8 @@ typedef struct bsmm_args {
                             /* The launchers check the descriptor against the kernel they are about to launch and return
                                BSMM_ERR_ARG on a mismatch (a plan built with other options, or for another pass).        */
     int32_t flags;          /* BSMM_FLAG_* (0 = none)                                                                 */
-    int32_t split;          /* updat with a plan: minibatch split factor (workgroups per work item); 0 = library chooses */
+    int32_t split;          /* updat with a plan: workgroups per work item (each takes a slice of the minibatch; > 1 or a
+                               gate: fp32 partial sums in the workspace + a finalize pass); 0 = library chooses         */
     int32_t blocks;         /* nonzero blocks                                                                        */
     int32_t bsize;          /* 8, 16 or 32                                                                           */
     int32_t segments;       /* xprop: number of lut headers (incl. empty output blocks)                              */

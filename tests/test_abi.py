@@ -165,8 +165,9 @@ def test_plan_builder_covers_every_block_once(lib):
 
 
 def test_updat_plan_covers_every_block_once(lib):
-    """bsmm_updat_plan_build: every weight block appears in exactly one (item, wave, slot), inside its window, items are
-    padded to a multiple of 8 (one list per XCD), every wave of an item has at most `nslots` blocks."""
+    """bsmm_updat_plan_build, round-1 windowed formats ('BSUP': axis 0, bsize 16, or BSMM_PLAN_WINDOW_* on axis 1): every weight
+    block appears in exactly one (item, wave, slot), inside its window, items are padded to a multiple of 8 (one list per XCD),
+    every wave of an item has at most `nslots` blocks."""
     import numpy as np
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_updat_plan
@@ -175,13 +176,11 @@ def test_updat_plan_covers_every_block_once(lib):
         lay = rng.random((CB, KB)) < dens
         lay[0, 0] = True
         t = L.build_tables(lay)
-        for bsize in (32, 16):
-            plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, bsize, lib.BF16, 1)
-            # window side: 256 features, or 512 (16 blocks of 32) for sparse bsize-32 layouts on axis 1
-            assert plan[0] == 0x42535550 and plan[5] == t["blocks"] and plan[2] in ((8, 16) if bsize == 32 else (16,))
-            if bsize == 32:
-                assert (int(plan[2]) == 16) == (t["blocks"] <= 16 * (-(-CB // 16)) * (-(-KB // 16)))
-                assert _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 0)[2] == 8      # axis 0: always 8x8
+        for bsize, axis, opt in ((32, 0, 0), (32, 1, lib.PLAN_WINDOW_8), (32, 1, lib.PLAN_WINDOW_16), (32, 1, lib.PLAN_WINDOW_16W), (16, 1, 0), (16, 0, 0)):
+            plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, bsize, lib.BF16, axis, opt)
+            assert plan[0] == 0x42535550 and plan[5] == t["blocks"]
+            want_w = {0: 8 if bsize == 32 else 16, lib.PLAN_WINDOW_8: 8, lib.PLAN_WINDOW_16: 16, lib.PLAN_WINDOW_16W: 16}[opt]
+            assert plan[2] == want_w and plan[7] == (16 if opt == lib.PLAN_WINDOW_16W else 8)
             UW, MAXB, nitems, waves = int(plan[2]), int(plan[3]), int(plan[4]), int(plan[7])
             assert nitems % 8 == 0
             isz = 4 + waves * MAXB * 2
@@ -220,6 +219,67 @@ def test_updat_plan_covers_every_block_once(lib):
     assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 32, lib.F32, 1) is None
     assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 8, lib.F32, 0) is None
     assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 8, lib.BF16, 0)[0] == 0x42535338   # 'BSS8' (tests/test_super8_plan.py)
+
+
+def test_streaming_updat_plan(lib):
+    """'BSU2' plans (bsize 32, axis 1: the default): every block in exactly one (item, wave, slot); a wave holds <= 4 blocks from
+    <= 2 rows of the window, group 0 first; a window side of 16 for layouts up to ~22 % density, 8 above; hub rows split over waves;
+    the two halves of the block rows alternate in the item list."""
+    import numpy as np
+    from blocksparse_amd import lut as L
+    from blocksparse_amd.matmul import _host_updat_plan
+    rng = np.random.default_rng(7)
+    cases = [(40, 52, 0.3), (128, 128, 0.2), (128, 128, 0.1), (128, 128, 0.5), (5, 3, 1.0), (1, 1, 1.0), (16, 16, 1.0), (33, 17, 0.05), (256, 256, 0.05)]
+    for CB, KB, dens in cases:
+        lay = rng.random((CB, KB)) < dens
+        lay[0, 0] = True
+        if CB >= 40:
+            lay[3, :] = True                                   # a hub row: more blocks than a wave has slots
+        t = L.build_tables(lay)
+        for opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8):
+            plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, opt)
+            assert plan[0] == 0x42535532 and plan[1] == 1 and plan[3] == 4 and plan[5] == t["blocks"] and plan[7] == 16
+            WS, nitems = int(plan[2]), int(plan[4])
+            if opt == 0:
+                assert WS == (16 if t["blocks"] <= 56 * (-(-CB // 16)) * (-(-KB // 16)) else 8)
+            else:
+                assert WS == (16 if opt == lib.PLAN_STREAM_16 else 8)
+            items = plan[plan[6]:].reshape(nitems, 4 + 16 * 5)
+            assert plan.size == plan[6] + nitems * 84
+            seen = set()
+            for it in items:
+                c0, k0, n = int(it[0]), int(it[1]), int(it[2])
+                assert c0 % WS == 0 and k0 % WS == 0 and 1 <= n <= 64
+                cnt = 0
+                for v in range(16):
+                    m = int(it[4 + 5 * v]) & 0xffffffff
+                    n0, n1 = m & 15, (m >> 4) & 15
+                    assert n0 + n1 <= 4 and (n1 == 0 or n0 > 0)
+                    rows = [(m >> 8) & 15] * n0 + [(m >> 12) & 15] * n1
+                    if n1:
+                        assert rows[0] != rows[-1]
+                    for j in range(4):
+                        w = int(it[4 + 5 * v + 1 + j])
+                        if j < n0 + n1:
+                            kidx = (m >> (16 + 4 * j)) & 15
+                            assert rows[j] < WS and kidx < WS
+                            assert tuple(t["updat_lut"][w]) == (c0 + rows[j], k0 + kidx)
+                            assert w not in seen
+                            seen.add(w)
+                            cnt += 1
+                        else:
+                            assert w == -1
+                assert cnt == n
+            assert seen == set(range(t["blocks"]))
+            # the upper / lower half of the window rows alternate while both lists last
+            wc = -(-CB // WS)
+            halves = [int(2 * (int(it[0]) // WS) >= wc) for it in items]
+            n_up = halves.count(0)
+            n_alt = 2 * min(n_up, nitems - n_up)
+            assert halves[:n_alt] == [0, 1] * (n_alt // 2)
+        if (CB, KB, dens) == (128, 128, 0.2):
+            p16 = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, 0)
+            assert 64 <= int(p16[4]) <= 72                      # ~one item per 16x16 window
 
 
 def test_host_class_surface():

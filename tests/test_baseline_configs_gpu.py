@@ -28,6 +28,13 @@ def env():
     return torch, BlocksparseMatMul, _lib
 
 
+def _updat_kernel(lib, axis, opt=0):
+    """which bsize-32 updat kernel a plan built with `opt` runs: axis 1 defaults to the streaming kernel (bsmm_updat_v2.h)"""
+    if axis == 1 and opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8):
+        return lib.K_UPDAT_STREAM
+    return lib.K_UPDAT_WIN
+
+
 def _inputs(torch, b, N, dtype, seed):
     """W ~ N(0, .01), X, E ~ N(0, .1) generated on the device, rounded to the storage type; host copies are exact."""
     td = getattr(torch, P.TORCH_DT[dtype])
@@ -96,7 +103,7 @@ def test_bench_shape_against_oracle(env, density, axis):
     torch, BSMM, lib = env
     layout = P.random_layout(128, 128, density, seed=1234)          # bench.py's layout
     b = BSMM(layout, block_size=32, feature_axis=axis)
-    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=11, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_WIN},
+    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=11, expect={"xprop": lib.K_XCOL32, "updat": _updat_kernel(lib, axis)},
                    ctx="bench d%d a%d" % (round(density * 100), axis))
 
 
@@ -105,7 +112,7 @@ def test_bench_shape_fp16_and_ragged_minibatch(env):
     torch, BSMM, lib = env
     layout = P.random_layout(128, 128, 0.2, seed=1234)
     b = BSMM(layout, block_size=32, feature_axis=1)
-    _check_sampled(torch, lib, b, layout, 8192 - 24, "f16", seed=12, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_WIN}, ctx="bench f16 ragged")
+    _check_sampled(torch, lib, b, layout, 8192 - 24, "f16", seed=12, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_STREAM}, ctx="bench f16 ragged")
 
 
 def test_bench_shape_skewed_layout(env):
@@ -114,7 +121,7 @@ def test_bench_shape_skewed_layout(env):
     torch, BSMM, lib = env
     layout = P.ba_layout(128, 14, seed=1)
     b = BSMM(layout, block_size=32, feature_axis=1)
-    _check_sampled(torch, lib, b, layout, 4096, "bf16", seed=13, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_WIN}, ctx="bench BA")
+    _check_sampled(torch, lib, b, layout, 4096, "bf16", seed=13, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_STREAM}, ctx="bench BA")
 
 
 # ---- (b) BASELINE configs[3] -----------------------------------------------------------------------------------------
@@ -126,7 +133,7 @@ def test_cfg3_8192_5pct(env, axis, N, force):
     torch, BSMM, lib = env
     layout = P.random_layout(256, 256, 0.05, seed=1234)
     b = BSMM(layout, block_size=32, feature_axis=axis)
-    expect = {"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_WIN} if (force or N >= 4096) else {}
+    expect = {"xprop": lib.K_XCOL32, "updat": _updat_kernel(lib, axis)} if (force or N >= 4096) else {}
     try:
         lib.set_kernel_variant(3 if force else 0)
         _check_sampled(torch, lib, b, layout, N, "bf16", seed=21, expect=expect, ctx="cfg3 a%d N%d force%d" % (axis, N, force))
@@ -135,17 +142,18 @@ def test_cfg3_8192_5pct(env, axis, N, force):
 
 
 # ---- (c) window variants ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("opt", ["PLAN_WINDOW_8", "PLAN_WINDOW_16", "PLAN_WINDOW_16W"])
+@pytest.mark.parametrize("opt", ["PLAN_WINDOW_8", "PLAN_WINDOW_16", "PLAN_WINDOW_16W", "PLAN_STREAM_16", "PLAN_STREAM_8"])
 @pytest.mark.parametrize("density", [0.05, 0.2])
 def test_updat_window_variants(env, opt, density):
     torch, BSMM, lib = env
     layout = P.random_layout(128, 128, density, seed=77)
     b = BSMM(layout, block_size=32, feature_axis=1, plan_options=getattr(lib, opt))
-    _check_sampled(torch, lib, b, layout, 2048, "bf16", seed=31, expect={"updat": lib.K_UPDAT_WIN}, ctx="%s d%.2f" % (opt, density), passes=("DW",))
+    _check_sampled(torch, lib, b, layout, 2048, "bf16", seed=31, expect={"updat": _updat_kernel(lib, 1, getattr(lib, opt))},
+                   ctx="%s d%.2f" % (opt, density), passes=("DW",))
 
 
 # ---- (d) small forced-plan layouts with several blocks per 16x16 window -----------------------------------------------
-@pytest.mark.parametrize("opt", [0, "PLAN_WINDOW_16", "PLAN_WINDOW_16W"])
+@pytest.mark.parametrize("opt", [0, "PLAN_WINDOW_16", "PLAN_WINDOW_16W", "PLAN_STREAM_8"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_small_layouts_multi_block_windows(env, opt, dtype):
     torch, BSMM, lib = env
@@ -161,10 +169,12 @@ def test_small_layouts_multi_block_windows(env, opt, dtype):
             for N in Ns:
                 W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=li * 7 + N)
                 x, e = P.to_dev(X, dtype, torch), P.to_dev(E, dtype, torch)
-                got = P.to_host(b.updat(x, e))
-                assert lib.last_kernel() == lib.K_UPDAT_WIN
-                l2, mx = P.errors(got, orc.round_to(orc.updat(t, X, E, 1), dtype))
-                assert l2 <= P.L2_BAR[dtype], (opt, li, N, l2)
+                for split in (0, 1, 3):                                 # library's choice / one workgroup per item / three
+                    b.updat_split = split
+                    got = P.to_host(b.updat(x, e))
+                    assert lib.last_kernel() == _updat_kernel(lib, 1, getattr(lib, opt) if opt else 0)
+                    l2, mx = P.errors(got, orc.round_to(orc.updat(t, X, E, 1), dtype))
+                    assert l2 <= P.L2_BAR[dtype], (opt, li, N, split, l2)
     finally:
         lib.set_kernel_variant(0)
 
