@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbsmm_hip.so")
+# BSMM_LIB: load another build of the same library (kernel A/B experiments: scripts/build_variants.py); product = the default
+LIB_PATH = os.environ.get("BSMM_LIB") or os.path.join(_HERE, "libbsmm_hip.so")
 
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2

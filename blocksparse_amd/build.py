@@ -18,6 +18,17 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(out, extra_flags):
+    """An experiment build of the whole library with extra compiler flags (-DU2_... switches) into `out` (see scripts/)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC] + list(extra_flags)
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + "\n".join([ln for ln in (r.stdout + r.stderr).splitlines() if "error" in ln][:10]))
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not _stale():
         return OUT

@@ -503,20 +503,24 @@ inline int device_cus() {
     return cus;
 }
 
-// Streaming kernel (bsmm_updat_v2.h, 'BSU2' plans).  Grid: a fixed number of workgroups over the flattened (item, chunk)
-// sequence -- one per CU, or `split` per item when the caller says so; one workgroup per item (split == 1, or so many items
-// that the tail does not matter) stores directly, otherwise partial sums meet in the fp32 workspace.
-struct U2Launch { int grid; bool scratch; };
+// Streaming kernel (bsmm_updat_v2.h, 'BSU2' plans).  Default grid: 8 x U workgroups (U = CUs / 8) in the XCD-aware schedule of
+// the plan (plan_inner = NSETS | common set size << 8).  Every item is ONE workgroup's -- and is stored directly -- when the plan
+// has 8 sets of equal size that fill whole rounds of U; otherwise partial sums meet in the fp32 workspace.  The caller can ask
+// for `split` workgroups per item instead (1: one per item, direct).
+struct U2Launch { int grid; bool scratch; int flat; };
 inline U2Launch updat2_shape(const bsmm_args* a, bool gated) {
-    const long nchunks = (a->N + U2_CH - 1) / U2_CH;
-    const long T = (long)a->plan_items * a->pcount * nchunks;
     const int cus = device_cus();
+    const int nsets = a->plan_inner & 255, common = a->plan_inner >> 8;
     U2Launch L;
-    if (a->split == 1 && !gated) { L.grid = a->plan_items; L.scratch = false; return L; }
-    if (a->split > 1) { L.grid = (int)std::min<long>((long)a->plan_items * a->split, std::max<long>(1, T)); L.scratch = true; return L; }
-    if (a->plan_items >= 4 * cus && !gated) { L.grid = a->plan_items; L.scratch = false; return L; }
-    L.grid = (int)std::max<long>(1, std::min<long>(cus, T / 4));     // >= 4 chunks per workgroup
-    L.scratch = true;
+    if (a->split >= 1) {
+        const long nchunks = (long)a->pcount * ((a->N + U2_CH - 1) / U2_CH);
+        const long sp = std::max<long>(1, std::min<long>(a->split, nchunks));
+        L.grid = (int)(a->plan_items * sp); L.scratch = sp > 1 || gated; L.flat = 1;
+        return L;
+    }
+    const int U = std::max(1, cus / 8);
+    L.grid = 8 * U; L.flat = 0;
+    L.scratch = gated || !(nsets == 8 && common > 0 && common % U == 0);
     return L;
 }
 
@@ -538,11 +542,11 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     if (a->plan_width == 16) {
         if (int rc = ensure_lds(&updat32_a1_v2_kernel<DT, 16>, u2_lds_bytes(16))) return rc;
         updat32_a1_v2_kernel<DT, 16><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(16), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                                     a->pcount, a->alpha, a->beta);
+                                                                                     a->pcount, a->alpha, a->beta, L.flat);
     } else {
         if (int rc = ensure_lds(&updat32_a1_v2_kernel<DT, 8>, u2_lds_bytes(8))) return rc;
         updat32_a1_v2_kernel<DT, 8><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(8), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                                   a->pcount, a->alpha, a->beta);
+                                                                                   a->pcount, a->alpha, a->beta, L.flat);
     }
     if (scratch)
         updat_finalize_gated_kernel<DT><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), nel, 1024, a->alpha, a->beta, gate);
@@ -599,7 +603,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                     // per-block kernel as fitted in round 1
                     const U2Launch L = updat2_shape(a, gated);
                     const double chunks = (double)a->plan_items * a->pcount * ((N + U2_CH - 1) / U2_CH);
-                    const double t_stream = 10.0 + std::ceil(chunks / L.grid) * 0.30 + (L.scratch ? 8.0 : 0.0);
+                    const double t_stream = 10.0 + std::ceil(chunks / L.grid) * 0.30 + (L.scratch ? 8.0 : 0.0);   // (refit after every kernel change)
                     const double rounds_b = std::max(1.0, std::ceil(a->blocks / 512.0));
                     const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * (N > 1024 ? 0.0105 : 0.0065);
                     stream = t_stream <= t_blk && !(gated && false);
@@ -926,7 +930,7 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
         // slack for the rows that do not pack: <= 56 on average), 8x8 windows for denser layouts
         const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);
         const int ws = force == BSMM_PLAN_STREAM_16 ? 16 : (force == BSMM_PLAN_STREAM_8 ? 8 : (blocks <= 56.0 * windows ? 16 : 8));
-        return build_updat2_plan(lut, blocks, CB, KB, ws, out);
+        return build_updat2_plan(lut, blocks, CB, KB, ws, out, (options >> 8) & 15);      // bits 8..11: item sets (experiments)
     }
     const int w = updat_window(blocks, CB, KB, axis, options);
     return build_updat_plan(lut, blocks, CB, KB, w == 8 ? 8 : 16, UP_MAXB, out, w == 1616 ? 16 : 8);
@@ -945,14 +949,15 @@ int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t
 }
 
 // descriptor of a flat (non-composite) plan: (magic, width, waves, items)
-static bool describe_flat(const int32_t* p, long words, int32_t d[4]) {
+static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
     if (words < 8) return false;
+    d[4] = 0;
     switch (p[0]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;
-        case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR) return false;   d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;
+        case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR) return false;   d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8] | (p[25] << 8); break;
         default: return false;
     }
     d[0] = p[0];
@@ -965,7 +970,7 @@ int bsmm_plan_attach(bsmm_args* a, const int32_t* host_plan, long words, const i
     a->plan_magic = a->plan_width = a->plan_waves = a->plan_items = a->plan_inner = 0;
     if (!device_plan) return BSMM_OK;
     if (!host_plan || words < 8 || (reinterpret_cast<uintptr_t>(device_plan) & 15)) return BSMM_ERR_ARG;
-    int32_t d[4];
+    int32_t d[5];
     if (host_plan[0] == S8PLAN_MAGIC) {
         if (host_plan[1] != S8PLAN_VERSION || host_plan[2] <= 0 || host_plan[6] != words) return BSMM_ERR_ARG;
         const int32_t off = host_plan[5];
@@ -974,7 +979,7 @@ int bsmm_plan_attach(bsmm_args* a, const int32_t* host_plan, long words, const i
         a->plan_magic = S8PLAN_MAGIC; a->plan_width = host_plan[2]; a->plan_waves = d[2]; a->plan_items = d[3]; a->plan_inner = d[1];
     } else {
         if (!describe_flat(host_plan, words, d)) return BSMM_ERR_ARG;
-        a->plan_magic = d[0]; a->plan_width = d[1]; a->plan_waves = d[2]; a->plan_items = d[3];
+        a->plan_magic = d[0]; a->plan_width = d[1]; a->plan_waves = d[2]; a->plan_items = d[3]; a->plan_inner = d[4];
     }
     a->plan = device_plan;
     return BSMM_OK;

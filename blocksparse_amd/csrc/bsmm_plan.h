@@ -440,13 +440,16 @@ inline long build_super8_updat_plan(const int32_t* updat_lut, int blocks, int CB
 // taken from at most TWO block rows of the window: the X^T fragment of a row is read from LDS once and reused by all of the
 // wave's blocks in that row (row pieces are packed first-fit-decreasing so that most waves hold a single row).  A window
 // with more blocks than slots, or whose rows cannot be packed that way, is cut into several items.
-// The kernel walks the flattened sequence (item, 16-row minibatch chunk) with a FIXED number of workgroups, each taking a
-// contiguous range of it, so any number of items fills the chip evenly; partial sums meet in an fp32 scratch (atomics).
-// Item order: workgroup u runs on XCD u % 8 (observed; speed only) and, at the bench shape, covers a quarter of the
-// minibatch of item u / 4 -- even list positions hold the windows of the upper half of the block rows, odd positions those
-// of the lower half, so an XCD's L2 sees one minibatch quarter of HALF of X and all of DY (1.5x the compulsory traffic
-// instead of 3x with a window patch per XCD).
+// Schedule: workgroup u runs on XCD u % 8 (observed; speed only).  The items are stored in NSETS lists ("sets": compact
+// patches of the window grid) and the minibatch is cut into 8 / NSETS parts; XCD x owns set x / (8 / NSETS) and part
+// x % (8 / NSETS), and its workgroups walk that set's items in lockstep through that part of the minibatch, so the slabs
+// of a window row / column are fetched into the XCD's L2 once and shared.  Few items (<= ~200: 16x16 windows of a 4096^2
+// layout) -> 2 sets (upper / lower half of the block rows) x 4 minibatch quarters: an XCD reads a quarter of HALF of X and
+// of all of DY (1.5x the compulsory traffic; a window patch per XCD reads 3x), partial sums meet in an fp32 scratch.
+// Many items -> 8 sets x the whole minibatch: every item is one workgroup's, stored directly.
 // Layout (int32): [0] magic 'BSU2' [1] version [2] WS [3] U2_SLOTS [4] nitems [5] nblocks [6] off_items [7] U2_WAVES
+//                 [8] NSETS (1, 2, 4 or 8) [9 + 2 s], [10 + 2 s] first item / item count of set s
+//                 [25] the item count of every set if they are all equal, else 0
 //   item: U2_ITEM = 4 + U2_WAVES * 5 words = (c0_block, k0_block, nblocks_in_item, 0) then per wave
 //         word 0 = n0 | n1 << 4 | cidx0 << 8 | cidx1 << 12 | kidx[0] << 16 | kidx[1] << 20 | kidx[2] << 24 | kidx[3] << 28
 //                  slots [0, n0) are blocks (cidx0, kidx[j]), slots [n0, n0 + n1) blocks (cidx1, kidx[j]) of the window
@@ -460,9 +463,9 @@ constexpr int U2_WAVES = 16;
 constexpr int U2_SLOTS = 4;
 constexpr int U2_WWORDS = 5;
 constexpr int U2_ITEM = 4 + U2_WAVES * U2_WWORDS;
-constexpr int U2_HDR = 8;
+constexpr int U2_HDR = 28;   // 9 + 2 * 8 set descriptors, padded to a multiple of 4 words
 
-inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out) {
+inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets = 0) {
     if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || (ws != 8 && ws != 16)) return -1;
     const int WS = ws;
     const int wc = (CB + WS - 1) / WS, wk = (KB + WS - 1) / WS;
@@ -475,7 +478,15 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
     }
     struct Piece { int row; std::vector<Ent> e; };            // <= U2_SLOTS blocks of one window row
     struct Wave { std::vector<Piece> p; int n = 0; };
-    std::vector<std::vector<int32_t>> half_items[2];           // items of the upper / lower half of the window rows
+    // sets: 2 -> upper / lower half of the window rows; 8 -> a 4 x 2 grid of window patches (as square as the grid allows)
+    long nwin = 0;
+    for (auto& v : win) nwin += !v.empty();
+    int nsets = (nwin >= 192 && wc >= 4 && wk >= 2) ? 8 : (wc >= 2 ? 2 : 1);
+    if (force_sets == 1 || (force_sets == 2 && wc >= 2) || (force_sets == 4 && wc >= 2 && wk >= 2) || (force_sets == 8 && wc >= 4 && wk >= 2))
+        nsets = force_sets;
+    const int pr = nsets == 8 ? 4 : (nsets == 4 ? 2 : nsets), pc = nsets >= 4 ? 2 : 1;       // patch grid over the windows
+    std::vector<std::vector<std::vector<int32_t>>> set_items(8), set_overflow(8);
+    bool overflow_item = false;
     auto emit = [&](int wi, int wj, const std::vector<Wave>& waves) {
         std::vector<int32_t> it(U2_ITEM, 0);
         int n = 0;
@@ -497,7 +508,8 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
             wd[0] = (int32_t)m;
         }
         it[0] = wi * WS; it[1] = wj * WS; it[2] = n;
-        half_items[(2 * wi >= wc) ? 1 : 0].push_back(std::move(it));
+        const int set = (nsets == 1) ? 0 : (((wi * pr / wc) * pc + (wj * pc / wk)) % nsets);
+        (overflow_item ? set_overflow : set_items)[set].push_back(std::move(it));
     };
     for (int wj = 0; wj < wk; ++wj)                 // column-major over the windows: consecutive items share their DY panel
         for (int wi = 0; wi < wc; ++wi) {
@@ -534,9 +546,11 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
             };
             std::vector<Wave> waves = pack(false);
             if (waves.size() > (size_t)U2_WAVES) waves = pack(true);
-            // more than U2_WAVES waves: the window becomes several items of about equal size (each streams the slabs once)
-            const size_t nit = (waves.size() + U2_WAVES - 1) / U2_WAVES;
-            const size_t per_item = (waves.size() + nit - 1) / nit;
+            // more than U2_WAVES waves: the window's main item takes the U2_WAVES most loaded waves, the few that remain
+            // become small OVERFLOW items at the end of the set's list -- the kernel cuts the last, incomplete round of a set
+            // into minibatch slices over all workgroups, so a small item there costs little (each slice adds its partial sums
+            // to the scratch: a big item in that position doubled the atomic traffic of the bench layout)
+            const size_t per_item = U2_WAVES;
             // spread the load over the four SIMDs: waves v, v+4, v+8, v+12 share a matrix pipe -> deal waves sorted by load
             std::sort(waves.begin(), waves.end(), [](const Wave& a, const Wave& b) { return a.n > b.n; });
             for (size_t beg = 0; beg < waves.size(); beg += per_item) {
@@ -550,20 +564,26 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
                     dealt[s + 4 * used[s]] = waves[beg + i];
                     load[s] += waves[beg + i].n; ++used[s];
                 }
+                overflow_item = beg > 0;
                 emit(wi, wj, dealt);
             }
         }
-    // interleave the two halves: even positions upper half, odd positions lower half (shorter list: the rest in sequence)
     std::vector<int32_t> items;
-    size_t ia = 0, ib = 0;
-    while (ia < half_items[0].size() || ib < half_items[1].size()) {
-        if (ia < half_items[0].size()) { items.insert(items.end(), half_items[0][ia].begin(), half_items[0][ia].end()); ++ia; }
-        if (ib < half_items[1].size()) { items.insert(items.end(), half_items[1][ib].begin(), half_items[1][ib].end()); ++ib; }
+    int32_t set_first[8] = {0}, set_count[8] = {0};
+    for (int st = 0; st < 8; ++st) {
+        set_first[st] = (int32_t)(items.size() / U2_ITEM);
+        set_count[st] = (int32_t)(set_items[st].size() + set_overflow[st].size());
+        for (auto& it : set_items[st]) items.insert(items.end(), it.begin(), it.end());
+        for (auto& it : set_overflow[st]) items.insert(items.end(), it.begin(), it.end());
     }
     const long nitems = (long)(items.size() / U2_ITEM);
     const long total = U2_HDR + (long)items.size();
     if (out) {
-        const int32_t hdr[U2_HDR] = {U2PLAN_MAGIC, U2PLAN_VERSION, WS, U2_SLOTS, (int32_t)nitems, blocks, U2_HDR, U2_WAVES};
+        int32_t hdr[U2_HDR] = {U2PLAN_MAGIC, U2PLAN_VERSION, WS, U2_SLOTS, (int32_t)nitems, blocks, U2_HDR, U2_WAVES, nsets};
+        for (int st = 0; st < 8; ++st) { hdr[9 + 2 * st] = set_first[st]; hdr[10 + 2 * st] = set_count[st]; }
+        bool equal = true;
+        for (int st = 1; st < nsets; ++st) equal = equal && set_count[st] == set_count[0];
+        hdr[25] = equal ? set_count[0] : 0;
         std::copy(hdr, hdr + U2_HDR, out);
         std::copy(items.begin(), items.end(), out + U2_HDR);
     }

@@ -10,15 +10,22 @@
 //     block; every slot of an item is a real block (per-wave slot counts, no padding MFMAs);
 //   * a wave's blocks come from at most two block ROWS of the window, whose X^T fragment is read once per row
 //     (2 + 2 n transposing reads for n blocks instead of 4 n);
-//   * 16-row chunks in a ring of four slots, the DMA of chunk i+3 requested right after the barrier of chunk i and
-//     `s_waitcnt vmcnt(2*NI)`: three chunks are always in flight and the queue never drains;
-//   * a FIXED grid walks the flattened (item, chunk) sequence, every workgroup a contiguous range of it: any item count
-//     fills the chip evenly, and the plan orders the items so that an XCD's workgroups read one minibatch quarter of half
-//     of X and all of DY (bsmm_plan.h);
-//   * partial sums of an item meet in the fp32 scratch (atomics; zeroed by the launcher) and updat_finalize_kernel applies
-//     alpha / beta (and the optional gate) with ONE rounding.  With one workgroup per item the tile is stored directly.
+//   * 16-row chunks in a ring of four slots, the DMA of chunk i+2 requested in interval i and `s_waitcnt vmcnt(NI)`:
+//     two chunks are always in flight and the queue never drains;
+//   * two wave sets per SIMD half an interval out of phase (one multiplies while the other's fragment reads are in flight);
+//   * the schedule of the plan (bsmm_plan.h): XCD x owns an item set and a part of the minibatch, its workgroups walk the
+//     set's items in lockstep through that part, so an XCD's L2 sees a quarter of half of X and of all of DY;
+//   * partial sums of an item meet in the fp32 scratch (atomics; zeroed by the launcher) and updat_finalize_gated_kernel
+//     applies alpha / beta (and the optional gate) with ONE rounding.  Items that are one workgroup's are stored directly.
 // LDS image of a chunk: X slab [16 rows][WS*64 B] then DY slab, 16-byte pieces of row r XOR-swizzled with 4*(r & 3)
 // (bank-conflict free for ds_read_b64_tr_b16, as in bsmm_updat_win.h).  1024 threads, 128 KiB (WS = 16): one workgroup per CU.
+//
+// Measured on the way (profiles/r02_updat_ablation.md): with everything but the loop skeleton compiled out (no DMA, no
+// fragment reads, no MFMA, no epilogue) the first version still took 53 of its 128 us -- ~600 cycles per 16-row interval of
+// scalar bookkeeping, branches and the barrier, against ~400 cycles of matrix work.  Hence the shape of the loop below: one
+// specialisation per (slots of row group 0, slots of row group 1, wave set), nothing but pointer increments in the regular
+// interval, and every irregularity (ragged last chunk of a pair, pair boundary, end of the range) inside `issue`, which
+// also ZEROES the rows past N in LDS so that the fragment reads never mask.
 #pragma once
 #include <type_traits>
 
@@ -28,9 +35,23 @@
 
 namespace bsmm {
 
-constexpr int U2_CH = 16;      // minibatch rows per chunk = one MFMA K-step
-constexpr int U2_D = 4;        // ring slots; prefetch distance U2_D - 1
+#ifndef U2_CH_ROWS
+#define U2_CH_ROWS 16
+#endif
+constexpr int U2_CH = U2_CH_ROWS;          // minibatch rows per chunk (one interval = one barrier): 16 or 32
+constexpr int U2_KS = U2_CH / 16;          // MFMA K-steps per chunk
+constexpr int U2_D = 64 / U2_CH;           // ring slots (128 KiB with 16x16 windows)
+constexpr int U2_AHEAD = U2_D / 2;         // prefetch distance in chunks (see the ring protocol at the chunk loop)
+static_assert(U2_CH == 16 || U2_CH == 32, "chunk = 1 or 2 K-steps");
 constexpr int u2_lds_bytes(int ws) { return U2_D * 2 * U2_CH * ws * 64; }
+
+// a wave-uniform pointer, provably so for the compiler (an "s" asm operand fed from a value it regards as divergent is
+// emitted as a VGPR and does not assemble)
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
+}
 
 // LDS-DMA with a scalar base and a 32-bit per-lane byte offset (saddr form): no 64-bit address VGPRs in the loop.
 __device__ __forceinline__ void glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
@@ -40,11 +61,42 @@ __device__ __forceinline__ void glds16_saddr(const void* sbase, uint32_t voff, u
                  : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
                  : "memory");
 }
+// NI consecutive 1 KiB pieces (LDS dst, dst + 1 KiB) from one scalar base: M0 is saved / restored once and stepped with a
+// scalar add; 5 scalar instructions for two DMAs.  (The CU has ONE scalar unit for its 16 waves: the ~40 scalar instructions
+// per wave and interval of the first version cost ~600 cycles per interval, more than the matrix work.)
+__device__ __forceinline__ void glds16_saddr_x2(const void* sbase, uint32_t voff0, uint32_t voff1, uint32_t lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff0), "v"(voff1), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ void glds16_saddr_x4(const void* sbase, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+}
+
+// entry `idx` (wave-uniform, runtime) of a pointer list that lives in kernel-argument SGPRs: a chain of scalar selects
+// (a dynamic index would make the compiler copy the list to scratch memory and read it back with vector loads)
+__device__ __forceinline__ const unsigned char* pick_ptr(const PtrList8& l, int idx) {
+    const void* p = l.p[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p = (idx == k) ? l.p[k] : p;
+    return static_cast<const unsigned char*>(p);
+}
 
 template <class DT, int WS>
 __global__ void __launch_bounds__(64 * U2_WAVES, 4)
 updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
-                     const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
+                     const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta, int flat) {
     typedef typename DT::T T;
     static_assert(DT::is16 && (WS == 8 || WS == 16), "updat v2: 16-bit storage types, 8x8 or 16x16 windows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -54,57 +106,81 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     constexpr int PPR = ROWB / 16;                // 16-byte pieces per row
     constexpr int RPI = 1024 / ROWB;              // rows per DMA instruction
     constexpr int IPO = U2_CH / RPI;              // DMA instructions per operand and chunk
-    constexpr int NI = 2 * IPO / U2_WAVES;        // DMA instructions per wave and chunk
-    static_assert(NI >= 1 && NI * U2_WAVES == 2 * IPO, "the chunk must split evenly over the waves");
+    constexpr int NI = 2 * IPO / U2_WAVES;        // DMA instructions per wave and chunk (consecutive pieces of ONE operand)
+    static_assert((NI == 1 || NI == 2 || NI == 4) && NI * U2_WAVES == 2 * IPO && IPO % NI == 0, "the chunk must split evenly over the waves");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nitems = plan[4];
     const int32_t* items = plan + plan[6];
     const int nchunks = (N + U2_CH - 1) / U2_CH;
-    const long CPI = (long)pcount * nchunks;                                  // chunks per item
-    const long TOT = (long)nitems * CPI;
-    long beg = (long)blockIdx.x * TOT / gridDim.x;
-    const long end = (long)(blockIdx.x + 1) * TOT / gridDim.x;
+    const int nfull = N / U2_CH;                                              // chunks of a pair with all U2_CH rows
+    const int CPI = pcount * nchunks;                                         // chunks per item (pairs back to back)
+    // ---- schedule (see bsmm_plan.h): XCD x = blockIdx.x % 8 owns item set x / nparts and minibatch part x % nparts; its
+    //      U = gridDim.x / 8 workgroups take the set's items in rounds of U, one item each over the whole part; a last
+    //      incomplete round of m items is cut into floor(U / m) slices of the part per item so that every workgroup works.
+    //      flat != 0: one set of all items, one part, the same rounds over all workgroups (grid = items x slices).
+    const bool xcd_mode = flat == 0 && (gridDim.x & 7) == 0;
+    const int nsets = xcd_mode ? plan[8] : 1;
+    const int nparts = xcd_mode ? 8 / nsets : 1;
+    const int U = xcd_mode ? gridDim.x >> 3 : gridDim.x;
+    const int xcd = xcd_mode ? (blockIdx.x & 7) : 0, uj = xcd_mode ? (blockIdx.x >> 3) : blockIdx.x;
+    const int set = xcd / nparts, part = xcd - set * nparts;
+    const int set_first = xcd_mode ? plan[9 + 2 * set] : 0, set_count = xcd_mode ? plan[10 + 2 * set] : plan[4];
+    const int part_lo = (int)((long)part * CPI / nparts), part_hi = (int)((long)(part + 1) * CPI / nparts);
+    const int full_rounds = set_count / U, m_last = set_count - full_rounds * U;
+    const int k_last = m_last > 0 ? U / m_last : 0;                          // slices per item of the last round
+    const int total_rounds = full_rounds + ((m_last > 0 && uj < m_last * k_last) ? 1 : 0);
 
     const uint32_t base_addr = lds_addr_of(smem);
-    // ---- DMA geometry of this wave: instruction NI*wave + i -> operand, rows, and this lane's 16-byte piece ----
-    int d_isE[NI], d_row[NI], d_piece[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int ii = NI * wave + i;
-        d_isE[i] = ii / IPO;                                                  // wave-uniform
-        const int row = (ii % IPO) * RPI + lane / PPR;
-        d_row[i] = row;
-        d_piece[i] = (lane % PPR) ^ (4 * (row & 3));                          // source piece of the LDS piece lane % PPR
-    }
+    // ---- DMA geometry of this wave: instructions NI*wave .. NI*wave + NI-1 of a chunk = consecutive 1 KiB pieces of one
+    //      operand's slab; instruction q covers slab rows d_row0 + q*RPI (+ lane / PPR), this lane's 16-byte piece lane % PPR ----
+    const int opE = (NI * wave) / IPO;                                        // 0: X slab, 1: DY slab (wave-uniform)
+    const int d_row0 = ((NI * wave) % IPO) * RPI + lane / PPR;
+    const uint32_t wave_off = opE * SLAB + ((NI * wave) % IPO) * 1024;        // my first piece inside a ring slot
+    const int F = opE ? Kf : Cf;                                              // row length of my operand
     // ---- fragment geometry (see bsmm_updat_tr.h): 16-lane group g16 -> features 16*(g16&1).., K half h ----
     const int g16 = lane >> 4, t16 = lane & 15;
     const int h = g16 >> 1;
     const int trow = t16 >> 2;
     const int tsub = (2 * (g16 & 1) + ((t16 & 3) >> 1)) * 16 + (t16 & 1) * 8;
     const int frag_row = (8 * h + trow) * ROWB + tsub;
+#ifdef U2_NO_PINGPONG
+    const bool setb = false;
+#else
+    const bool setb = wave >= U2_WAVES / 2;
+#endif
 
-    while (beg < end) {
-        const int item = (int)(beg / CPI);
-        const long r0 = beg - (long)item * CPI;
-        const int cnt = (int)((CPI - r0 < end - beg) ? (CPI - r0) : (end - beg));
-        beg += cnt;
+    for (int round = 0; round < total_rounds; ++round) {
+        int item, r0, cnt;
+        if (round < full_rounds) {
+            item = set_first + round * U + uj;
+            r0 = part_lo; cnt = part_hi - part_lo;
+        } else {
+            const int which = uj / k_last, slice = uj - which * k_last, L = part_hi - part_lo;
+            item = set_first + full_rounds * U + which;
+            r0 = part_lo + (int)((long)slice * L / k_last);
+            cnt = part_lo + (int)((long)(slice + 1) * L / k_last) - r0;
+        }
+        if (cnt <= 0) continue;
+        item = __builtin_amdgcn_readfirstlane(item);           // (wave-uniform by construction; say so to the compiler)
+        r0 = __builtin_amdgcn_readfirstlane(r0);
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
         const int32_t* it = items + (size_t)item * U2_ITEM;
         const int c0 = it[0], k0 = it[1];
         const int32_t* wd = it + 4 + wave * U2_WWORDS;
         const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane(wd[0]);
         const int n0 = meta & 15, n1 = (meta >> 4) & 15;
-        int wid[U2_SLOTS];
-#pragma unroll
-        for (int j = 0; j < U2_SLOTS; ++j) wid[j] = __builtin_amdgcn_readfirstlane(wd[1 + j]);
 
-        // per-lane source offsets (elements) inside a row of X / DY, clamped inside the matrix (clamped pieces belong to
-        // window columns no block of the item uses)
-        int d_col[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-            d_col[i] = d_isE[i] ? min(k0 * 32 + d_piece[i] * 8, Kf - 8) : min(c0 * 32 + d_piece[i] * 8, Cf - 8);
+        // per-lane byte offsets of my pieces inside a regular chunk (source columns clamped inside the matrix: clamped
+        // pieces belong to window columns no block of the item uses)
+        // (plain scalars, not arrays: with NI == 1 hipcc left a one-element array that lambdas capture by reference in scratch memory)
+        auto piece_off = [&](int q) {
+            const int row = d_row0 + q * RPI;
+            const int piece = (lane % PPR) ^ (4 * (row & 3));                 // source piece of the LDS piece lane % PPR
+            const int col = min((opE ? k0 : c0) * 32 + piece * 8, F - 8);
+            return (uint32_t)(row * F + col) * 2u;
+        };
+        const uint32_t voff0 = piece_off(0), voff1 = NI > 1 ? piece_off(1) : 0u, voff2 = NI > 2 ? piece_off(2) : 0u, voff3 = NI > 2 ? piece_off(3) : 0u;
         // fragment offsets inside a ring slot
         int aoff[2], boff[U2_SLOTS];
         aoff[0] = frag_row + ((((meta >> 8) & 15) ^ trow) << 6);
@@ -118,100 +194,202 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-        // the range's chunks are (pair, chunk-in-pair) = (ip, iq), (ip, iq + 1), ... wrapping into the next pair; the issue
-        // cursor runs U2_D - 1 chunks ahead of the compute cursor and stops at the range's last chunk (re-fetched, never read)
-        const int p_first = (int)(r0 / nchunks), q_first = (int)(r0 - (long)p_first * nchunks);
-        int ip = p_first, iq = q_first, issued = 0;
-        auto issue = [&](int pos) {
-            const int n_first = iq * U2_CH;
-            const T* Xp = static_cast<const T*>(Xs.p[ip]);
-            const T* Ep = static_cast<const T*>(Es.p[ip]);
-            if (++issued < cnt) {
-                if (++iq == nchunks) { iq = 0; ++ip; }
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int row = min(n_first + d_row[i], N - 1);               // rows past N: clamped re-reads, masked below
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(base_addr + pos * SLOT + d_isE[i] * SLAB + ((NI * wave + i) % IPO) * 1024);
-                const uint32_t voff = (uint32_t)(row * (d_isE[i] ? Kf : Cf) + d_col[i]) * 2u;
-                glds16_saddr(d_isE[i] ? (const void*)Ep : (const void*)Xp, voff, dst);
-            }
-        };
-
-        auto run = [&](auto n0_tag, auto n1_tag) {
+        // ---- DMA issue.  Issue k (k = 0 .. cnt + U2_AHEAD - 1; the first U2_AHEAD prime the ring, one more per interval) fetches
+        //      chunk min(k, cnt - 1) of the range into ring slot k % U2_D: exactly NI instructions per wave every time, so one
+        //      constant vmcnt tells that a chunk has landed (the issues past the end re-fetch the last chunk into a slot nobody
+        //      reads).  REGULAR issue: the chunk follows the previous one in the same pair and has all its rows -> the per-lane
+        //      offsets just advance by one chunk (vector ALU), `reg_left` counts how many such issues lie ahead.  Everything
+        //      else (first chunk, ragged last chunk of a pair: rows past N re-read row N - 1 and are zeroed in LDS before use,
+        //      pair boundary, past the end) goes through issue_slow, which recomputes the cursor from k.
+        const uint32_t fstride = (uint32_t)(U2_CH * F) * 2u;
+        // Two wave sets per SIMD (waves v, v+4 | v+8, v+12), half an interval out of phase: set A reads the fragments of
+        // chunk i and multiplies them; set B multiplies the fragments it read during the PREVIOUS interval and then reads
+        // chunk i's.  While one set's transposing reads are in flight the other set feeds the matrix pipe, with one barrier
+        // per chunk and no second fragment set in registers.  Ring protocol: at the top of interval i chunk i has landed
+        // (my share: vmcnt, everyone's: the barrier); the DMA issued in interval i fills slot (i + 2) % 4, last read in
+        // interval i - 2, and set B consumed those reads (its MFMAs of interval i - 1) before it passed barrier i.
+        // Scalar instructions per regular interval: the DMA block (5), its ring offset (3), reg_left and the loop (4) -- the CU
+        // has ONE scalar unit for its 16 waves; the fragment-read ring offset and the source offsets advance on the vector ALU.
+        auto run = [&](auto n0_tag, auto n1_tag, auto setb_tag) {
             constexpr int N0 = decltype(n0_tag)::value, N1 = decltype(n1_tag)::value;
+            constexpr bool SETB = decltype(setb_tag)::value;
+            uint4 a0 = zero_u4(), a1 = zero_u4(), b[(N0 + N1) ? (N0 + N1) : 1];
 #pragma unroll
-            for (int d = 0; d < U2_D - 1; ++d) issue(d);
-            int cq = q_first;
-            for (int i = 0; i < cnt; ++i) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (U2_D - 2)) : "memory");   // my share of chunk i has landed
-                __builtin_amdgcn_s_barrier();                                          // everyone's has; everyone left chunk i-1
-                issue((i + U2_D - 1) & (U2_D - 1));                                    // refills the slot chunk i-1 used
-                const int n_first = cq * U2_CH;
-                if (++cq == nchunks) cq = 0;
-                if constexpr (N0 > 0) {
-                    const unsigned char* slot = smem + (i & (U2_D - 1)) * SLOT;
-                    uint4 a0, a1;
-                    {
-                        const uint2 lo = ds_tr16(slot + aoff[0]), hi = ds_tr16(slot + aoff[0] + 4 * ROWB);
-                        a0 = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    }
-                    if constexpr (N1 > 0) {
-                        const uint2 lo = ds_tr16(slot + aoff[1]), hi = ds_tr16(slot + aoff[1] + 4 * ROWB);
-                        a1 = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    }
-                    if (n_first + U2_CH > N) {      // ragged tail: rows >= N were clamped re-reads -> zero them (X side suffices)
-                        const int nb = n_first + 8 * h;
-                        uint32_t* u0 = reinterpret_cast<uint32_t*>(&a0);
-                        uint32_t* u1 = reinterpret_cast<uint32_t*>(&a1);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
-                            u0[e] &= (lo | hi);
-                            if constexpr (N1 > 0) u1[e] &= (lo | hi);
-                        }
-                    }
-                    uint4 b[N0 + N1];
-#pragma unroll
-                    for (int j = 0; j < N0 + N1; ++j) {
-                        const uint2 lo = ds_tr16(slot + boff[j]), hi = ds_tr16(slot + boff[j] + 4 * ROWB);
-                        b[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    }
-#pragma unroll
-                    for (int j = 0; j < N0; ++j) acc[j] = DT::mfma32(a0, b[j], acc[j]);
-                    if constexpr (N1 > 0) {
-#pragma unroll
-                        for (int j = 0; j < N1; ++j) acc[N0 + j] = DT::mfma32(a1, b[N0 + j], acc[N0 + j]);
-                    }
+            for (int j = 0; j < N0 + N1; ++j) b[j] = zero_u4();   // set B multiplies "the previous fragments" from interval 0 on
+            auto read_frags = [&](const unsigned char* slot) {
+#ifdef U2_NO_READS
+                asm volatile("" ::"s"(slot));
+                return;
+#endif
+                {
+                    const uint2 lo = ds_tr16(slot + aoff[0]), hi = ds_tr16(slot + aoff[0] + 4 * ROWB);
+                    a0 = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 }
+                if constexpr (N1 > 0) {
+                    const uint2 lo = ds_tr16(slot + aoff[1]), hi = ds_tr16(slot + aoff[1] + 4 * ROWB);
+                    a1 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+#pragma unroll
+                for (int j = 0; j < N0 + N1; ++j) {
+                    const uint2 lo = ds_tr16(slot + boff[j]), hi = ds_tr16(slot + boff[j] + 4 * ROWB);
+                    b[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            };
+            auto multiply = [&]() {
+#ifndef U2_NO_MFMA
+#pragma unroll
+                for (int j = 0; j < N0; ++j) acc[j] = DT::mfma32(a0, b[j], acc[j]);
+                if constexpr (N1 > 0) {
+#pragma unroll
+                    for (int j = 0; j < N1; ++j) acc[N0 + j] = DT::mfma32(a1, b[N0 + j], acc[N0 + j]);
+                }
+#else
+#pragma unroll
+                for (int j = 0; j < N0 + N1; ++j) asm volatile("" ::"v"(b[j].x), "v"(b[j].y), "v"(b[j].z), "v"(b[j].w));
+                asm volatile("" ::"v"(a0.x), "v"(a0.y), "v"(a0.z), "v"(a0.w));
+                if constexpr (N1 > 0) asm volatile("" ::"v"(a1.x), "v"(a1.y), "v"(a1.z), "v"(a1.w));
+#endif
+            };
+            // issue state: plain locals of this scope, updated only by the two macros below (lambdas that captured them by
+            // reference made hipcc keep them in scratch memory, with vmcnt(0) waits around every access)
+            const unsigned char* fb = nullptr;      // base pointer of the current pair in my operand
+            uint32_t rv0 = 0, rv1 = 0, rv2 = 0, rv3 = 0;   // per-lane byte offsets of the NEXT regular issue
+            int reg_left = 0, k_issue = 0;
+#define U2_ISSUE_SLOW()                                                                                                      \
+    do {                                                                                                                     \
+        const int kk_ = min(k_issue, cnt - 1);                                                                               \
+        const int g_ = r0 + kk_, p_ = __builtin_amdgcn_readfirstlane(g_ / nchunks), q_ = g_ - p_ * nchunks;                  \
+        fb = static_cast<const unsigned char*>(uniform_ptr(opE ? pick_ptr(Es, p_) : pick_ptr(Xs, p_)));                      \
+        const uint32_t dst_ = __builtin_amdgcn_readfirstlane(base_addr + wave_off + (uint32_t)(k_issue & (U2_D - 1)) * SLOT); \
+        const uint32_t row_off_ = (uint32_t)(q_ * U2_CH * F) * 2u;                                                           \
+        const int over0_ = max(0, q_ * U2_CH + d_row0 - (N - 1)), over1_ = max(0, q_ * U2_CH + d_row0 + RPI - (N - 1));     \
+        const int over2_ = max(0, q_ * U2_CH + d_row0 + 2 * RPI - (N - 1)), over3_ = max(0, q_ * U2_CH + d_row0 + 3 * RPI - (N - 1)); \
+        U2_DMA1(fb, voff0 + row_off_ - (uint32_t)(over0_ * F) * 2u, dst_);                                                   \
+        if constexpr (NI >= 2) U2_DMA1(fb, voff1 + row_off_ - (uint32_t)(over1_ * F) * 2u, dst_ + 1024);                     \
+        if constexpr (NI == 4) U2_DMA1(fb, voff2 + row_off_ - (uint32_t)(over2_ * F) * 2u, dst_ + 2048);                     \
+        if constexpr (NI == 4) U2_DMA1(fb, voff3 + row_off_ - (uint32_t)(over3_ * F) * 2u, dst_ + 3072);                     \
+        rv0 = voff0 + row_off_ + fstride;                                                                                    \
+        rv1 = voff1 + row_off_ + fstride;                                                                                    \
+        rv2 = voff2 + row_off_ + fstride;                                                                                    \
+        rv3 = voff3 + row_off_ + fstride;                                                                                    \
+        reg_left = __builtin_amdgcn_readfirstlane(max(0, min(nfull - (q_ + 1), cnt - 1 - kk_)));                             \
+        ++k_issue;                                                                                                           \
+    } while (0)
+#ifndef U2_NO_DMA
+#define U2_DMA1(b_, v_, d_) glds16_saddr(b_, v_, d_)
+#define U2_DMA2(b_, v0_, v1_, d_) glds16_saddr_x2(b_, v0_, v1_, d_)
+#define U2_DMA4(b_, v0_, v1_, v2_, v3_, d_) glds16_saddr_x4(b_, v0_, v1_, v2_, v3_, d_)
+#else
+#define U2_DMA1(b_, v_, d_) asm volatile("" ::"v"(v_), "s"(d_), "s"(b_))
+#define U2_DMA2(b_, v0_, v1_, d_) asm volatile("" ::"v"(v0_), "v"(v1_), "s"(d_), "s"(b_))
+#define U2_DMA4(b_, v0_, v1_, v2_, v3_, d_) asm volatile("" ::"v"(v0_), "v"(v1_), "v"(v2_), "v"(v3_), "s"(d_), "s"(b_))
+#endif
+// one issue per interval: regular (pointer arithmetic only) or slow
+#define U2_ISSUE()                                                                                                           \
+    do {                                                                                                                     \
+        if (reg_left > 0) {                                                                                                  \
+            --reg_left; ++k_issue;                                                                                           \
+            if constexpr (NI == 4)      U2_DMA4(fb, rv0, rv1, rv2, rv3, ring_base + doff);                                       \
+            else if constexpr (NI == 2) U2_DMA2(fb, rv0, rv1, ring_base + doff);                                                 \
+            else                        U2_DMA1(fb, rv0, ring_base + doff);                                                      \
+            rv0 += fstride;                                                                                                  \
+            rv1 += fstride;                                                                                                  \
+            if constexpr (NI == 4) { rv2 += fstride; rv3 += fstride; }                                                       \
+        } else {                                                                                                             \
+            U2_ISSUE_SLOW();                                                                                                 \
+        }                                                                                                                    \
+        doff = (doff + SLOT) & (U2_D * SLOT - 1);                                                                            \
+    } while (0)
+            k_issue = 0; reg_left = 0;
+#pragma unroll
+            for (int d = 0; d < U2_AHEAD; ++d) U2_ISSUE_SLOW();
+            uint32_t vslot = 0;
+            asm volatile("" : "+v"(vslot));                     // the ring offset of the fragment reads lives on the vector ALU
+            uint32_t doff = (uint32_t)U2_AHEAD * SLOT;          // ring offset of the next DMA destination
+            const uint32_t ring_base = __builtin_amdgcn_readfirstlane(base_addr + wave_off);
+            int cq = __builtin_amdgcn_readfirstlane(r0 - (r0 / nchunks) * nchunks);   // chunk-in-pair index of the compute cursor (ragged N only)
+#pragma unroll 1
+            for (int i = 0; i < cnt; ++i) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * U2_AHEAD - NI) : "memory");   // my share of chunk i has landed
+                if (nfull != nchunks) {            // N % 16 != 0: is chunk i the ragged last chunk of its pair?  zero its rows >= N
+                    if (cq == nfull) {
+#pragma unroll
+                        for (int e = 0; e < NI; ++e)
+                            if (cq * U2_CH + d_row0 + e * RPI >= N)
+                                *reinterpret_cast<uint4*>(smem + (i & (U2_D - 1)) * SLOT + wave_off + e * 1024 + lane * 16) = zero_u4();
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    if (++cq == nchunks) cq = 0;
+                }
+                // (two-slot ring: the slot refilled in this interval is the one set B read at the END of the previous interval --
+                //  those reads must have returned before anyone may request the refill)
+                if constexpr (U2_D == 2 && SETB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef U2_NO_BARRIER
+                __builtin_amdgcn_s_barrier();                                               // everyone's has
+#endif
+                const unsigned char* slot = smem + vslot;
+                if constexpr (N0 == 0) {
+                    U2_ISSUE();
+                } else if constexpr (!SETB) {
+                    read_frags(slot);
+                    U2_ISSUE();
+                    multiply();
+#pragma unroll
+                    for (int ks = 1; ks < U2_KS; ++ks) { read_frags(slot + ks * 16 * ROWB); multiply(); }
+                } else {
+                    multiply();
+                    __builtin_amdgcn_sched_barrier(0);
+                    U2_ISSUE();
+#pragma unroll
+                    for (int ks = 0; ks < U2_KS - 1; ++ks) { read_frags(slot + ks * 16 * ROWB); multiply(); }
+                    read_frags(slot + (U2_KS - 1) * 16 * ROWB);
+                }
+                vslot = (vslot + SLOT) & (U2_D * SLOT - 1);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the run-ahead DMAs: the ring is re-primed by the next range
-            __builtin_amdgcn_s_barrier();
+#undef U2_ISSUE
+#undef U2_ISSUE_SLOW
+#undef U2_DMA1
+#undef U2_DMA2
+#undef U2_DMA4
+            if constexpr (SETB && N0 > 0) multiply();           // the fragments of the last chunk
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the re-fetches past the end
+            __builtin_amdgcn_s_barrier();                       // everyone has read the ring: the next range may re-prime it
         };
         using std::integral_constant;
+#define RUN(A, B)                                                                                                          \
+    do {                                                                                                                   \
+        if (setb) run(integral_constant<int, A>{}, integral_constant<int, B>{}, integral_constant<bool, true>{});          \
+        else      run(integral_constant<int, A>{}, integral_constant<int, B>{}, integral_constant<bool, false>{});         \
+    } while (0)
         switch (n0 * 8 + n1) {
-            case 0 * 8 + 0: run(integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
-            case 1 * 8 + 0: run(integral_constant<int, 1>{}, integral_constant<int, 0>{}); break;
-            case 1 * 8 + 1: run(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
-            case 1 * 8 + 2: run(integral_constant<int, 1>{}, integral_constant<int, 2>{}); break;
-            case 1 * 8 + 3: run(integral_constant<int, 1>{}, integral_constant<int, 3>{}); break;
-            case 2 * 8 + 0: run(integral_constant<int, 2>{}, integral_constant<int, 0>{}); break;
-            case 2 * 8 + 1: run(integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
-            case 2 * 8 + 2: run(integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
-            case 3 * 8 + 0: run(integral_constant<int, 3>{}, integral_constant<int, 0>{}); break;
-            case 3 * 8 + 1: run(integral_constant<int, 3>{}, integral_constant<int, 1>{}); break;
-            default:        run(integral_constant<int, 4>{}, integral_constant<int, 0>{}); break;
+            case 0 * 8 + 0: RUN(0, 0); break;
+            case 1 * 8 + 0: RUN(1, 0); break;
+            case 1 * 8 + 1: RUN(1, 1); break;
+            case 1 * 8 + 2: RUN(1, 2); break;
+            case 1 * 8 + 3: RUN(1, 3); break;
+            case 2 * 8 + 0: RUN(2, 0); break;
+            case 2 * 8 + 1: RUN(2, 1); break;
+            case 2 * 8 + 2: RUN(2, 2); break;
+            case 3 * 8 + 0: RUN(3, 0); break;
+            case 3 * 8 + 1: RUN(3, 1); break;
+            default:        RUN(4, 0); break;
         }
+#undef RUN
 
         // D[ci][ko]: col = ko = lane & 31, row ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
         for (int j = 0; j < U2_SLOTS; ++j) {
             if (j >= n0 + n1) break;
-            const size_t base = (size_t)wid[j] * 1024 + (lane & 31);
+            const int wid = __builtin_amdgcn_readfirstlane(wd[1 + j]);
+            const size_t base = (size_t)wid * 1024 + (lane & 31);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                 const size_t idx = base + ci * 32;
+#ifdef U2_NO_EPILOGUE
+                if (alpha == 12345.f) DW[idx] = DT::from_f32(acc[j][reg]);
+                continue;
+#endif
                 if (scratch == nullptr) {
                     float out = alpha * acc[j][reg];
                     if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);

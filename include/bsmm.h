@@ -98,7 +98,8 @@ typedef struct bsmm_args {
     int32_t plan_width;     /*   output blocks per workgroup (xprop) / window side (updat); bsize 8: number of super-blocks */
     int32_t plan_waves;     /*   waves per workgroup the schedule was dealt for                                          */
     int32_t plan_items;     /*   updat: number of work items (= grid size)                                               */
-    int32_t plan_inner;     /*   bsize 8: width / window side of the nested bsize-32 plan                                */
+    int32_t plan_inner;     /*   bsize 8: width / window side of the nested bsize-32 plan; streaming updat plan: its item
+                                 sets (header word [8] | word [25] << 8)                                                */
                             /* The launchers check the descriptor against the kernel they are about to launch and return
                                BSMM_ERR_ARG on a mismatch (a plan built with other options, or for another pass).        */
     int32_t flags;          /* BSMM_FLAG_* (0 = none)                                                                 */

@@ -271,12 +271,19 @@ def test_streaming_updat_plan(lib):
                             assert w == -1
                 assert cnt == n
             assert seen == set(range(t["blocks"]))
-            # the upper / lower half of the window rows alternate while both lists last
+            # the item sets (one per XCD group): contiguous lists that cover the items, each a compact patch of the window grid
+            nsets = int(plan[8])
+            assert nsets in (1, 2, 8)
+            firsts = [int(plan[9 + 2 * s_]) for s_ in range(8)]
+            counts = [int(plan[10 + 2 * s_]) for s_ in range(8)]
+            assert sum(counts) == nitems and all(c == 0 for c in counts[nsets:])
+            assert firsts[0] == 0 and all(firsts[i + 1] == firsts[i] + counts[i] for i in range(7))
+            assert int(plan[25]) == (counts[0] if len(set(counts[:nsets])) == 1 else 0)
             wc = -(-CB // WS)
-            halves = [int(2 * (int(it[0]) // WS) >= wc) for it in items]
-            n_up = halves.count(0)
-            n_alt = 2 * min(n_up, nitems - n_up)
-            assert halves[:n_alt] == [0, 1] * (n_alt // 2)
+            if nsets == 2:
+                for s_ in range(2):
+                    rows = set(int(it[0]) // WS for it in items[firsts[s_]:firsts[s_] + counts[s_]])
+                    assert all((2 * r >= wc) == bool(s_) for r in rows)
         if (CB, KB, dens) == (128, 128, 0.2):
             p16 = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, 0)
             assert 64 <= int(p16[4]) <= 72                      # ~one item per 16x16 window
