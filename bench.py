@@ -306,7 +306,7 @@ def main():
         print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get("BSMM_FORCE_DIST") == "1"   # the env forces the RCCL path at world_size 1 (self-test)
-    if use_dist:
+    if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     _lib.load()
 
@@ -337,19 +337,29 @@ def main():
 
     def run(b, w, x, dy, steps, warmup):
         """(seconds for `steps` steps [max over ranks], mean ms of fprop / updat / bprop from HIP events on the launch stream)"""
-        red = DwAllReduce(accumulate_fp32=True)
+        red = DwAllReduce(accumulate_fp32=True, force=use_dist)
         dw = torch.empty(b.w_shape, dtype=td, device="cuda")
+        fused = use_dist and a.bsize == 32 and a.axis == 1 and a.dtype != "f32"   # the streaming updat kernel can hand over fp32 sums
 
         def step(ev=None):
             if ev: ev[0].record()
             y = b.fprop(x, w)
             if ev: ev[1].record()
-            b.updat(x, dy, dw=dw)
-            if ev: ev[2].record()
-            red.start(dw)                  # overlaps with bprop
-            dx = b.bprop(dy, w)
-            if ev: ev[3].record()
-            red.wait()
+            if fused:
+                sums = b.updat(x, dy, sums_only=True)      # raw fp32 sums of this rank's minibatch shard
+                if ev: ev[2].record()
+                red.start(sums)                            # RCCL all-reduce in fp32, in place, on the library's side stream
+                dx = b.bprop(dy, w)                        # ... overlaps with bprop
+                if ev: ev[3].record()
+                red.wait()
+                b.updat_finalize(sums, dw=dw)              # one rounding, after the cross-rank sum
+            else:
+                b.updat(x, dy, dw=dw)
+                if ev: ev[2].record()
+                red.start(dw)                              # (fp32 copy inside: accumulate_fp32)
+                dx = b.bprop(dy, w)
+                if ev: ev[3].record()
+                red.wait()
             return y, dx
 
         if a.prewarm_seconds > 0:
@@ -362,18 +372,18 @@ def main():
             step()
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
         torch.cuda.synchronize()
-        if use_dist:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             step(evs[i])
         torch.cuda.synchronize()
-        if use_dist:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if use_dist:
+        if world > 1:
             t = torch.tensor([el], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -432,19 +442,23 @@ def main():
         out.update(parity_check(torch, b, layout, w, x, dy, a.dtype))
     if use_dist:
         # the dw all-reduce on its own (it overlaps with bprop inside the step): time alone, and how much of it the step hides
-        red = DwAllReduce(accumulate_fp32=True)
-        dw_t = torch.zeros(b.w_shape, dtype=td, device="cuda")
+        red = DwAllReduce(accumulate_fp32=True, force=True)
+        dw_t = torch.zeros(b.w_shape, dtype=torch.float32, device="cuda")
         for _ in range(5):
             red.start(dw_t); red.wait()
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
         t_ar = time.perf_counter()
         for _ in range(20):
             red.start(dw_t); red.wait()
         torch.cuda.synchronize()
         ar_ms = (time.perf_counter() - t_ar) / 20 * 1e3
-        tt = torch.tensor([ar_ms], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ar_ms = float(tt.item())
+        if world > 1:
+            tt = torch.tensor([ar_ms], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ar_ms = float(tt.item())
         compute_ms = sum(per)
         ms_step = head["ms_per_step"]
         out["allreduce"] = {"bytes": int(dw_t.numel() * 4), "dtype": "f32", "ms_alone": round(ar_ms, 4),
@@ -517,7 +531,7 @@ def main():
         sys.stdout.flush()
 
     flush_c_stdio()
-    if use_dist:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -12,16 +12,18 @@ LIB_PATH = os.environ.get("BSMM_LIB") or os.path.join(_HERE, "libbsmm_hip.so")
 
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
-FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN = 1, 2, 4, 8
+FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN, FLAG_DW_SUMS = 1, 2, 4, 8, 16
 # bsmm_args.trace codes (include/bsmm.h BSMM_K_*)
 K_XPROP_VALU, K_XPROP_SEGMENT, K_XCOL32, K_XCOL16, K_XCOL32_F32SPLIT, K_XCOL32_F32MFMA, K_XPROP_SUPER8 = 1, 2, 3, 4, 5, 6, 7
 K_UPDAT_VALU, K_UPDAT_BLOCK, K_UPDAT_BLOCK_TR, K_UPDAT_WIN, K_UPDAT16_WIN, K_UPDAT_SUPER8, K_UPDAT_STREAM = 16, 17, 18, 19, 20, 21, 22
 # plan-builder options (BSMM_PLAN_*)
 PLAN_XCOL_NARROW, PLAN_F32_MFMA, PLAN_WINDOW_8, PLAN_WINDOW_16, PLAN_WINDOW_16W, PLAN_STREAM_16, PLAN_STREAM_8 = 1, 2, 0x10, 0x20, 0x30, 0x40, 0x50
 
-SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_sparse_op", "bsmm_sparse_mul_grad", "bsmm_workspace_bytes",
+SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_updat_finalize", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_sparse_op", "bsmm_sparse_mul_grad", "bsmm_workspace_bytes",
            "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
            "bsmm_plan_attach", "bsmm_error_string", "bsmm_version")
+DIST_SYMBOLS = ("bsmm_dist_unique_id", "bsmm_dist_create", "bsmm_dist_allreduce_begin", "bsmm_dist_allreduce_end", "bsmm_dist_stream",
+                "bsmm_dist_world", "bsmm_dist_destroy")
 BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask")
 
 
@@ -98,6 +100,22 @@ def load():
     lib.bsmm_bprop.restype = ctypes.c_int
     lib.bsmm_updat.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), vp, pargs]
     lib.bsmm_updat.restype = ctypes.c_int
+    lib.bsmm_updat_finalize.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, vp]
+    lib.bsmm_updat_finalize.restype = ctypes.c_int
+    lib.bsmm_dist_unique_id.argtypes = [vp]
+    lib.bsmm_dist_unique_id.restype = ctypes.c_int
+    lib.bsmm_dist_create.argtypes = [ctypes.POINTER(vp), vp, i32, i32, i32]
+    lib.bsmm_dist_create.restype = ctypes.c_int
+    lib.bsmm_dist_allreduce_begin.argtypes = [vp, vp, ctypes.c_size_t, i32, vp]
+    lib.bsmm_dist_allreduce_begin.restype = ctypes.c_int
+    lib.bsmm_dist_allreduce_end.argtypes = [vp, vp]
+    lib.bsmm_dist_allreduce_end.restype = ctypes.c_int
+    lib.bsmm_dist_stream.argtypes = [vp]
+    lib.bsmm_dist_stream.restype = vp
+    lib.bsmm_dist_world.argtypes = [vp]
+    lib.bsmm_dist_world.restype = ctypes.c_int
+    lib.bsmm_dist_destroy.argtypes = [vp]
+    lib.bsmm_dist_destroy.restype = ctypes.c_int
     lib.bsmm_identity_init.argtypes = [vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.bsmm_identity_init.restype = ctypes.c_int
     lib.bsmm_gate_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]

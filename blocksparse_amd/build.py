@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 OUT = os.path.join(_HERE, "libbsmm_hip.so")
-SOURCES = ["bsmm_api.hip", "bst_api.hip"]
+SOURCES = ["bsmm_api.hip", "bst_api.hip", "bsmm_dist.hip"]
 HEADERS = ["bsmm_common.h", "bsmm_xprop.h", "bsmm_updat.h", "bsmm_plan.h", "bsmm_updat_tr.h", "bsmm_updat_win.h", "bsmm_updat_v2.h", "bsmm_xcol.h", "bsmm_xcol16.h", "bsmm_super8.h", "bsmm_xcols.h", "bst_kernels.h", "bsmm_l2norm.h", "bsmm_sparse_proj.h"]
 
 
@@ -14,7 +14,7 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "bsmm.h"), os.path.join(INCLUDE, "bst.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "bsmm.h"), os.path.join(INCLUDE, "bst.h"), os.path.join(INCLUDE, "bsmm_dist.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -22,7 +22,7 @@ def build_variant(out, extra_flags):
     """An experiment build of the whole library with extra compiler flags (-DU2_... switches) into `out` (see scripts/)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC] + list(extra_flags)
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + "\n".join([ln for ln in (r.stdout + r.stderr).splitlines() if "error" in ln][:10]))
@@ -37,7 +37,7 @@ def build(force=False, verbose=False):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, "-I" + CSRC]
     cmd += os.environ.get("BSMM_EXTRA_CXXFLAGS", "").split()
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     tmp = OUT + ".tmp"

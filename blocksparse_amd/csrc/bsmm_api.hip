@@ -529,7 +529,9 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     typedef typename DT::T T;
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     if (a->plan_magic != U2PLAN_MAGIC || a->plan_waves != U2_WAVES || a->plan_items <= 0 || (a->plan_width != 16 && a->plan_width != 8)) return BSMM_ERR_ARG;
-    const U2Launch L = updat2_shape(a, gate != nullptr);
+    U2Launch L = updat2_shape(a, gate != nullptr);
+    const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;
+    if (sums_only) L.scratch = true;
     float* scratch = nullptr;
     const size_t nel = (size_t)a->blocks * 1024;
     if (L.scratch) {
@@ -548,7 +550,7 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
         updat32_a1_v2_kernel<DT, 8><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(8), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
                                                                                    a->pcount, a->alpha, a->beta, L.flat);
     }
-    if (scratch)
+    if (scratch && !sums_only)
         updat_finalize_gated_kernel<DT><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), nel, 1024, a->alpha, a->beta, gate);
     return (int)hipGetLastError();
 }
@@ -566,6 +568,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     }
     const int variant = call_variant(a);
     const bool use_valu = (BS == 8) || variant == 1 || !vec_ok;
+    const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;     // only the streaming kernel can leave raw sums
     const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;   // gated dw: per-block kernels only
     const bool gated = ug != nullptr;
     if constexpr (BS == 8 && DT::is16) {
@@ -606,11 +609,12 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                     const double t_stream = 10.0 + std::ceil(chunks / L.grid) * 0.30 + (L.scratch ? 8.0 : 0.0);   // (refit after every kernel change)
                     const double rounds_b = std::max(1.0, std::ceil(a->blocks / 512.0));
                     const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * (N > 1024 ? 0.0105 : 0.0065);
-                    stream = t_stream <= t_blk && !(gated && false);
+                    stream = t_stream <= t_blk || sums_only;
                 }
                 if (stream) return launch_updat2<DT>(xs, es, DW, a, ug);
             }
         }
+        if (sums_only) return BSMM_ERR_UNSUPPORTED;
         if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_magic == UPLAN_MAGIC && a->plan_items > 0) {   // windowed kernels (plan = bsmm_updat_plan_build)
             // Sparse layouts at small minibatch (BASELINE configs[3]'s per-GPU shard: 8192^2, 5 %, N = 512): a window holds ~3
             // blocks, so the windowed kernel streams 64 KiB per chunk for almost nothing, while the per-block transposing-read
@@ -743,6 +747,8 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
     if (!X || !DY || !DW) return BSMM_ERR_ARG;
     if (a->pcount < 1 || a->pcount > 8) return BSMM_ERR_ARG;
     if ((rc = check_plan(true, a))) return rc;
+    if ((a->flags & BSMM_FLAG_DW_SUMS) && !(a->bsize == 32 && a->axis == 1 && a->dtype != BSMM_F32 && a->plan && a->plan_magic == U2PLAN_MAGIC))
+        return BSMM_ERR_UNSUPPORTED;
     PtrList8 xs, es;
     for (int p = 0; p < 8; ++p) {
         xs.p[p] = p < a->pcount ? X[p] : nullptr;
@@ -755,6 +761,23 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
         case BSMM_BF16: return updat_dt<DTbf16>(xs, es, DW, a);
     }
     return BSMM_ERR_UNSUPPORTED;
+}
+
+int bsmm_updat_finalize(const float* sums, void* DW, const float* gate, int32_t blocks, int32_t bsize, int32_t dtype, float alpha, float beta,
+                        void* stream) {
+    if (!sums || !DW || blocks <= 0) return BSMM_ERR_ARG;
+    if (bsize != 8 && bsize != 16 && bsize != 32) return BSMM_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(sums) & 15) || (reinterpret_cast<uintptr_t>(DW) & 7)) return BSMM_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t nel = (size_t)blocks * bsize * bsize;
+    const unsigned grid = (unsigned)((nel / 4 + 255) / 256);
+    switch (dtype) {
+        case BSMM_F16:  updat_finalize_gated_kernel<DTf16><<<grid, 256, 0, st>>>(sums, static_cast<uint16_t*>(DW), nel, bsize * bsize, alpha, beta, gate); break;
+        case BSMM_BF16: updat_finalize_gated_kernel<DTbf16><<<grid, 256, 0, st>>>(sums, static_cast<uint16_t*>(DW), nel, bsize * bsize, alpha, beta, gate); break;
+        case BSMM_F32:  updat_finalize_gated_kernel<DTf32><<<grid, 256, 0, st>>>(sums, static_cast<float*>(DW), nel, bsize * bsize, alpha, beta, gate); break;
+        default: return BSMM_ERR_UNSUPPORTED;
+    }
+    return (int)hipGetLastError();
 }
 
 int bsmm_l2_normalize(void* y, float* sum_sqr, const void* x, const float* gain, const int32_t* l2_lut, int32_t cols, int32_t bsize,

@@ -1,9 +1,15 @@
 """Data-parallel use of the hot path: replicate layout tables and W, shard the minibatch N over ranks
-(one process per GPU), sum the partial weight gradients with ONE all-reduce (RCCL over xGMI when the
-backend is "nccl"; gloo on CPU for tests).  fprop/bprop need no communication: every minibatch column
-is independent.  Replaces the reference's AllreduceNccl op for this path
-(/root/reference/src/nccl_op.cc:166-201, blocksparse/nccl.py:27-56).
-"""
+(one process per GPU), sum the partial weight gradients with ONE all-reduce per step.  fprop/bprop need no
+communication: every minibatch column is independent.  Replaces the reference's AllreduceNccl op
+for this path (/root/reference/src/nccl_op.cc:166-201, blocksparse/nccl.py:27-56).
+
+On ROCm devices the collective is RCCL over xGMI, called through the library's own C entry points
+(include/bsmm_dist.h: communicator + side stream + two events per handle, the record-on-compute / wait-on-comm
+pattern of src/nccl_op.cc:513,168) -- no Python-side async machinery between the kernels of a step.
+``torch.distributed`` is only the bootstrap channel that carries the 128-byte RCCL id from rank 0 to the others
+(any backend), and the data path for CPU tensors in the gloo tests."""
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -26,36 +32,112 @@ def shard_minibatch(t, feature_axis, rank, world):
     return flat[lo:hi].contiguous()
 
 
+class RcclComm(object):
+    """One RCCL communicator of the library (bsmm_dist_*) for this process' device.  world == 1 needs no bootstrap;
+    otherwise torch.distributed (already initialised, any backend) broadcasts rank 0's id."""
+
+    def __init__(self, device=None, group=None):
+        from . import _lib
+        self._lib = _lib.load()
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, self.world = 0, 1
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(self._lib.bsmm_dist_unique_id(ident), "bsmm_dist_unique_id")
+        if self.world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.bsmm_dist_create(ctypes.byref(h), ident, self.rank, self.world, self.device.index or 0), "bsmm_dist_create")
+        self._h = h
+        self._check = _lib.check
+
+    def begin(self, t):
+        """in-place all-reduce(sum) of a contiguous CUDA tensor, ordered after the work enqueued so far on the current stream"""
+        from .matmul import _dtype_code
+        st = torch.cuda.current_stream(t.device).cuda_stream
+        self._check(self._lib.bsmm_dist_allreduce_begin(self._h, t.data_ptr(), t.numel(), _dtype_code(t.dtype), st), "bsmm_dist_allreduce_begin")
+
+    def end(self):
+        """make the current stream wait for the collective"""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.bsmm_dist_allreduce_end(self._h, st), "bsmm_dist_allreduce_end")
+
+    def close(self):
+        if self._h:
+            self._lib.bsmm_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DwAllReduce(object):
     """Sum partial dw over ranks, overlapped with whatever the caller enqueues next (normally bprop).
 
-    start(dw) issues the collective asynchronously (for the NCCL/RCCL backend torch runs it on its own
-    communication stream, ordered after the producing kernel through an event -- the same
-    record-on-compute / wait-on-comm pattern as src/nccl_op.cc:513,168); wait() makes the current stream
-    wait for it.  ``accumulate_fp32`` all-reduces an fp32 copy so the cross-rank sum is not rounded to
-    16 bit per hop (RCCL supports bf16 too; the reference's op only took fp16/fp32, src/nccl_op.cc:140)."""
+    start(t) issues the collective and returns at once; wait() makes the current stream wait for it.  CUDA tensors go
+    through the library's RCCL handle (``comm``, created on first use) IN PLACE -- pass the fp32 sums of
+    ``BlocksparseMatMul.updat(sums_only=True)`` and the cross-rank sum is never rounded to 16 bit; a 16-bit tensor is
+    reduced in its own type unless ``accumulate_fp32`` (then through an fp32 copy).  CPU tensors (gloo tests) use
+    torch.distributed."""
 
-    def __init__(self, group=None, accumulate_fp32=False):
+    def __init__(self, group=None, accumulate_fp32=False, comm=None, force=False):
         self.group = group
         self.accumulate_fp32 = accumulate_fp32
+        self.comm = comm
+        self.force = force          # run the RCCL path also at world size 1 (self-test of the overlap machinery)
         self._work = None
         self._buf = None
         self._dst = None
+        self._direct = False
 
-    def start(self, dw):
-        if not dist.is_initialized():
-            self._work = None
-            return dw
-        if self.accumulate_fp32 and dw.dtype != torch.float32:
-            self._buf = dw.float()
-            self._dst = dw
+    def _active(self):
+        return self.force or (dist.is_initialized() and dist.get_world_size(self.group) > 1)
+
+    def start(self, t):
+        self._direct = False
+        if not self._active():
+            return t
+        if t.is_cuda:
+            if self.comm is None:
+                self.comm = RcclComm(t.device, self.group)
+            if self.accumulate_fp32 and t.dtype != torch.float32:
+                if self._buf is None or self._buf.shape != t.shape:
+                    self._buf = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+                self._buf.copy_(t)
+                self._dst = t
+                self.comm.begin(self._buf)
+            else:
+                self._dst = None
+                self.comm.begin(t)
+            self._direct = True
+            return t
+        if self.accumulate_fp32 and t.dtype != torch.float32:
+            self._buf = t.float()
+            self._dst = t
         else:
-            self._buf = dw
+            self._buf = t
             self._dst = None
         self._work = dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return dw
+        return t
 
     def wait(self):
+        if self._direct:
+            self.comm.end()
+            if self._dst is not None:
+                self._dst.copy_(self._buf)
+            self._dst = None
+            self._direct = False
+            return
         if self._work is not None:
             self._work.wait()
             self._work = None

@@ -288,11 +288,14 @@ class BlocksparseMatMul(object):
         _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
         return dx
 
-    def updat(self, xs, dys, alpha=1.0, beta=0.0, dw=None, gate=None):
+    def updat(self, xs, dys, alpha=1.0, beta=0.0, dw=None, gate=None, sums_only=False):
         """DW = alpha * sum_p updat(X_p, DY_p) + beta * DW  (ops BlocksparseMatmulDW / ...DWA).
 
         ``xs``/``dys``: one tensor each or equally long lists of up to 8 tensors (the reference's Plist).
-        ``gate``: gated dw (op attr gated_dw): the sum of block w is scaled by gate[w]."""
+        ``gate``: gated dw (op attr gated_dw): the sum of block w is scaled by gate[w].
+        ``sums_only``: return the raw fp32 sums [blocks, bs, bs] (a view of the call's workspace, valid until the next updat on
+        this stream) instead of DW -- the data-parallel path all-reduces them in fp32 and calls ``updat_finalize``; only the
+        streaming kernel (bsize 32, feature axis 1, 16-bit types) can, other configurations raise BsmmError(-2)."""
         if isinstance(xs, torch.Tensor):
             xs, dys = [xs], [dys]
         if len(xs) != len(dys) or not 1 <= len(xs) <= 8:
@@ -310,7 +313,9 @@ class BlocksparseMatMul(object):
         lib = _lib.load()
         dev = xs[0].device
         tabs = self._tables_on(dev)
-        if dw is None:
+        if sums_only:
+            dw = None
+        elif dw is None:
             if beta != 0.0:
                 raise ValueError("beta != 0 needs dw")
             dw = torch.empty(self.w_shape, dtype=xs[0].dtype, device=dev)
@@ -321,13 +326,33 @@ class BlocksparseMatMul(object):
         a = self._args(tabs.updat, None, N, self.C, self.K, xs[0].dtype, pcount=len(xs), alpha=alpha, beta=beta,
                        plan=tabs.updat_plan if xs[0].dtype != torch.float32 else None)
         gate = self._check_gate(gate, dev)
-        if gate is not None:
+        if gate is not None and not sums_only:
             a.gate, a.flags = gate.data_ptr(), a.flags | _lib.FLAG_GATED_DW
-        self._workspace(a, _lib.OP_UPDAT, dev)
+        if sums_only:
+            a.flags |= _lib.FLAG_DW_SUMS
+        ws = self._workspace(a, _lib.OP_UPDAT, dev)
         arr = ctypes.c_void_p * len(xs)
         xp = arr(*[t.data_ptr() for t in xs])
         ep = arr(*[t.data_ptr() for t in dys])
-        _lib.check(lib.bsmm_updat(xp, ep, dw.data_ptr(), ctypes.byref(a)), "bsmm_updat")
+        _lib.check(lib.bsmm_updat(xp, ep, dw.data_ptr() if dw is not None else 16, ctypes.byref(a)), "bsmm_updat")
+        if sums_only:
+            n = self.blocks * self.bsize * self.bsize
+            return ws[:4 * n].view(torch.float32).view(self.w_shape)
+        return dw
+
+    def updat_finalize(self, sums, alpha=1.0, beta=0.0, dw=None, gate=None, dtype=None):
+        """DW = alpha * [gate *] sums + beta * DW, rounded once: the second half of ``updat(..., sums_only=True)``."""
+        self._check_tensor(sums, "sums")
+        if sums.dtype != torch.float32 or tuple(sums.shape) != self.w_shape or not sums.is_contiguous():
+            raise ValueError("sums must be the contiguous float32 %s tensor updat(sums_only=True) returned" % (self.w_shape,))
+        if dw is None:
+            if beta != 0.0:
+                raise ValueError("beta != 0 needs dw")
+            dw = torch.empty(self.w_shape, dtype=dtype or torch.bfloat16, device=sums.device)
+        gate = self._check_gate(gate, sums.device)
+        st = torch.cuda.current_stream(sums.device).cuda_stream
+        _lib.check(_lib.load().bsmm_updat_finalize(sums.data_ptr(), dw.data_ptr(), gate.data_ptr() if gate is not None else None, self.blocks,
+                                                   self.bsize, _dtype_code(dw.dtype), alpha, beta, st), "bsmm_updat_finalize")
         return dw
 
     def updat_grouped(self, xs, dys, group_size=8, dw=None, alpha=1.0):

@@ -50,7 +50,11 @@ enum {
     BSMM_FLAG_GATED_DW = 1,     /* updat: scale dw by the gate (op attr gated_dw, src/blocksparse_matmul_op.cc:363,403)  */
     BSMM_FLAG_FORCE_VALU = 2,   /* per call: plain V_FMA kernels for every bsize (independent second implementation)      */
     BSMM_FLAG_NO_PLAN = 4,      /* per call: ignore bsmm_args.plan (per-segment / per-block matrix-core kernels)          */
-    BSMM_FLAG_FORCE_PLAN = 8    /* per call: take the plan kernels whenever a plan is given, whatever the size heuristic   */
+    BSMM_FLAG_FORCE_PLAN = 8,   /* per call: take the plan kernels whenever a plan is given, whatever the size heuristic   */
+    BSMM_FLAG_DW_SUMS = 16      /* updat: leave the raw fp32 sums sum_p X_p DY_p^T of every block in the workspace
+                                   ([blocks][bsize][bsize] floats at its start) and do NOT write DW -- the data-parallel path
+                                   all-reduces those sums in fp32 and then calls bsmm_updat_finalize().  Kernels that cannot
+                                   (no plan / not the streaming kernel) answer BSMM_ERR_UNSUPPORTED                          */
 };
 
 /* bsmm_args.trace: which kernel family a call dispatched to (tests assert that the intended kernel ran) */
@@ -133,6 +137,11 @@ int bsmm_bprop(const void* DY, const void* W, void* DX, const bsmm_args* args);
 /* DW = alpha * sum_{p<pcount} updat(X[p], DY[p]) + beta * DW.  args->lut = updat_lut.
  * X and DY are HOST arrays of pcount device pointers. */
 int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm_args* args);
+
+/* Second half of an updat issued with BSMM_FLAG_DW_SUMS: DW[w] = alpha * [gate[w] *] sums[w] + beta * DW[w], one rounding.
+ * sums: fp32 [blocks][bsize][bsize] (the workspace of that call, possibly all-reduced in between); gate may be NULL. */
+int bsmm_updat_finalize(const float* sums, void* DW, const float* gate, int32_t blocks, int32_t bsize, int32_t dtype, float alpha,
+                        float beta, void* stream);
 
 /* W[w] = scale * I if (c % KB) == (k % CB) else 0, (c,k) = updat_lut[w];  dtype as BSMM_* */
 int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks,

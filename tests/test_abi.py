@@ -395,3 +395,16 @@ def test_library_reads_no_environment_and_keeps_no_switches(lib):
         src += open(os.path.join(ROOT, "blocksparse_amd", "csrc", f)).read()
     assert "getenv" not in src and "g_variant" not in src and "static bool attr_set" not in src
     assert not hasattr(ctypes.CDLL(lib.LIB_PATH), "bsmm_set_kernel_variant")
+
+
+def test_dist_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "bsmm_dist.h")).read()
+    declared = set(re.findall(r"\b(bsmm_dist_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(lib.DIST_SYMBOLS), declared ^ set(lib.DIST_SYMBOLS)
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    for s in declared:
+        getattr(raw, s)
+    L = lib.load()
+    assert L.bsmm_dist_unique_id(None) == -1                       # argument checks come before RCCL is touched
+    assert L.bsmm_dist_allreduce_begin(None, None, 0, 0, None) == -1
+    assert L.bsmm_dist_destroy(None) == 0
