@@ -48,7 +48,7 @@ class BstArgs(ctypes.Structure):
         ("lut", ctypes.c_void_p), ("lut_heads", ctypes.c_int32), ("lut_dim", ctypes.c_int32),
         ("blocks", ctypes.c_int32), ("bsize", ctypes.c_int32), ("batch", ctypes.c_int32), ("heads", ctypes.c_int32),
         ("head_state", ctypes.c_int32), ("ctx_blks_q", ctypes.c_int32), ("ctx_blks_k", ctypes.c_int32),
-        ("dtype", ctypes.c_int32), ("score_dtype", ctypes.c_int32), ("stream", ctypes.c_void_p),
+        ("dtype", ctypes.c_int32), ("score_dtype", ctypes.c_int32), ("flags", ctypes.c_int32), ("stream", ctypes.c_void_p),
     ]
 
 

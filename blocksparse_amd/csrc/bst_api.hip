@@ -75,7 +75,7 @@ int bst_nt(const void* a_, const void* b_, void* s_, const bst_args* a) {
                     constexpr int CH = decltype(ch_tag)::value;
                     const int il = 1;     // heads of an XCD interleaved workgroup by workgroup: 2 / 4 / 8 made no difference
                     const int grid = xcd_head_grid((ntiles + NT_NB - 1) / NT_NB, a->heads, a->batch, il);
-                    static const bool split = [] { const char* e = getenv("BST_NT_SPLIT"); return e ? atoi(e) != 0 : true; }();
+                    const bool split = !(a->flags & BST_FLAG_FP32_MFMA);
                     if constexpr (!TA::is16) {
                         if (split) {     // fp32 activations: exact bf16 piece products on the 16-bit matrix core
                             bst_nt_mfma_kernel<TA, TS, BS, CH, true><<<grid, 64, 0, st>>>(A, B, S, a->lut, lut_stride(a), a->blocks, a->heads, a->batch, a->head_state, rq, rk, il);
@@ -127,8 +127,8 @@ static int bst_xn(const void* s_, const void* b_, void* c_, const bst_args* a, b
                     }
                 }
                 if constexpr (BS >= 32 && std::is_same<TB, DTf32>::value && std::is_same<TS, DTbf16>::value) {
-                    // fp32 activations x bf16 scores: exact three-way bf16 split on the 16-bit matrix core (BST_XN_SPLIT=0: fp32 MFMA)
-                    static const bool split = [] { const char* e = getenv("BST_XN_SPLIT"); return e ? atoi(e) != 0 : true; }();
+                    // fp32 activations x bf16 scores: exact three-way bf16 split on the 16-bit matrix core (BST_FLAG_FP32_MFMA: fp32 MFMA)
+                    const bool split = !(a->flags & BST_FLAG_FP32_MFMA);
                     if (split) {
                         constexpr int SUBS = BS / 32;
                         const int grids = xcd_head_grid(ctx_c * SUBS * ((a->head_state + 31) / 32), a->heads, a->batch);

@@ -36,6 +36,8 @@
 extern "C" {
 #endif
 
+enum { BST_FLAG_FP32_MFMA = 1 };   /* fp32 activations: the fp32 matrix-core kernels instead of the exact bf16 three-piece split (A/B) */
+
 typedef struct bst_args {
     const int32_t* lut;   /* device: the table this entry point walks (nt: nt_lut, nn: nn_lut, tn: tn_lut, softmax: nn_lut) */
     int32_t lut_heads;    /* heads or 1                                                                                      */
@@ -49,6 +51,7 @@ typedef struct bst_args {
     int32_t ctx_blks_k;   /* key    blocks (columns of the layout)                                                            */
     int32_t dtype;        /* activations: BSMM_F32 / BSMM_F16 / BSMM_BF16                                                     */
     int32_t score_dtype;  /* scores: BSMM_BF16 / BSMM_F16                                                                     */
+    int32_t flags;        /* BST_FLAG_* (0 = none); kernel choice is a function of the arguments only, never of the environment */
     void* stream;         /* hipStream_t                                                                                      */
 } bst_args;
 

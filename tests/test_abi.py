@@ -391,7 +391,7 @@ def test_plan_attach_descriptor_and_host_side_rejection(lib):
 def test_library_reads_no_environment_and_keeps_no_switches(lib):
     """include/bsmm.h promises a stateless library: no getenv, no process-wide kernel switch in the sources."""
     src = ""
-    for f in ("bsmm_api.hip",):
+    for f in ("bsmm_api.hip", "bst_api.hip", "bsmm_dist.hip"):
         src += open(os.path.join(ROOT, "blocksparse_amd", "csrc", f)).read()
     assert "getenv" not in src and "g_variant" not in src and "static bool attr_set" not in src
     assert not hasattr(ctypes.CDLL(lib.LIB_PATH), "bsmm_set_kernel_variant")
