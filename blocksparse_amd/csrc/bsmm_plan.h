@@ -172,6 +172,109 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
 }  // namespace bsmm
 
 // =================================================================================================
+// staged xcol plan ('BSX2'): schedule of the kernel that stages the weight blocks through LDS as well (bsmm_xcol_v2.h).
+// Groups of X2_G = 16 consecutive output blocks as in the xcol plan, wave v owns output block first + v.  The pair walk of a
+// group is cut into PHASES: up to two steps (pairs) and up to X2_WCAP weight blocks, which is what the two halves of the
+// LDS ring hold (2 x 2 activation slabs of 16 KiB + 2 x X2_WCAP weight blocks of 2 KiB).  A step with more blocks than
+// that is split into sub-steps (the same pair twice).  Every weight block of a phase has a SLOT in the phase's half of the
+// weight ring; its two 1 KiB halves are fetched by DMA instructions dealt evenly over the 16 waves (<= 3 each).
+// Layout (int32): [0] magic 'BSX2' [1] version [2] X2_G [3] ngroups [4] nphases_total [5] off_groups [6] off_px
+//                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] X2_WCAP [10] max phases of a group
+//   groups[ngroups][4] = (phase_off, nphases, first_out_block, n_out_blocks_in_group)
+//   px [nphases_total]           pair of step 0 | pair of step 1 << 16   (0xffff = no such step)
+//   tab[nphases_total][16][4]    per phase and wave:
+//        [0] slots this wave multiplies: byte 2*u + half = slot of (step u, half of the pair), 0xff = none
+//        [1..3] DMA duties: (2 * weight block + half) | (2 * slot + half) << 26, or -1
+// =================================================================================================
+namespace bsmm {
+
+constexpr int32_t X2PLAN_MAGIC = 0x42535832;
+constexpr int32_t X2PLAN_VERSION = 1;
+constexpr int X2_G = 16;
+constexpr int X2_WCAP = 24;
+constexpr int X2_HDR = 12;
+
+inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
+    if (blocks >= (1 << 25)) return 0;                                       // field widths of the tables
+    const int G = X2_G, ngroups = (n_out_blocks + G - 1) / G;
+    struct E { int p, wave, half, w; };
+    std::vector<std::vector<E>> per_group(ngroups);
+    for (int s = 0; s < segments; ++s) {
+        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
+        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
+        for (int e = 0; e < cnt; ++e) {
+            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
+            if (w < 0 || w >= blocks || c < 0) return -1;
+            if (c >= 2 * 0xffff) return 0;
+            per_group[ob / G].push_back({c >> 1, ob % G, c & 1, w});
+        }
+    }
+    std::vector<int32_t> groups, px, tab;
+    int max_ph = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        auto& v = per_group[g];
+        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : (a.wave != b.wave ? a.wave < b.wave : a.half < b.half); });
+        // steps: runs of equal pair, at most X2_WCAP entries each (a wave's two halves stay in one step)
+        struct Step { int p; size_t lo, hi; };
+        std::vector<Step> steps;
+        for (size_t i = 0; i < v.size();) {
+            size_t j = i;
+            while (j < v.size() && v[j].p == v[i].p) ++j;
+            size_t lo = i;
+            while (lo < j) {
+                size_t hi = std::min(j, lo + X2_WCAP);
+                if (hi < j && v[hi].wave == v[hi - 1].wave) --hi;          // do not part the halves of one wave
+                steps.push_back({v[i].p, lo, hi});
+                lo = hi;
+            }
+            i = j;
+        }
+        const int phase_off = (int)px.size();
+        for (size_t s = 0; s < steps.size();) {
+            const size_t n0 = steps[s].hi - steps[s].lo;
+            const bool two = s + 1 < steps.size() && n0 + (steps[s + 1].hi - steps[s + 1].lo) <= (size_t)X2_WCAP;
+            const int nst = two ? 2 : 1;
+            px.push_back(steps[s].p | ((two ? steps[s + 1].p : 0xffff) << 16));
+            std::vector<int32_t> row((size_t)G * 4, -1);
+            int slot = 0, duty = (int)(px.size() * 5) % G;                 // rotate the wave that gets the first duty
+            std::vector<int> nduty(G, 0);
+            for (int u = 0; u < nst; ++u)
+                for (size_t i = steps[s + u].lo; i < steps[s + u].hi; ++i, ++slot) {
+                    const E& e = v[i];
+                    int32_t& cw = row[(size_t)e.wave * 4];
+                    const int sh = 8 * (2 * u + e.half);
+                    cw = (int32_t)(((uint32_t)cw & ~(0xffu << sh)) | ((uint32_t)slot << sh));
+                    for (int hb = 0; hb < 2; ++hb) {
+                        const int wv = duty; duty = (duty + 1) % G;
+                        row[(size_t)wv * 4 + 1 + nduty[wv]++] = (int32_t)((uint32_t)(2 * e.w + hb) | ((uint32_t)(2 * slot + hb) << 26));
+                    }
+                }
+            tab.insert(tab.end(), row.begin(), row.end());
+            s += nst;
+        }
+        const int nph = (int)px.size() - phase_off;
+        max_ph = std::max(max_ph, nph);
+        groups.insert(groups.end(), {phase_off, nph, g * G, std::min(G, n_out_blocks - g * G)});
+    }
+    const int off_groups = X2_HDR, off_px = off_groups + (int)groups.size();
+    const int off_tab = (off_px + (int)px.size() + 3) & ~3;
+    const long total = off_tab + (long)tab.size();
+    if (out) {
+        std::fill(out, out + off_tab, 0);
+        const int32_t hdr[X2_HDR] = {X2PLAN_MAGIC, X2PLAN_VERSION, G, ngroups, (int32_t)px.size(), off_groups, off_px, off_tab,
+                                     n_out_blocks, X2_WCAP, max_ph, 0};
+        std::copy(hdr, hdr + X2_HDR, out);
+        std::copy(groups.begin(), groups.end(), out + off_groups);
+        std::copy(px.begin(), px.end(), out + off_px);
+        std::copy(tab.begin(), tab.end(), out + off_tab);
+    }
+    return total;
+}
+
+}  // namespace bsmm
+
+// =================================================================================================
 // xcolf plan (bsize 32, fp32): the groups and pair walk of the xcol plan, but the work is dealt differently because the
 // fp32 kernel is MFMA-bound and must keep every wave equally busy: wave (t, c) owns row tile t of the workgroup's 128
 // minibatch rows and output blocks 4c..4c+3 of the group, so all waves of class c do identical work, and the two classes

@@ -1,0 +1,221 @@
+// bsmm_xcol_v2.h -- xprop kernel "wave owns an output column" with the WEIGHTS staged through LDS too ('BSX2' plans),
+// feature_axis = 1, bsize 32, 16-bit storage types.
+//
+// What bounded bsmm_xcol.h (99 us per pass at the bench shape against ~22 us of matrix work): a wave fetched its weight
+// fragments into registers with ordinary loads one step ahead, and the vector-memory counter is in order -- so the
+// `s_waitcnt vmcnt(0)` in front of every step also waited for the activation slabs of the NEXT phase that had just been
+// requested (16 drains per phase; a phase was one memory round trip long whatever the matrix work), and four register sets
+// of fragments kept the kernel on the 128-register edge.  Here everything a phase needs comes by LDS-DMA, requested one
+// whole phase ahead by whichever wave the plan names, and there is ONE wait per phase:
+//   workgroup = 16 output blocks x 128 minibatch rows, 16 waves, wave v owns output block v (4 row tiles x 16 accumulators);
+//   phase = up to 2 pair steps and up to X2_WCAP weight blocks (bsmm_plan.h); LDS = 2 halves x (2 activation slabs of
+//   16 KiB + X2_WCAP weight blocks of 2 KiB) = 160 KiB;
+//   per phase and wave: vmcnt(0) + barrier; 2 slab DMAs + <= 3 weight DMAs for the next phase; then for each of its <= 4
+//   blocks 2 + 8 ds_read_b128 and 8 MFMAs.
+//   activation slab: rows of 128 B, the eight 16-byte pieces of row r XOR-swizzled with (r >> 1) & 7;
+//   weight block:   rows of 64 B, the four pieces of row r XOR-swizzled with (r >> 2) & 3 (both conflict-free for b128).
+#pragma once
+#include "bsmm_common.h"
+#include "bsmm_plan.h"
+#include "bsmm_updat_v2.h"   // glds16_saddr, uniform_ptr
+#include "bsmm_xprop.h"      // XMap
+
+namespace bsmm {
+
+// measurement switches (ablation builds, scripts/build_variants.py): wrong results by construction
+#ifndef X2_NO_XDMA
+#define X2_NO_XDMA 0
+#endif
+#ifndef X2_NO_WDMA
+#define X2_NO_WDMA 0
+#endif
+#ifndef X2_NO_READS
+#define X2_NO_READS 0
+#endif
+#ifndef X2_NO_MFMA
+#define X2_NO_MFMA 0
+#endif
+#ifndef X2_NO_EPILOGUE
+#define X2_NO_EPILOGUE 0
+#endif
+#ifndef X2_READS_FIRST
+#define X2_READS_FIRST 0     // 1: all ten fragment reads of a block before its first MFMA
+#endif
+#ifndef X2_LATE_ISSUE
+#define X2_LATE_ISSUE 0      // 1: odd waves request the next phase AFTER their blocks
+#endif
+constexpr int X2_R = 128;                          // minibatch rows per workgroup
+constexpr int X2_SLAB = X2_R * 128;                // 16 KiB
+constexpr int X2_XHALF = 2 * X2_SLAB;              // activation bytes per ring half
+constexpr int X2_WHALF = X2_WCAP * 2048;           // weight bytes per ring half
+constexpr int X2_WBASE = 2 * X2_XHALF;             // weight ring behind the activation ring
+constexpr int X2_LDS = X2_WBASE + 2 * X2_WHALF;    // 160 KiB
+static_assert(X2_LDS <= 163840 && X2_R * X2_G * 64 <= X2_LDS, "ring and epilogue tile must fit the LDS");
+
+template <class DT>
+__global__ void __launch_bounds__(64 * X2_G, 4)
+xcol32_a1_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
+                    typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "xcol v2 kernel: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile, grp;
+    if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
+    const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
+    const int ph_off = __builtin_amdgcn_readfirstlane(gh.x), nph = __builtin_amdgcn_readfirstlane(gh.y);
+    const int ob0 = __builtin_amdgcn_readfirstlane(gh.z), nob = __builtin_amdgcn_readfirstlane(gh.w);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t* pxt = plan + plan[6] + ph_off;
+    const int4* tab = reinterpret_cast<const int4*>(plan + plan[7]) + (size_t)ph_off * X2_G + wave;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_tile = tile * X2_R;
+    const uint32_t base_addr = lds_addr_of(smem);
+    const int npairs_full = Cin / 64;
+
+    // activation DMA: a slab is 16 instructions of 1 KiB (8 rows of 128 B); wave v issues instruction v of each slab
+    const unsigned char* xt = reinterpret_cast<const unsigned char*>(X);
+    uint32_t xvoff, xvoff_tail;
+    {
+        const int row = 8 * wave + (lane >> 3);
+        const int xr = min(n_tile + row, N - 1) - n_tile;            // rows past N are clamped (never stored)
+        const int piece = (lane & 7) ^ ((row >> 1) & 7);
+        xvoff = (uint32_t)xr * (uint32_t)Cin * 2u + piece * 16;
+        xvoff_tail = xvoff - ((piece & 4) ? 64 : 0);                  // last pair of an odd block count: re-read its even half
+    }
+    const unsigned char* xtile = static_cast<const unsigned char*>(uniform_ptr(xt + (size_t)n_tile * Cin * 2));
+    const unsigned char* wsel = static_cast<const unsigned char*>(uniform_ptr(Wsel));
+    // weight DMA: lane i of an instruction writes piece i of a 1 KiB half block (rows 16*hb + (i >> 2)); it fetches the
+    // piece that the swizzle puts there: (i & 3) ^ ((row >> 2) & 3) = (i & 3) ^ ((i >> 4) & 3)
+    const uint32_t wvoff = (uint32_t)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+
+    // fragment read offsets
+    const int xsw = (r >> 1) & 7;
+    uint32_t xrd[2][2];      // [half][kk], inside a 32-row band of slab 0 of ring half 0
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xrd[half][kk] = r * 128 + (((4 * half + 2 * kk + h) ^ xsw) << 4);
+    uint32_t wrd[2];         // [kk], inside slot 0 of ring half 0
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) wrd[kk] = X2_WBASE + r * 64 + (((2 * kk + h) ^ ((r >> 2) & 3)) << 4);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // DMAs of one phase into ring half `hb`: px = pair of step 0 | pair of step 1 << 16, d0..d2 = weight duties
+#define X2_ISSUE(px_, d0_, d1_, d2_, hb_)                                                                                   \
+    do {                                                                                                                    \
+        const uint32_t xdst = base_addr + (hb_) * X2_XHALF + wave * 1024;                                                   \
+        const uint32_t wdst = base_addr + X2_WBASE + (hb_) * X2_WHALF;                                                      \
+        const int p0 = (px_) & 0xffff, p1 = (int)((uint32_t)(px_) >> 16);                                                   \
+        if (!X2_NO_XDMA) glds16_saddr(xtile + (size_t)p0 * 128, p0 < npairs_full ? xvoff : xvoff_tail, xdst);               \
+        if (!X2_NO_XDMA && p1 != 0xffff) glds16_saddr(xtile + (size_t)p1 * 128, p1 < npairs_full ? xvoff : xvoff_tail, xdst + X2_SLAB); \
+        if (X2_NO_WDMA) break;                                                                                              \
+        if ((d0_) != -1) glds16_saddr(wsel + ((size_t)((d0_) & 0x3ffffff) << 10), wvoff, wdst + (((uint32_t)(d0_) >> 26) << 10)); \
+        if ((d1_) != -1) glds16_saddr(wsel + ((size_t)((d1_) & 0x3ffffff) << 10), wvoff, wdst + (((uint32_t)(d1_) >> 26) << 10)); \
+        if ((d2_) != -1) glds16_saddr(wsel + ((size_t)((d2_) & 0x3ffffff) << 10), wvoff, wdst + (((uint32_t)(d2_) >> 26) << 10)); \
+    } while (0)
+
+    // one block: weight fragment from its slot, the four row tiles' activation fragments, 8 MFMAs
+    auto block = [&](uint32_t xoff, uint32_t woff, int half) {
+        if (X2_NO_READS) return;
+        uint4 wq[2], xf[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) wq[kk] = *reinterpret_cast<const uint4*>(smem + wrd[kk] + woff);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xf[t][kk] = *reinterpret_cast<const uint4*>(smem + xrd[half][kk] + xoff + t * 4096);
+#if X2_READS_FIRST
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (X2_NO_MFMA) asm volatile("" ::"v"(wq[kk].x), "v"(wq[kk].w), "v"(xf[t][kk].x), "v"(xf[t][kk].w));
+                else acc[t] = DT::mfma32(wq[kk], xf[t][kk], acc[t]);
+            }
+    };
+
+    if (nph > 0) {
+        {   // prologue: phase 0 into ring half 0
+            const int4 d = tab[0];
+            const int px0 = __builtin_amdgcn_readfirstlane(pxt[0]);
+            const int d0 = __builtin_amdgcn_readfirstlane(d.y), d1 = __builtin_amdgcn_readfirstlane(d.z), d2 = __builtin_amdgcn_readfirstlane(d.w);
+            X2_ISSUE(px0, d0, d1, d2, 0);
+        }
+        int hb = 0;
+        for (int tb = 0; tb < nph; tb += 64) {       // lane-indexed tables for phases [tb, tb + 64)
+            const int idx = min(tb + lane, nph - 1), idn = min(tb + lane + 1, nph - 1);
+            int cwv = tab[(size_t)idx * X2_G].x;
+            const int4 dn = tab[(size_t)idn * X2_G];
+            int d0v = dn.y, d1v = dn.z, d2v = dn.w, pxv = pxt[idn];
+            // the table loads must have landed before the loop: a wait the compiler places INSIDE it would drain the DMA queue
+            asm volatile("" : "+v"(cwv), "+v"(d0v), "+v"(d1v), "+v"(d2v), "+v"(pxv));
+            const int tend = min(64, nph - tb);
+            for (int qi = 0; qi < tend; ++qi) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA shares of this phase have landed
+                __builtin_amdgcn_s_barrier();                        // everyone's have; everyone left the previous phase
+                const bool late = X2_LATE_ISSUE && (wave & 1);
+                if (!late && tb + qi + 1 < nph) {
+                    const int px1 = __builtin_amdgcn_readlane(pxv, qi);
+                    const int d0 = __builtin_amdgcn_readlane(d0v, qi), d1 = __builtin_amdgcn_readlane(d1v, qi), d2 = __builtin_amdgcn_readlane(d2v, qi);
+                    X2_ISSUE(px1, d0, d1, d2, hb ^ 1);
+                }
+                const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane(cwv, qi);
+                const uint32_t xo = hb * X2_XHALF, wo = hb * X2_WHALF;
+                if ((cw & 0xff) != 0xff)         block(xo, wo + ((cw & 0xff) << 11), 0);
+                if (((cw >> 8) & 0xff) != 0xff)  block(xo, wo + (((cw >> 8) & 0xff) << 11), 1);
+                if (((cw >> 16) & 0xff) != 0xff) block(xo + X2_SLAB, wo + (((cw >> 16) & 0xff) << 11), 0);
+                if ((cw >> 24) != 0xff)          block(xo + X2_SLAB, wo + ((cw >> 24) << 11), 1);
+                if (late && tb + qi + 1 < nph) {
+                    const int px1 = __builtin_amdgcn_readlane(pxv, qi);
+                    const int d0 = __builtin_amdgcn_readlane(d0v, qi), d1 = __builtin_amdgcn_readlane(d1v, qi), d2 = __builtin_amdgcn_readlane(d2v, qi);
+                    X2_ISSUE(px1, d0, d1, d2, hb ^ 1);
+                }
+                hb ^= 1;
+            }
+        }
+    }
+#undef X2_ISSUE
+
+    // Epilogue (as bsmm_xcol.h): D[o][n]: col = n = r (lane), rows o = (reg & 3) + 8 * (reg >> 2) + 4h.  The 16 waves own 16
+    // ADJACENT output blocks = 1024 contiguous bytes per minibatch row: staged through the idle ring as [128 rows][1024 B]
+    // (16-byte pieces of row n XOR-swizzled with n & 31) and stored as full rows.
+    constexpr int ROWB = X2_G * 64;
+    if (X2_NO_EPILOGUE) { if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) Y[0] = DT::from_f32(1.f); return; }
+    __syncthreads();
+    if (wave < nob) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = t * 32 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t lo = (uint32_t)DT::from_f32(acc[t][4 * q + 0]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 1]) << 16);
+                const uint32_t hi = (uint32_t)DT::from_f32(acc[t][4 * q + 2]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 3]) << 16);
+                const int piece = wave * 4 + q;
+                *reinterpret_cast<uint2*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4) + 8 * h) = make_uint2(lo, hi);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int rowbytes = nob * 64;
+        T* ybase = Y + (size_t)ob0 * 32;
+        constexpr int PPR = ROWB / 16;
+        for (int i = threadIdx.x; i < X2_R * PPR; i += 64 * X2_G) {
+            const int n = i / PPR, piece = i % PPR;
+            if (n_tile + n < N && piece * 16 < rowbytes) {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)(n_tile + n) * Kout) + piece * 16) = v;
+            }
+        }
+    }
+}
+
+}  // namespace bsmm

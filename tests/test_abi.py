@@ -164,6 +164,57 @@ def test_plan_builder_covers_every_block_once(lib):
     assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 8, lib.BF16, 1) is None
 
 
+def test_staged_xcol_plan(lib):
+    """'BSX2' plans (BSMM_PLAN_XCOL_STAGED, bsmm_xcol_v2.h): every lut entry is multiplied exactly once, by the wave that owns
+    its output block, from a slot of the phase's ring half that exactly one pair of DMA duties fills with that weight block;
+    phases hold <= 2 steps and <= WCAP blocks, waves <= 3 duties."""
+    import numpy as np
+    from blocksparse_amd import lut as L
+    from blocksparse_amd.matmul import _host_plan
+    rng = np.random.default_rng(5)
+    for CB, KB, dens in ((128, 128, 0.2), (40, 52, 0.3), (9, 35, 1.0), (1, 1, 1.0), (64, 16, 0.6)):
+        lay = rng.random((CB, KB)) < dens
+        lay[0, :] = True
+        t = L.build_tables(lay)
+        for side, n_out in (("fprop", KB), ("bprop", CB)):
+            f = t[side]
+            plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, 1, lib.PLAN_XCOL_STAGED)
+            assert plan[0] == 0x42535832 and int(plan[2]) == 16 and plan[8] == n_out and plan[7] % 4 == 0
+            WCAP = int(plan[9])
+            groups = plan[plan[5]:plan[5] + 4 * int(plan[3])].reshape(-1, 4)
+            px = plan[plan[6]:plan[6] + int(plan[4])]
+            tab = plan[plan[7]:plan[7] + int(plan[4]) * 64].reshape(-1, 16, 4)
+            got = set()
+            for g, (po, nph, ob0, nob) in enumerate(groups):
+                assert ob0 == 16 * g and nob == min(16, n_out - ob0)
+                for ph in range(po, po + nph):
+                    pairs = (int(px[ph]) & 0xffff, (int(px[ph]) >> 16) & 0xffff)
+                    assert pairs[0] != 0xffff
+                    slots = {}
+                    for wave in range(16):
+                        duties = [int(d) & 0xffffffff for d in tab[ph, wave, 1:] if d != -1]
+                        for d in duties:
+                            blk2, slot2 = d & 0x3ffffff, d >> 26
+                            assert blk2 & 1 == slot2 & 1 and slot2 < 2 * WCAP
+                            slots.setdefault(slot2 >> 1, []).append(blk2)
+                    for sl, halves in slots.items():
+                        assert sorted(halves) == [2 * (halves[0] >> 1), 2 * (halves[0] >> 1) + 1]
+                    used = set()
+                    for wave in range(16):
+                        cw = int(tab[ph, wave, 0]) & 0xffffffff
+                        for j in range(4):
+                            sl = (cw >> (8 * j)) & 0xff
+                            if sl == 0xff:
+                                continue
+                            u, half = j >> 1, j & 1
+                            assert wave < nob and pairs[u] != 0xffff and sl in slots and sl not in used
+                            used.add(sl)
+                            got.add((ob0 + wave, 2 * pairs[u] + half, slots[sl][0] >> 1))
+                    assert used == set(slots) and len(used) <= WCAP
+            want = {(ob, c, w) for ob, col in f["cols"] for c, w in col}
+            assert got == want
+
+
 def test_updat_plan_covers_every_block_once(lib):
     """bsmm_updat_plan_build, round-1 windowed formats ('BSUP': axis 0, bsize 16, or BSMM_PLAN_WINDOW_* on axis 1): every weight
     block appears in exactly one (item, wave, slot), inside its window, items are padded to a multiple of 8 (one list per XCD),
