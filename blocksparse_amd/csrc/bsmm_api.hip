@@ -260,8 +260,8 @@ int launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hi
     return BSMM_ERR_ARG;
 }
 
-template <class DT>
-int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+template <class DT, int NW>
+int launch_xcol_v2_nw(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
     XMap m;
@@ -270,11 +270,21 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds(&xcol32_a1_v2_kernel<DT>, X2_LDS)) return rc;
+    if (int rc = ensure_lds(&xcol32_a1_v2_kernel<DT, NW>, X2_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_STAGED);
-    xcol32_a1_v2_kernel<DT><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                               a->N, a->C, a->K);
+    xcol32_a1_v2_kernel<DT, NW><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                   a->N, a->C, a->K);
     return (int)hipGetLastError();
+}
+template <class DT>
+int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    switch (a->plan_inner) {     // DMA requests per wave and row the plan was scheduled for
+        case 1: return launch_xcol_v2_nw<DT, 1>(X, Wsel, Y, a, st);
+        case 2: return launch_xcol_v2_nw<DT, 2>(X, Wsel, Y, a, st);
+        case 3: return launch_xcol_v2_nw<DT, 3>(X, Wsel, Y, a, st);
+        case 4: return launch_xcol_v2_nw<DT, 4>(X, Wsel, Y, a, st);
+    }
+    return BSMM_ERR_ARG;
 }
 
 template <class DT, int AXIS>
@@ -901,6 +911,7 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
 
 #ifdef BSMM_XC_TRACE
 int bsmm_debug_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_xc_trace), sizeof(bsmm::g_xc_trace)); }
+int bsmm_debug_trace_copy2(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x2_trace), sizeof(bsmm::g_x2_trace)); }
 #endif
 
 int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks, int32_t bsize,
@@ -939,7 +950,7 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
     }
     if (bsize == 16) return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
     if ((options & BSMM_PLAN_XCOL_STAGED) && axis == 1) {
-        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out);
+        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out, (options >> 8) & 7);   // bits 8..10: requests per row (experiments)
         if (n != 0) return n;                                            // 0: the layout does not fit the table fields
     }
     return build_xcol_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));
@@ -1004,7 +1015,7 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
     d[4] = 0;
     switch (p[0]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
-        case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
+        case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[9]; break;
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;

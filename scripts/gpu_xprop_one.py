@@ -7,7 +7,9 @@ import torch
 import _parity as P
 from blocksparse_amd import BlocksparseMatMul, _lib
 
-def timeit(fn, reps=100, warm=30):
+REPS = int(os.environ.get('XP_REPS', '100'))
+def timeit(fn, reps=None, warm=None):
+    reps = reps or REPS; warm = warm or max(3, REPS // 3)
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -20,7 +22,8 @@ tag = os.path.basename(os.environ.get("BSMM_LIB", "default"))
 dens = [int(a) for a in sys.argv[1:]] or [10, 20, 50]
 check = os.environ.get("XP_CHECK", "1") == "1"
 for d in dens:
-    lay = P.random_layout(128, 128, d / 100.0, 1234)
+    CB = int(os.environ.get("XP_CB", "128"))
+    lay = P.random_layout(CB, CB, d / 100.0, 1234)
     res = {}
     for name, opt in (("base", 0), ("staged", _lib.PLAN_XCOL_STAGED)):
         b = BlocksparseMatMul(lay, block_size=32, feature_axis=1, plan_options=opt)
@@ -34,5 +37,5 @@ for d in dens:
     same = ""
     if check:
         same = " same_bits fprop=%s bprop=%s" % (torch.equal(res["base"][2], res["staged"][2]), torch.equal(res["base"][3], res["staged"][3]))
-    print("%-24s d%-3d base f %.1f b %.1f (k%d) | staged f %.1f b %.1f (k%d)%s" % (tag, d, res["base"][0], res["base"][1], res["base"][4],
+    print("%-24s cb%d d%-3d base f %.1f b %.1f (k%d) | staged f %.1f b %.1f (k%d)%s" % (tag, CB, d, res["base"][0], res["base"][1], res["base"][4],
           res["staged"][0], res["staged"][1], res["staged"][4], same), flush=True)
