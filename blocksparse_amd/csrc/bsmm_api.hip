@@ -260,8 +260,8 @@ int launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hi
     return BSMM_ERR_ARG;
 }
 
-template <class DT, int NW>
-int launch_xcol_v2_nw(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+template <class DT, bool TRANSW>
+int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
     XMap m;
@@ -270,27 +270,19 @@ int launch_xcol_v2_nw(const void* X, const void* Wsel, void* Y, const bsmm_args*
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds(&xcol32_a1_v2_kernel<DT, NW>, X2_LDS)) return rc;
+    if (int rc = ensure_lds(&xcol32_a1_v2_kernel<DT, TRANSW>, X2_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_STAGED);
-    xcol32_a1_v2_kernel<DT, NW><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                                   a->N, a->C, a->K);
+    xcol32_a1_v2_kernel<DT, TRANSW><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                               a->N, a->C, a->K);
     return (int)hipGetLastError();
-}
-template <class DT>
-int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    switch (a->plan_inner) {     // DMA requests per wave and row the plan was scheduled for
-        case 1: return launch_xcol_v2_nw<DT, 1>(X, Wsel, Y, a, st);
-        case 2: return launch_xcol_v2_nw<DT, 2>(X, Wsel, Y, a, st);
-        case 3: return launch_xcol_v2_nw<DT, 3>(X, Wsel, Y, a, st);
-        case 4: return launch_xcol_v2_nw<DT, 4>(X, Wsel, Y, a, st);
-    }
-    return BSMM_ERR_ARG;
 }
 
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
     if (a->plan_magic == X2PLAN_MAGIC) {
-        if constexpr (AXIS == 1) { if (!transw && a->plan_width == X2_G) return launch_xcol_v2<DT>(X, Wsel, Y, a, st); }
+        if constexpr (AXIS == 1) {
+            if (a->plan_width == X2_G) return transw ? launch_xcol_v2<DT, true>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false>(X, Wsel, Y, a, st);
+        }
         return BSMM_ERR_ARG;
     }
     if (a->plan_magic != XCPLAN_MAGIC) return BSMM_ERR_ARG;
@@ -401,7 +393,8 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     float* yacc = nullptr;
     size_t off = 0;
     const void* Wsel = W;
-    if (fprop && path != XP_VALU) {
+    const bool staged = path == XP_XCOL32 && a->plan_magic == X2PLAN_MAGIC;   // transposes the staged blocks itself
+    if (fprop && path != XP_VALU && !staged) {
         if constexpr (BS != 8) {
             if (!a->workspace || a->workspace_bytes < wt_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
             const int rc = launch_transpose<DT, BS>(W, a->workspace, a->blocks, st);
@@ -431,7 +424,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
             if constexpr (BS != 8) rc = launch_xprop_mfma<DT, BS, AXIS>(X, Wsel, Y, a, st, yacc);
             break;
         case XP_XCOL32:
-            if constexpr (BS == 32 && DT::is16) rc = launch_xgroup32<DT, AXIS>(X, Wsel, Y, a, st, false);
+            if constexpr (BS == 32 && DT::is16) rc = launch_xgroup32<DT, AXIS>(X, Wsel, Y, a, st, staged && fprop);
             break;
         case XP_XCOL16:
             if constexpr (BS == 16 && DT::is16) rc = launch_xcol16<DT, AXIS>(X, Wsel, Y, a, st);
@@ -911,7 +904,6 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
 
 #ifdef BSMM_XC_TRACE
 int bsmm_debug_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_xc_trace), sizeof(bsmm::g_xc_trace)); }
-int bsmm_debug_trace_copy2(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x2_trace), sizeof(bsmm::g_x2_trace)); }
 #endif
 
 int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks, int32_t bsize,
@@ -949,8 +941,8 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
                                               : build_xcol_plan(lut, segments, blocks, n_out, out, XS_G);
     }
     if (bsize == 16) return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
-    if ((options & BSMM_PLAN_XCOL_STAGED) && axis == 1) {
-        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out, (options >> 8) & 7);   // bits 8..10: requests per row (experiments)
+    if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW)) && axis == 1) {   // default: the staged kernel
+        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out);
         if (n != 0) return n;                                            // 0: the layout does not fit the table fields
     }
     return build_xcol_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));
@@ -1015,7 +1007,7 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
     d[4] = 0;
     switch (p[0]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
-        case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[9]; break;
+        case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;

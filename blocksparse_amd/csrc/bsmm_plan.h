@@ -172,40 +172,33 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
 }  // namespace bsmm
 
 // =================================================================================================
-// staged xcol plan ('BSX2'): a static software pipeline for the kernel that stages activations AND weight blocks through
-// LDS (bsmm_xcol_v2.h).  Groups of X2_G = 16 consecutive output blocks as in the xcol plan; wave 4c + t of the workgroup
-// owns row tile t (32 of the 128 minibatch rows) of output blocks 4c .. 4c+3 ("class" c): the four waves of a class do
-// identical work and sit on the four SIMDs, so every SIMD carries the same matrix work whatever the layout.
-// The kernel runs ROWS: in row r every wave requests one 1 KiB piece of the activation slab of row r+3 (ring of four
-// slabs) and NW 1 KiB half weight blocks -- a constant number of DMA instructions, so `s_waitcnt vmcnt(2 * (1 + NW))` at the
-// top of a row means "everything requested three rows ago has landed" -- and multiplies the blocks of the step scheduled
-// for row r.  This builder decides what is requested when: weight blocks live in a circular pool of X2_POOL slots of
-// 2 KiB, handed out in the order (step, class, half of the pair, column in the class) so that a class's blocks of a step
-// are consecutive; a block is requested as early as its slot is free (its previous occupant's step ran in an earlier
-// row), at most 16 * NW half blocks per row, and a step runs in the first row that is three rows after its last request
-// (rows in between are bubbles: nothing to multiply).  Requests that have nothing to fetch re-read a valid address into
-// the dummy slot.  NW (1 .. 4) is chosen from the mean number of blocks per step.
-// Layout (int32): [0] magic 'BSX2' [1] version [2] X2_G [3] ngroups [4] nrows_total [5] off_groups [6] off_px
-//                 [7] off_cw [8] n_out_blocks [9] NW [10] off_duty [11] X2_POOL
-//   groups[ngroups][4] = (row_off, nrows, first_out_block, n_out_blocks_in_group)      nrows >= 3 (or 0: no blocks)
-//   px  [nrows_total]             pair whose activation slab is requested in this row (for the step of row + 3)
-//   cw  [nrows_total][4]          per class: first slot | mask << 8, mask bit 4 * half + j = block at (half, column 4c + j)
-//   duty[nrows_total][16][NW][2]  per wave: (byte offset of the half block in W, byte offset of its place in the pool)
+// staged xcol plan ('BSX2'): schedule of the kernel that stages the weight blocks through LDS as well (bsmm_xcol_v2.h).
+// Groups of X2_G = 16 consecutive output blocks as in the xcol plan, wave v owns output block first + v.  The pair walk of a
+// group is cut into PHASES: up to two steps (pairs) and up to X2_WCAP weight blocks, which is what the two halves of the
+// LDS ring hold (2 x 2 activation slabs of 16 KiB + 2 x X2_WCAP weight blocks of 2 KiB).  A step with more blocks than
+// that is split into sub-steps (the same pair twice).  Every weight block of a phase has a SLOT in the phase's half of the
+// weight ring; its two 1 KiB halves are fetched by DMA instructions dealt evenly over the 16 waves (<= 3 each).
+// Layout (int32): [0] magic 'BSX2' [1] version [2] X2_G [3] ngroups [4] nphases_total [5] off_groups [6] off_px
+//                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] X2_WCAP [10] max phases of a group
+//   groups[ngroups][4] = (phase_off, nphases, first_out_block, n_out_blocks_in_group)
+//   px [nphases_total]           pair of step 0 | pair of step 1 << 16   (0xffff = no such step)
+//   tab[nphases_total][16][4]    per phase and wave:
+//        [0] slots this wave multiplies: byte 2*u + half = slot of (step u, half of the pair), 0xff = none
+//        [1..3] DMA duties: (2 * weight block + half) | (2 * slot + half) << 26, or -1
 // =================================================================================================
 namespace bsmm {
 
 constexpr int32_t X2PLAN_MAGIC = 0x42535832;
-constexpr int32_t X2PLAN_VERSION = 3;
+constexpr int32_t X2PLAN_VERSION = 1;
 constexpr int X2_G = 16;
-constexpr int X2_POOL = 47;            // usable weight slots; slot X2_POOL is the dummy target
-constexpr int X2_AHEAD = 3;            // rows between a request and its use
+constexpr int X2_WCAP = 24;
 constexpr int X2_HDR = 12;
 
-inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int force_nw = 0) {
+inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
-    if (blocks >= (1 << 21)) return 0;                                       // 32-bit byte offsets into W
+    if (blocks >= (1 << 25)) return 0;                                       // field widths of the tables
     const int G = X2_G, ngroups = (n_out_blocks + G - 1) / G;
-    struct E { int p, col, half, w; };
+    struct E { int p, wave, half, w; };
     std::vector<std::vector<E>> per_group(ngroups);
     for (int s = 0; s < segments; ++s) {
         const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
@@ -213,121 +206,68 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
         for (int e = 0; e < cnt; ++e) {
             const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
             if (w < 0 || w >= blocks || c < 0) return -1;
-            if (c >= (1 << 24)) return 0;
+            if (c >= 2 * 0xffff) return 0;
             per_group[ob / G].push_back({c >> 1, ob % G, c & 1, w});
         }
     }
-    // steps of every group (runs of equal pair), blocks ordered (class, half, column in class)
-    struct Step { int p; size_t lo, hi; };
-    std::vector<std::vector<Step>> gsteps(ngroups);
-    size_t nsteps_all = 0, nblocks_all = 0;
+    std::vector<int32_t> groups, px, tab;
+    int max_ph = 0;
     for (int g = 0; g < ngroups; ++g) {
         auto& v = per_group[g];
-        std::sort(v.begin(), v.end(), [](const E& a, const E& b) {
-            if (a.p != b.p) return a.p < b.p;
-            if ((a.col >> 2) != (b.col >> 2)) return (a.col >> 2) < (b.col >> 2);
-            if (a.half != b.half) return a.half < b.half;
-            return a.col < b.col;
-        });
+        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : (a.wave != b.wave ? a.wave < b.wave : a.half < b.half); });
+        // steps: runs of equal pair, at most X2_WCAP entries each (a wave's two halves stay in one step)
+        struct Step { int p; size_t lo, hi; };
+        std::vector<Step> steps;
         for (size_t i = 0; i < v.size();) {
             size_t j = i;
             while (j < v.size() && v[j].p == v[i].p) ++j;
-            gsteps[g].push_back({v[i].p, i, j});
+            size_t lo = i;
+            while (lo < j) {
+                size_t hi = std::min(j, lo + X2_WCAP);
+                if (hi < j && v[hi].wave == v[hi - 1].wave) --hi;          // do not part the halves of one wave
+                steps.push_back({v[i].p, lo, hi});
+                lo = hi;
+            }
             i = j;
         }
-        nsteps_all += gsteps[g].size();
-        nblocks_all += v.size();
-    }
-    int NW = force_nw;
-    if (NW < 1 || NW > 4) {
-        const double mean = nsteps_all ? (double)nblocks_all / nsteps_all : 0.0;
-        NW = mean <= 6.9 ? 1 : (mean <= 13.8 ? 2 : (mean <= 20.7 ? 3 : 4));
-    }
-    const int cap = 16 * NW;
-    std::vector<int32_t> groups, px, cw, duty;
-    for (int g = 0; g < ngroups; ++g) {
-        const auto& v = per_group[g];
-        const auto& st = gsteps[g];
-        const int S = (int)st.size();
-        const int row_off = (int)px.size();
-        if (S == 0) { groups.insert(groups.end(), {row_off, 0, g * G, std::min(G, n_out_blocks - g * G)}); continue; }
-        // pool slots in request order; a class's blocks of a step are consecutive (runs do not wrap)
-        std::vector<int> slot(v.size());
-        {
-            int next = 0;
-            for (int s = 0; s < S; ++s)
-                for (size_t i = st[s].lo; i < st[s].hi;) {
-                    size_t j = i;
-                    while (j < st[s].hi && (v[j].col >> 2) == (v[i].col >> 2)) ++j;
-                    if (next + (int)(j - i) > X2_POOL) next = 0;
-                    for (size_t k = i; k < j; ++k) slot[k] = next++;
-                    i = j;
+        const int phase_off = (int)px.size();
+        for (size_t s = 0; s < steps.size();) {
+            const size_t n0 = steps[s].hi - steps[s].lo;
+            const bool two = s + 1 < steps.size() && n0 + (steps[s + 1].hi - steps[s + 1].lo) <= (size_t)X2_WCAP;
+            const int nst = two ? 2 : 1;
+            px.push_back(steps[s].p | ((two ? steps[s + 1].p : 0xffff) << 16));
+            std::vector<int32_t> row((size_t)G * 4, -1);
+            int slot = 0, duty = (int)(px.size() * 5) % G;                 // rotate the wave that gets the first duty
+            std::vector<int> nduty(G, 0);
+            for (int u = 0; u < nst; ++u)
+                for (size_t i = steps[s + u].lo; i < steps[s + u].hi; ++i, ++slot) {
+                    const E& e = v[i];
+                    int32_t& cw = row[(size_t)e.wave * 4];
+                    const int sh = 8 * (2 * u + e.half);
+                    cw = (int32_t)(((uint32_t)cw & ~(0xffu << sh)) | ((uint32_t)slot << sh));
+                    for (int hb = 0; hb < 2; ++hb) {
+                        const int wv = duty; duty = (duty + 1) % G;
+                        row[(size_t)wv * 4 + 1 + nduty[wv]++] = (int32_t)((uint32_t)(2 * e.w + hb) | ((uint32_t)(2 * slot + hb) << 26));
+                    }
                 }
+            tab.insert(tab.end(), row.begin(), row.end());
+            s += nst;
         }
-        std::vector<int> free_row(X2_POOL, -1);       // last row that reads the slot's current / previous occupant
-        std::vector<int> comp_row(S, -1);
-        size_t head = 0;                              // next half-block request: block head / 2, half head & 1
-        int next_step = 0, row = 0;
-        std::vector<int32_t> gpx, gcw, gduty;
-        const int32_t dummy_dst = X2_POOL * 2048;
-        while (next_step < S || row < comp_row[S - 1] + 1) {
-            if (row > 8 * S + 64) return -1;           // cannot happen (see the pool argument in bsmm_xcol_v2.h)
-            gcw.insert(gcw.end(), 4, 0);
-            gduty.resize(gduty.size() + (size_t)16 * NW * 2);
-            int32_t* d = &gduty[gduty.size() - (size_t)16 * NW * 2];
-            for (int k = 0; k < 16 * NW; ++k) { d[2 * k] = 0; d[2 * k + 1] = dummy_dst; }
-            int issued = 0;
-            const int rot = (row * 5) % 16;
-            while (issued < cap && head < 2 * v.size()) {
-                const size_t b = head >> 1;
-                const int hb = (int)(head & 1);
-                if (hb == 0 && free_row[slot[b]] >= row) break;          // its slot is still read in this row or later
-                const int wave = (issued + rot) % 16, di = issued / 16;
-                d[(wave * NW + di) * 2] = (int32_t)((uint32_t)v[b].w * 2048u + (uint32_t)hb * 1024u);
-                d[(wave * NW + di) * 2 + 1] = slot[b] * 2048 + hb * 1024;
-                if (hb == 0) free_row[slot[b]] = 1 << 30;                // occupied until its step is scheduled
-                ++issued; ++head;
-            }
-            // the step that runs in row + X2_AHEAD: the next one, if all its blocks are requested by now
-            int xp = st[std::min(next_step, S - 1)].p;
-            if (next_step < S && head >= 2 * st[next_step].hi) {
-                comp_row[next_step] = row + X2_AHEAD;
-                for (size_t i = st[next_step].lo; i < st[next_step].hi; ++i) free_row[slot[i]] = row + X2_AHEAD;
-                ++next_step;
-            }
-            gpx.push_back(xp);
-            ++row;
-        }
-        const int nrows = row;
-        for (int s = 0; s < S; ++s) {                  // class words of the rows that run a step
-            const int r = comp_row[s];
-            if (r < X2_AHEAD || r >= nrows) return -1;
-            bool seen[4] = {false, false, false, false};
-            for (size_t i = st[s].lo; i < st[s].hi; ++i) {
-                const int c = v[i].col >> 2;
-                uint32_t& word = reinterpret_cast<uint32_t&>(gcw[(size_t)r * 4 + c]);
-                if (!seen[c]) { seen[c] = true; word = (uint32_t)slot[i]; }
-                word |= 1u << (8 + 4 * v[i].half + (v[i].col & 3));
-            }
-        }
-        px.insert(px.end(), gpx.begin(), gpx.end());
-        cw.insert(cw.end(), gcw.begin(), gcw.end());
-        duty.insert(duty.end(), gduty.begin(), gduty.end());
-        groups.insert(groups.end(), {row_off, nrows, g * G, std::min(G, n_out_blocks - g * G)});
+        const int nph = (int)px.size() - phase_off;
+        max_ph = std::max(max_ph, nph);
+        groups.insert(groups.end(), {phase_off, nph, g * G, std::min(G, n_out_blocks - g * G)});
     }
     const int off_groups = X2_HDR, off_px = off_groups + (int)groups.size();
-    const int off_cw = (off_px + (int)px.size() + 3) & ~3;
-    const int off_duty = off_cw + (int)cw.size();
-    const long total = off_duty + (long)duty.size();
+    const int off_tab = (off_px + (int)px.size() + 3) & ~3;
+    const long total = off_tab + (long)tab.size();
     if (out) {
-        std::fill(out, out + off_cw, 0);
-        const int32_t hdr[X2_HDR] = {X2PLAN_MAGIC, X2PLAN_VERSION, G, ngroups, (int32_t)px.size(), off_groups, off_px, off_cw,
-                                     n_out_blocks, NW, off_duty, X2_POOL};
+        std::fill(out, out + off_tab, 0);
+        const int32_t hdr[X2_HDR] = {X2PLAN_MAGIC, X2PLAN_VERSION, G, ngroups, (int32_t)px.size(), off_groups, off_px, off_tab,
+                                     n_out_blocks, X2_WCAP, max_ph, 0};
         std::copy(hdr, hdr + X2_HDR, out);
         std::copy(groups.begin(), groups.end(), out + off_groups);
         std::copy(px.begin(), px.end(), out + off_px);
-        std::copy(cw.begin(), cw.end(), out + off_cw);
-        std::copy(duty.begin(), duty.end(), out + off_duty);
+        std::copy(tab.begin(), tab.end(), out + off_tab);
     }
     return total;
 }

@@ -6,7 +6,7 @@ import numpy as np, torch
 import _parity as P
 from blocksparse_amd import BlocksparseMatMul, _lib
 d = float(sys.argv[1]) if len(sys.argv) > 1 else 0.2
-b = BlocksparseMatMul(P.random_layout(128, 128, d, seed=1234), block_size=32, feature_axis=1, plan_options=_lib.PLAN_XCOL_STAGED)
+b = BlocksparseMatMul(P.random_layout(128, 128, d, seed=1234), block_size=32, feature_axis=1)
 N = 8192
 w = (torch.randn(b.w_shape, device="cuda") * 0.01).bfloat16()
 dy = (torch.randn(b.o_shape(N), device="cuda") * 0.1).bfloat16()

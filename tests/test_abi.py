@@ -126,7 +126,7 @@ def test_plan_builder_covers_every_block_once(lib):
         for axis in (0, 1):
             for side, n_out in (("fprop", KB), ("bprop", CB)):
                 f = t[side]
-                plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, axis)
+                plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, axis, lib.PLAN_XCOL_UNSTAGED)   # 'BSXC'
                 got = _check_xcol_plan(plan, f, t, n_out)
                 want = set()
                 for ob, col in f["cols"]:
@@ -165,57 +165,52 @@ def test_plan_builder_covers_every_block_once(lib):
 
 
 def test_staged_xcol_plan(lib):
-    """'BSX2' plans (BSMM_PLAN_XCOL_STAGED, bsmm_xcol_v2.h), simulated as the kernel runs them: every row requests one slab and
-    16 * NW half blocks; what a row multiplies -- the slab requested three rows earlier, the pool slots its class words count
-    through -- must have been requested at least three rows earlier, must not be overwritten before it is read, and over
-    the whole walk every lut entry is multiplied exactly once under the right output block."""
+    """'BSX2' plans (the default for bsize 32, 16-bit, feature_axis 1; bsmm_xcol_v2.h): every lut entry is multiplied exactly once, by the wave that owns
+    its output block, from a slot of the phase's ring half that exactly one pair of DMA duties fills with that weight block;
+    phases hold <= 2 steps and <= WCAP blocks, waves <= 3 duties."""
     import numpy as np
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_plan
     rng = np.random.default_rng(5)
-    for CB, KB, dens, nw in ((128, 128, 0.2, 0), (40, 52, 0.3, 0), (9, 35, 1.0, 0), (1, 1, 1.0, 0), (64, 16, 0.6, 0), (64, 48, 0.5, 1)):
+    for CB, KB, dens in ((128, 128, 0.2), (40, 52, 0.3), (9, 35, 1.0), (1, 1, 1.0), (64, 16, 0.6)):
         lay = rng.random((CB, KB)) < dens
         lay[0, :] = True
         t = L.build_tables(lay)
         for side, n_out in (("fprop", KB), ("bprop", CB)):
             f = t[side]
-            plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, 1, lib.PLAN_XCOL_STAGED | (nw << 8))
+            plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, 1)
             assert plan[0] == 0x42535832 and int(plan[2]) == 16 and plan[8] == n_out and plan[7] % 4 == 0
-            NW, POOL = int(plan[9]), int(plan[11])
-            assert 1 <= NW <= 4 and (nw == 0 or NW == nw)
-            R = int(plan[4])
+            WCAP = int(plan[9])
             groups = plan[plan[5]:plan[5] + 4 * int(plan[3])].reshape(-1, 4)
-            px = plan[plan[6]:plan[6] + R]
-            cw = plan[plan[7]:plan[7] + 4 * R].reshape(R, 4)
-            duty = plan[plan[10]:plan[10] + R * 16 * NW * 2].reshape(R, 16 * NW, 2)
+            px = plan[plan[6]:plan[6] + int(plan[4])]
+            tab = plan[plan[7]:plan[7] + int(plan[4]) * 64].reshape(-1, 16, 4)
             got = set()
-            for g, (ro, nrows, ob0, nob) in enumerate(groups):
-                assert ob0 == 16 * g and nob == min(16, n_out - ob0) and (nrows == 0 or nrows > 3)
-                pool = {}                                   # half slot -> (half block id, row requested)
-                for row in range(ro, ro + nrows):
-                    # what this row reads (before its own requests can land: they are issued after the barrier, but a slot
-                    # read in this row must not be a target of this row's requests either)
-                    reads = set()
-                    for cls in range(4):
-                        word = int(cw[row, cls]) & 0xffffffff
-                        slot, mask = word & 0xff, (word >> 8) & 0xff
-                        assert word >> 16 == 0 and (mask == 0 or row - ro >= 3)
-                        for bit in range(8):
-                            if not (mask >> bit) & 1:
+            for g, (po, nph, ob0, nob) in enumerate(groups):
+                assert ob0 == 16 * g and nob == min(16, n_out - ob0)
+                for ph in range(po, po + nph):
+                    pairs = (int(px[ph]) & 0xffff, (int(px[ph]) >> 16) & 0xffff)
+                    assert pairs[0] != 0xffff
+                    slots = {}
+                    for wave in range(16):
+                        duties = [int(d) & 0xffffffff for d in tab[ph, wave, 1:] if d != -1]
+                        for d in duties:
+                            blk2, slot2 = d & 0x3ffffff, d >> 26
+                            assert blk2 & 1 == slot2 & 1 and slot2 < 2 * WCAP
+                            slots.setdefault(slot2 >> 1, []).append(blk2)
+                    for sl, halves in slots.items():
+                        assert sorted(halves) == [2 * (halves[0] >> 1), 2 * (halves[0] >> 1) + 1]
+                    used = set()
+                    for wave in range(16):
+                        cw = int(tab[ph, wave, 0]) & 0xffffffff
+                        for j in range(4):
+                            sl = (cw >> (8 * j)) & 0xff
+                            if sl == 0xff:
                                 continue
-                            half, col = bit >> 2, 4 * cls + (bit & 3)
-                            assert col < nob and slot < POOL
-                            (b0, r0), (b1, r1) = pool[2 * slot], pool[2 * slot + 1]
-                            assert b0 + 1 == b1 and b0 % 2 == 0 and max(r0, r1) <= row - 3      # both halves landed
-                            got.add((ob0 + col, 2 * int(px[row - 3]) + half, b0 // 2))
-                            reads.add(slot)
-                            slot += 1
-                    for src, dst in duty[row]:
-                        assert src % 1024 == 0 and dst % 1024 == 0 and 0 <= dst < (POOL + 1) * 2048
-                        if dst // 2048 == POOL:
-                            continue                           # dummy request
-                        assert dst // 2048 not in reads         # not while the row still reads the slot
-                        pool[dst // 1024] = (src // 1024, row)
+                            u, half = j >> 1, j & 1
+                            assert wave < nob and pairs[u] != 0xffff and sl in slots and sl not in used
+                            used.add(sl)
+                            got.add((ob0 + wave, 2 * pairs[u] + half, slots[sl][0] >> 1))
+                    assert used == set(slots) and len(used) <= WCAP
             want = {(ob, c, w) for ob, col in f["cols"] for c, w in col}
             assert got == want
 
@@ -401,8 +396,12 @@ def test_plan_attach_descriptor_and_host_side_rejection(lib):
         assert L.bsmm_plan_attach(ctypes.byref(a), words.ctypes.data_as(ip), words.size, dev) == 0
         return a
     xp = _host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1)
-    a = attach(xp)
-    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items, a.plan_inner) == (0x42535843, 16, 16, 0, 0) and a.plan == 4096
+    a = attach(xp)                                  # default for bsize 32 / 16-bit / axis 1: the staged kernel's 'BSX2' plan
+    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items, a.plan_inner) == (0x42535832, 16, 16, 0, 0) and a.plan == 4096
+    a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_UNSTAGED))
+    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items, a.plan_inner) == (0x42535843, 16, 16, 0, 0)
+    a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 0))
+    assert a.plan_magic == 0x42535843               # feature_axis 0: round-1 format
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_NARROW))
     assert (a.plan_width, a.plan_waves) == (8, 8)
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.F32, 1, lib.PLAN_F32_MFMA))

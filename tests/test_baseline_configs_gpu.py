@@ -35,6 +35,11 @@ def _updat_kernel(lib, axis, opt=0):
     return lib.K_UPDAT_WIN
 
 
+def _xprop_kernel(lib, axis, opt=0):
+    """which bsize-32 16-bit xprop plan kernel runs: axis 1 defaults to the staged kernel (bsmm_xcol_v2.h)"""
+    return lib.K_XCOL32_STAGED if axis == 1 and not (opt & (lib.PLAN_XCOL_UNSTAGED | lib.PLAN_XCOL_NARROW)) else lib.K_XCOL32
+
+
 def _inputs(torch, b, N, dtype, seed):
     """W ~ N(0, .01), X, E ~ N(0, .1) generated on the device, rounded to the storage type; host copies are exact."""
     td = getattr(torch, P.TORCH_DT[dtype])
@@ -103,7 +108,7 @@ def test_bench_shape_against_oracle(env, density, axis):
     torch, BSMM, lib = env
     layout = P.random_layout(128, 128, density, seed=1234)          # bench.py's layout
     b = BSMM(layout, block_size=32, feature_axis=axis)
-    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=11, expect={"xprop": lib.K_XCOL32, "updat": _updat_kernel(lib, axis)},
+    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=11, expect={"xprop": _xprop_kernel(lib, axis), "updat": _updat_kernel(lib, axis)},
                    ctx="bench d%d a%d" % (round(density * 100), axis))
 
 
@@ -112,7 +117,7 @@ def test_bench_shape_fp16_and_ragged_minibatch(env):
     torch, BSMM, lib = env
     layout = P.random_layout(128, 128, 0.2, seed=1234)
     b = BSMM(layout, block_size=32, feature_axis=1)
-    _check_sampled(torch, lib, b, layout, 8192 - 24, "f16", seed=12, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_STREAM}, ctx="bench f16 ragged")
+    _check_sampled(torch, lib, b, layout, 8192 - 24, "f16", seed=12, expect={"xprop": lib.K_XCOL32_STAGED, "updat": lib.K_UPDAT_STREAM}, ctx="bench f16 ragged")
 
 
 def test_bench_shape_skewed_layout(env):
@@ -121,7 +126,7 @@ def test_bench_shape_skewed_layout(env):
     torch, BSMM, lib = env
     layout = P.ba_layout(128, 14, seed=1)
     b = BSMM(layout, block_size=32, feature_axis=1)
-    _check_sampled(torch, lib, b, layout, 4096, "bf16", seed=13, expect={"xprop": lib.K_XCOL32, "updat": lib.K_UPDAT_STREAM}, ctx="bench BA")
+    _check_sampled(torch, lib, b, layout, 4096, "bf16", seed=13, expect={"xprop": lib.K_XCOL32_STAGED, "updat": lib.K_UPDAT_STREAM}, ctx="bench BA")
 
 
 # ---- (b) BASELINE configs[3] -----------------------------------------------------------------------------------------
@@ -133,7 +138,7 @@ def test_cfg3_8192_5pct(env, axis, N, force):
     torch, BSMM, lib = env
     layout = P.random_layout(256, 256, 0.05, seed=1234)
     b = BSMM(layout, block_size=32, feature_axis=axis)
-    expect = {"xprop": lib.K_XCOL32, "updat": _updat_kernel(lib, axis)} if (force or N >= 4096) else {}
+    expect = {"xprop": _xprop_kernel(lib, axis), "updat": _updat_kernel(lib, axis)} if (force or N >= 4096) else {}
     try:
         lib.set_kernel_variant(3 if force else 0)
         _check_sampled(torch, lib, b, layout, N, "bf16", seed=21, expect=expect, ctx="cfg3 a%d N%d force%d" % (axis, N, force))
@@ -181,6 +186,55 @@ def test_small_layouts_multi_block_windows(env, opt, dtype):
                     assert l2 <= P.L2_BAR[dtype], (opt, li, N, split, l2)
     finally:
         lib.set_kernel_variant(0)
+
+
+# ---- (d2) xprop plan kernels on small forced layouts: staged (default) and round-1 ------------------------------------
+@pytest.mark.parametrize("opt", [0, "PLAN_XCOL_UNSTAGED", "PLAN_XCOL_NARROW"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_small_layouts_xprop_plan_kernels(env, opt, dtype):
+    """fprop (in-kernel transposing reads of the staged weight blocks) and bprop against the full float64 oracle: dense layouts
+    (steps with 32 blocks are split over phases), odd block counts (half-empty last pair), partial last group, one block,
+    minibatches that are not a multiple of the 128-row tile."""
+    torch, BSMM, lib = env
+    o = getattr(lib, opt) if opt else 0
+    cases = [(np.ones((9, 35), dtype=bool), (72, 200)),                 # dense: 32 blocks per step > 24 slots per ring half
+             (P.random_layout(33, 17, 0.3, seed=3), (100, 8)),          # odd block counts on both sides
+             (np.ones((1, 1), dtype=bool), (40,)),                      # one block, one group of one column
+             (P.random_layout(40, 40, 0.15, seed=2), (392, 128)),
+             (P.ba_layout(40, 3, seed=1), (264,))]
+    try:
+        lib.set_kernel_variant(3)
+        for li, (layout, Ns) in enumerate(cases):
+            b = BSMM(layout, block_size=32, feature_axis=1, plan_options=o)
+            t = orc.build_layout_luts(layout, 32)
+            for N in Ns:
+                W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=li * 5 + N)
+                w, x, e = P.to_dev(W, dtype, torch), P.to_dev(X, dtype, torch), P.to_dev(E, dtype, torch)
+                y = P.to_host(b.fprop(x, w))
+                assert lib.last_kernel() == _xprop_kernel(lib, 1, o)
+                dx = P.to_host(b.bprop(e, w))
+                assert lib.last_kernel() == _xprop_kernel(lib, 1, o)
+                l2y, _ = P.errors(y, orc.round_to(orc.fprop(t, X, W, 1), dtype))
+                l2x, _ = P.errors(dx, orc.round_to(orc.bprop(t, E, W, 1), dtype))
+                assert l2y <= P.L2_BAR[dtype] and l2x <= P.L2_BAR[dtype], (opt, li, N, l2y, l2x)
+    finally:
+        lib.set_kernel_variant(0)
+
+
+def test_staged_and_round1_xprop_kernels_agree_bitwise(env):
+    """Both plan kernels accumulate a block column in the same order (pairs ascending, even half first) with the same MFMAs:
+    identical bits at the bench shape, fprop and bprop."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(128, 128, 0.2, seed=1234)
+    outs = []
+    for o in (0, lib.PLAN_XCOL_UNSTAGED):
+        b = BSMM(layout, block_size=32, feature_axis=1, plan_options=o)
+        w, x, e = _inputs(torch, b, 8192, "bf16", seed=5)
+        y = b.fprop(x, w); k1 = lib.last_kernel()
+        dx = b.bprop(e, w)
+        assert k1 == lib.last_kernel() == _xprop_kernel(lib, 1, o)
+        outs.append((y, dx))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 # ---- (e) the reference's own test matrix ------------------------------------------------------------------------------
