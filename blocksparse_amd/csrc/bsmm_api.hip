@@ -533,20 +533,26 @@ inline int device_cus() {
 // the plan (plan_inner = NSETS | common set size << 8).  Every item is ONE workgroup's -- and is stored directly -- when the plan
 // has 8 sets of equal size that fill whole rounds of U; otherwise partial sums meet in the fp32 workspace.  The caller can ask
 // for `split` workgroups per item instead (1: one per item, direct).
-struct U2Launch { int grid; bool scratch; int flat; };
+// partial-sum path of the streaming kernel: the workspace holds the fp32 sums [blocks][1024] (only written for
+// BSMM_FLAG_DW_SUMS) and behind them one region of 64 accumulator slots x 4 KiB per (round, workgroup)
+struct U2Launch { int grid; bool scratch; int flat; int rounds; };
+inline size_t u2_sums_bytes(const bsmm_args* a) { return round16((size_t)a->blocks * 1024 * sizeof(float)); }
+inline size_t u2_region_bytes() { return (size_t)U2_WAVES * U2_SLOTS * 4096; }
 inline U2Launch updat2_shape(const bsmm_args* a, bool gated) {
     const int cus = device_cus();
-    const int nsets = a->plan_inner & 255, common = a->plan_inner >> 8;
+    const int nsets = a->plan_inner & 15, longest = a->plan_inner >> 8, common = (a->plan_inner & 16) ? longest : 0;
     U2Launch L;
     if (a->split >= 1) {
         const long nchunks = (long)a->pcount * ((a->N + U2_CH - 1) / U2_CH);
         const long sp = std::max<long>(1, std::min<long>(a->split, nchunks));
         L.grid = (int)(a->plan_items * sp); L.scratch = sp > 1 || gated; L.flat = 1;
+        L.rounds = (a->plan_items + L.grid - 1) / L.grid;
         return L;
     }
     const int U = std::max(1, cus / 8);
     L.grid = 8 * U; L.flat = 0;
     L.scratch = gated || !(nsets == 8 && common > 0 && common % U == 0);
+    L.rounds = (longest + U - 1) / U;
     return L;
 }
 
@@ -558,13 +564,13 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     U2Launch L = updat2_shape(a, gate != nullptr);
     const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;
     if (sums_only) L.scratch = true;
-    float* scratch = nullptr;
-    const size_t nel = (size_t)a->blocks * 1024;
+    float* scratch = nullptr;      // the partial-sum regions
+    float* sums = nullptr;
     if (L.scratch) {
-        if (!a->workspace || a->workspace_bytes < nel * sizeof(float) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
-        scratch = static_cast<float*>(a->workspace);
-        hipError_t e = hipMemsetAsync(scratch, 0, nel * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+        const size_t need = u2_sums_bytes(a) + (size_t)L.rounds * L.grid * u2_region_bytes();
+        if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+        sums = static_cast<float*>(a->workspace);
+        scratch = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + u2_sums_bytes(a));
     }
     trace(a, BSMM_K_UPDAT_STREAM);
     if (a->plan_width == 16) {
@@ -576,8 +582,11 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
         updat32_a1_v2_kernel<DT, 8><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(8), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
                                                                                    a->pcount, a->alpha, a->beta, L.flat);
     }
-    if (scratch && !sums_only)
-        updat_finalize_gated_kernel<DT><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), nel, 1024, a->alpha, a->beta, gate);
+    if (scratch) {
+        const int CPI = a->pcount * ((a->N + U2_CH - 1) / U2_CH);
+        if (sums_only) updat2_reduce_kernel<DT, true><<<a->blocks, 256, 0, st>>>(scratch, nullptr, sums, a->plan, nullptr, L.grid, L.flat, CPI, 1.f, 0.f);
+        else           updat2_reduce_kernel<DT, false><<<a->blocks, 256, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, gate, L.grid, L.flat, CPI, a->alpha, a->beta);
+    }
     return (int)hipGetLastError();
 }
 
@@ -1011,7 +1020,7 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;
-        case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR) return false;   d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8] | (p[25] << 8); break;
+        case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR) return false;   d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8] | (p[25] > 0 ? 16 : 0) | (p[27] << 8); break;   // item sets | all equally long | longest set
         default: return false;
     }
     d[0] = p[0];
@@ -1050,8 +1059,13 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
         const size_t blk = (size_t)a->plan_width * 1024;
         return op == BSMM_OP_UPDAT ? blk * sizeof(float) : std::max(blk * elem_size(a->dtype), lock);
     }
-    if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32)
+    if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32) {
+        if (a->plan_magic == U2PLAN_MAGIC) {   // streaming kernel: the fp32 sums + one region of partial sums per (round, workgroup)
+            const U2Launch L = updat2_shape(a, true);
+            return u2_sums_bytes(a) + (size_t)L.rounds * L.grid * u2_region_bytes();
+        }
         return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float);   // fp32 partial sums of the split-minibatch path
+    }
     if (xprop_op && a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && a->plan_magic == XCPLAN_MAGIC)
         return xcols_workspace_bytes(a);   // bf16 pieces of the activations and the weights (bsmm_xcols.h)
     // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)

@@ -552,7 +552,8 @@ inline long build_super8_updat_plan(const int32_t* updat_lut, int blocks, int CB
 // Many items -> 8 sets x the whole minibatch: every item is one workgroup's, stored directly.
 // Layout (int32): [0] magic 'BSU2' [1] version [2] WS [3] U2_SLOTS [4] nitems [5] nblocks [6] off_items [7] U2_WAVES
 //                 [8] NSETS (1, 2, 4 or 8) [9 + 2 s], [10 + 2 s] first item / item count of set s
-//                 [25] the item count of every set if they are all equal, else 0
+//                 [25] the item count of every set if they are all equal, else 0  [26] off_bmap  [27] longest set
+//   bmap[nblocks] (behind the items): item << 8 | wave * U2_SLOTS + slot  of every block
 //   item: U2_ITEM = 4 + U2_WAVES * 5 words = (c0_block, k0_block, nblocks_in_item, 0) then per wave
 //         word 0 = n0 | n1 << 4 | cidx0 << 8 | cidx1 << 12 | kidx[0] << 16 | kidx[1] << 20 | kidx[2] << 24 | kidx[3] << 28
 //                  slots [0, n0) are blocks (cidx0, kidx[j]), slots [n0, n0 + n1) blocks (cidx1, kidx[j]) of the window
@@ -680,15 +681,34 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
         for (auto& it : set_overflow[st]) items.insert(items.end(), it.begin(), it.end());
     }
     const long nitems = (long)(items.size() / U2_ITEM);
-    const long total = U2_HDR + (long)items.size();
+    const long off_bmap = U2_HDR + (long)items.size();
+    const long total = off_bmap + blocks;
     if (out) {
         int32_t hdr[U2_HDR] = {U2PLAN_MAGIC, U2PLAN_VERSION, WS, U2_SLOTS, (int32_t)nitems, blocks, U2_HDR, U2_WAVES, nsets};
         for (int st = 0; st < 8; ++st) { hdr[9 + 2 * st] = set_first[st]; hdr[10 + 2 * st] = set_count[st]; }
         bool equal = true;
-        for (int st = 1; st < nsets; ++st) equal = equal && set_count[st] == set_count[0];
+        int32_t longest = 0;
+        for (int st = 0; st < nsets; ++st) { equal = equal && set_count[st] == set_count[0]; longest = std::max(longest, set_count[st]); }
         hdr[25] = equal ? set_count[0] : 0;
+        hdr[26] = (int32_t)off_bmap;
+        hdr[27] = longest;
         std::copy(hdr, hdr + U2_HDR, out);
         std::copy(items.begin(), items.end(), out + U2_HDR);
+        // block -> (item, accumulator slot wave * U2_SLOTS + j) for the summing pass over the per-workgroup partial sums
+        int32_t* bmap = out + off_bmap;
+        std::fill(bmap, bmap + blocks, -1);
+        for (long it = 0; it < nitems; ++it) {
+            const int32_t* ip = items.data() + it * U2_ITEM;
+            for (int wv = 0; wv < U2_WAVES; ++wv) {
+                const int32_t* wd = ip + 4 + wv * U2_WWORDS;
+                const int n = (wd[0] & 15) + ((wd[0] >> 4) & 15);
+                for (int j = 0; j < n; ++j) {
+                    if (wd[1 + j] < 0 || wd[1 + j] >= blocks || bmap[wd[1 + j]] != -1) return -1;
+                    bmap[wd[1 + j]] = (int32_t)((it << 8) | (wv * U2_SLOTS + j));
+                }
+            }
+        }
+        for (int w = 0; w < blocks; ++w) if (bmap[w] == -1) return -1;
     }
     return total;
 }

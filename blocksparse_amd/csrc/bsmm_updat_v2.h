@@ -377,27 +377,115 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
 #undef RUN
 
         // D[ci][ko]: col = ko = lane & 31, row ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        if (scratch != nullptr) {
+            // partial sums of this workgroup's (item, minibatch range): plain 16-byte stores in REGISTER order into the region of
+            // this (round, workgroup) -- [slot = wave * 4 + j][quad q][lane] float4, 1 KiB per instruction; updat2_reduce_kernel
+            // knows the schedule, sums the regions of a block and undoes the order.  (Round 2 first used fp32 atomics into
+            // one zeroed image: 52 MiB of cross-XCD atomics per pass, ~30 us of the 112.)
+            float4* reg_base = reinterpret_cast<float4*>(scratch) + ((size_t)(round * gridDim.x + blockIdx.x) * (U2_WAVES * U2_SLOTS) + wave * U2_SLOTS) * 256 + lane;
 #pragma unroll
-        for (int j = 0; j < U2_SLOTS; ++j) {
-            if (j >= n0 + n1) break;
-            const int wid = __builtin_amdgcn_readfirstlane(wd[1 + j]);
-            const size_t base = (size_t)wid * 1024 + (lane & 31);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const size_t idx = base + ci * 32;
+            for (int j = 0; j < U2_SLOTS; ++j) {
+                if (j >= n0 + n1) break;
 #ifdef U2_NO_EPILOGUE
-                if (alpha == 12345.f) DW[idx] = DT::from_f32(acc[j][reg]);
-                continue;
+                if (alpha != 12345.f) continue;
 #endif
-                if (scratch == nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    reg_base[(j * 4 + q) * 64] = make_float4(acc[j][4 * q + 0], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < U2_SLOTS; ++j) {
+                if (j >= n0 + n1) break;
+                const int wid = __builtin_amdgcn_readfirstlane(wd[1 + j]);
+                const size_t base = (size_t)wid * 1024 + (lane & 31);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    const size_t idx = base + ci * 32;
+#ifdef U2_NO_EPILOGUE
+                    if (alpha == 12345.f) DW[idx] = DT::from_f32(acc[j][reg]);
+                    continue;
+#endif
                     float out = alpha * acc[j][reg];
                     if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
                     DW[idx] = DT::from_f32(out);
-                } else {
-                    __hip_atomic_fetch_add(scratch + idx, acc[j][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+        }
+    }
+}
+
+// Second pass of the partial-sum path: one workgroup per block w sums the regions that hold a partial sum of w -- it walks
+// the SAME schedule as updat32_a1_v2_kernel (keep the two in step) -- and writes DW[w] = alpha * [gate[w] *] sum + beta * DW[w]
+// rounded once, or (SUMS) the raw fp32 sums [blocks][32][32] for the data-parallel all-reduce.
+// thread = (quad q = tid >> 6, lane l = tid & 63): elements ci = 8 q + 4 (l >> 5) + e, e = 0..3, ko = l & 31.
+template <class DT, bool SUMS>
+__global__ void __launch_bounds__(256)
+updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict__ DW, float* __restrict__ sums, const int32_t* __restrict__ plan,
+                     const float* __restrict__ gate, int grid, int flat, int CPI, float alpha, float beta) {
+    const int w = blockIdx.x;
+    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int32_t bm = plan[plan[26] + w];
+    const int item = bm >> 8, slot = bm & 255;
+    const bool xcd_mode = flat == 0 && (grid & 7) == 0;
+    const int nsets = xcd_mode ? plan[8] : 1;
+    const int nparts = xcd_mode ? 8 / nsets : 1;
+    const int U = xcd_mode ? grid >> 3 : grid;
+    int set = 0;
+    if (xcd_mode)
+        for (int s = 1; s < nsets; ++s) if (item >= plan[9 + 2 * s]) set = s;
+    const int set_first = xcd_mode ? plan[9 + 2 * set] : 0, set_count = xcd_mode ? plan[10 + 2 * set] : plan[4];
+    const int pos = item - set_first;
+    const int full_rounds = set_count / U, m_last = set_count - full_rounds * U;
+    const int k_last = m_last > 0 ? U / m_last : 0;
+    const float4* base = reinterpret_cast<const float4*>(parts) + ((size_t)slot * 4 + q) * 64 + l;
+    constexpr size_t REGION = (size_t)U2_WAVES * U2_SLOTS * 256;       // float4 per region
+    // the partial sums of this block: one region per (part, slice); independent loads, four in flight per thread, and no
+    // 64-bit division in the walk (a first version spent 40 us at 20 % density on index arithmetic and serial loads)
+    const bool sliced = pos >= full_rounds * U;
+    const int which = pos - full_rounds * U;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = zero4;
+    for (int part = 0; part < nparts; ++part) {
+        const unsigned part_lo = (unsigned)part * (unsigned)CPI / (unsigned)nparts, part_hi = (unsigned)(part + 1) * (unsigned)CPI / (unsigned)nparts;
+        const int L = (int)(part_hi - part_lo);
+        if (L <= 0) continue;
+        const int xcd = set * nparts + part;
+        if (!sliced) {
+            const int round = pos / U, uj = pos - round * U;
+            const float4 v = base[((size_t)round * grid + (xcd_mode ? uj * 8 + xcd : uj)) * REGION];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        } else {
+            const float4* rb = base + (size_t)full_rounds * grid * REGION;
+            auto fetch = [&](int slice) -> float4 {
+                if (slice >= k_last) return zero4;
+                if (L < k_last) {      // fewer chunks than slices: some slices are empty and wrote nothing
+                    const unsigned lo = (unsigned)slice * (unsigned)L / (unsigned)k_last, hi = (unsigned)(slice + 1) * (unsigned)L / (unsigned)k_last;
+                    if (hi == lo) return zero4;
+                }
+                const int uj = which * k_last + slice;
+                return rb[(size_t)(xcd_mode ? uj * 8 + xcd : uj) * REGION];
+            };
+            for (int sl = 0; sl < k_last; sl += 4) {
+                const float4 v0 = fetch(sl), v1 = fetch(sl + 1), v2 = fetch(sl + 2), v3 = fetch(sl + 3);
+                acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+                acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+            }
+        }
+    }
+    const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+    const size_t o = (size_t)w * 1024 + (size_t)(8 * q + 4 * (l >> 5)) * 32 + (l & 31);
+    if constexpr (SUMS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sums[o + e * 32] = r[e];
+    } else {
+        const float a = gate ? alpha * gate[w] : alpha;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = a * r[e];
+            if (beta != 0.f) v += beta * DT::to_f32(DW[o + e * 32]);
+            DW[o + e * 32] = DT::from_f32(v);
         }
     }
 }

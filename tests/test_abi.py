@@ -295,10 +295,11 @@ def test_streaming_updat_plan(lib):
                 assert WS == (16 if t["blocks"] <= 56 * (-(-CB // 16)) * (-(-KB // 16)) else 8)
             else:
                 assert WS == (16 if opt == lib.PLAN_STREAM_16 else 8)
-            items = plan[plan[6]:].reshape(nitems, 4 + 16 * 5)
-            assert plan.size == plan[6] + nitems * 84
+            items = plan[plan[6]:plan[6] + nitems * 84].reshape(nitems, 4 + 16 * 5)
+            assert int(plan[26]) == plan[6] + nitems * 84 and plan.size == int(plan[26]) + t["blocks"]
+            bmap = plan[int(plan[26]):]                       # block -> item << 8 | wave * 4 + slot (for the summing pass)
             seen = set()
-            for it in items:
+            for ii, it in enumerate(items):
                 c0, k0, n = int(it[0]), int(it[1]), int(it[2])
                 assert c0 % WS == 0 and k0 % WS == 0 and 1 <= n <= 64
                 cnt = 0
@@ -315,7 +316,7 @@ def test_streaming_updat_plan(lib):
                             kidx = (m >> (16 + 4 * j)) & 15
                             assert rows[j] < WS and kidx < WS
                             assert tuple(t["updat_lut"][w]) == (c0 + rows[j], k0 + kidx)
-                            assert w not in seen
+                            assert w not in seen and int(bmap[w]) == (ii << 8 | (4 * v + j))
                             seen.add(w)
                             cnt += 1
                         else:
@@ -329,7 +330,7 @@ def test_streaming_updat_plan(lib):
             counts = [int(plan[10 + 2 * s_]) for s_ in range(8)]
             assert sum(counts) == nitems and all(c == 0 for c in counts[nsets:])
             assert firsts[0] == 0 and all(firsts[i + 1] == firsts[i] + counts[i] for i in range(7))
-            assert int(plan[25]) == (counts[0] if len(set(counts[:nsets])) == 1 else 0)
+            assert int(plan[25]) == (counts[0] if len(set(counts[:nsets])) == 1 else 0) and int(plan[27]) == max(counts)
             wc = -(-CB // WS)
             if nsets == 2:
                 for s_ in range(2):
