@@ -358,8 +358,15 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         const double rounds = std::max(1.0, std::ceil(ntiles * ngroups / 256.0));
         const double dens = std::min(1.0, a->blocks / std::max(1.0, CB * KB));
         const double steps = std::ceil(CB / 2.0) * (1.0 - std::pow(1.0 - dens, 2.0 * G));
-        const double t_group = rounds * (0.48 * steps + 0.045 * a->blocks / ngroups) + 8.0;
-        const double t_segment = 17.0 + 1.04e-5 * (double)a->blocks * a->N;
+        double t_group = rounds * (0.48 * steps + 0.045 * a->blocks / ngroups) + 8.0;
+        double t_segment = 17.0 + 1.04e-5 * (double)a->blocks * a->N;
+        if (a->plan_magic == X2PLAN_MAGIC) {
+            // staged kernel, refit (scripts/gpu_xprop_sweep.py, 4096^2 20 % / 5 %, 8192^2 5 %, 2048^2 20 %, N = 128 .. 8192): a round
+            // costs 0.28 us per pair step + 0.040 us per block of the group, up to 20 % more when the round fills all CUs
+            const double fill = std::min(1.0, ntiles * ngroups / rounds / 256.0);
+            t_group = rounds * (0.28 * steps + 0.040 * a->blocks / ngroups) * (1.0 + 0.2 * fill) + 4.0;
+            t_segment = std::max(14.4, 10.0 + 1.04e-5 * (double)a->blocks * a->N);
+        }
         return t_group < t_segment ? XP_XCOL32 : XP_SEGMENT;
     }
     return XP_SEGMENT;
@@ -637,13 +644,27 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                 (long)N * std::max(a->C, a->K) < (1L << 30)) {
                 bool stream = true;
                 if (variant == 0) {
-                    // ~0.3 us per 16-row chunk of a workgroup's range (L2 -> LDS bound), + zero-fill / finalize of the scratch;
-                    // per-block kernel as fitted in round 1
+                    // Fitted to scripts/gpu_updat_sweep.py (4096^2 20 % / 5 %, 8192^2 5 %, 2048^2 20 %, N = 128 .. 8192, us):
+                    // streaming kernel: 6 + 0.40 per 16-row chunk of a workgroup's share + 0.45 per MiB of partial sums (written by the
+                    // kernel, read back by the reduce pass; a block has nparts partial sums, times the slices of the last round);
+                    // per-block transposing-read kernel: 8 + rounds of 512 blocks * N * r, r = 0.004 while X and DY are small
+                    // (16 MiB), rising to 0.0105 at 128 MiB.
                     const U2Launch L = updat2_shape(a, gated);
                     const double chunks = (double)a->plan_items * a->pcount * ((N + U2_CH - 1) / U2_CH);
-                    const double t_stream = 10.0 + std::ceil(chunks / L.grid) * 0.30 + (L.scratch ? 8.0 : 0.0);   // (refit after every kernel change)
+                    double t_stream = 6.0 + chunks / L.grid * 0.40;
+                    if (L.scratch && !L.flat) {
+                        const int nsets = a->plan_inner & 15, longest = a->plan_inner >> 8, U = std::max(1, L.grid / 8);
+                        const int m_last = longest % U;
+                        const double sliced = longest > 0 ? (double)m_last / longest : 0.0;
+                        const double mult = (8.0 / std::max(1, nsets)) * ((1.0 - sliced) + sliced * (m_last > 0 ? U / m_last : 1));
+                        t_stream += 0.45 * mult * a->blocks * 4096.0 / 1048576.0;
+                    } else if (L.scratch) {
+                        t_stream += 8.0;
+                    }
                     const double rounds_b = std::max(1.0, std::ceil(a->blocks / 512.0));
-                    const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * (N > 1024 ? 0.0105 : 0.0065);
+                    const double foot = (double)N * a->pcount * (a->C + a->K) * 2.0 / 1048576.0;                 // MiB of X and DY
+                    const double rate = std::min(0.0105, std::max(0.004, 0.004 + 0.0065 * (foot - 16.0) / 112.0));
+                    const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * rate;
                     stream = t_stream <= t_blk || sums_only;
                 }
                 if (stream) return launch_updat2<DT>(xs, es, DW, a, ug);

@@ -15,8 +15,9 @@
 //   * two wave sets per SIMD half an interval out of phase (one multiplies while the other's fragment reads are in flight);
 //   * the schedule of the plan (bsmm_plan.h): XCD x owns an item set and a part of the minibatch, its workgroups walk the
 //     set's items in lockstep through that part, so an XCD's L2 sees a quarter of half of X and of all of DY;
-//   * partial sums of an item meet in the fp32 scratch (atomics; zeroed by the launcher) and updat_finalize_gated_kernel
-//     applies alpha / beta (and the optional gate) with ONE rounding.  Items that are one workgroup's are stored directly.
+//   * the partial sums of a workgroup's (item, minibatch range) leave as plain 16-byte stores in register order into that
+//     (round, workgroup)'s region of the workspace; updat2_reduce_kernel walks the same schedule, sums the regions of every
+//     block and applies alpha / beta (and the optional gate) with ONE rounding.  Items that are one workgroup's are stored directly.
 // LDS image of a chunk: X slab [16 rows][WS*64 B] then DY slab, 16-byte pieces of row r XOR-swizzled with 4*(r & 3)
 // (bank-conflict free for ds_read_b64_tr_b16, as in bsmm_updat_win.h).  1024 threads, 128 KiB (WS = 16): one workgroup per CU.
 //
