@@ -188,6 +188,35 @@ def test_small_layouts_multi_block_windows(env, opt, dtype):
         lib.set_kernel_variant(0)
 
 
+# ---- (d1) streaming updat at the bench layouts with FEW chunks: empty minibatch parts and empty slices ------------------
+@pytest.mark.parametrize("density", [0.1, 0.2])
+@pytest.mark.parametrize("N", [16, 40, 200])
+def test_streaming_updat_partial_sums_with_few_chunks(env, density, N):
+    """The kernel writes one region of partial sums per (round, workgroup) and updat2_reduce_kernel walks the same schedule
+    to sum them.  With 1 .. 13 chunks of 16 rows for 4 minibatch parts and up to 32 slices per item of the last round, most
+    (part, slice) ranges are EMPTY -- both sides must skip exactly the same ones.  Also two (x, dy) pairs and beta != 0."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(128, 128, density, seed=1234)
+    b = BSMM(layout, block_size=32, feature_axis=1)
+    try:
+        lib.set_kernel_variant(3)
+        _check_sampled(torch, lib, b, layout, N, "bf16", seed=31 + N, expect={"updat": lib.K_UPDAT_STREAM}, ctx="few chunks d%d N%d" % (round(density * 100), N),
+                       passes=("DW",))
+        t = orc.build_layout_luts(layout, 32)
+        Xs, Es = [], []
+        for p in range(2):
+            _, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "bf16", seed=50 + p)
+            Xs.append(X); Es.append(E)
+        dw0 = orc.round_bf16(np.random.RandomState(2).normal(size=b.w_shape).astype(np.float32) * 0.05)
+        out = P.to_host(b.updat([P.to_dev(x, "bf16", torch) for x in Xs], [P.to_dev(e, "bf16", torch) for e in Es], alpha=0.25, beta=1.5,
+                                dw=P.to_dev(dw0, "bf16", torch)))
+        assert lib.last_kernel() == lib.K_UPDAT_STREAM
+        l2, _ = P.errors(out, orc.round_bf16(orc.updat(t, Xs, Es, 1, alpha=0.25, beta=1.5, dw_in=dw0)))
+        assert l2 <= P.L2_BAR["bf16"], l2
+    finally:
+        lib.set_kernel_variant(0)
+
+
 # ---- (d2) xprop plan kernels on small forced layouts: staged (default) and round-1 ------------------------------------
 @pytest.mark.parametrize("opt", [0, "PLAN_XCOL_UNSTAGED", "PLAN_XCOL_NARROW"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
