@@ -75,7 +75,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32 && a->axis == 1)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 16) return (m == XC16PLAN_MAGIC && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return ((m == XCPLAN_MAGIC && a->plan_width == XS_G) || m == XFPLAN_MAGIC) ? BSMM_OK : BSMM_ERR_ARG;
-    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->axis == 1 && a->plan_width == X2_G)) ? BSMM_OK : BSMM_ERR_ARG;
+    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G)) ? BSMM_OK : BSMM_ERR_ARG;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,7 +260,7 @@ int launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hi
     return BSMM_ERR_ARG;
 }
 
-template <class DT, bool TRANSW>
+template <class DT, bool TRANSW, int AXIS>
 int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
@@ -270,9 +270,9 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds(&xcol32_a1_v2_kernel<DT, TRANSW>, X2_LDS)) return rc;
+    if (int rc = ensure_lds(&xcol32_v2_kernel<DT, TRANSW, AXIS>, X2_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_STAGED);
-    xcol32_a1_v2_kernel<DT, TRANSW><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+    xcol32_v2_kernel<DT, TRANSW, AXIS><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                a->N, a->C, a->K);
     return (int)hipGetLastError();
 }
@@ -280,9 +280,7 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
     if (a->plan_magic == X2PLAN_MAGIC) {
-        if constexpr (AXIS == 1) {
-            if (a->plan_width == X2_G) return transw ? launch_xcol_v2<DT, true>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false>(X, Wsel, Y, a, st);
-        }
+        if (a->plan_width == X2_G) return transw ? launch_xcol_v2<DT, true, AXIS>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false, AXIS>(X, Wsel, Y, a, st);
         return BSMM_ERR_ARG;
     }
     if (a->plan_magic != XCPLAN_MAGIC) return BSMM_ERR_ARG;
@@ -347,7 +345,6 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     }
     if constexpr (BS == 32 && DT::is16) {
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // axis-0 xcol needs 16-byte aligned row pieces
-        if (a->plan_magic == X2PLAN_MAGIC && (AXIS != 1 || a->C % 32 != 0)) return XP_SEGMENT;
         if (force) return XP_XCOL32;
         // Cost model fitted to the measurements in profiles/r01_sweeps.md (4096^2 / 20 % and 8192^2 / 5 %, N = 512 .. 8192):
         // the grouped kernel pays ~0.48 us per pair step of a group plus ~0.045 us per block, once per round of 256
@@ -971,7 +968,7 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
                                               : build_xcol_plan(lut, segments, blocks, n_out, out, XS_G);
     }
     if (bsize == 16) return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
-    if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW)) && axis == 1) {   // default: the staged kernel
+    if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel (either feature axis)
         const long n = build_xcol2_plan(lut, segments, blocks, n_out, out);
         if (n != 0) return n;                                            // 0: the layout does not fit the table fields
     }

@@ -55,9 +55,12 @@ static_assert(X2_LDS <= 163840 && X2_R * X2_G * 64 <= X2_LDS, "ring and epilogue
 // TRANSW = true (fprop): Wsel is W in its natural [c-in-block][k-in-block] layout; the blocks are staged unswizzled and the
 // fragment (8 consecutive c for one k per lane) is built with four transposing 8-byte reads -- no transposed copy of W, no
 // pre-pass, no workspace.
-template <class DT, bool TRANSW>
+// AXIS = 0: activations (C, N), minibatch contiguous: a slab is [64 feature rows] x [128 minibatch columns] (256 B per row,
+// 16-byte pieces XOR-swizzled with 4 * (row & 3)), the B operand (8 consecutive FEATURES of one minibatch column per lane) is
+// built with transposing reads as in xcol32_a0_kernel, output rows are features.  Requires N % 8 == 0.  Same plans.
+template <class DT, bool TRANSW, int AXIS = 1>
 __global__ void __launch_bounds__(64 * X2_G, 4)
-xcol32_a1_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
+xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
                     typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
     typedef typename DT::T T;
     static_assert(DT::is16, "xcol v2 kernel: 16-bit storage types");
@@ -79,14 +82,23 @@ xcol32_a1_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* 
     // activation DMA: a slab is 16 instructions of 1 KiB (8 rows of 128 B); wave v issues instruction v of each slab
     const unsigned char* xt = reinterpret_cast<const unsigned char*>(X);
     uint32_t xvoff, xvoff_tail;
-    {
+    if constexpr (AXIS == 1) {
         const int row = 8 * wave + (lane >> 3);
         const int xr = min(n_tile + row, N - 1) - n_tile;            // rows past N are clamped (never stored)
         const int piece = (lane & 7) ^ ((row >> 1) & 7);
         xvoff = (uint32_t)xr * (uint32_t)Cin * 2u + piece * 16;
         xvoff_tail = xvoff - ((piece & 4) ? 64 : 0);                  // last pair of an odd block count: re-read its even half
+    } else {
+        // instruction v = slab rows 4v .. 4v+3 (256 B each): lane -> (row, stored piece lane & 15); columns past N are clamped
+        const int row = 4 * wave + (lane >> 4);
+        const int piece = (lane & 15) ^ (4 * (row & 3));
+        const int col = min(n_tile + piece * 8, N - 8) - n_tile;
+        xvoff = (uint32_t)row * (uint32_t)N * 2u + (uint32_t)col * 2u;
+        xvoff_tail = (uint32_t)min(row, 31) * (uint32_t)N * 2u + (uint32_t)col * 2u;   // missing odd block: re-read row 31 of the even one
     }
-    const unsigned char* xtile = static_cast<const unsigned char*>(uniform_ptr(xt + (size_t)n_tile * Cin * 2));
+    // per pair step the source moves by 128 B (axis 1: 64 features of a row) / by 64 rows of N elements (axis 0)
+    const size_t xstep = AXIS == 1 ? (size_t)128 : (size_t)N * 128;
+    const unsigned char* xtile = static_cast<const unsigned char*>(uniform_ptr(xt + (AXIS == 1 ? (size_t)n_tile * Cin * 2 : (size_t)n_tile * 2)));
     const unsigned char* wsel = static_cast<const unsigned char*>(uniform_ptr(Wsel));
     // weight DMA: lane i of an instruction writes piece i of a 1 KiB half block (rows 16*hb + (i >> 2)); it fetches the
     // piece that the swizzle puts there: (i & 3) ^ ((row >> 2) & 3) = (i & 3) ^ ((i >> 4) & 3)
@@ -94,11 +106,15 @@ xcol32_a1_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* 
 
     // fragment read offsets
     const int xsw = (r >> 1) & 7;
-    uint32_t xrd[2][2];      // [half][kk], inside a 32-row band of slab 0 of ring half 0
+    uint32_t xrd[2][2];      // axis 1: [half][kk], inside a 32-row band of slab 0 of ring half 0
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) xrd[half][kk] = r * 128 + (((4 * half + 2 * kk + h) ^ xsw) << 4);
+    // axis 0 (xcol32_a0_kernel): 16-lane group g16 -> minibatch columns 16 * (g16 & 1) .. of a 32-column tile, K half g16 >> 1;
+    // lane t16 points at row (t16 >> 2) of a 4-row band, 8 bytes at column 4 * (t16 & 3)
+    const int g16x = lane >> 4, t16x = lane & 15, trowx = t16x >> 2;
+    const int tcolbx = (16 * (g16x & 1) + 4 * (t16x & 3)) * 2;
     uint32_t wrd[2];         // [kk], inside slot 0 of ring half 0
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -122,8 +138,8 @@ xcol32_a1_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* 
         const uint32_t xdst = base_addr + (hb_) * X2_XHALF + wave * 1024;                                                   \
         const uint32_t wdst = base_addr + X2_WBASE + (hb_) * X2_WHALF;                                                      \
         const int p0 = (px_) & 0xffff, p1 = (int)((uint32_t)(px_) >> 16);                                                   \
-        if (!X2_NO_XDMA) glds16_saddr(xtile + (size_t)p0 * 128, p0 < npairs_full ? xvoff : xvoff_tail, xdst);               \
-        if (!X2_NO_XDMA && p1 != 0xffff) glds16_saddr(xtile + (size_t)p1 * 128, p1 < npairs_full ? xvoff : xvoff_tail, xdst + X2_SLAB); \
+        if (!X2_NO_XDMA) glds16_saddr(xtile + (size_t)p0 * xstep, p0 < npairs_full ? xvoff : xvoff_tail, xdst);             \
+        if (!X2_NO_XDMA && p1 != 0xffff) glds16_saddr(xtile + (size_t)p1 * xstep, p1 < npairs_full ? xvoff : xvoff_tail, xdst + X2_SLAB); \
         if (X2_NO_WDMA) break;                                                                                              \
         if ((d0_) != -1) glds16_saddr(wsel + ((size_t)((d0_) & 0x3ffffff) << 10), wvoff, wdst + (((uint32_t)(d0_) >> 26) << 10)); \
         if ((d1_) != -1) glds16_saddr(wsel + ((size_t)((d1_) & 0x3ffffff) << 10), wvoff, wdst + (((uint32_t)(d1_) >> 26) << 10)); \
@@ -146,7 +162,18 @@ xcol32_a1_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xf[t][kk] = *reinterpret_cast<const uint4*>(smem + xrd[half][kk] + xoff + t * 4096);
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (AXIS == 1) {
+                    xf[t][kk] = *reinterpret_cast<const uint4*>(smem + xrd[half][kk] + xoff + t * 4096);
+                } else {
+                    // rows (features) 32 * half + 16 * kk + 8 * (g16 >> 1) + {0..3 | 4..7}; row & 3 == trow for both bands
+                    const int row0 = 32 * half + 16 * kk + 8 * (g16x >> 1) + trowx;
+                    const int byte = 64 * t + tcolbx;                             // byte inside the 256-byte row (before swizzle)
+                    const int sw = (((byte >> 4) ^ (4 * trowx)) << 4) | (byte & 15);
+                    const uint2 lo = ds_tr16(smem + xoff + row0 * 256 + sw), hi = ds_tr16(smem + xoff + (row0 + 4) * 256 + sw);
+                    xf[t][kk] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+            }
 #if X2_READS_FIRST
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -201,6 +228,22 @@ xcol32_a1_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* 
     }
 #undef X2_ISSUE
 
+    if constexpr (AXIS == 0) {
+        // D[o][n]: col = n = r, rows o = (reg & 3) + 8 * (reg >> 2) + 4h  ->  Y[(ob * 32 + o) * N + n]: 64-byte row segments
+        if (X2_NO_EPILOGUE) { if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) Y[0] = DT::from_f32(1.f); return; }
+        if (wave >= nob) return;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = n_tile + t * 32 + r;
+            if (n >= N) continue;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int o = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                Y[(size_t)((ob0 + wave) * 32 + o) * N + n] = DT::from_f32(acc[t][reg]);
+            }
+        }
+        return;
+    }
     // Epilogue (as bsmm_xcol.h): D[o][n]: col = n = r (lane), rows o = (reg & 3) + 8 * (reg >> 2) + 4h.  The 16 waves own 16
     // ADJACENT output blocks = 1024 contiguous bytes per minibatch row: staged through the idle ring as [128 rows][1024 B]
     // (16-byte pieces of row n XOR-swizzled with n & 31) and stored as full rows.

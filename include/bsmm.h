@@ -70,7 +70,7 @@ enum {
 enum {
     BSMM_PLAN_XCOL_NARROW = 1,      /* xprop bsize 32 / 16: 8 (16) output blocks per workgroup instead of 16 (32)            */
     BSMM_PLAN_F32_MFMA = 2,         /* xprop fp32 bsize 32: schedule for the fp32 matrix-core kernel instead of the bf16 split */
-    BSMM_PLAN_XCOL_UNSTAGED = 4,    /* xprop bsize 32, 16-bit, axis 1: the round-1 kernel (weights by register loads, bsmm_xcol.h)
+    BSMM_PLAN_XCOL_UNSTAGED = 4,    /* xprop bsize 32, 16-bit: the round-1 kernel (weights by register loads, bsmm_xcol.h)
                                        instead of the staged one (weights through LDS as well, bsmm_xcol_v2.h)                */
     BSMM_PLAN_WINDOW_8 = 0x10,      /* updat bsize 32: round-1 windowed kernel, 8x8-block windows, 8 waves                  */
     BSMM_PLAN_WINDOW_16 = 0x20,     /*                 round-1 windowed kernel, 16x16-block windows, 8 waves                */

@@ -26,7 +26,7 @@ for d in dens:
     lay = P.random_layout(CB, CB, d / 100.0, 1234)
     res = {}
     for name, opt in (("base", _lib.PLAN_XCOL_UNSTAGED), ("staged", 0)):
-        b = BlocksparseMatMul(lay, block_size=32, feature_axis=1, plan_options=opt)
+        b = BlocksparseMatMul(lay, block_size=32, feature_axis=int(os.environ.get("XP_AXIS", "1")), plan_options=opt)
         g = torch.Generator(device="cuda").manual_seed(1)
         w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.05).bfloat16()
         x = (torch.randn(b.i_shape(8192), device="cuda", generator=g) * 0.1).bfloat16()

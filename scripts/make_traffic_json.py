@@ -4,6 +4,7 @@ import json, sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 txt = open("profiles/%s_pmc.txt" % rnd).read().split("## density ")[1:]
 NAMES = (("updat32_a1_v2", "bsmm_updat"), ("updat2_reduce", "bsmm_updat_reduce"), ("updat_finalize", "bsmm_updat_finalize"),
+         ("xcol32_v2_kernel<bsmm::DTbf16, false", "bsmm_xprop(bprop)"), ("xcol32_v2_kernel<bsmm::DTbf16, true", "bsmm_xprop(fprop)"),
          ("xcol32_a1_v2_kernel<bsmm::DTbf16, false", "bsmm_xprop(bprop)"), ("xcol32_a1_v2_kernel<bsmm::DTbf16, true", "bsmm_xprop(fprop)"),
          ("xcol32_a1_kernel", "bsmm_xprop_round1"), ("transpose_blocks", "bsmm_transpose_blocks"))
 data = {}

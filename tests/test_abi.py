@@ -402,7 +402,7 @@ def test_plan_attach_descriptor_and_host_side_rejection(lib):
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_UNSTAGED))
     assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items, a.plan_inner) == (0x42535843, 16, 16, 0, 0)
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 0))
-    assert a.plan_magic == 0x42535843               # feature_axis 0: round-1 format
+    assert a.plan_magic == 0x42535832               # feature_axis 0: the same staged plan
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_NARROW))
     assert (a.plan_width, a.plan_waves) == (8, 8)
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.F32, 1, lib.PLAN_F32_MFMA))

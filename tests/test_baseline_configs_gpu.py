@@ -36,8 +36,8 @@ def _updat_kernel(lib, axis, opt=0):
 
 
 def _xprop_kernel(lib, axis, opt=0):
-    """which bsize-32 16-bit xprop plan kernel runs: axis 1 defaults to the staged kernel (bsmm_xcol_v2.h)"""
-    return lib.K_XCOL32_STAGED if axis == 1 and not (opt & (lib.PLAN_XCOL_UNSTAGED | lib.PLAN_XCOL_NARROW)) else lib.K_XCOL32
+    """which bsize-32 16-bit xprop plan kernel runs: the staged kernel (bsmm_xcol_v2.h) unless the plan options say otherwise"""
+    return lib.K_XCOL32_STAGED if not (opt & (lib.PLAN_XCOL_UNSTAGED | lib.PLAN_XCOL_NARROW)) else lib.K_XCOL32
 
 
 def _inputs(torch, b, N, dtype, seed):
@@ -218,50 +218,52 @@ def test_streaming_updat_partial_sums_with_few_chunks(env, density, N):
 
 
 # ---- (d2) xprop plan kernels on small forced layouts: staged (default) and round-1 ------------------------------------
+@pytest.mark.parametrize("axis", [1, 0])
 @pytest.mark.parametrize("opt", [0, "PLAN_XCOL_UNSTAGED", "PLAN_XCOL_NARROW"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_small_layouts_xprop_plan_kernels(env, opt, dtype):
+def test_small_layouts_xprop_plan_kernels(env, opt, dtype, axis):
     """fprop (in-kernel transposing reads of the staged weight blocks) and bprop against the full float64 oracle: dense layouts
     (steps with 32 blocks are split over phases), odd block counts (half-empty last pair), partial last group, one block,
-    minibatches that are not a multiple of the 128-row tile."""
+    minibatches that are not a multiple of the 128-row tile (axis 0: multiples of 8, the plan kernels' alignment rule)."""
     torch, BSMM, lib = env
     o = getattr(lib, opt) if opt else 0
     cases = [(np.ones((9, 35), dtype=bool), (72, 200)),                 # dense: 32 blocks per step > 24 slots per ring half
-             (P.random_layout(33, 17, 0.3, seed=3), (100, 8)),          # odd block counts on both sides
+             (P.random_layout(33, 17, 0.3, seed=3), (104, 8)),          # odd block counts on both sides
              (np.ones((1, 1), dtype=bool), (40,)),                      # one block, one group of one column
              (P.random_layout(40, 40, 0.15, seed=2), (392, 128)),
              (P.ba_layout(40, 3, seed=1), (264,))]
     try:
         lib.set_kernel_variant(3)
         for li, (layout, Ns) in enumerate(cases):
-            b = BSMM(layout, block_size=32, feature_axis=1, plan_options=o)
+            b = BSMM(layout, block_size=32, feature_axis=axis, plan_options=o)
             t = orc.build_layout_luts(layout, 32)
             for N in Ns:
                 W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=li * 5 + N)
                 w, x, e = P.to_dev(W, dtype, torch), P.to_dev(X, dtype, torch), P.to_dev(E, dtype, torch)
                 y = P.to_host(b.fprop(x, w))
-                assert lib.last_kernel() == _xprop_kernel(lib, 1, o)
+                assert lib.last_kernel() == _xprop_kernel(lib, axis, o)
                 dx = P.to_host(b.bprop(e, w))
-                assert lib.last_kernel() == _xprop_kernel(lib, 1, o)
-                l2y, _ = P.errors(y, orc.round_to(orc.fprop(t, X, W, 1), dtype))
-                l2x, _ = P.errors(dx, orc.round_to(orc.bprop(t, E, W, 1), dtype))
-                assert l2y <= P.L2_BAR[dtype] and l2x <= P.L2_BAR[dtype], (opt, li, N, l2y, l2x)
+                assert lib.last_kernel() == _xprop_kernel(lib, axis, o)
+                l2y, _ = P.errors(y, orc.round_to(orc.fprop(t, X, W, axis), dtype))
+                l2x, _ = P.errors(dx, orc.round_to(orc.bprop(t, E, W, axis), dtype))
+                assert l2y <= P.L2_BAR[dtype] and l2x <= P.L2_BAR[dtype], (opt, axis, li, N, l2y, l2x)
     finally:
         lib.set_kernel_variant(0)
 
 
-def test_staged_and_round1_xprop_kernels_agree_bitwise(env):
+@pytest.mark.parametrize("axis", [1, 0])
+def test_staged_and_round1_xprop_kernels_agree_bitwise(env, axis):
     """Both plan kernels accumulate a block column in the same order (pairs ascending, even half first) with the same MFMAs:
-    identical bits at the bench shape, fprop and bprop."""
+    identical bits at the bench shape, fprop and bprop, either feature axis."""
     torch, BSMM, lib = env
     layout = P.random_layout(128, 128, 0.2, seed=1234)
     outs = []
     for o in (0, lib.PLAN_XCOL_UNSTAGED):
-        b = BSMM(layout, block_size=32, feature_axis=1, plan_options=o)
+        b = BSMM(layout, block_size=32, feature_axis=axis, plan_options=o)
         w, x, e = _inputs(torch, b, 8192, "bf16", seed=5)
         y = b.fprop(x, w); k1 = lib.last_kernel()
         dx = b.bprop(e, w)
-        assert k1 == lib.last_kernel() == _xprop_kernel(lib, 1, o)
+        assert k1 == lib.last_kernel() == _xprop_kernel(lib, axis, o)
         outs.append((y, dx))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
