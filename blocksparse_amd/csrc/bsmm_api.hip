@@ -19,6 +19,7 @@
 #include "bsmm_xcol.h"
 #include "bsmm_xcol_v2.h"
 #include "bsmm_xcol16.h"
+#include "bsmm_xcol16_v2.h"
 #include "bsmm_xprop.h"
 
 using namespace bsmm;
@@ -73,7 +74,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     const int32_t m = a->plan_magic;
     if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32 && a->axis == 1)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
-    if (a->bsize == 16) return (m == XC16PLAN_MAGIC && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
+    if (a->bsize == 16) return ((m == XC16PLAN_MAGIC || (m == X7PLAN_MAGIC && a->plan_width == X7_G)) && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return ((m == XCPLAN_MAGIC && a->plan_width == XS_G) || m == XFPLAN_MAGIC) ? BSMM_OK : BSMM_ERR_ARG;
     return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G)) ? BSMM_OK : BSMM_ERR_ARG;
 }
@@ -158,7 +159,25 @@ int launch_xcol16_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a
 }
 
 template <class DT, int AXIS>
+int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    typedef typename DT::T T;
+    const int n_out = a->K / 16;
+    XMap m;
+    m.ntiles = (a->N + XC_R - 1) / XC_R;
+    m.segments = (n_out + X7_G - 1) / X7_G;
+    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+    if (m.P > m.segments) m.P = m.segments;
+    m.SP = (m.segments + m.P - 1) / m.P;
+    if (int rc = ensure_lds(&xcol16_v2_kernel<DT, AXIS>, X7_LDS)) return rc;
+    trace(a, BSMM_K_XCOL16_STAGED);
+    xcol16_v2_kernel<DT, AXIS><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                              a->N, a->C, a->K);
+    return (int)hipGetLastError();
+}
+
+template <class DT, int AXIS>
 int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    if (a->plan_magic == X7PLAN_MAGIC) return a->plan_width == X7_G ? launch_xcol16_v2<DT, AXIS>(X, Wsel, Y, a, st) : BSMM_ERR_ARG;
     if (a->plan_magic != XC16PLAN_MAGIC) return BSMM_ERR_ARG;
     if (a->plan_width == 32) return launch_xcol16_g<DT, AXIS, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
     if (a->plan_width == XC16_G) return launch_xcol16_g<DT, AXIS, 8, XC_PH>(X, Wsel, Y, a, st);
@@ -967,7 +986,13 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
         return (options & BSMM_PLAN_F32_MFMA) ? build_xcolf_plan(lut, segments, blocks, n_out, out)
                                               : build_xcol_plan(lut, segments, blocks, n_out, out, XS_G);
     }
-    if (bsize == 16) return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
+    if (bsize == 16) {
+        if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel
+            const long n = build_xcol16s_plan(lut, segments, blocks, n_out, out);
+            if (n != 0) return n;
+        }
+        return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
+    }
     if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel (either feature axis)
         const long n = build_xcol2_plan(lut, segments, blocks, n_out, out);
         if (n != 0) return n;                                            // 0: the layout does not fit the table fields
@@ -1035,6 +1060,7 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
     switch (p[0]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
+        case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;

@@ -275,6 +275,110 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
 }  // namespace bsmm
 
 // =================================================================================================
+// staged xcol16 plan ('BSX7', bsize 16): the staged scheme of the 'BSX2' plan for 16x16 blocks (bsmm_xcol16_v2.h).  Groups of
+// X7_G = 32 consecutive output blocks, wave v of 16 owns blocks 2v and 2v+1; a step is a QUAD of input blocks (64 features);
+// a phase = up to two steps and up to X7_WCAP weight blocks = one half of the LDS ring (2 activation slabs of 16 KiB + X7_WCAP
+// slots of 512 B).  Weight blocks are fetched two at a time (one 1 KiB DMA instruction = slots 2j and 2j+1), the instructions
+// dealt evenly over the 16 waves (<= 3 each).
+// Layout (int32): [0] magic 'BSX7' [1] version [2] X7_G [3] ngroups [4] nphases_total [5] off_groups [6] off_px
+//                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] X7_WCAP [10] max phases of a group
+//   groups[ngroups][4] = (phase_off, nphases, first_out_block, n_out_blocks_in_group)
+//   px [nphases_total]           quad of step 0 | quad of step 1 << 16   (0xffff = no such step)
+//   tab[nphases_total][16][12]   per phase and wave:
+//        [0..3]  16 slot bytes: byte 8 * u + 4 * c + sub = slot of (step u, my output block c, input block sub of the quad), 0xff = none
+//        [4..9]  three DMA duties (A, B): A = first weight block | slot pair << 26 (or -1: no duty), B = second weight block
+//        [10..11] 0
+// =================================================================================================
+namespace bsmm {
+
+constexpr int32_t X7PLAN_MAGIC = 0x42535837;
+constexpr int32_t X7PLAN_VERSION = 1;
+constexpr int X7_G = 32;
+constexpr int X7_WCAP = 94;            // even; slot X7_WCAP of each ring half stays zero (the fragment of an absent block)
+constexpr int X7_ROW = 12;             // words per (phase, wave)
+
+inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
+    if (blocks >= (1 << 23)) return 0;                                       // 32-bit byte offsets into W
+    const int G = X7_G, ngroups = (n_out_blocks + G - 1) / G;
+    struct E { int p, col, sub, w; };
+    std::vector<std::vector<E>> per_group(ngroups);
+    for (int s = 0; s < segments; ++s) {
+        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
+        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
+        for (int e = 0; e < cnt; ++e) {
+            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
+            if (w < 0 || w >= blocks || c < 0) return -1;
+            if (c >= 4 * 0xffff) return 0;
+            per_group[ob / G].push_back({c >> 2, ob % G, c & 3, w});
+        }
+    }
+    std::vector<int32_t> groups, px, tab;
+    int max_ph = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        auto& v = per_group[g];
+        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : (a.col != b.col ? a.col < b.col : a.sub < b.sub); });
+        struct Step { int p; size_t lo, hi; };      // runs of equal quad, at most X7_WCAP entries each
+        std::vector<Step> steps;
+        for (size_t i = 0; i < v.size();) {
+            size_t j = i;
+            while (j < v.size() && v[j].p == v[i].p) ++j;
+            for (size_t lo = i; lo < j; lo += X7_WCAP) steps.push_back({v[i].p, lo, std::min(j, lo + (size_t)X7_WCAP)});
+            i = j;
+        }
+        const int phase_off = (int)px.size();
+        for (size_t s = 0; s < steps.size();) {
+            const size_t n0 = steps[s].hi - steps[s].lo;
+            const bool two = s + 1 < steps.size() && n0 + (steps[s + 1].hi - steps[s + 1].lo) <= (size_t)X7_WCAP;
+            const int nst = two ? 2 : 1;
+            px.push_back(steps[s].p | ((two ? steps[s + 1].p : 0xffff) << 16));
+            std::vector<int32_t> row((size_t)16 * X7_ROW, 0);
+            for (int wv = 0; wv < 16; ++wv)
+                for (int k = 0; k < 10; ++k) row[(size_t)wv * X7_ROW + k] = -1;
+            std::vector<int32_t> ws;                 // weight block of every slot, in slot order
+            for (int u = 0; u < nst; ++u)
+                for (size_t i = steps[s + u].lo; i < steps[s + u].hi; ++i) {
+                    const E& e = v[i];
+                    const int slot = (int)ws.size();
+                    ws.push_back(e.w);
+                    const int byte = 8 * u + 4 * (e.col & 1) + e.sub;
+                    uint32_t& word = reinterpret_cast<uint32_t&>(row[(size_t)(e.col >> 1) * X7_ROW + (byte >> 2)]);
+                    word = (word & ~(0xffu << (8 * (byte & 3)))) | ((uint32_t)slot << (8 * (byte & 3)));
+                }
+            int duty = (int)(px.size() * 5) % 16;
+            std::vector<int> nduty(16, 0);
+            for (size_t pair = 0; 2 * pair < ws.size(); ++pair) {
+                const int32_t a = ws[2 * pair], b = (2 * pair + 1 < ws.size()) ? ws[2 * pair + 1] : ws[2 * pair];
+                const int wv = duty; duty = (duty + 1) % 16;
+                row[(size_t)wv * X7_ROW + 4 + 2 * nduty[wv]] = (int32_t)((uint32_t)a | ((uint32_t)pair << 26));
+                row[(size_t)wv * X7_ROW + 5 + 2 * nduty[wv]] = b;
+                ++nduty[wv];
+            }
+            tab.insert(tab.end(), row.begin(), row.end());
+            s += nst;
+        }
+        const int nph = (int)px.size() - phase_off;
+        max_ph = std::max(max_ph, nph);
+        groups.insert(groups.end(), {phase_off, nph, g * G, std::min(G, n_out_blocks - g * G)});
+    }
+    const int off_groups = XC_HDR, off_px = off_groups + (int)groups.size();
+    const int off_tab = (off_px + (int)px.size() + 3) & ~3;
+    const long total = off_tab + (long)tab.size();
+    if (out) {
+        std::fill(out, out + off_tab, 0);
+        const int32_t hdr[XC_HDR] = {X7PLAN_MAGIC, X7PLAN_VERSION, G, ngroups, (int32_t)px.size(), off_groups, off_px, off_tab,
+                                     n_out_blocks, X7_WCAP, max_ph, 0};
+        std::copy(hdr, hdr + XC_HDR, out);
+        std::copy(groups.begin(), groups.end(), out + off_groups);
+        std::copy(px.begin(), px.end(), out + off_px);
+        std::copy(tab.begin(), tab.end(), out + off_tab);
+    }
+    return total;
+}
+
+}  // namespace bsmm
+
+// =================================================================================================
 // xcolf plan (bsize 32, fp32): the groups and pair walk of the xcol plan, but the work is dealt differently because the
 // fp32 kernel is MFMA-bound and must keep every wave equally busy: wave (t, c) owns row tile t of the workgroup's 128
 // minibatch rows and output blocks 4c..4c+3 of the group, so all waves of class c do identical work, and the two classes

@@ -1,0 +1,231 @@
+// bsmm_xcol16_v2.h -- bsize 16 xprop kernel with the weight blocks staged through LDS ('BSX7' plans): the scheme of
+// bsmm_xcol_v2.h for 16x16 blocks, 16-bit storage types, both feature axes.
+//
+// bsmm_xcol16.h fetched a wave's weight fragments into registers one step ahead with ordinary loads; the vector-memory counter
+// is in order, so the wait in front of every step also drained the activation slabs of the next phase.  Here, as in
+// bsmm_xcol_v2.h, everything a phase needs comes by LDS-DMA one phase ahead and there is one wait per phase:
+//   workgroup = 32 output blocks (512 features) x 128 minibatch rows, 16 waves, wave v owns output blocks 2v, 2v+1 for all rows
+//   (2 x 8 row tiles of 16 x 4 accumulator registers); step = QUAD of input blocks (64 features), the activation slab is
+//   byte-for-byte the slab of a bsize-32 pair step; phase = up to two steps and up to X7_WCAP weight blocks;
+//   LDS = 2 halves x (2 slabs of 16 KiB + 96 slots of 512 B) = 160 KiB; slot X7_WCAP of each half is zero: the fragment of a
+//   block that does not exist (v_mfma_f32_16x16x32 K-concatenates two input blocks: lane (o, q) takes its 8 weights from
+//   block 2 * ks + (q >> 1) of the quad).
+//   Weight DMA: one instruction = two blocks (lanes 0..31 / 32..63), slots 2j and 2j+1.
+#pragma once
+#include "bsmm_common.h"
+#include "bsmm_plan.h"
+#include "bsmm_updat_v2.h"   // glds16_saddr, uniform_ptr
+#include "bsmm_xcol.h"       // slab geometry
+#include "bsmm_xcol16.h"     // BSMM_XC16_TH_*
+
+namespace bsmm {
+
+constexpr int X7_SLAB = XC_SLAB;                       // 16 KiB
+constexpr int X7_XHALF = 2 * X7_SLAB;
+constexpr int X7_WHALF = (X7_WCAP + 2) * 512;          // the phase's slots, the zero slot, one spare
+constexpr int X7_WBASE = 2 * X7_XHALF;
+constexpr int X7_LDS = X7_WBASE + 2 * X7_WHALF;        // 160 KiB
+static_assert(X7_LDS <= 163840 && XC_R * X7_G * 32 <= X7_LDS && X7_WCAP % 2 == 0, "ring and epilogue tile must fit the LDS");
+
+template <class DT, int AXIS>
+__global__ void __launch_bounds__(1024, 4)
+xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
+                 typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "xcol16 v2 kernel: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile, grp;
+    if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
+    const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
+    const int ph_off = __builtin_amdgcn_readfirstlane(gh.x), nph = __builtin_amdgcn_readfirstlane(gh.y);
+    const int ob0 = __builtin_amdgcn_readfirstlane(gh.z), nob = __builtin_amdgcn_readfirstlane(gh.w);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t* pxt = plan + plan[6] + ph_off;
+    const int4* tab = reinterpret_cast<const int4*>(plan + plan[7]) + ((size_t)ph_off * 16 + wave) * 3;   // X7_ROW = 12 words
+    const int o16 = lane & 15, q = lane >> 4;
+    const int n_tile = tile * XC_R;
+    const uint32_t base_addr = lds_addr_of(smem);
+    const int nquads_full = Cin / 64;
+
+    // the zero slots (before anyone can read them: the first barrier of the phase loop orders this)
+    if (threadIdx.x < 64) *reinterpret_cast<uint4*>(smem + X7_WBASE + (lane >> 5) * X7_WHALF + X7_WCAP * 512 + (lane & 31) * 16) = zero_u4();
+    __syncthreads();
+
+    // activation DMA: wave v issues instruction v of each slab (16 x 1 KiB), geometry of bsmm_xcol_v2.h
+    uint32_t xvoff, xvoff_tail;
+    if constexpr (AXIS == 1) {
+        const int row = 8 * wave + (lane >> 3);
+        const int xr = min(n_tile + row, N - 1) - n_tile;
+        const int piece = (lane & 7) ^ ((row >> 1) & 7);
+        xvoff = (uint32_t)xr * (uint32_t)Cin * 2u + piece * 16;
+        // a trailing quad may lack blocks (Cin % 64 != 0): pieces past the row end re-read the row's last 16 bytes
+        xvoff_tail = xvoff - 2u * (uint32_t)max(0, nquads_full * 64 + piece * 8 + 8 - Cin);
+    } else {
+        const int row = 4 * wave + (lane >> 4);
+        const int piece = (lane & 15) ^ (4 * (row & 3));
+        const int col = min(n_tile + piece * 8, N - 8) - n_tile;
+        xvoff = (uint32_t)row * (uint32_t)N * 2u + (uint32_t)col * 2u;
+        xvoff_tail = (uint32_t)min(row, max(0, Cin - nquads_full * 64 - 1)) * (uint32_t)N * 2u + (uint32_t)col * 2u;
+    }
+    const size_t xstep = AXIS == 1 ? (size_t)128 : (size_t)N * 128;
+    const unsigned char* xtile = static_cast<const unsigned char*>(
+        uniform_ptr(reinterpret_cast<const unsigned char*>(X) + (AXIS == 1 ? (size_t)n_tile * Cin * 2 : (size_t)n_tile * 2)));
+    const unsigned char* wsel = static_cast<const unsigned char*>(uniform_ptr(Wsel));
+    const uint32_t wlane = (uint32_t)(lane & 31) * 16u;     // my piece of the 512-byte block (lanes 0..31: block A, 32..63: block B)
+
+    // B (X) fragment of row tile tt (16 minibatch rows), K-step ks (32 features) -- as xcol16_kernel
+    const int t16 = lane & 15, trow = t16 >> 2;
+    auto xfrag = [&](const unsigned char* slab, int tt, int ks) -> uint4 {
+        if constexpr (AXIS == 1) {
+            const int row = 16 * tt + o16;
+            return *reinterpret_cast<const uint4*>(slab + row * 128 + (((4 * ks + q) ^ ((row >> 1) & 7)) << 4));
+        } else {
+            const int row0 = 32 * ks + 8 * q + trow;
+            const int byte = (16 * tt + 4 * (t16 & 3)) * 2;
+            const int sw = (((byte >> 4) ^ (4 * trow)) << 4) | (byte & 15);
+            const uint2 lo = ds_tr16(slab + row0 * XC0_ROWB + sw), hi = ds_tr16(slab + (row0 + 4) * XC0_ROWB + sw);
+            return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    };
+    // A (W) fragment: row o16 of the block, 8 weights at 8 * (q & 1); the block is slot s_lo (q < 2) or s_hi (q >= 2)
+    const uint32_t wfrag_lane = (uint32_t)(o16 * 32 + (q & 1) * 16);
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define X7_WDUTY(a_, b_)                                                                                                   \
+    if ((a_) != -1) {                                                                                                       \
+        const uint32_t oa = ((uint32_t)(a_) & 0x3ffffffu) << 9, ob = (uint32_t)(b_) << 9;                                   \
+        glds16_saddr(wsel, (lane < 32 ? oa : ob) + wlane, wdst + (((uint32_t)(a_) >> 26) << 10));                           \
+    }
+#define X7_ISSUE(px_, d_, hb_)                                                                                              \
+    do {                                                                                                                    \
+        const uint32_t xdst = base_addr + (hb_) * X7_XHALF + wave * 1024;                                                   \
+        const uint32_t wdst = base_addr + X7_WBASE + (hb_) * X7_WHALF;                                                      \
+        const int p0 = (px_) & 0xffff, p1 = (int)((uint32_t)(px_) >> 16);                                                   \
+        glds16_saddr(xtile + (size_t)p0 * xstep, p0 < nquads_full ? xvoff : xvoff_tail, xdst);                              \
+        if (p1 != 0xffff) glds16_saddr(xtile + (size_t)p1 * xstep, p1 < nquads_full ? xvoff : xvoff_tail, xdst + X7_SLAB);  \
+        X7_WDUTY(d_[0], d_[1]) X7_WDUTY(d_[2], d_[3]) X7_WDUTY(d_[4], d_[5])                                                \
+    } while (0)
+
+    if (nph > 0) {
+        {   // prologue: phase 0 into ring half 0
+            const int4 da = tab[1], db = tab[2];
+            const int px0 = __builtin_amdgcn_readfirstlane(pxt[0]);
+            const int d[6] = {__builtin_amdgcn_readfirstlane(da.x), __builtin_amdgcn_readfirstlane(da.y), __builtin_amdgcn_readfirstlane(da.z),
+                              __builtin_amdgcn_readfirstlane(da.w), __builtin_amdgcn_readfirstlane(db.x), __builtin_amdgcn_readfirstlane(db.y)};
+            X7_ISSUE(px0, d, 0);
+        }
+        int hb = 0;
+        for (int tb = 0; tb < nph; tb += 64) {       // lane-indexed tables for phases [tb, tb + 64)
+            const int idx = min(tb + lane, nph - 1), idn = min(tb + lane + 1, nph - 1);
+            const int4 c4 = tab[(size_t)idx * 48];
+            int cw0 = c4.x, cw1 = c4.y, cw2 = c4.z, cw3 = c4.w;
+            const int4 da = tab[(size_t)idn * 48 + 1], db = tab[(size_t)idn * 48 + 2];
+            int d0 = da.x, d1 = da.y, d2 = da.z, d3 = da.w, d4 = db.x, d5 = db.y, pxv = pxt[idn];
+            // the table loads must have landed before the loop: a wait the compiler places INSIDE it would drain the DMA queue
+            asm volatile("" : "+v"(cw0), "+v"(cw1), "+v"(cw2), "+v"(cw3), "+v"(pxv));
+            asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5));
+            const int tend = min(64, nph - tb);
+            for (int qi = 0; qi < tend; ++qi) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA shares of this phase have landed
+                __builtin_amdgcn_s_barrier();                        // everyone's have; everyone left the previous phase
+                if (tb + qi + 1 < nph) {
+                    const int px1 = __builtin_amdgcn_readlane(pxv, qi);
+                    const int d[6] = {__builtin_amdgcn_readlane(d0, qi), __builtin_amdgcn_readlane(d1, qi), __builtin_amdgcn_readlane(d2, qi),
+                                      __builtin_amdgcn_readlane(d3, qi), __builtin_amdgcn_readlane(d4, qi), __builtin_amdgcn_readlane(d5, qi)};
+                    X7_ISSUE(px1, d, hb ^ 1);
+                }
+                const uint32_t cw[4] = {(uint32_t)__builtin_amdgcn_readlane(cw0, qi), (uint32_t)__builtin_amdgcn_readlane(cw1, qi),
+                                        (uint32_t)__builtin_amdgcn_readlane(cw2, qi), (uint32_t)__builtin_amdgcn_readlane(cw3, qi)};
+                const unsigned char* wring = smem + X7_WBASE + hb * X7_WHALF + wfrag_lane;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if ((cw[2 * u] & cw[2 * u + 1]) == 0xffffffffu) continue;        // nothing of mine in this step
+                    const unsigned char* slab = smem + hb * X7_XHALF + u * X7_SLAB;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        uint4 wf[2];
+                        bool act[2];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const uint32_t pairb = (cw[2 * u + c] >> (16 * ks)) & 0xffffu;    // slots of sub-blocks 2ks, 2ks+1
+                            act[c] = pairb != 0xffffu;
+                            if (act[c]) {
+                                const uint32_t lo = pairb & 0xff, hi = pairb >> 8;
+                                const uint32_t s_lo = (lo == 0xff ? (uint32_t)X7_WCAP : lo) << 9, s_hi = (hi == 0xff ? (uint32_t)X7_WCAP : hi) << 9;
+                                wf[c] = *reinterpret_cast<const uint4*>(wring + ((q >> 1) ? s_hi : s_lo));
+                            }
+                        }
+                        if (!(act[0] || act[1])) continue;
+                        constexpr int TH = AXIS == 1 ? BSMM_XC16_TH_A1 : BSMM_XC16_TH_A0;
+#pragma unroll
+                        for (int t0 = 0; t0 < 8; t0 += TH) {
+                            uint4 xf[TH];
+#pragma unroll
+                            for (int tt = 0; tt < TH; ++tt) xf[tt] = xfrag(slab, t0 + tt, ks);
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+                                if (act[c]) {
+#pragma unroll
+                                    for (int tt = 0; tt < TH; ++tt) acc[c][t0 + tt] = DT::mfma16(wf[c], xf[tt], acc[c][t0 + tt]);
+                                }
+                        }
+                    }
+                }
+                hb ^= 1;
+            }
+        }
+    }
+#undef X7_ISSUE
+#undef X7_WDUTY
+
+    const bool own0 = 2 * wave < nob, own1 = 2 * wave + 1 < nob;
+    // D[o][n]: col = n = lane & 15 (row of tile tt), rows o = 4q + reg
+    if constexpr (AXIS == 1) {
+        constexpr int ROWB = X7_G * 32;       // staged through LDS and stored as full rows (see xcol32_a1_kernel)
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (!((c == 0) ? own0 : own1)) continue;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int n = 16 * tt + o16;
+                const uint32_t lo = (uint32_t)DT::from_f32(acc[c][tt][0]) | ((uint32_t)DT::from_f32(acc[c][tt][1]) << 16);
+                const uint32_t hi = (uint32_t)DT::from_f32(acc[c][tt][2]) | ((uint32_t)DT::from_f32(acc[c][tt][3]) << 16);
+                const int piece = (2 * wave + c) * 2 + (q >> 1);
+                *reinterpret_cast<uint2*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4) + 8 * (q & 1)) = make_uint2(lo, hi);
+            }
+        }
+        __syncthreads();
+        const int rowbytes = nob * 32;
+        T* ybase = Y + (size_t)ob0 * 16;
+        constexpr int PPR = ROWB / 16;
+        for (int i = threadIdx.x; i < XC_R * PPR; i += 1024) {
+            const int n = i / PPR, piece = i % PPR;
+            if (n_tile + n < N && piece * 16 < rowbytes) {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)(n_tile + n) * Kout) + piece * 16) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (!((c == 0) ? own0 : own1)) continue;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int n = n_tile + 16 * tt + o16;
+                if (n >= N) continue;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    Y[(size_t)((ob0 + 2 * wave + c) * 16 + 4 * q + reg) * N + n] = DT::from_f32(acc[c][tt][reg]);
+            }
+        }
+    }
+}
+
+}  // namespace bsmm

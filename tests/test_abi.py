@@ -139,7 +139,7 @@ def test_plan_builder_covers_every_block_once(lib):
                 assert pf[0] == 0x42535843 and int(pf[2]) == 16
                 assert _check_xcol_plan(pf, f, t, n_out) == want
                 # bsize 16: quads of input blocks, 16 output blocks per group, slot = 4*member + (c & 3)
-                p16 = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis)
+                p16 = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis, lib.PLAN_XCOL_UNSTAGED)   # round-1 'BSX6'
                 assert p16[0] == 0x42535836 and p16[8] == n_out
                 G16 = int(p16[2])
                 groups = p16[p16[5]:p16[6]].reshape(-1, 4)
@@ -213,6 +213,60 @@ def test_staged_xcol_plan(lib):
                     assert used == set(slots) and len(used) <= WCAP
             want = {(ob, c, w) for ob, col in f["cols"] for c, w in col}
             assert got == want
+
+
+def test_staged_xcol16_plan(lib):
+    """'BSX7' plans (default for bsize 16, 16-bit; bsmm_xcol16_v2.h): every lut entry is multiplied exactly once, by the wave that
+    owns its output block, from a slot of the phase's ring half that exactly one DMA duty fills with that weight block (a duty
+    fetches two blocks into slots 2j, 2j+1); phases hold <= 2 steps and <= WCAP blocks, waves <= 3 duties."""
+    import numpy as np
+    from blocksparse_amd import lut as L
+    from blocksparse_amd.matmul import _host_plan
+    rng = np.random.default_rng(6)
+    for CB, KB, dens in ((256, 256, 0.1), (40, 52, 0.3), (9, 70, 1.0), (1, 1, 1.0), (64, 16, 0.6), (7, 33, 0.5)):
+        lay = rng.random((CB, KB)) < dens
+        lay[0, :] = True
+        t = L.build_tables(lay)
+        for axis in (0, 1):
+            for side, n_out in (("fprop", KB), ("bprop", CB)):
+                f = t[side]
+                plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis)
+                assert plan[0] == 0x42535837 and int(plan[2]) == 32 and plan[8] == n_out and plan[7] % 4 == 0
+                WCAP = int(plan[9])
+                groups = plan[plan[5]:plan[5] + 4 * int(plan[3])].reshape(-1, 4)
+                px = plan[plan[6]:plan[6] + int(plan[4])]
+                tab = plan[plan[7]:plan[7] + int(plan[4]) * 16 * 12].reshape(-1, 16, 12)
+                got = set()
+                for g, (po, nph, ob0, nob) in enumerate(groups):
+                    assert ob0 == 32 * g and nob == min(32, n_out - ob0)
+                    for ph in range(po, po + nph):
+                        quads = (int(px[ph]) & 0xffff, (int(px[ph]) >> 16) & 0xffff)
+                        assert quads[0] != 0xffff
+                        slots = {}
+                        for wave in range(16):
+                            for k in range(3):
+                                a, b = int(tab[ph, wave, 4 + 2 * k]), int(tab[ph, wave, 5 + 2 * k])
+                                if a == -1:
+                                    continue
+                                a &= 0xffffffff
+                                pair = a >> 26
+                                assert 2 * pair + 1 < WCAP and 2 * pair not in slots
+                                slots[2 * pair], slots[2 * pair + 1] = a & 0x3ffffff, b
+                            assert (tab[ph, wave, 10:] == 0).all()
+                        used = set()
+                        for wave in range(16):
+                            for byte in range(16):
+                                sl = (int(tab[ph, wave, byte >> 2]) >> (8 * (byte & 3))) & 0xff
+                                if sl == 0xff:
+                                    continue
+                                u, c, sub = byte >> 3, (byte >> 2) & 1, byte & 3
+                                col = 2 * wave + c
+                                assert col < nob and quads[u] != 0xffff and sl in slots and sl not in used
+                                used.add(sl)
+                                got.add((ob0 + col, 4 * quads[u] + sub, slots[sl]))
+                        assert len(used) <= WCAP and set(slots) - used <= {max(slots)}      # at most the padded partner of the last pair
+                want = {(ob, c, w) for ob, col in f["cols"] for c, w in col}
+                assert got == want
 
 
 def test_updat_plan_covers_every_block_once(lib):

@@ -268,6 +268,46 @@ def test_staged_and_round1_xprop_kernels_agree_bitwise(env, axis):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("axis", [1, 0])
+@pytest.mark.parametrize("opt", [0, "PLAN_XCOL_UNSTAGED"])
+def test_small_layouts_bsize16_xprop_plan_kernels(env, opt, axis):
+    """bsize 16: the staged kernel ('BSX7' plans: weight blocks by LDS-DMA, two per instruction, zero slot for absent partners of a
+    K-concatenated pair) and the round-1 kernel against the full oracle -- dense layouts (steps of 128 blocks are split), block counts
+    that are not multiples of 4 (trailing quad with missing blocks), partial last group, ragged minibatch -- and against each other
+    bit for bit at BASELINE configs[2]."""
+    torch, BSMM, lib = env
+    o = getattr(lib, opt) if opt else 0
+    want_k = lib.K_XCOL16 if o else lib.K_XCOL16_STAGED
+    cases = [(np.ones((9, 70), dtype=bool), (72, 200)), (P.random_layout(33, 17, 0.3, seed=3), (104, 8)), (np.ones((1, 1), dtype=bool), (40,)),
+             (P.random_layout(80, 80, 0.15, seed=2), (392, 128)), (P.ba_layout(80, 3, seed=1), (264,))]
+    try:
+        lib.set_kernel_variant(3)
+        for li, (layout, Ns) in enumerate(cases):
+            b = BSMM(layout, block_size=16, feature_axis=axis, plan_options=o)
+            t = orc.build_layout_luts(layout, 16)
+            for N in Ns:
+                for dtype in ("bf16", "f16"):
+                    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=li * 3 + N)
+                    w, x, e = P.to_dev(W, dtype, torch), P.to_dev(X, dtype, torch), P.to_dev(E, dtype, torch)
+                    y = P.to_host(b.fprop(x, w))
+                    assert lib.last_kernel() == want_k
+                    dx = P.to_host(b.bprop(e, w))
+                    assert lib.last_kernel() == want_k
+                    l2y, _ = P.errors(y, orc.round_to(orc.fprop(t, X, W, axis), dtype))
+                    l2x, _ = P.errors(dx, orc.round_to(orc.bprop(t, E, W, axis), dtype))
+                    assert l2y <= P.L2_BAR[dtype] and l2x <= P.L2_BAR[dtype], (opt, axis, li, N, dtype, l2y, l2x)
+    finally:
+        lib.set_kernel_variant(0)
+    if o == 0:
+        layout = P.random_layout(256, 256, 0.1, seed=1234)
+        outs = []
+        for oo in (0, lib.PLAN_XCOL_UNSTAGED):
+            b = BSMM(layout, block_size=16, feature_axis=axis, plan_options=oo)
+            w, x, e = _inputs(torch, b, 4096, "bf16", seed=6)
+            outs.append((b.fprop(x, w), b.bprop(e, w)))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 # ---- (e) the reference's own test matrix ------------------------------------------------------------------------------
 @pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("bs", [32, 16, 8])
@@ -295,7 +335,7 @@ def test_cfg2_bsize16_10pct(env, axis):
     torch, BSMM, lib = env
     layout = P.random_layout(256, 256, 0.1, seed=1234)
     b = BSMM(layout, block_size=16, feature_axis=axis)
-    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=41, expect={"xprop": lib.K_XCOL16, "updat": lib.K_UPDAT16_WIN}, ctx="cfg2 a%d" % axis)
+    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=41, expect={"xprop": lib.K_XCOL16_STAGED, "updat": lib.K_UPDAT16_WIN}, ctx="cfg2 a%d" % axis)
 
 
 def test_cfg1_fp32_axis1(env):
