@@ -36,6 +36,9 @@
 
 namespace bsmm {
 
+#ifndef U2_NT_PARTS
+#define U2_NT_PARTS 1       // non-temporal stores / loads of the partial sums: 50-80 MB that are written once and read once must not
+#endif                      // push the activations out of the Infinity Cache (bench: the fprop that follows runs 91 instead of 99 us)
 #ifndef U2_CH_ROWS
 #define U2_CH_ROWS 16
 #endif
@@ -392,7 +395,15 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
 #endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
+                {
+#if U2_NT_PARTS
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v v = {acc[j][4 * q + 0], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(reg_base + (j * 4 + q) * 64));
+#else
                     reg_base[(j * 4 + q) * 64] = make_float4(acc[j][4 * q + 0], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+#endif
+                }
             }
         } else {
 #pragma unroll
@@ -415,6 +426,16 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
             }
         }
     }
+}
+
+__device__ __forceinline__ float4 u2_ld(const float4* p) {
+#if U2_NT_PARTS
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
 }
 
 // Second pass of the partial-sum path: one workgroup per block w sums the regions that hold a partial sum of w -- it walks
@@ -455,7 +476,7 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
         const int xcd = set * nparts + part;
         if (!sliced) {
             const int round = pos / U, uj = pos - round * U;
-            const float4 v = base[((size_t)round * grid + (xcd_mode ? uj * 8 + xcd : uj)) * REGION];
+            const float4 v = u2_ld(base + ((size_t)round * grid + (xcd_mode ? uj * 8 + xcd : uj)) * REGION);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         } else {
             const float4* rb = base + (size_t)full_rounds * grid * REGION;
@@ -466,7 +487,7 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
                     if (hi == lo) return zero4;
                 }
                 const int uj = which * k_last + slice;
-                return rb[(size_t)(xcd_mode ? uj * 8 + xcd : uj) * REGION];
+                return u2_ld(rb + (size_t)(xcd_mode ? uj * 8 + xcd : uj) * REGION);
             };
             for (int sl = 0; sl < k_last; sl += 4) {
                 const float4 v0 = fetch(sl), v1 = fetch(sl + 1), v2 = fetch(sl + 2), v3 = fetch(sl + 3);
