@@ -607,8 +607,9 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     }
     if (scratch) {
         const int CPI = a->pcount * ((a->N + U2_CH - 1) / U2_CH);
-        if (sums_only) updat2_reduce_kernel<DT, true><<<a->blocks, 256, 0, st>>>(scratch, nullptr, sums, a->plan, nullptr, L.grid, L.flat, CPI, 1.f, 0.f);
-        else           updat2_reduce_kernel<DT, false><<<a->blocks, 256, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, gate, L.grid, L.flat, CPI, a->alpha, a->beta);
+        const int32_t* bmap = a->plan + U2_HDR + (size_t)a->plan_items * U2_ITEM;     // behind the items (bsmm_plan.h)
+        if (sums_only) updat2_reduce_kernel<DT, true><<<a->blocks, 128, 0, st>>>(scratch, nullptr, sums, a->plan, bmap, nullptr, L.grid, L.flat, CPI, 1.f, 0.f);
+        else           updat2_reduce_kernel<DT, false><<<a->blocks, 128, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, bmap, gate, L.grid, L.flat, CPI, a->alpha, a->beta);
     }
     return (int)hipGetLastError();
 }

@@ -443,12 +443,14 @@ __device__ __forceinline__ float4 u2_ld(const float4* p) {
 // rounded once, or (SUMS) the raw fp32 sums [blocks][32][32] for the data-parallel all-reduce.
 // thread = (quad q = tid >> 6, lane l = tid & 63): elements ci = 8 q + 4 (l >> 5) + e, e = 0..3, ko = l & 31.
 template <class DT, bool SUMS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(128)
 updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict__ DW, float* __restrict__ sums, const int32_t* __restrict__ plan,
-                     const float* __restrict__ gate, int grid, int flat, int CPI, float alpha, float beta) {
+                     const int32_t* __restrict__ bmap, const float* __restrict__ gate, int grid, int flat, int CPI, float alpha, float beta) {
+    // 128 threads = (quad pair qq = tid >> 6, lane l): quads qq and qq + 2 -- all workgroups of the bench shape are resident at once,
+    // and the block map is addressed from an argument so that its load does not wait for the plan header
     const int w = blockIdx.x;
-    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int32_t bm = plan[plan[26] + w];
+    const int qq = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int32_t bm = bmap[w];
     const int item = bm >> 8, slot = bm & 255;
     const bool xcd_mode = flat == 0 && (grid & 7) == 0;
     const int nsets = xcd_mode ? plan[8] : 1;
@@ -461,53 +463,79 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
     const int pos = item - set_first;
     const int full_rounds = set_count / U, m_last = set_count - full_rounds * U;
     const int k_last = m_last > 0 ? U / m_last : 0;
-    const float4* base = reinterpret_cast<const float4*>(parts) + ((size_t)slot * 4 + q) * 64 + l;
+    const float4* base = reinterpret_cast<const float4*>(parts) + ((size_t)slot * 4 + qq) * 64 + l;    // quad qq; quad qq + 2 is 128 float4 further
     constexpr size_t REGION = (size_t)U2_WAVES * U2_SLOTS * 256;       // float4 per region
-    // the partial sums of this block: one region per (part, slice); independent loads, four in flight per thread, and no
-    // 64-bit division in the walk (a first version spent 40 us at 20 % density on index arithmetic and serial loads)
+    // the partial sums of this block: one region per (part, slice); independent loads in flight, no 64-bit division in the
+    // walk (a first version spent 40 us at 20 % density on index arithmetic and serial loads)
     const bool sliced = pos >= full_rounds * U;
     const int which = pos - full_rounds * U;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 acc = zero4;
-    for (int part = 0; part < nparts; ++part) {
+    float4 acc0 = zero4, acc1 = zero4;
+    auto part_len = [&](int part) -> int {
         const unsigned part_lo = (unsigned)part * (unsigned)CPI / (unsigned)nparts, part_hi = (unsigned)(part + 1) * (unsigned)CPI / (unsigned)nparts;
-        const int L = (int)(part_hi - part_lo);
-        if (L <= 0) continue;
-        const int xcd = set * nparts + part;
-        if (!sliced) {
-            const int round = pos / U, uj = pos - round * U;
-            const float4 v = u2_ld(base + ((size_t)round * grid + (xcd_mode ? uj * 8 + xcd : uj)) * REGION);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        } else {
+        return (int)(part_hi - part_lo);
+    };
+    auto add = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    if (!sliced) {
+        // one region per minibatch part (<= 8): all loads first
+        const int round = pos / U, uj = pos - round * U;
+        float4 v0[8], v1[8];
+#pragma unroll
+        for (int part = 0; part < 8; ++part) {
+            v0[part] = v1[part] = zero4;
+            if (part < nparts && part_len(part) > 0) {
+                const int xcd = set * nparts + part;
+                const float4* p = base + ((size_t)round * grid + (xcd_mode ? uj * 8 + xcd : uj)) * REGION;
+                v0[part] = u2_ld(p); v1[part] = u2_ld(p + 128);
+            }
+        }
+#pragma unroll
+        for (int part = 0; part < 8; ++part) { add(acc0, v0[part]); add(acc1, v1[part]); }
+    } else {
+        for (int part = 0; part < nparts; ++part) {
+            const int L = part_len(part);
+            if (L <= 0) continue;
+            const int xcd = set * nparts + part;
             const float4* rb = base + (size_t)full_rounds * grid * REGION;
-            auto fetch = [&](int slice) -> float4 {
-                if (slice >= k_last) return zero4;
+            auto where = [&](int slice) -> const float4* {
+                if (slice >= k_last) return nullptr;
                 if (L < k_last) {      // fewer chunks than slices: some slices are empty and wrote nothing
                     const unsigned lo = (unsigned)slice * (unsigned)L / (unsigned)k_last, hi = (unsigned)(slice + 1) * (unsigned)L / (unsigned)k_last;
-                    if (hi == lo) return zero4;
+                    if (hi == lo) return nullptr;
                 }
                 const int uj = which * k_last + slice;
-                return u2_ld(rb + (size_t)(xcd_mode ? uj * 8 + xcd : uj) * REGION);
+                return rb + (size_t)(xcd_mode ? uj * 8 + xcd : uj) * REGION;
             };
             for (int sl = 0; sl < k_last; sl += 4) {
-                const float4 v0 = fetch(sl), v1 = fetch(sl + 1), v2 = fetch(sl + 2), v3 = fetch(sl + 3);
-                acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
-                acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+                float4 a[4], b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4* p = where(sl + e);
+                    a[e] = b[e] = zero4;
+                    if (p) { a[e] = u2_ld(p); b[e] = u2_ld(p + 128); }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { add(acc0, a[e]); add(acc1, b[e]); }
             }
         }
     }
-    const float r[4] = {acc.x, acc.y, acc.z, acc.w};
-    const size_t o = (size_t)w * 1024 + (size_t)(8 * q + 4 * (l >> 5)) * 32 + (l & 31);
-    if constexpr (SUMS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sums[o + e * 32] = r[e];
-    } else {
-        const float a = gate ? alpha * gate[w] : alpha;
+    for (int hq = 0; hq < 2; ++hq) {
+        const int q = qq + 2 * hq;
+        const float4 acc = hq ? acc1 : acc0;
+        const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+        const size_t o = (size_t)w * 1024 + (size_t)(8 * q + 4 * (l >> 5)) * 32 + (l & 31);
+        if constexpr (SUMS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = a * r[e];
-            if (beta != 0.f) v += beta * DT::to_f32(DW[o + e * 32]);
-            DW[o + e * 32] = DT::from_f32(v);
+            for (int e = 0; e < 4; ++e) sums[o + e * 32] = r[e];
+        } else {
+            const float a = gate ? alpha * gate[w] : alpha;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = a * r[e];
+                if (beta != 0.f) v += beta * DT::to_f32(DW[o + e * 32]);
+                DW[o + e * 32] = DT::from_f32(v);
+            }
         }
     }
 }
