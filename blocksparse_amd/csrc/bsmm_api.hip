@@ -279,7 +279,7 @@ int launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hi
     return BSMM_ERR_ARG;
 }
 
-template <class DT, bool TRANSW, int AXIS>
+template <class DT, bool TRANSW, int AXIS, bool GATED = false>
 int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
@@ -289,18 +289,19 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds(&xcol32_v2_kernel<DT, TRANSW, AXIS>, X2_LDS)) return rc;
+    if (int rc = ensure_lds(&xcol32_v2_kernel<DT, TRANSW, AXIS, GATED>, X2_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_STAGED);
-    xcol32_v2_kernel<DT, TRANSW, AXIS><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                               a->N, a->C, a->K);
+    xcol32_v2_kernel<DT, TRANSW, AXIS, GATED><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                                 a->N, a->C, a->K, GATED ? a->gate : nullptr);
     return (int)hipGetLastError();
 }
 
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
     if (a->plan_magic == X2PLAN_MAGIC) {
-        if (a->plan_width == X2_G) return transw ? launch_xcol_v2<DT, true, AXIS>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false, AXIS>(X, Wsel, Y, a, st);
-        return BSMM_ERR_ARG;
+        if (a->plan_width != X2_G) return BSMM_ERR_ARG;
+        if (a->gate) return transw ? launch_xcol_v2<DT, true, AXIS, true>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false, AXIS, true>(X, Wsel, Y, a, st);
+        return transw ? launch_xcol_v2<DT, true, AXIS>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false, AXIS>(X, Wsel, Y, a, st);
     }
     if (a->plan_magic != XCPLAN_MAGIC) return BSMM_ERR_ARG;
     if constexpr (AXIS == 1) return transw ? launch_xcol<DT, true>(X, Wsel, Y, a, st) : launch_xcol<DT, false>(X, Wsel, Y, a, st);
@@ -333,7 +334,9 @@ template <class DT, int BS, int AXIS>
 XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a) {
     const int variant = call_variant(a);
     const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
-    const bool plan_ok = a->plan != nullptr && a->gate == nullptr && vec_ok && (variant == 0 || variant == 3);   // gated calls: per-segment kernels
+    // gated calls: only the staged bsize-32 kernel applies gates (exactly, bsmm_xcol_v2.h); everything else runs the per-segment kernels
+    const bool gate_ok = a->gate == nullptr || (BS == 32 && DT::is16 && a->plan_magic == X2PLAN_MAGIC);
+    const bool plan_ok = a->plan != nullptr && gate_ok && vec_ok && (variant == 0 || variant == 3);
     const bool force = variant == 3;
     if constexpr (BS == 8) {
         if constexpr (DT::is16) {

@@ -191,7 +191,7 @@ namespace bsmm {
 constexpr int32_t X2PLAN_MAGIC = 0x42535832;
 constexpr int32_t X2PLAN_VERSION = 1;
 constexpr int X2_G = 16;
-constexpr int X2_WCAP = 24;
+constexpr int X2_WCAP = 23;            // slots per ring half the plan uses; the 24th holds the phase's gate table (bsmm_xcol_v2.h)
 constexpr int X2_HDR = 12;
 
 inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {

@@ -47,7 +47,8 @@ namespace bsmm {
 constexpr int X2_R = 128;                          // minibatch rows per workgroup
 constexpr int X2_SLAB = X2_R * 128;                // 16 KiB
 constexpr int X2_XHALF = 2 * X2_SLAB;              // activation bytes per ring half
-constexpr int X2_WHALF = X2_WCAP * 2048;           // weight bytes per ring half
+constexpr int X2_WHALF = (X2_WCAP + 1) * 2048;     // weight bytes per ring half: the plan's slots + one for the gate table
+constexpr int X2_GTAB = X2_WCAP * 2048;            // the gate table of a ring half: fp32 per slot (gated calls)
 constexpr int X2_WBASE = 2 * X2_XHALF;             // weight ring behind the activation ring
 constexpr int X2_LDS = X2_WBASE + 2 * X2_WHALF;    // 160 KiB
 static_assert(X2_LDS <= 163840 && X2_R * X2_G * 64 <= X2_LDS, "ring and epilogue tile must fit the LDS");
@@ -58,10 +59,17 @@ static_assert(X2_LDS <= 163840 && X2_R * X2_G * 64 <= X2_LDS, "ring and epilogue
 // AXIS = 0: activations (C, N), minibatch contiguous: a slab is [64 feature rows] x [128 minibatch columns] (256 B per row,
 // 16-byte pieces XOR-swizzled with 4 * (row & 3)), the B operand (8 consecutive FEATURES of one minibatch column per lane) is
 // built with transposing reads as in xcol32_a0_kernel, output rows are features.  Requires N % 8 == 0.  Same plans.
-template <class DT, bool TRANSW, int AXIS = 1>
+// GATED: per-block fp32 gates (hgemm_blocksparse_*_sdd's `Gate`, src/blocksparse_hgemm_cn_64_op_gpu.cu:54-66,96-124).  The wave that
+// requests a weight block also fetches its gate into the ring half's gate table; a block with gate 0 is skipped, otherwise
+// g * w is formed in fp32 per fragment element and split into TWO 16-bit pieces (hi = round(g w), lo = round(g w - hi)) that are
+// both multiplied: the product is exact to ~2^-17 instead of the 2^-9 of a single bf16 rounding of g * w (which measured
+// 2.2e-3 against the oracle, above the 1e-3 bar) -- the reference applies the gate to the fp32 block product
+// (blocksparse/matmul.py:367-373); twice the MFMAs and ~80 vector instructions per block, for gated calls only.
+template <class DT, bool TRANSW, int AXIS = 1, bool GATED = false>
 __global__ void __launch_bounds__(64 * X2_G, 4)
 xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
-                    typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
+                    typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout,
+                    const float* __restrict__ gate = nullptr) {
     typedef typename DT::T T;
     static_assert(DT::is16, "xcol v2 kernel: 16-bit storage types");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,6 +140,19 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
+    // gated calls: lanes 0..2 fetch the gates of my three duties (first half block of a block only) for ring half hb_; the
+    // values are written into that half's gate table at the top of the next phase, behind the same wait as the DMAs
+    float gpend = 0.f;
+    uint32_t gaddr = X2_WBASE + X2_GTAB + 31 * 4;      // LDS address my pending gate goes to (slot 31: nobody's)
+    auto fetch_gates = [&](int d0, int d1, int d2, int hbn) {
+        if constexpr (GATED) {
+            const int dsel = lane == 0 ? d0 : (lane == 1 ? d1 : d2);
+            const bool valid = lane < 3 && dsel != -1 && !(dsel & 1);
+            gpend = valid ? gate[(dsel & 0x3ffffff) >> 1] : 0.f;
+            gaddr = X2_WBASE + hbn * X2_WHALF + X2_GTAB + (valid ? (((uint32_t)dsel >> 26) >> 1) : 31u) * 4;
+        }
+    };
+
     // DMAs of one phase into ring half `hb`: px = pair of step 0 | pair of step 1 << 16, d0..d2 = weight duties
 #define X2_ISSUE(px_, d0_, d1_, d2_, hb_)                                                                                   \
     do {                                                                                                                    \
@@ -147,9 +168,27 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     } while (0)
 
     // one block: weight fragment from its slot, the four row tiles' activation fragments, 8 MFMAs
-    auto block = [&](uint32_t xoff, uint32_t woff, int half) {
+    auto block = [&](uint32_t xoff, uint32_t wbase_half, uint32_t slot, int half) {
         if (X2_NO_READS) return;
-        uint4 wq[2], xf[4][2];
+        const uint32_t woff = wbase_half + (slot << 11);
+        float g = 1.f;
+        if constexpr (GATED) {
+            g = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t*>(smem + X2_WBASE + wbase_half + X2_GTAB + slot * 4)));
+            if (g == 0.f) return;
+        }
+        auto xread = [&](int t, int kk) -> uint4 {
+            if constexpr (AXIS == 1) {
+                return *reinterpret_cast<const uint4*>(smem + xrd[half][kk] + xoff + t * 4096);
+            } else {
+                // rows (features) 32 * half + 16 * kk + 8 * (g16 >> 1) + {0..3 | 4..7}; row & 3 == trow for both bands
+                const int row0 = 32 * half + 16 * kk + 8 * (g16x >> 1) + trowx;
+                const int byte = 64 * t + tcolbx;                             // byte inside the 256-byte row (before swizzle)
+                const int sw = (((byte >> 4) ^ (4 * trowx)) << 4) | (byte & 15);
+                const uint2 lo = ds_tr16(smem + xoff + row0 * 256 + sw), hi = ds_tr16(smem + xoff + (row0 + 4) * 256 + sw);
+                return make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        };
+        uint4 wq[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             if constexpr (TRANSW) {
@@ -159,21 +198,41 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
                 wq[kk] = *reinterpret_cast<const uint4*>(smem + wrd[kk] + woff);
             }
         }
+        if constexpr (GATED) {
+            // one K half at a time (4 activation fragments live instead of 8: the split pieces need the registers)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 xg[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xg[t] = xread(t, kk);
+                uint4 whi = wq[kk], wlo = zero_u4();
+                if (g != 1.f) {              // (gate 1 -- the usual value of a pruning mask -- needs no arithmetic: hi = w, lo = 0)
+                    uint32_t hi[4], lo[4];
+                    const uint32_t src[4] = {wq[kk].x, wq[kk].y, wq[kk].z, wq[kk].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p0 = g * DT::to_f32((uint16_t)(src[e] & 0xffffu)), p1 = g * DT::to_f32((uint16_t)(src[e] >> 16));
+                        const uint16_t h0 = DT::from_f32(p0), h1 = DT::from_f32(p1);
+                        const uint16_t l0 = DT::from_f32(p0 - DT::to_f32(h0)), l1 = DT::from_f32(p1 - DT::to_f32(h1));
+                        hi[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                        lo[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                    }
+                    whi = make_uint4(hi[0], hi[1], hi[2], hi[3]); wlo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = DT::mfma32(whi, xg[t], acc[t]);
+                if (g != 1.f) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = DT::mfma32(wlo, xg[t], acc[t]);
+                }
+            }
+            return;
+        }
+        uint4 xf[4][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if constexpr (AXIS == 1) {
-                    xf[t][kk] = *reinterpret_cast<const uint4*>(smem + xrd[half][kk] + xoff + t * 4096);
-                } else {
-                    // rows (features) 32 * half + 16 * kk + 8 * (g16 >> 1) + {0..3 | 4..7}; row & 3 == trow for both bands
-                    const int row0 = 32 * half + 16 * kk + 8 * (g16x >> 1) + trowx;
-                    const int byte = 64 * t + tcolbx;                             // byte inside the 256-byte row (before swizzle)
-                    const int sw = (((byte >> 4) ^ (4 * trowx)) << 4) | (byte & 15);
-                    const uint2 lo = ds_tr16(smem + xoff + row0 * 256 + sw), hi = ds_tr16(smem + xoff + (row0 + 4) * 256 + sw);
-                    xf[t][kk] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
-            }
+            for (int t = 0; t < 4; ++t) xf[t][kk] = xread(t, kk);
 #if X2_READS_FIRST
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -192,6 +251,7 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             const int px0 = __builtin_amdgcn_readfirstlane(pxt[0]);
             const int d0 = __builtin_amdgcn_readfirstlane(d.y), d1 = __builtin_amdgcn_readfirstlane(d.z), d2 = __builtin_amdgcn_readfirstlane(d.w);
             X2_ISSUE(px0, d0, d1, d2, 0);
+            fetch_gates(d0, d1, d2, 0);
         }
         int hb = 0;
         for (int tb = 0; tb < nph; tb += 64) {       // lane-indexed tables for phases [tb, tb + 64)
@@ -204,19 +264,24 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             const int tend = min(64, nph - tb);
             for (int qi = 0; qi < tend; ++qi) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA shares of this phase have landed
+                if constexpr (GATED) {                               // ... and the gates I fetched with them: into this half's table
+                    *reinterpret_cast<float*>(smem + gaddr) = gpend;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_s_barrier();                        // everyone's have; everyone left the previous phase
                 const bool late = X2_LATE_ISSUE && (wave & 1);
                 if (!late && tb + qi + 1 < nph) {
                     const int px1 = __builtin_amdgcn_readlane(pxv, qi);
                     const int d0 = __builtin_amdgcn_readlane(d0v, qi), d1 = __builtin_amdgcn_readlane(d1v, qi), d2 = __builtin_amdgcn_readlane(d2v, qi);
                     X2_ISSUE(px1, d0, d1, d2, hb ^ 1);
+                    fetch_gates(d0, d1, d2, hb ^ 1);
                 }
                 const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane(cwv, qi);
                 const uint32_t xo = hb * X2_XHALF, wo = hb * X2_WHALF;
-                if ((cw & 0xff) != 0xff)         block(xo, wo + ((cw & 0xff) << 11), 0);
-                if (((cw >> 8) & 0xff) != 0xff)  block(xo, wo + (((cw >> 8) & 0xff) << 11), 1);
-                if (((cw >> 16) & 0xff) != 0xff) block(xo + X2_SLAB, wo + (((cw >> 16) & 0xff) << 11), 0);
-                if ((cw >> 24) != 0xff)          block(xo + X2_SLAB, wo + ((cw >> 24) << 11), 1);
+                if ((cw & 0xff) != 0xff)         block(xo, wo, cw & 0xff, 0);
+                if (((cw >> 8) & 0xff) != 0xff)  block(xo, wo, (cw >> 8) & 0xff, 1);
+                if (((cw >> 16) & 0xff) != 0xff) block(xo + X2_SLAB, wo, (cw >> 16) & 0xff, 0);
+                if ((cw >> 24) != 0xff)          block(xo + X2_SLAB, wo, cw >> 24, 1);
                 if (late && tb + qi + 1 < nph) {
                     const int px1 = __builtin_amdgcn_readlane(pxv, qi);
                     const int d0 = __builtin_amdgcn_readlane(d0v, qi), d1 = __builtin_amdgcn_readlane(d1v, qi), d2 = __builtin_amdgcn_readlane(d2v, qi);

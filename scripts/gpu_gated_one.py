@@ -1,0 +1,34 @@
+"""gated vs ungated fprop / bprop at the bench shape (bsize 32, bf16, N = 8192), both axes: plan kernel (default) and per-segment kernel"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import _parity as P
+from blocksparse_amd import BlocksparseMatMul, _lib
+
+def timeit(fn, reps=60, warm=20):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+lay = P.random_layout(128, 128, 0.2, 1234)
+for axis in (1, 0):
+    b = BlocksparseMatMul(lay, block_size=32, feature_axis=axis)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.05).bfloat16()
+    x = (torch.randn(b.i_shape(8192), device="cuda", generator=g) * 0.1).bfloat16()
+    dy = (torch.randn(b.o_shape(8192), device="cuda", generator=g) * 0.1).bfloat16()
+    gate = torch.rand(b.blocks, device="cuda", generator=g) * 2 - 0.5
+    gate[::7] = 0
+    out = []
+    mask = (torch.rand(b.blocks, device="cuda", generator=g) < 0.8).float()
+    for name, gt, var in (("ungated", None, 0), ("gated plan", gate, 0), ("0/1 mask (80 % ones) plan", mask, 0), ("gated per-segment", gate, 2)):
+        _lib.set_kernel_variant(var)
+        b.fprop(x, w, gate=gt); k = _lib.last_kernel()
+        out.append("%s f %.1f b %.1f (k%d)" % (name, timeit(lambda: b.fprop(x, w, gate=gt)), timeit(lambda: b.bprop(dy, w, gate=gt)), k))
+    _lib.set_kernel_variant(0)
+    print("axis %d: %s" % (axis, " | ".join(out)), flush=True)
