@@ -461,7 +461,7 @@ def main():
             ar_ms = float(tt.item())
         compute_ms = sum(per)
         ms_step = head["ms_per_step"]
-        out["allreduce"] = {"bytes": int(dw_t.numel() * 4), "dtype": "f32", "ms_alone": round(ar_ms, 4),
+        out["allreduce"] = {"bytes": int(dw_t.numel() * 4), "dtype": "f32", "via": red.via, "ms_alone": round(ar_ms, 4),
                             "compute_ms": round(compute_ms, 4),
                             "exposed_ms": round(max(0.0, ms_step - compute_ms), 4),
                             "hidden_frac": round(max(0.0, min(1.0, 1.0 - max(0.0, ms_step - compute_ms) / max(ar_ms, 1e-9))), 3)}

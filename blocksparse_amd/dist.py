@@ -99,6 +99,11 @@ class DwAllReduce(object):
         self._buf = None
         self._dst = None
         self._direct = False
+        self._fallback = False      # True: the library handle could not be made on every rank -> torch.distributed collectives
+
+    @property
+    def via(self):
+        return "torch.distributed" if self._fallback else "bsmm_dist (library RCCL handle)"
 
     def _active(self):
         return self.force or (dist.is_initialized() and dist.get_world_size(self.group) > 1)
@@ -107,9 +112,27 @@ class DwAllReduce(object):
         self._direct = False
         if not self._active():
             return t
-        if t.is_cuda:
-            if self.comm is None:
+        if t.is_cuda and self.comm is None and not self._fallback:
+            # the library's own communicator; every rank must end up on the same path, so the ranks agree on whether all of
+            # them got one (otherwise: torch.distributed's collective on the same tensor, said loudly on stderr)
+            try:
                 self.comm = RcclComm(t.device, self.group)
+                ok = 1
+            except Exception as e:          # noqa: BLE001 -- any failure of the bootstrap means "use the other path"
+                self.comm, ok = None, 0
+                import sys
+                print("blocksparse_amd.dist: library RCCL handle unavailable (%s); falling back to torch.distributed" % (e,), file=sys.stderr)
+            if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                flag = torch.tensor([ok], device=t.device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                ok = int(flag.item())
+            if not ok:
+                if self.comm is not None:
+                    self.comm.close()
+                self.comm, self._fallback = None, True
+                if not dist.is_initialized():
+                    raise RuntimeError("blocksparse_amd.dist: no RCCL handle and torch.distributed is not initialised")
+        if t.is_cuda and self.comm is not None:
             if self.accumulate_fp32 and t.dtype != torch.float32:
                 if self._buf is None or self._buf.shape != t.shape:
                     self._buf = torch.empty(t.shape, dtype=torch.float32, device=t.device)
