@@ -279,8 +279,8 @@ int launch_xcol(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hi
     return BSMM_ERR_ARG;
 }
 
-template <class DT, bool TRANSW, int AXIS, bool GATED = false>
-int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+template <class DT, bool TRANSW, int AXIS, bool GATED, int PH>
+int launch_xcol_v2_ph(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
     XMap m;
@@ -289,11 +289,21 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds(&xcol32_v2_kernel<DT, TRANSW, AXIS, GATED>, X2_LDS)) return rc;
+    if (int rc = ensure_lds(&xcol32_v2_kernel<DT, TRANSW, AXIS, GATED, PH>, X2_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_STAGED);
-    xcol32_v2_kernel<DT, TRANSW, AXIS, GATED><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+    xcol32_v2_kernel<DT, TRANSW, AXIS, GATED, PH><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                                  a->N, a->C, a->K, GATED ? a->gate : nullptr);
     return (int)hipGetLastError();
+}
+
+template <class DT, bool TRANSW, int AXIS, bool GATED = false>
+int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    switch (a->plan_inner) {     // steps per phase the plan was cut for
+        case 2: return launch_xcol_v2_ph<DT, TRANSW, AXIS, GATED, 2>(X, Wsel, Y, a, st);
+        case 3: return launch_xcol_v2_ph<DT, TRANSW, AXIS, GATED, 3>(X, Wsel, Y, a, st);
+        case 4: return launch_xcol_v2_ph<DT, TRANSW, AXIS, GATED, 4>(X, Wsel, Y, a, st);
+    }
+    return BSMM_ERR_ARG;
 }
 
 template <class DT, int AXIS>
@@ -998,7 +1008,7 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
         return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
     }
     if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel (either feature axis)
-        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out);
+        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out, (options >> 8) & 7);   // bits 8..10: steps per phase (experiments)
         if (n != 0) return n;                                            // 0: the layout does not fit the table fields
     }
     return build_xcol_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));
@@ -1063,7 +1073,7 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
     d[4] = 0;
     switch (p[0]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
-        case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
+        case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR || p[11] < 2 || p[11] > 4) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
         case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;

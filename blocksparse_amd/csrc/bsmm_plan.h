@@ -174,27 +174,31 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
 // =================================================================================================
 // staged xcol plan ('BSX2'): schedule of the kernel that stages the weight blocks through LDS as well (bsmm_xcol_v2.h).
 // Groups of X2_G = 16 consecutive output blocks as in the xcol plan, wave v owns output block first + v.  The pair walk of a
-// group is cut into PHASES: up to two steps (pairs) and up to X2_WCAP weight blocks, which is what the two halves of the
-// LDS ring hold (2 x 2 activation slabs of 16 KiB + 2 x X2_WCAP weight blocks of 2 KiB).  A step with more blocks than
-// that is split into sub-steps (the same pair twice).  Every weight block of a phase has a SLOT in the phase's half of the
-// weight ring; its two 1 KiB halves are fetched by DMA instructions dealt evenly over the 16 waves (<= 3 each).
+// group is cut into PHASES: up to PH steps (pairs) and up to WCAP weight blocks, which is what one half of the LDS ring holds:
+// 80 KiB = PH activation slabs of 16 KiB + WCAP + 1 slots of 2 KiB (the last one is the gate table of gated calls).  PH is
+// chosen per plan from the mean number of blocks per step: 2 (WCAP 23) for the bench densities, 3 (WCAP 15) / 4 (WCAP 7) for
+// sparse layouts, where a phase's cost is the memory round trip it waits for rather than its bytes: fewer, longer phases.
+// A step with more blocks than WCAP is split into sub-steps (the same pair twice).  Every weight block of a phase has a SLOT
+// in the phase's half of the weight ring; its two 1 KiB halves are fetched by DMA instructions dealt evenly over the 16 waves
+// (<= 3 each).
 // Layout (int32): [0] magic 'BSX2' [1] version [2] X2_G [3] ngroups [4] nphases_total [5] off_groups [6] off_px
-//                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] X2_WCAP [10] max phases of a group
+//                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] WCAP [10] max phases of a group [11] PH
 //   groups[ngroups][4] = (phase_off, nphases, first_out_block, n_out_blocks_in_group)
-//   px [nphases_total]           pair of step 0 | pair of step 1 << 16   (0xffff = no such step)
-//   tab[nphases_total][16][4]    per phase and wave:
-//        [0] slots this wave multiplies: byte 2*u + half = slot of (step u, half of the pair), 0xff = none
-//        [1..3] DMA duties: (2 * weight block + half) | (2 * slot + half) << 26, or -1
+//   px [nphases_total][2]        pairs of steps 0, 1 | 2, 3: 16 bits each, 0xffff = no such step
+//   tab[nphases_total][16][8]    per phase and wave:
+//        [0..1] slots this wave multiplies: byte 2*u + half = slot of (step u, half of the pair), 0xff = none
+//        [2..4] DMA duties: (2 * weight block + half) | (2 * slot + half) << 26, or -1        [5..7] 0
 // =================================================================================================
 namespace bsmm {
 
 constexpr int32_t X2PLAN_MAGIC = 0x42535832;
-constexpr int32_t X2PLAN_VERSION = 1;
+constexpr int32_t X2PLAN_VERSION = 2;
 constexpr int X2_G = 16;
-constexpr int X2_WCAP = 23;            // slots per ring half the plan uses; the 24th holds the phase's gate table (bsmm_xcol_v2.h)
 constexpr int X2_HDR = 12;
+constexpr int X2_ROW = 8;                                            // words per (phase, wave)
+constexpr int x2_wcap(int ph) { return (81920 - ph * 16384) / 2048 - 1; }   // 23, 15, 7 for PH = 2, 3, 4
 
-inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int force_ph = 0) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
     if (blocks >= (1 << 25)) return 0;                                       // field widths of the tables
     const int G = X2_G, ngroups = (n_out_blocks + G - 1) / G;
@@ -210,12 +214,22 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
             per_group[ob / G].push_back({c >> 1, ob % G, c & 1, w});
         }
     }
+    // steps per phase from the mean number of blocks per (group, pair) step, with 30 % headroom for the spread
+    size_t nsteps_all = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        auto& v = per_group[g];
+        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : (a.wave != b.wave ? a.wave < b.wave : a.half < b.half); });
+        for (size_t i = 0; i < v.size(); ++i) nsteps_all += (i == 0 || v[i].p != v[i - 1].p);
+    }
+    const double mean = nsteps_all ? (double)blocks / (double)nsteps_all : 0.0;
+    int PH = force_ph;
+    if (PH < 2 || PH > 4) PH = (4 * mean * 1.3 <= x2_wcap(4)) ? 4 : ((3 * mean * 1.3 <= x2_wcap(3)) ? 3 : 2);
+    const int WCAP = x2_wcap(PH);
     std::vector<int32_t> groups, px, tab;
     int max_ph = 0;
     for (int g = 0; g < ngroups; ++g) {
         auto& v = per_group[g];
-        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : (a.wave != b.wave ? a.wave < b.wave : a.half < b.half); });
-        // steps: runs of equal pair, at most X2_WCAP entries each (a wave's two halves stay in one step)
+        // steps: runs of equal pair, at most WCAP entries each (a wave's two halves stay in one step)
         struct Step { int p; size_t lo, hi; };
         std::vector<Step> steps;
         for (size_t i = 0; i < v.size();) {
@@ -223,37 +237,44 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
             while (j < v.size() && v[j].p == v[i].p) ++j;
             size_t lo = i;
             while (lo < j) {
-                size_t hi = std::min(j, lo + X2_WCAP);
-                if (hi < j && v[hi].wave == v[hi - 1].wave) --hi;          // do not part the halves of one wave
+                size_t hi = std::min(j, lo + WCAP);
+                if (hi < j && hi - lo > 1 && v[hi].wave == v[hi - 1].wave) --hi;   // do not part the halves of one wave
                 steps.push_back({v[i].p, lo, hi});
                 lo = hi;
             }
             i = j;
         }
-        const int phase_off = (int)px.size();
+        const int phase_off = (int)(px.size() / 2);
         for (size_t s = 0; s < steps.size();) {
-            const size_t n0 = steps[s].hi - steps[s].lo;
-            const bool two = s + 1 < steps.size() && n0 + (steps[s + 1].hi - steps[s + 1].lo) <= (size_t)X2_WCAP;
-            const int nst = two ? 2 : 1;
-            px.push_back(steps[s].p | ((two ? steps[s + 1].p : 0xffff) << 16));
-            std::vector<int32_t> row((size_t)G * 4, -1);
-            int slot = 0, duty = (int)(px.size() * 5) % G;                 // rotate the wave that gets the first duty
+            int nst = 1;
+            size_t n = steps[s].hi - steps[s].lo;
+            while (nst < PH && s + nst < steps.size() && n + (steps[s + nst].hi - steps[s + nst].lo) <= (size_t)WCAP) {
+                n += steps[s + nst].hi - steps[s + nst].lo;
+                ++nst;
+            }
+            uint32_t pw[2] = {0xffffffffu, 0xffffffffu};
+            for (int u = 0; u < nst; ++u) pw[u >> 1] = (pw[u >> 1] & ~(0xffffu << (16 * (u & 1)))) | ((uint32_t)steps[s + u].p << (16 * (u & 1)));
+            px.push_back((int32_t)pw[0]); px.push_back((int32_t)pw[1]);
+            std::vector<int32_t> row((size_t)G * X2_ROW, 0);
+            for (int wv = 0; wv < G; ++wv)
+                for (int k = 0; k < 5; ++k) row[(size_t)wv * X2_ROW + k] = -1;
+            int slot = 0, duty = (int)((px.size() / 2) * 5) % G;           // rotate the wave that gets the first duty
             std::vector<int> nduty(G, 0);
             for (int u = 0; u < nst; ++u)
                 for (size_t i = steps[s + u].lo; i < steps[s + u].hi; ++i, ++slot) {
                     const E& e = v[i];
-                    int32_t& cw = row[(size_t)e.wave * 4];
-                    const int sh = 8 * (2 * u + e.half);
-                    cw = (int32_t)(((uint32_t)cw & ~(0xffu << sh)) | ((uint32_t)slot << sh));
+                    const int byte = 2 * u + e.half;
+                    uint32_t& cw = reinterpret_cast<uint32_t&>(row[(size_t)e.wave * X2_ROW + (byte >> 2)]);
+                    cw = (cw & ~(0xffu << (8 * (byte & 3)))) | ((uint32_t)slot << (8 * (byte & 3)));
                     for (int hb = 0; hb < 2; ++hb) {
                         const int wv = duty; duty = (duty + 1) % G;
-                        row[(size_t)wv * 4 + 1 + nduty[wv]++] = (int32_t)((uint32_t)(2 * e.w + hb) | ((uint32_t)(2 * slot + hb) << 26));
+                        row[(size_t)wv * X2_ROW + 2 + nduty[wv]++] = (int32_t)((uint32_t)(2 * e.w + hb) | ((uint32_t)(2 * slot + hb) << 26));
                     }
                 }
             tab.insert(tab.end(), row.begin(), row.end());
             s += nst;
         }
-        const int nph = (int)px.size() - phase_off;
+        const int nph = (int)(px.size() / 2) - phase_off;
         max_ph = std::max(max_ph, nph);
         groups.insert(groups.end(), {phase_off, nph, g * G, std::min(G, n_out_blocks - g * G)});
     }
@@ -262,8 +283,8 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
     const long total = off_tab + (long)tab.size();
     if (out) {
         std::fill(out, out + off_tab, 0);
-        const int32_t hdr[X2_HDR] = {X2PLAN_MAGIC, X2PLAN_VERSION, G, ngroups, (int32_t)px.size(), off_groups, off_px, off_tab,
-                                     n_out_blocks, X2_WCAP, max_ph, 0};
+        const int32_t hdr[X2_HDR] = {X2PLAN_MAGIC, X2PLAN_VERSION, G, ngroups, (int32_t)(px.size() / 2), off_groups, off_px, off_tab,
+                                     n_out_blocks, WCAP, max_ph, PH};
         std::copy(hdr, hdr + X2_HDR, out);
         std::copy(groups.begin(), groups.end(), out + off_groups);
         std::copy(px.begin(), px.end(), out + off_px);

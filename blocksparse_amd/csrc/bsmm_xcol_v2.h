@@ -46,12 +46,8 @@ namespace bsmm {
 #endif
 constexpr int X2_R = 128;                          // minibatch rows per workgroup
 constexpr int X2_SLAB = X2_R * 128;                // 16 KiB
-constexpr int X2_XHALF = 2 * X2_SLAB;              // activation bytes per ring half
-constexpr int X2_WHALF = (X2_WCAP + 1) * 2048;     // weight bytes per ring half: the plan's slots + one for the gate table
-constexpr int X2_GTAB = X2_WCAP * 2048;            // the gate table of a ring half: fp32 per slot (gated calls)
-constexpr int X2_WBASE = 2 * X2_XHALF;             // weight ring behind the activation ring
-constexpr int X2_LDS = X2_WBASE + 2 * X2_WHALF;    // 160 KiB
-static_assert(X2_LDS <= 163840 && X2_R * X2_G * 64 <= X2_LDS, "ring and epilogue tile must fit the LDS");
+constexpr int X2_LDS = 163840;                     // 160 KiB: two ring halves of 80 KiB = PH slabs + (WCAP + 1) weight slots (bsmm_plan.h)
+static_assert(X2_R * X2_G * 64 <= X2_LDS && x2_wcap(2) == 23 && x2_wcap(3) == 15 && x2_wcap(4) == 7, "ring and epilogue tile must fit the LDS");
 
 // TRANSW = true (fprop): Wsel is W in its natural [c-in-block][k-in-block] layout; the blocks are staged unswizzled and the
 // fragment (8 consecutive c for one k per lane) is built with four transposing 8-byte reads -- no transposed copy of W, no
@@ -65,13 +61,18 @@ static_assert(X2_LDS <= 163840 && X2_R * X2_G * 64 <= X2_LDS, "ring and epilogue
 // both multiplied: the product is exact to ~2^-17 instead of the 2^-9 of a single bf16 rounding of g * w (which measured
 // 2.2e-3 against the oracle, above the 1e-3 bar) -- the reference applies the gate to the fp32 block product
 // (blocksparse/matmul.py:367-373); twice the MFMAs and ~80 vector instructions per block, for gated calls only.
-template <class DT, bool TRANSW, int AXIS = 1, bool GATED = false>
+// PH = steps per phase (2, 3 or 4; the plan's choice): LDS half = PH slabs of 16 KiB + x2_wcap(PH) weight slots + the gate table.
+template <class DT, bool TRANSW, int AXIS = 1, bool GATED = false, int PH = 2>
 __global__ void __launch_bounds__(64 * X2_G, 4)
 xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
                     typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout,
                     const float* __restrict__ gate = nullptr) {
     typedef typename DT::T T;
-    static_assert(DT::is16, "xcol v2 kernel: 16-bit storage types");
+    static_assert(DT::is16 && PH >= 2 && PH <= 4, "xcol v2 kernel: 16-bit storage types, 2..4 steps per phase");
+    constexpr int X2_XHALF = PH * X2_SLAB;                 // activation bytes per ring half
+    constexpr int X2_WHALF = 81920 - X2_XHALF;             // weight bytes per ring half: the plan's slots + one for the gate table
+    constexpr int X2_GTAB = x2_wcap(PH) * 2048;            // the gate table of a ring half: fp32 per slot (gated calls)
+    constexpr int X2_WBASE = 2 * X2_XHALF;                 // weight ring behind the activation ring
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile, grp;
     if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
@@ -80,8 +81,8 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     const int ob0 = __builtin_amdgcn_readfirstlane(gh.z), nob = __builtin_amdgcn_readfirstlane(gh.w);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int32_t* pxt = plan + plan[6] + ph_off;
-    const int4* tab = reinterpret_cast<const int4*>(plan + plan[7]) + (size_t)ph_off * X2_G + wave;
+    const int32_t* pxt = plan + plan[6] + 2 * ph_off;                                                   // two words per phase
+    const int4* tab = reinterpret_cast<const int4*>(plan + plan[7]) + ((size_t)ph_off * X2_G + wave) * 2;   // X2_ROW = 8 words
     const int r = lane & 31, h = lane >> 5;
     const int n_tile = tile * X2_R;
     const uint32_t base_addr = lds_addr_of(smem);
@@ -154,13 +155,15 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     };
 
     // DMAs of one phase into ring half `hb`: px = pair of step 0 | pair of step 1 << 16, d0..d2 = weight duties
-#define X2_ISSUE(px_, d0_, d1_, d2_, hb_)                                                                                   \
+#define X2_ISSUE(px_, pxb_, d0_, d1_, d2_, hb_)                                                                                   \
     do {                                                                                                                    \
         const uint32_t xdst = base_addr + (hb_) * X2_XHALF + wave * 1024;                                                   \
         const uint32_t wdst = base_addr + X2_WBASE + (hb_) * X2_WHALF;                                                      \
-        const int p0 = (px_) & 0xffff, p1 = (int)((uint32_t)(px_) >> 16);                                                   \
-        if (!X2_NO_XDMA) glds16_saddr(xtile + (size_t)p0 * xstep, p0 < npairs_full ? xvoff : xvoff_tail, xdst);             \
-        if (!X2_NO_XDMA && p1 != 0xffff) glds16_saddr(xtile + (size_t)p1 * xstep, p1 < npairs_full ? xvoff : xvoff_tail, xdst + X2_SLAB); \
+        _Pragma("unroll") for (int u_ = 0; u_ < PH; ++u_) {                                                                 \
+            const int pu = (int)(((u_ < 2 ? (uint32_t)(px_) : (uint32_t)(pxb_)) >> (16 * (u_ & 1))) & 0xffffu);             \
+            if (!X2_NO_XDMA && (u_ == 0 || pu != 0xffff))                                                                   \
+                glds16_saddr(xtile + (size_t)pu * xstep, pu < npairs_full ? xvoff : xvoff_tail, xdst + u_ * X2_SLAB);       \
+        }                                                                                                                   \
         if (X2_NO_WDMA) break;                                                                                              \
         if ((d0_) != -1) glds16_saddr(wsel + ((size_t)((d0_) & 0x3ffffff) << 10), wvoff, wdst + (((uint32_t)(d0_) >> 26) << 10)); \
         if ((d1_) != -1) glds16_saddr(wsel + ((size_t)((d1_) & 0x3ffffff) << 10), wvoff, wdst + (((uint32_t)(d1_) >> 26) << 10)); \
@@ -247,20 +250,21 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
 
     if (nph > 0) {
         {   // prologue: phase 0 into ring half 0
-            const int4 d = tab[0];
-            const int px0 = __builtin_amdgcn_readfirstlane(pxt[0]);
-            const int d0 = __builtin_amdgcn_readfirstlane(d.y), d1 = __builtin_amdgcn_readfirstlane(d.z), d2 = __builtin_amdgcn_readfirstlane(d.w);
-            X2_ISSUE(px0, d0, d1, d2, 0);
+            const int4 d = tab[0], e = tab[1];
+            const int px0 = __builtin_amdgcn_readfirstlane(pxt[0]), px0b = __builtin_amdgcn_readfirstlane(pxt[1]);
+            const int d0 = __builtin_amdgcn_readfirstlane(d.z), d1 = __builtin_amdgcn_readfirstlane(d.w), d2 = __builtin_amdgcn_readfirstlane(e.x);
+            X2_ISSUE(px0, px0b, d0, d1, d2, 0);
             fetch_gates(d0, d1, d2, 0);
         }
         int hb = 0;
         for (int tb = 0; tb < nph; tb += 64) {       // lane-indexed tables for phases [tb, tb + 64)
             const int idx = min(tb + lane, nph - 1), idn = min(tb + lane + 1, nph - 1);
-            int cwv = tab[(size_t)idx * X2_G].x;
-            const int4 dn = tab[(size_t)idn * X2_G];
-            int d0v = dn.y, d1v = dn.z, d2v = dn.w, pxv = pxt[idn];
+            const int4 cn = tab[(size_t)idx * X2_G * 2];
+            int cwv = cn.x, cwv2 = cn.y;
+            const int4 dn = tab[(size_t)idn * X2_G * 2], en = tab[(size_t)idn * X2_G * 2 + 1];
+            int d0v = dn.z, d1v = dn.w, d2v = en.x, pxv = pxt[2 * idn], pxv2 = pxt[2 * idn + 1];
             // the table loads must have landed before the loop: a wait the compiler places INSIDE it would drain the DMA queue
-            asm volatile("" : "+v"(cwv), "+v"(d0v), "+v"(d1v), "+v"(d2v), "+v"(pxv));
+            asm volatile("" : "+v"(cwv), "+v"(cwv2), "+v"(d0v), "+v"(d1v), "+v"(d2v), "+v"(pxv), "+v"(pxv2));
             const int tend = min(64, nph - tb);
             for (int qi = 0; qi < tend; ++qi) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA shares of this phase have landed
@@ -271,9 +275,9 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
                 __builtin_amdgcn_s_barrier();                        // everyone's have; everyone left the previous phase
                 const bool late = X2_LATE_ISSUE && (wave & 1);
                 if (!late && tb + qi + 1 < nph) {
-                    const int px1 = __builtin_amdgcn_readlane(pxv, qi);
+                    const int px1 = __builtin_amdgcn_readlane(pxv, qi), px1b = PH > 2 ? __builtin_amdgcn_readlane(pxv2, qi) : -1;
                     const int d0 = __builtin_amdgcn_readlane(d0v, qi), d1 = __builtin_amdgcn_readlane(d1v, qi), d2 = __builtin_amdgcn_readlane(d2v, qi);
-                    X2_ISSUE(px1, d0, d1, d2, hb ^ 1);
+                    X2_ISSUE(px1, px1b, d0, d1, d2, hb ^ 1);
                     fetch_gates(d0, d1, d2, hb ^ 1);
                 }
                 const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane(cwv, qi);
@@ -282,10 +286,19 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
                 if (((cw >> 8) & 0xff) != 0xff)  block(xo, wo, (cw >> 8) & 0xff, 1);
                 if (((cw >> 16) & 0xff) != 0xff) block(xo + X2_SLAB, wo, (cw >> 16) & 0xff, 0);
                 if ((cw >> 24) != 0xff)          block(xo + X2_SLAB, wo, cw >> 24, 1);
+                if constexpr (PH > 2) {
+                    const uint32_t cw2 = (uint32_t)__builtin_amdgcn_readlane(cwv2, qi);
+                    if ((cw2 & 0xff) != 0xff)        block(xo + 2 * X2_SLAB, wo, cw2 & 0xff, 0);
+                    if (((cw2 >> 8) & 0xff) != 0xff) block(xo + 2 * X2_SLAB, wo, (cw2 >> 8) & 0xff, 1);
+                    if constexpr (PH > 3) {
+                        if (((cw2 >> 16) & 0xff) != 0xff) block(xo + 3 * X2_SLAB, wo, (cw2 >> 16) & 0xff, 0);
+                        if ((cw2 >> 24) != 0xff)          block(xo + 3 * X2_SLAB, wo, cw2 >> 24, 1);
+                    }
+                }
                 if (late && tb + qi + 1 < nph) {
-                    const int px1 = __builtin_amdgcn_readlane(pxv, qi);
+                    const int px1 = __builtin_amdgcn_readlane(pxv, qi), px1b = PH > 2 ? __builtin_amdgcn_readlane(pxv2, qi) : -1;
                     const int d0 = __builtin_amdgcn_readlane(d0v, qi), d1 = __builtin_amdgcn_readlane(d1v, qi), d2 = __builtin_amdgcn_readlane(d2v, qi);
-                    X2_ISSUE(px1, d0, d1, d2, hb ^ 1);
+                    X2_ISSUE(px1, px1b, d0, d1, d2, hb ^ 1);
                 }
                 hb ^= 1;
             }

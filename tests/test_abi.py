@@ -165,34 +165,44 @@ def test_plan_builder_covers_every_block_once(lib):
 
 
 def test_staged_xcol_plan(lib):
-    """'BSX2' plans (the default for bsize 32, 16-bit, feature_axis 1; bsmm_xcol_v2.h): every lut entry is multiplied exactly once, by the wave that owns
-    its output block, from a slot of the phase's ring half that exactly one pair of DMA duties fills with that weight block;
-    phases hold <= 2 steps and <= WCAP blocks, waves <= 3 duties."""
+    """'BSX2' plans (the default for bsize 32, 16-bit; bsmm_xcol_v2.h): every lut entry is multiplied exactly once, by the wave that
+    owns its output block, from a slot of the phase's ring half that exactly one pair of DMA duties fills with that weight block;
+    phases hold <= PH steps and <= WCAP blocks (PH = 2 / 3 / 4 by density: WCAP 23 / 15 / 7), waves <= 3 duties."""
     import numpy as np
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_plan
     rng = np.random.default_rng(5)
-    for CB, KB, dens in ((128, 128, 0.2), (40, 52, 0.3), (9, 35, 1.0), (1, 1, 1.0), (64, 16, 0.6)):
+    for CB, KB, dens, ph in ((128, 128, 0.2, 2), (128, 128, 0.08, 3), (128, 128, 0.02, 4), (40, 52, 0.3, 2), (9, 35, 1.0, 2), (1, 1, 1.0, None),
+                             (64, 16, 0.6, 2), (64, 48, 0.5, (3 << 8)), (64, 48, 0.5, (4 << 8))):
         lay = rng.random((CB, KB)) < dens
         lay[0, :] = True
         t = L.build_tables(lay)
+        opt = ph if (ph is not None and ph >= 256) else 0
         for side, n_out in (("fprop", KB), ("bprop", CB)):
             f = t[side]
-            plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, 1)
+            plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, 1, opt)
             assert plan[0] == 0x42535832 and int(plan[2]) == 16 and plan[8] == n_out and plan[7] % 4 == 0
-            WCAP = int(plan[9])
+            WCAP, PH = int(plan[9]), int(plan[11])
+            assert (PH, WCAP) in ((2, 23), (3, 15), (4, 7))
+            if opt:
+                assert PH == opt >> 8
+            elif ph is not None and CB == 128:
+                assert (PH == 2) if ph == 2 else (PH >= 3), (dens, PH)      # sparse layouts get longer phases
+            nph_total = int(plan[4])
             groups = plan[plan[5]:plan[5] + 4 * int(plan[3])].reshape(-1, 4)
-            px = plan[plan[6]:plan[6] + int(plan[4])]
-            tab = plan[plan[7]:plan[7] + int(plan[4]) * 64].reshape(-1, 16, 4)
+            px = plan[plan[6]:plan[6] + 2 * nph_total].reshape(-1, 2)
+            tab = plan[plan[7]:plan[7] + nph_total * 128].reshape(-1, 16, 8)
             got = set()
             for g, (po, nph, ob0, nob) in enumerate(groups):
                 assert ob0 == 16 * g and nob == min(16, n_out - ob0)
-                for ph in range(po, po + nph):
-                    pairs = (int(px[ph]) & 0xffff, (int(px[ph]) >> 16) & 0xffff)
-                    assert pairs[0] != 0xffff
+                for phs in range(po, po + nph):
+                    pw = [int(px[phs, 0]) & 0xffffffff, int(px[phs, 1]) & 0xffffffff]
+                    pairs = [(pw[u >> 1] >> (16 * (u & 1))) & 0xffff for u in range(4)]
+                    assert pairs[0] != 0xffff and all(p == 0xffff for p in pairs[PH:])
                     slots = {}
                     for wave in range(16):
-                        duties = [int(d) & 0xffffffff for d in tab[ph, wave, 1:] if d != -1]
+                        duties = [int(d) & 0xffffffff for d in tab[phs, wave, 2:5] if d != -1]
+                        assert (tab[phs, wave, 5:] == 0).all()
                         for d in duties:
                             blk2, slot2 = d & 0x3ffffff, d >> 26
                             assert blk2 & 1 == slot2 & 1 and slot2 < 2 * WCAP
@@ -201,13 +211,12 @@ def test_staged_xcol_plan(lib):
                         assert sorted(halves) == [2 * (halves[0] >> 1), 2 * (halves[0] >> 1) + 1]
                     used = set()
                     for wave in range(16):
-                        cw = int(tab[ph, wave, 0]) & 0xffffffff
-                        for j in range(4):
-                            sl = (cw >> (8 * j)) & 0xff
+                        for byte in range(8):
+                            sl = (int(tab[phs, wave, byte >> 2]) >> (8 * (byte & 3))) & 0xff
                             if sl == 0xff:
                                 continue
-                            u, half = j >> 1, j & 1
-                            assert wave < nob and pairs[u] != 0xffff and sl in slots and sl not in used
+                            u, half = byte >> 1, byte & 1
+                            assert u < PH and wave < nob and pairs[u] != 0xffff and sl in slots and sl not in used
                             used.add(sl)
                             got.add((ob0 + wave, 2 * pairs[u] + half, slots[sl][0] >> 1))
                     assert used == set(slots) and len(used) <= WCAP
@@ -452,7 +461,7 @@ def test_plan_attach_descriptor_and_host_side_rejection(lib):
         return a
     xp = _host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1)
     a = attach(xp)                                  # default for bsize 32 / 16-bit / axis 1: the staged kernel's 'BSX2' plan
-    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items, a.plan_inner) == (0x42535832, 16, 16, 0, 0) and a.plan == 4096
+    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items) == (0x42535832, 16, 16, 0) and a.plan_inner in (2, 3, 4) and a.plan == 4096   # plan_inner: steps per phase
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_UNSTAGED))
     assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items, a.plan_inner) == (0x42535843, 16, 16, 0, 0)
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 0))
