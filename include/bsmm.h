@@ -93,8 +93,10 @@ typedef struct bsmm_args {
     const int32_t* lut;     /* device: fprop_lut (fprop) / bprop_lut (bprop) / updat_lut (updat)                    */
     const float* gate;      /* optional per-block fp32 gate [blocks] (reference: Gate, src/gpu_types.h:175).  xprop: block
                                w contributes gate[w] * (its product), gate 0 = skipped; updat: only read when
-                               flags & BSMM_FLAG_GATED_DW, then DW[w] = alpha * gate[w] * sum + beta * DW[w].  A gated call
-                               runs the per-segment / per-block kernels (the plan is ignored).                          */
+                               flags & BSMM_FLAG_GATED_DW, then DW[w] = alpha * gate[w] * sum + beta * DW[w].  Gated calls run
+                               the plan kernels for bsize 32 with 16-bit types (staged xprop kernel: exact two-piece split
+                               of gate * w; streaming updat kernel: gate applied in its reduce pass), else the per-segment /
+                               per-block kernels.                                                                        */
     void* workspace;        /* device scratch of >= bsmm_workspace_bytes(op, args) bytes (may be NULL when that is 0) */
     size_t workspace_bytes;
     const int32_t* plan;    /* optional device copy of the schedule built by bsmm_xprop_plan_build() (fprop/bprop) or
@@ -104,13 +106,13 @@ typedef struct bsmm_args {
     int32_t plan_width;     /*   output blocks per workgroup (xprop) / window side (updat); bsize 8: number of super-blocks */
     int32_t plan_waves;     /*   waves per workgroup the schedule was dealt for                                          */
     int32_t plan_items;     /*   updat: number of work items (= grid size)                                               */
-    int32_t plan_inner;     /*   bsize 8: width / window side of the nested bsize-32 plan; streaming updat plan: its item
-                                 sets (header word [8] | word [25] << 8)                                                */
+    int32_t plan_inner;     /*   bsize 8: width / window side of the nested bsize-32 plan; staged xprop plan: steps per phase;
+                                 streaming updat plan: item sets | 16 if all equally long | longest set << 8            */
                             /* The launchers check the descriptor against the kernel they are about to launch and return
                                BSMM_ERR_ARG on a mismatch (a plan built with other options, or for another pass).        */
     int32_t flags;          /* BSMM_FLAG_* (0 = none)                                                                 */
     int32_t split;          /* updat with a plan: workgroups per work item (each takes a slice of the minibatch; > 1 or a
-                               gate: fp32 partial sums in the workspace + a finalize pass); 0 = library chooses         */
+                               gate: fp32 partial sums in the workspace + a summing pass); 0 = library chooses          */
     int32_t blocks;         /* nonzero blocks                                                                        */
     int32_t bsize;          /* 8, 16 or 32                                                                           */
     int32_t segments;       /* xprop: number of lut headers (incl. empty output blocks)                              */
@@ -128,8 +130,9 @@ typedef struct bsmm_args {
     int32_t* trace;         /* optional HOST pointer: receives the BSMM_K_* code of the kernel this call dispatched to  */
 } bsmm_args;
 
-/* Y = fprop(X, W).  args->lut = fprop_lut.  Needs workspace: a transposed copy of W; bsize 8 with a plan: the expanded W;
- * fp32 / bsize 32 with a plan: the bf16 pieces of X and W (6 bytes per element) -- ask bsmm_workspace_bytes(). */
+/* Y = fprop(X, W).  args->lut = fprop_lut.  Workspace: a transposed copy of W (not read by the staged bsize-32 kernel, which
+ * transposes in LDS); bsize 8 with a plan: the expanded W; fp32 / bsize 32 with a plan: the bf16 pieces of X and W (6 bytes per
+ * element) -- ask bsmm_workspace_bytes(). */
 int bsmm_fprop(const void* X, const void* W, void* Y, const bsmm_args* args);
 
 /* DX = bprop(DY, W).  args->lut = bprop_lut, args->C/K swapped by the caller.  Workspace only for bsize 8 with a plan
@@ -196,7 +199,8 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
 
 /* Host-only: work items of the windowed weight-gradient kernel for an updat lut in HOST memory (CB/KB = block rows /
  * columns of the layout).  Same conventions as the xprop plan (options: BSMM_PLAN_WINDOW_* or 0).
- * With a plan, bsmm_updat may need workspace (fp32 partial sums): ask bsmm_workspace_bytes(BSMM_OP_UPDAT, args).
+ * With a plan, bsmm_updat needs workspace (the fp32 sums and, for the streaming kernel, one 256 KiB region of partial sums per
+ * round and workgroup: 141 MB at 4096^2 / 20 % / N = 8192): ask bsmm_workspace_bytes(BSMM_OP_UPDAT, args).
  * bsize 8 (16-bit types, CB % 4 == 0 and KB % 4 == 0): composite 'BSS8' plan as above. */
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize,
                            int32_t dtype, int32_t axis, int32_t options);
