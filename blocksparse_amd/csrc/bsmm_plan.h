@@ -278,6 +278,16 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
         max_ph = std::max(max_ph, nph);
         groups.insert(groups.end(), {phase_off, nph, g * G, std::min(G, n_out_blocks - g * G)});
     }
+    // longest groups first: workgroup (tile, group index i) runs groups[i], and the CUs that finish a short group of one row tile
+    // pick up the long groups of the next (skewed layouts: a Barabasi-Albert layout has 1.7x the blocks in its first group)
+    {
+        std::vector<int> order(ngroups);
+        for (int g = 0; g < ngroups; ++g) order[g] = g;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[4 * a + 1] > groups[4 * b + 1]; });
+        std::vector<int32_t> sorted;
+        for (int g : order) sorted.insert(sorted.end(), groups.begin() + 4 * g, groups.begin() + 4 * g + 4);
+        groups.swap(sorted);
+    }
     const int off_groups = X2_HDR, off_px = off_groups + (int)groups.size();
     const int off_tab = (off_px + (int)px.size() + 3) & ~3;
     const long total = off_tab + (long)tab.size();
@@ -714,7 +724,11 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
     if (force_sets == 1 || (force_sets == 2 && wc >= 2) || (force_sets == 4 && wc >= 2 && wk >= 2) || (force_sets == 8 && wc >= 4 && wk >= 2))
         nsets = force_sets;
     const int pr = nsets == 8 ? 4 : (nsets == 4 ? 2 : nsets), pc = nsets >= 4 ? 2 : 1;       // patch grid over the windows
-    std::vector<std::vector<std::vector<int32_t>>> set_items(8), set_overflow(8);
+    // items are collected per window ROW first: with two sets the split row is chosen afterwards so that both sets hold about
+    // as many items (a Barabasi-Albert layout has three times the blocks in its first window rows: cutting the grid in the
+    // middle gave 50 + 33 items, i.e. a whole extra round for half of the XCDs)
+    std::vector<std::vector<std::vector<int32_t>>> row_items(wc), row_overflow(wc);
+    std::vector<std::vector<int>> row_items_wj(wc), row_overflow_wj(wc);
     bool overflow_item = false;
     auto emit = [&](int wi, int wj, const std::vector<Wave>& waves) {
         std::vector<int32_t> it(U2_ITEM, 0);
@@ -737,8 +751,8 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
             wd[0] = (int32_t)m;
         }
         it[0] = wi * WS; it[1] = wj * WS; it[2] = n;
-        const int set = (nsets == 1) ? 0 : (((wi * pr / wc) * pc + (wj * pc / wk)) % nsets);
-        (overflow_item ? set_overflow : set_items)[set].push_back(std::move(it));
+        (overflow_item ? row_overflow : row_items)[wi].push_back(std::move(it));
+        (overflow_item ? row_overflow_wj : row_items_wj)[wi].push_back(wj);
     };
     for (int wj = 0; wj < wk; ++wj)                 // column-major over the windows: consecutive items share their DY panel
         for (int wi = 0; wi < wc; ++wi) {
@@ -795,6 +809,34 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
                 }
                 overflow_item = beg > 0;
                 emit(wi, wj, dealt);
+            }
+        }
+    // window row -> row band of the set grid: equal thirds / halves of the grid, except for two sets: balanced item counts
+    std::vector<int> band(wc);
+    for (int wi = 0; wi < wc; ++wi) band[wi] = wi * pr / wc;
+    if (nsets == 2) {
+        long total_items = 0, acc_items = 0, best = -1;
+        for (int wi = 0; wi < wc; ++wi) total_items += (long)(row_items[wi].size() + row_overflow[wi].size());
+        int split = wc / 2;
+        for (int r = 1; r < wc; ++r) {                      // rows [0, r) -> set 0
+            acc_items += (long)(row_items[r - 1].size() + row_overflow[r - 1].size());
+            const long diff = std::labs(2 * acc_items - total_items);
+            if (best < 0 || diff < best) { best = diff; split = r; }
+        }
+        for (int wi = 0; wi < wc; ++wi) band[wi] = wi < split ? 0 : 1;
+    }
+    std::vector<std::vector<std::vector<int32_t>>> set_items(8), set_overflow(8);
+    // (column-major over the windows inside a set, as the items were produced: consecutive items share their DY panel)
+    for (int wj = 0; wj < wk; ++wj)
+        for (int wi = 0; wi < wc; ++wi) {
+            for (int o = 0; o < 2; ++o) {
+                auto& src = o ? row_overflow[wi] : row_items[wi];
+                auto& swj = o ? row_overflow_wj[wi] : row_items_wj[wi];
+                for (size_t i = 0; i < src.size(); ++i) {
+                    if (swj[i] != wj) continue;
+                    const int set = (nsets == 1) ? 0 : ((band[wi] * pc + (wj * pc / wk)) % nsets);
+                    (o ? set_overflow : set_items)[set].push_back(src[i]);
+                }
             }
         }
     std::vector<int32_t> items;

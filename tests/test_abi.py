@@ -193,8 +193,10 @@ def test_staged_xcol_plan(lib):
             px = plan[plan[6]:plan[6] + 2 * nph_total].reshape(-1, 2)
             tab = plan[plan[7]:plan[7] + nph_total * 128].reshape(-1, 16, 8)
             got = set()
+            assert sorted(int(x) for x in groups[:, 2]) == [16 * g for g in range(len(groups))]      # every group once ...
+            assert all(groups[i, 1] >= groups[i + 1, 1] for i in range(len(groups) - 1))              # ... longest first
             for g, (po, nph, ob0, nob) in enumerate(groups):
-                assert ob0 == 16 * g and nob == min(16, n_out - ob0)
+                assert nob == min(16, n_out - ob0)
                 for phs in range(po, po + nph):
                     pw = [int(px[phs, 0]) & 0xffffffff, int(px[phs, 1]) & 0xffffffff]
                     pairs = [(pw[u >> 1] >> (16 * (u & 1))) & 0xffff for u in range(4)]
@@ -395,10 +397,13 @@ def test_streaming_updat_plan(lib):
             assert firsts[0] == 0 and all(firsts[i + 1] == firsts[i] + counts[i] for i in range(7))
             assert int(plan[25]) == (counts[0] if len(set(counts[:nsets])) == 1 else 0) and int(plan[27]) == max(counts)
             wc = -(-CB // WS)
-            if nsets == 2:
-                for s_ in range(2):
-                    rows = set(int(it[0]) // WS for it in items[firsts[s_]:firsts[s_] + counts[s_]])
-                    assert all((2 * r >= wc) == bool(s_) for r in rows)
+            if nsets == 2:                                    # a split row: set 0 above it, set 1 below, item counts as equal as rows allow
+                rows0 = set(int(it[0]) // WS for it in items[firsts[0]:firsts[0] + counts[0]])
+                rows1 = set(int(it[0]) // WS for it in items[firsts[1]:firsts[1] + counts[1]])
+                assert rows0 and rows1 and max(rows0) < min(rows1)
+                per_row = np.bincount([int(it[0]) // WS for it in items], minlength=wc)
+                best = min(abs(2 * int(per_row[:r].sum()) - nitems) for r in range(1, wc))
+                assert abs(counts[0] - counts[1]) == best
         if (CB, KB, dens) == (128, 128, 0.2):
             p16 = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, 0)
             assert 64 <= int(p16[4]) <= 72                      # ~one item per 16x16 window
