@@ -127,7 +127,9 @@ class BlocksparseMatMul(object):
                  updat_split=0):
         """``plan_options``: BSMM_PLAN_* bits for the library's schedule builders (0 = its defaults); ``updat_split``: minibatch
         split of the windowed updat kernels (0 = the library chooses).  Both are tuning / test knobs, not semantics."""
-        if feature_axis not in (0, 1) or block_size not in (8, 16, 32):
+        # the reference allows axis 0 with 8 / 16 / 32 and axis 1 with 32 / 64 (blocksparse/matmul.py:84-89); here 8 / 16 / 32 run
+        # natively on both axes and 64 (axis 1) runs on the bsize-32 kernels: a 64x64 block is four 32x32 blocks
+        if feature_axis not in (0, 1) or not (block_size in (8, 16, 32) or (block_size == 64 and feature_axis == 1)):
             raise ValueError("Unsupported block size with this feature axis")
         layout = np.asarray(layout)
         assert len(layout.shape) == 2
@@ -165,6 +167,36 @@ class BlocksparseMatMul(object):
         self.layout = ref["layout"]
         self._device_cache = {}
         self._workspaces = {}
+        self._inner = None
+        if block_size == 64:
+            # same weights, cut into 32x32 blocks: inner block n is quadrant (i, j) of outer block b
+            self._inner = BlocksparseMatMul(np.kron(self.layout, np.ones((2, 2), dtype=self.layout.dtype)), block_size=32, feature_axis=feature_axis,
+                                            z_order=z_order, name=self.name + "/32", plan_options=plan_options, updat_split=updat_split)
+            where = {ck: b for b, ck in enumerate(self.updat_list)}
+            self._perm64 = np.array([where[(c // 2, k // 2)] * 4 + (c & 1) * 2 + (k & 1) for c, k in self._inner.updat_list], dtype=np.int64)
+            self._inv64 = np.argsort(self._perm64)
+            self._perm64_dev = {}
+
+    # ---- bsize 64 on the bsize-32 kernels --------------------------------------------------------
+    def _idx64(self, device):
+        key = (device.type, device.index)
+        if key not in self._perm64_dev:
+            self._perm64_dev[key] = (torch.from_numpy(self._perm64).to(device), torch.from_numpy(self._inv64).to(device))
+        return self._perm64_dev[key]
+
+    def _split64(self, w):
+        perm, _ = self._idx64(w.device)
+        return w.contiguous().view(self.blocks, 2, 32, 2, 32).permute(0, 1, 3, 2, 4).reshape(4 * self.blocks, 32, 32).index_select(0, perm)
+
+    def _merge64(self, w32):
+        _, inv = self._idx64(w32.device)
+        return w32.index_select(0, inv).view(self.blocks, 2, 2, 32, 32).permute(0, 1, 3, 2, 4).reshape(self.blocks, 64, 64)
+
+    def _gate64(self, gate):
+        if gate is None:
+            return None
+        perm, _ = self._idx64(gate.device)
+        return gate.index_select(0, perm // 4)
 
     # ---- shapes ----------------------------------------------------------------------------------
     def i_shape(self, N):
@@ -258,6 +290,8 @@ class BlocksparseMatMul(object):
         gate = self._check_gate(gate, x.device)
         if x.dtype != w.dtype:
             raise TypeError("x and w must have the same dtype")
+        if self._inner is not None:
+            return self._inner.fprop(x, self._split64(w), gate=self._gate64(gate))
         x = x.contiguous(); w = w.contiguous()
         N = self._n_of(x, self.C)
         lib = _lib.load()
@@ -276,6 +310,8 @@ class BlocksparseMatMul(object):
         gate = self._check_gate(gate, dy.device)
         if dy.dtype != w.dtype:
             raise TypeError("dy and w must have the same dtype")
+        if self._inner is not None:
+            return self._inner.bprop(dy, self._split64(w), gate=self._gate64(gate))
         dy = dy.contiguous(); w = w.contiguous()
         N = self._n_of(dy, self.K)
         lib = _lib.load()
@@ -310,6 +346,18 @@ class BlocksparseMatMul(object):
         for x, dy in zip(xs, dys):
             if self._n_of(x, self.C) != N or self._n_of(dy, self.K) != N:
                 raise ValueError("all pairs must share the minibatch size")
+        if self._inner is not None:      # bsize 64: the gradient of the four 32x32 quadrants, put back together
+            if sums_only:
+                raise _lib.BsmmError(-2, "bsmm_updat(sums_only) with bsize 64")
+            if beta != 0.0 and dw is None:
+                raise ValueError("beta != 0 needs dw")
+            dw32 = self._inner.updat(xs, dys, alpha=alpha, beta=beta, dw=self._split64(dw) if (dw is not None and beta != 0.0) else None,
+                                     gate=self._gate64(self._check_gate(gate, xs[0].device)))
+            out = self._merge64(dw32)
+            if dw is not None:
+                dw.copy_(out)
+                return dw
+            return out
         lib = _lib.load()
         dev = xs[0].device
         tabs = self._tables_on(dev)

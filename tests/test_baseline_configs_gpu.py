@@ -308,6 +308,33 @@ def test_small_layouts_bsize16_xprop_plan_kernels(env, opt, axis):
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_bsize64_axis1(env):
+    """bsize 64 on feature_axis 1 (the reference's second axis-1 block size, blocksparse/matmul.py:84-89): the host class runs it on the
+    bsize-32 kernels (a 64x64 block = four 32x32 blocks) -- fprop / bprop / updat with alpha, beta and a gate against the oracle at bsize 64."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(24, 40, 0.25, seed=9)
+    b = BSMM(layout, block_size=64, feature_axis=1)
+    assert b.w_shape == (int(layout.sum()), 64, 64) and b.C == 24 * 64 and b.K == 40 * 64
+    t = orc.build_layout_luts(layout, 64)
+    for dtype in ("bf16", "f32"):
+        for N in (72, 520):
+            W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=3 + N)
+            w, x, e = P.to_dev(W, dtype, torch), P.to_dev(X, dtype, torch), P.to_dev(E, dtype, torch)
+            g = np.random.default_rng(N).random(b.blocks).astype(np.float32)
+            g[::3] = 0
+            tg = torch.from_numpy(g).cuda()
+            dw0 = orc.round_to(np.random.default_rng(1).normal(size=b.w_shape).astype(np.float32) * 0.05, dtype)
+            got = {"Y": b.fprop(x, w), "DX": b.bprop(e, w), "Yg": b.fprop(x, w, gate=tg), "DW": b.updat(x, e),
+                   "DWab": b.updat(x, e, alpha=0.5, beta=2.0, dw=P.to_dev(dw0, dtype, torch))}
+            want = {"Y": orc.fprop(t, X, W, 1), "DX": orc.bprop(t, E, W, 1), "Yg": orc.fprop(t, X, W, 1, gate=g), "DW": orc.updat(t, X, E, 1),
+                    "DWab": orc.updat(t, X, E, 1, alpha=0.5, beta=2.0, dw_in=dw0)}
+            for k in got:
+                l2, _ = P.errors(P.to_host(got[k]), orc.round_to(want[k], dtype))
+                assert l2 <= P.L2_BAR[dtype], (dtype, N, k, l2)
+    with pytest.raises(ValueError):
+        BSMM(layout, block_size=64, feature_axis=0)
+
+
 # ---- (e) the reference's own test matrix ------------------------------------------------------------------------------
 @pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("bs", [32, 16, 8])
