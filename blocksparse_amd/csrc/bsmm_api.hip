@@ -686,7 +686,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                         const int nsets = a->plan_inner & 15, longest = a->plan_inner >> 8, U = std::max(1, L.grid / 8);
                         const int m_last = longest % U;
                         const double sliced = longest > 0 ? (double)m_last / longest : 0.0;
-                        const double mult = (8.0 / std::max(1, nsets)) * ((1.0 - sliced) + sliced * (m_last > 0 ? U / m_last : 1));
+                        const double mult = (8.0 / std::max(1, nsets)) * ((1.0 - sliced) + sliced * (m_last > 0 ? std::min(U / m_last, U2_MAX_SLICES) : 1));
                         t_stream += 0.45 * mult * a->blocks * 4096.0 / 1048576.0;
                     } else if (L.scratch) {
                         t_stream += 8.0;

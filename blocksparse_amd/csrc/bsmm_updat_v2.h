@@ -39,6 +39,11 @@ namespace bsmm {
 #ifndef U2_NT_PARTS
 #define U2_NT_PARTS 1       // non-temporal stores / loads of the partial sums: 50-80 MB that are written once and read once must not
 #endif                      // push the activations out of the Infinity Cache (bench: the fprop that follows runs 91 instead of 99 us)
+// slices per item of a set's last, incomplete round: every slice leaves a partial sum that the reduce pass reads back -- with 16 or 32
+// slices of two left-over items the blocks of those items made that pass 22 us long (a serial chain of loads), for 2 us of kernel time
+#ifndef U2_MAX_SLICES
+#define U2_MAX_SLICES 8
+#endif
 #ifndef U2_CH_ROWS
 #define U2_CH_ROWS 16
 #endif
@@ -132,7 +137,7 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     const int set_first = xcd_mode ? plan[9 + 2 * set] : 0, set_count = xcd_mode ? plan[10 + 2 * set] : plan[4];
     const int part_lo = (int)((long)part * CPI / nparts), part_hi = (int)((long)(part + 1) * CPI / nparts);
     const int full_rounds = set_count / U, m_last = set_count - full_rounds * U;
-    const int k_last = m_last > 0 ? U / m_last : 0;                          // slices per item of the last round
+    const int k_last = m_last > 0 ? min(U / m_last, U2_MAX_SLICES) : 0;      // slices per item of the last round
     const int total_rounds = full_rounds + ((m_last > 0 && uj < m_last * k_last) ? 1 : 0);
 
     const uint32_t base_addr = lds_addr_of(smem);
@@ -462,7 +467,7 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
     const int set_first = xcd_mode ? plan[9 + 2 * set] : 0, set_count = xcd_mode ? plan[10 + 2 * set] : plan[4];
     const int pos = item - set_first;
     const int full_rounds = set_count / U, m_last = set_count - full_rounds * U;
-    const int k_last = m_last > 0 ? U / m_last : 0;
+    const int k_last = m_last > 0 ? min(U / m_last, U2_MAX_SLICES) : 0;
     const float4* base = reinterpret_cast<const float4*>(parts) + ((size_t)slot * 4 + qq) * 64 + l;    // quad qq; quad qq + 2 is 128 float4 further
     constexpr size_t REGION = (size_t)U2_WAVES * U2_SLOTS * 256;       // float4 per region
     // the partial sums of this block: one region per (part, slice); independent loads in flight, no 64-bit division in the
@@ -506,16 +511,16 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
                 const int uj = which * k_last + slice;
                 return rb + (size_t)(xcd_mode ? uj * 8 + xcd : uj) * REGION;
             };
-            for (int sl = 0; sl < k_last; sl += 4) {
-                float4 a[4], b[4];
+            for (int sl = 0; sl < k_last; sl += 8) {
+                float4 a[8], b[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 8; ++e) {
                     const float4* p = where(sl + e);
                     a[e] = b[e] = zero4;
                     if (p) { a[e] = u2_ld(p); b[e] = u2_ld(p + 128); }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { add(acc0, a[e]); add(acc1, b[e]); }
+                for (int e = 0; e < 8; ++e) { add(acc0, a[e]); add(acc1, b[e]); }
             }
         }
     }
