@@ -364,6 +364,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     if constexpr (BS == 16) {
         if constexpr (!DT::is16) return XP_SEGMENT;
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // 16-byte aligned row pieces
+        if (a->plan_magic == X7PLAN_MAGIC && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;   // 32-bit lane offsets
         const bool enough = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 16 + XC16_G - 1) / XC16_G) >= 224;
         return (enough || force) ? XP_XCOL16 : XP_SEGMENT;
     }
@@ -377,6 +378,8 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     }
     if constexpr (BS == 32 && DT::is16) {
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // axis-0 xcol needs 16-byte aligned row pieces
+        // staged kernel: 32-bit per-lane byte offsets inside a slab's source (128 rows of C elements / 64 rows of N elements)
+        if (a->plan_magic == X2PLAN_MAGIC && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;
         if (force) return XP_XCOL32;
         // Cost model fitted to the measurements in profiles/r01_sweeps.md (4096^2 / 20 % and 8192^2 / 5 %, N = 512 .. 8192):
         // the grouped kernel pays ~0.48 us per pair step of a group plus ~0.045 us per block, once per round of 256
