@@ -12,13 +12,14 @@ worst = 0.0
 _lib.set_kernel_variant(3)
 for it in range(ncase):
     bs = int(rng.choice([32, 32, 16]))
-    CB, KB = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    big = os.environ.get("FUZZ_BIG") == "1"
+    CB, KB = int(rng.integers(1, 200 if big else 70)), int(rng.integers(1, 200 if big else 70))
     dens = float(rng.choice([0.03, 0.1, 0.2, 0.5, 1.0]))
     lay = rng.random((CB, KB)) < dens
     lay[rng.integers(0, CB), rng.integers(0, KB)] = True
     axis = int(rng.integers(0, 2))
     dtype = str(rng.choice(["bf16", "f16"]))
-    N = int(rng.choice([8, 40, 128, 200, 264, 520]))
+    N = int(rng.choice([8, 40, 128, 200, 264, 520] + ([1032, 2056, 4096] if os.environ.get("FUZZ_BIG") == "1" else [])))
     if axis == 0: N = (N + 7) // 8 * 8
     b = BlocksparseMatMul(lay, block_size=bs, feature_axis=axis)
     t = orc.build_layout_luts(lay, bs)
