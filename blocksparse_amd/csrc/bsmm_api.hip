@@ -18,7 +18,6 @@
 #include "bsmm_xcols.h"
 #include "bsmm_xcol.h"
 #include "bsmm_xcol_v2.h"
-#include "bsmm_xcol_v3.h"
 #include "bsmm_xcol16.h"
 #include "bsmm_xcol16_v2.h"
 #include "bsmm_xprop.h"
@@ -77,7 +76,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32 && a->axis == 1)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 16) return ((m == XC16PLAN_MAGIC || (m == X7PLAN_MAGIC && a->plan_width == X7_G)) && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return ((m == XCPLAN_MAGIC && a->plan_width == XS_G) || m == XFPLAN_MAGIC) ? BSMM_OK : BSMM_ERR_ARG;
-    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G) || (m == X3PLAN_MAGIC && a->axis == 1 && a->plan_width == X3_G)) ? BSMM_OK : BSMM_ERR_ARG;
+    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G)) ? BSMM_OK : BSMM_ERR_ARG;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -307,39 +306,8 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     return BSMM_ERR_ARG;
 }
 
-template <class DT, bool TRANSW, int NW>
-int launch_xcol_v3_nw(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    typedef typename DT::T T;
-    const int n_out = a->K / 32;
-    XMap m;
-    m.ntiles = (a->N + X3_R - 1) / X3_R;
-    m.segments = (n_out + X3_G - 1) / X3_G;
-    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
-    if (m.P > m.segments) m.P = m.segments;
-    m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds(&xcol32_v3_kernel<DT, TRANSW, NW>, X3_LDS)) return rc;
-    trace(a, BSMM_K_XCOL32_PIPELINED);
-    xcol32_v3_kernel<DT, TRANSW, NW><<<m.grid(), 64 * X3_G, X3_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                                        a->N, a->C, a->K);
-    return (int)hipGetLastError();
-}
-template <class DT, bool TRANSW>
-int launch_xcol_v3(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    switch (a->plan_inner) {     // DMA requests per wave and iteration the plan was scheduled for
-        case 1: return launch_xcol_v3_nw<DT, TRANSW, 1>(X, Wsel, Y, a, st);
-        case 2: return launch_xcol_v3_nw<DT, TRANSW, 2>(X, Wsel, Y, a, st);
-        case 3: return launch_xcol_v3_nw<DT, TRANSW, 3>(X, Wsel, Y, a, st);
-        case 4: return launch_xcol_v3_nw<DT, TRANSW, 4>(X, Wsel, Y, a, st);
-    }
-    return BSMM_ERR_ARG;
-}
-
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
-    if (a->plan_magic == X3PLAN_MAGIC) {
-        if constexpr (AXIS == 1) { if (a->plan_width == X3_G && !a->gate) return transw ? launch_xcol_v3<DT, true>(X, Wsel, Y, a, st) : launch_xcol_v3<DT, false>(X, Wsel, Y, a, st); }
-        return BSMM_ERR_ARG;
-    }
     if (a->plan_magic == X2PLAN_MAGIC) {
         if (a->plan_width != X2_G) return BSMM_ERR_ARG;
         if (a->gate) return transw ? launch_xcol_v2<DT, true, AXIS, true>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false, AXIS, true>(X, Wsel, Y, a, st);
@@ -411,7 +379,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     if constexpr (BS == 32 && DT::is16) {
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // axis-0 xcol needs 16-byte aligned row pieces
         // staged kernel: 32-bit per-lane byte offsets inside a slab's source (128 rows of C elements / 64 rows of N elements)
-        if ((a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC) && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;
+        if (a->plan_magic == X2PLAN_MAGIC && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;
         if (force) return XP_XCOL32;
         // Cost model fitted to the measurements in profiles/r01_sweeps.md (4096^2 / 20 % and 8192^2 / 5 %, N = 512 .. 8192):
         // the grouped kernel pays ~0.48 us per pair step of a group plus ~0.045 us per block, once per round of 256
@@ -464,7 +432,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     float* yacc = nullptr;
     size_t off = 0;
     const void* Wsel = W;
-    const bool staged = path == XP_XCOL32 && (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC);   // transposes the staged blocks itself
+    const bool staged = path == XP_XCOL32 && a->plan_magic == X2PLAN_MAGIC;   // transposes the staged blocks itself
     if (fprop && path != XP_VALU && !staged) {
         if constexpr (BS != 8) {
             if (!a->workspace || a->workspace_bytes < wt_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
@@ -1042,10 +1010,6 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
         }
         return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
     }
-    if ((options & BSMM_PLAN_XCOL_PIPELINED) && axis == 1) {
-        const long n = build_xcol3_plan(lut, segments, blocks, n_out, out, (options >> 8) & 7);   // bits 8..10: requests per iteration (experiments)
-        if (n != 0) return n;
-    }
     if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel (either feature axis)
         const long n = build_xcol2_plan(lut, segments, blocks, n_out, out, (options >> 8) & 7);   // bits 8..10: steps per phase (experiments)
         if (n != 0) return n;                                            // 0: the layout does not fit the table fields
@@ -1113,7 +1077,6 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
     switch (p[0]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR || p[11] < 2 || p[11] > 4) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
-        case X3PLAN_MAGIC:   if (p[1] != X3PLAN_VERSION || words < XC_HDR || p[9] < 1 || p[9] > 4) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[9]; break;
         case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;

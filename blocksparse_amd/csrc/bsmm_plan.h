@@ -306,164 +306,6 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
 }  // namespace bsmm
 
 // =================================================================================================
-// pipelined xcol plan ('BSX3'): a static software pipeline for bsmm_xcol_v3.h -- the staged scheme of 'BSX2' with the memory
-// round trip of a phase hidden behind the phase before it.  Workgroup = X3_G = 16 output blocks x 64 minibatch rows, wave v
-// owns output block first + v.  The pair walk of a group is cut into ROWS of up to two steps; the kernel runs ITERATIONS:
-// in iteration i every wave issues ONE 1 KiB piece of the two activation slabs of the row that runs in iteration i + 2
-// (ring of 3 x 2 slabs of 8 KiB) and NW half weight blocks for rows that run in iteration i + 2 or later -- a constant number of
-// DMA instructions, so `s_waitcnt vmcnt(1 + NW)` at the top of an iteration means "everything requested two iterations ago
-// has landed" while the requests of the previous iteration stay in flight.  This builder decides what is requested when:
-// weight blocks live in a circular pool of X3_POOL slots of 2 KiB handed out in request order; a block is requested as early
-// as its slot is free (its previous occupant's row ran in an earlier iteration), at most 16 * NW half blocks per iteration,
-// and a row runs in the first iteration that is two after its last request (iterations in between are bubbles).  Requests
-// with nothing to fetch re-read a valid address into the dummy slot.  NW (1 .. 4) from the mean number of blocks per row.
-// Layout (int32): [0] magic 'BSX3' [1] version [2] X3_G [3] ngroups [4] niters_total [5] off_groups [6] off_px
-//                 [7] off_cw [8] n_out_blocks [9] NW [10] off_duty [11] X3_POOL
-//   groups[ngroups][4] = (iter_off, niters, first_out_block, n_out_blocks_in_group)      niters >= 3 (or 0: no blocks)
-//   px  [niters_total]             pairs of the row that runs two iterations later: step 0 | step 1 << 16 (a missing step
-//                                  repeats a valid pair: its slab is fetched and never read)
-//   cw  [niters_total][16]         per wave: slot bytes of the row that runs in THIS iteration, byte 2 * u + half, 0xff = none
-//   duty[niters_total][16][NW][2]  per wave: (byte offset of the half block in W, byte offset of its place in the pool)
-// =================================================================================================
-namespace bsmm {
-
-constexpr int32_t X3PLAN_MAGIC = 0x42535833;
-constexpr int32_t X3PLAN_VERSION = 1;
-constexpr int X3_G = 16;
-constexpr int X3_POOL = 55;            // usable weight slots; slot X3_POOL is the dummy target
-constexpr int X3_AHEAD = 2;            // iterations between a request and its use
-constexpr int X3_ROWCAP = 40;          // blocks per row: leaves the pool room for the requests of the rows behind it
-
-inline long build_xcol3_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int force_nw = 0) {
-    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
-    if (blocks >= (1 << 21)) return 0;                                       // 32-bit byte offsets into W
-    const int G = X3_G, ngroups = (n_out_blocks + G - 1) / G;
-    struct E { int p, col, half, w; };
-    std::vector<std::vector<E>> per_group(ngroups);
-    for (int s = 0; s < segments; ++s) {
-        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
-        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
-        for (int e = 0; e < cnt; ++e) {
-            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
-            if (w < 0 || w >= blocks || c < 0) return -1;
-            if (c >= 2 * 0xffff) return 0;
-            per_group[ob / G].push_back({c >> 1, ob % G, c & 1, w});
-        }
-    }
-    // rows of every group: up to two steps (runs of equal pair) with at most X3_ROWCAP blocks
-    struct Row { int p[2]; size_t lo, mid, hi; };     // step 0 = [lo, mid), step 1 = [mid, hi) (empty: one step)
-    std::vector<std::vector<Row>> grows(ngroups);
-    size_t nrows_all = 0, nblocks_all = 0;
-    for (int g = 0; g < ngroups; ++g) {
-        auto& v = per_group[g];
-        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : (a.col != b.col ? a.col < b.col : a.half < b.half); });
-        std::vector<std::pair<size_t, size_t>> steps;
-        for (size_t i = 0; i < v.size();) {
-            size_t j = i;
-            while (j < v.size() && v[j].p == v[i].p) ++j;
-            steps.push_back({i, j});
-            i = j;
-        }
-        for (size_t s = 0; s < steps.size();) {
-            Row r;
-            r.lo = steps[s].first; r.mid = steps[s].second; r.hi = r.mid;
-            r.p[0] = v[r.lo].p; r.p[1] = r.p[0];
-            if (s + 1 < steps.size() && steps[s + 1].second - r.lo <= (size_t)X3_ROWCAP) {
-                r.hi = steps[s + 1].second; r.p[1] = v[r.mid].p;
-                s += 2;
-            } else {
-                s += 1;
-            }
-            grows[g].push_back(r);
-        }
-        nrows_all += grows[g].size();
-        nblocks_all += v.size();
-    }
-    int NW = force_nw;
-    if (NW < 1 || NW > 4) {
-        const double mean = nrows_all ? (double)nblocks_all / nrows_all : 0.0;     // blocks per row; 8 * NW can be requested per iteration
-        NW = mean <= 7.0 ? 1 : (mean <= 14.5 ? 2 : (mean <= 22.0 ? 3 : 4));
-    }
-    const int cap = 16 * NW;
-    std::vector<int32_t> groups, px, cw, duty;
-    for (int g = 0; g < ngroups; ++g) {
-        const auto& v = per_group[g];
-        const auto& rw = grows[g];
-        const int S = (int)rw.size();
-        const int it_off = (int)px.size();
-        if (S == 0) { groups.insert(groups.end(), {it_off, 0, g * G, std::min(G, n_out_blocks - g * G)}); continue; }
-        std::vector<int> slot(v.size());
-        for (size_t i = 0; i < v.size(); ++i) slot[i] = (int)(i % X3_POOL);        // request order, circular
-        std::vector<int> free_it(X3_POOL, -1);        // last iteration that reads the slot's current / previous occupant
-        std::vector<int> comp_it(S, -1);
-        size_t head = 0;                              // next half-block request: block head / 2, half head & 1
-        int next_row = 0, it = 0;
-        std::vector<int32_t> gpx, gcw, gduty;
-        const int32_t dummy_dst = X3_POOL * 2048;
-        while (next_row < S || it < comp_it[S - 1] + 1) {
-            if (it > 8 * S + 64) return -1;            // cannot happen: a slot's previous occupant belongs to an earlier row
-            gcw.insert(gcw.end(), 16, -1);
-            gduty.resize(gduty.size() + (size_t)16 * NW * 2);
-            int32_t* d = &gduty[gduty.size() - (size_t)16 * NW * 2];
-            for (int k = 0; k < 16 * NW; ++k) { d[2 * k] = 0; d[2 * k + 1] = dummy_dst; }
-            int issued = 0;
-            const int rot = (it * 5) % 16;
-            while (issued < cap && head < 2 * v.size()) {
-                const size_t b = head >> 1;
-                const int hb = (int)(head & 1);
-                if (hb == 0 && free_it[slot[b]] >= it) break;            // its slot is still read in this iteration or later
-                const int wave = (issued + rot) % 16, di = issued / 16;
-                d[(wave * NW + di) * 2] = (int32_t)((uint32_t)v[b].w * 2048u + (uint32_t)hb * 1024u);
-                d[(wave * NW + di) * 2 + 1] = slot[b] * 2048 + hb * 1024;
-                if (hb == 0) free_it[slot[b]] = 1 << 30;                 // occupied until its row is scheduled
-                ++issued; ++head;
-            }
-            // the row that runs in it + X3_AHEAD: the next one, if all its blocks are requested by now
-            const Row& nr = rw[std::min(next_row, S - 1)];
-            gpx.push_back((int32_t)((uint32_t)nr.p[0] | ((uint32_t)nr.p[1] << 16)));
-            if (next_row < S && head >= 2 * rw[next_row].hi) {
-                comp_it[next_row] = it + X3_AHEAD;
-                for (size_t i = rw[next_row].lo; i < rw[next_row].hi; ++i) free_it[slot[i]] = it + X3_AHEAD;
-                ++next_row;
-            }
-            ++it;
-        }
-        const int niters = it;
-        for (int s = 0; s < S; ++s) {                  // slot bytes of the iterations that run a row
-            const int r = comp_it[s];
-            if (r < X3_AHEAD || r >= niters) return -1;
-            for (size_t i = rw[s].lo; i < rw[s].hi; ++i) {
-                const int u = i >= rw[s].mid ? 1 : 0;
-                uint32_t& word = reinterpret_cast<uint32_t&>(gcw[(size_t)r * 16 + v[i].col]);
-                const int sh = 8 * (2 * u + v[i].half);
-                word = (word & ~(0xffu << sh)) | ((uint32_t)slot[i] << sh);
-            }
-        }
-        px.insert(px.end(), gpx.begin(), gpx.end());
-        cw.insert(cw.end(), gcw.begin(), gcw.end());
-        duty.insert(duty.end(), gduty.begin(), gduty.end());
-        groups.insert(groups.end(), {it_off, niters, g * G, std::min(G, n_out_blocks - g * G)});
-    }
-    const int off_groups = XC_HDR, off_px = off_groups + (int)groups.size();
-    const int off_cw = (off_px + (int)px.size() + 3) & ~3;
-    const int off_duty = off_cw + (int)cw.size();
-    const long total = off_duty + (long)duty.size();
-    if (out) {
-        std::fill(out, out + off_cw, 0);
-        const int32_t hdr[XC_HDR] = {X3PLAN_MAGIC, X3PLAN_VERSION, G, ngroups, (int32_t)px.size(), off_groups, off_px, off_cw,
-                                     n_out_blocks, NW, off_duty, X3_POOL};
-        std::copy(hdr, hdr + XC_HDR, out);
-        std::copy(groups.begin(), groups.end(), out + off_groups);
-        std::copy(px.begin(), px.end(), out + off_px);
-        std::copy(cw.begin(), cw.end(), out + off_cw);
-        std::copy(duty.begin(), duty.end(), out + off_duty);
-    }
-    return total;
-}
-
-}  // namespace bsmm
-
-// =================================================================================================
 // staged xcol16 plan ('BSX7', bsize 16): the staged scheme of the 'BSX2' plan for 16x16 blocks (bsmm_xcol16_v2.h).  Groups of
 // X7_G = 32 consecutive output blocks, wave v of 16 owns blocks 2v and 2v+1; a step is a QUAD of input blocks (64 features);
 // a phase = up to two steps and up to X7_WCAP weight blocks = one half of the LDS ring (2 activation slabs of 16 KiB + X7_WCAP

@@ -25,7 +25,7 @@ for d in dens:
     CB = int(os.environ.get("XP_CB", "128"))
     lay = P.random_layout(CB, CB, d / 100.0, 1234)
     res = {}
-    for name, opt in (("base", int(os.environ.get("XP_BASE", str(_lib.PLAN_XCOL_UNSTAGED)), 0)), ("staged", int(os.environ.get("XP_OPT", "0"), 0))):
+    for name, opt in (("base", _lib.PLAN_XCOL_UNSTAGED), ("staged", int(os.environ.get("XP_OPT", "0"), 0))):
         b = BlocksparseMatMul(lay, block_size=32, feature_axis=int(os.environ.get("XP_AXIS", "1")), plan_options=opt)
         g = torch.Generator(device="cuda").manual_seed(1)
         w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.05).bfloat16()

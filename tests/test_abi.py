@@ -226,60 +226,6 @@ def test_staged_xcol_plan(lib):
             assert got == want
 
 
-def test_pipelined_xcol_plan(lib):
-    """'BSX3' plans (BSMM_PLAN_XCOL_PIPELINED, bsmm_xcol_v3.h), simulated as the kernel runs them: every iteration requests the two
-    slabs of the row that runs two iterations later and 16 * NW half blocks; what an iteration multiplies -- those slabs, the pool
-    slots its slot bytes name -- must have been requested at least two iterations earlier and not be overwritten before it is read;
-    over the whole walk every lut entry is multiplied exactly once under the right output block."""
-    import numpy as np
-    from blocksparse_amd import lut as L
-    from blocksparse_amd.matmul import _host_plan
-    rng = np.random.default_rng(8)
-    for CB, KB, dens, nw in ((128, 128, 0.2, 0), (128, 128, 0.1, 0), (40, 52, 0.3, 0), (9, 35, 1.0, 0), (1, 1, 1.0, 0), (64, 48, 0.5, 1), (33, 17, 0.3, 3)):
-        lay = rng.random((CB, KB)) < dens
-        lay[0, :] = True
-        t = L.build_tables(lay)
-        for side, n_out in (("fprop", KB), ("bprop", CB)):
-            f = t[side]
-            plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, 1, lib.PLAN_XCOL_PIPELINED | (nw << 8))
-            assert plan[0] == 0x42535833 and int(plan[2]) == 16 and plan[8] == n_out and plan[7] % 4 == 0
-            NW, POOL = int(plan[9]), int(plan[11])
-            assert 1 <= NW <= 4 and (nw == 0 or NW == nw)
-            T = int(plan[4])
-            groups = plan[plan[5]:plan[5] + 4 * int(plan[3])].reshape(-1, 4)
-            px = plan[plan[6]:plan[6] + T]
-            cw = plan[plan[7]:plan[7] + 16 * T].reshape(T, 16)
-            duty = plan[plan[10]:plan[10] + T * 16 * NW * 2].reshape(T, 16 * NW, 2)
-            got = set()
-            for g, (io, nit, ob0, nob) in enumerate(groups):
-                assert ob0 == 16 * g and nob == min(16, n_out - ob0) and (nit == 0 or nit > 2)
-                pool = {}                                   # half slot -> (half block id, iteration requested)
-                for it in range(io, io + nit):
-                    reads = set()
-                    for wave in range(16):
-                        word = int(cw[it, wave]) & 0xffffffff
-                        for byte in range(4):
-                            sl = (word >> (8 * byte)) & 0xff
-                            if sl == 0xff:
-                                continue
-                            assert it - io >= 2 and wave < nob and sl < POOL
-                            u, half = byte >> 1, byte & 1
-                            pair = (int(px[it - 2]) >> (16 * u)) & 0xffff          # the slabs requested two iterations ago
-                            (b0, r0), (b1, r1) = pool[2 * sl], pool[2 * sl + 1]
-                            assert b0 + 1 == b1 and b0 % 2 == 0 and max(r0, r1) <= it - 2       # both halves landed
-                            got.add((ob0 + wave, 2 * pair + half, b0 // 2))
-                            assert sl not in reads
-                            reads.add(sl)
-                    for src, dst in duty[it]:
-                        assert src % 1024 == 0 and dst % 1024 == 0 and 0 <= dst < (POOL + 1) * 2048
-                        if dst // 2048 == POOL:
-                            continue                           # dummy request
-                        assert dst // 2048 not in reads         # not while the iteration still reads the slot
-                        pool[dst // 1024] = (src // 1024, it)
-            want = {(ob, c, w) for ob, col in f["cols"] for c, w in col}
-            assert got == want
-
-
 def test_staged_xcol16_plan(lib):
     """'BSX7' plans (default for bsize 16, 16-bit; bsmm_xcol16_v2.h): every lut entry is multiplied exactly once, by the wave that
     owns its output block, from a slot of the phase's ring half that exactly one DMA duty fills with that weight block (a duty
