@@ -697,7 +697,7 @@ inline long build_super8_updat_plan(const int32_t* updat_lut, int blocks, int CB
 namespace bsmm {
 
 constexpr int32_t U2PLAN_MAGIC = 0x42535532;
-constexpr int32_t U2PLAN_VERSION = 1;
+constexpr int32_t U2PLAN_VERSION = 2;   // 2: block map behind the items (header words 26, 27)
 constexpr int U2_WAVES = 16;
 constexpr int U2_SLOTS = 4;
 constexpr int U2_WWORDS = 5;

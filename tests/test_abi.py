@@ -354,7 +354,7 @@ def test_streaming_updat_plan(lib):
         t = L.build_tables(lay)
         for opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8):
             plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, opt)
-            assert plan[0] == 0x42535532 and plan[1] == 1 and plan[3] == 4 and plan[5] == t["blocks"] and plan[7] == 16
+            assert plan[0] == 0x42535532 and plan[1] == 2 and plan[3] == 4 and plan[5] == t["blocks"] and plan[7] == 16
             WS, nitems = int(plan[2]), int(plan[4])
             if opt == 0:
                 assert WS == (16 if t["blocks"] <= 56 * (-(-CB // 16)) * (-(-KB // 16)) else 8)
