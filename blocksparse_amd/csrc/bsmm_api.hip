@@ -18,6 +18,7 @@
 #include "bsmm_xcols.h"
 #include "bsmm_xcol.h"
 #include "bsmm_xcol_v2.h"
+#include "bsmm_xcol_v3.h"
 #include "bsmm_xcol16.h"
 #include "bsmm_xcol16_v2.h"
 #include "bsmm_xprop.h"
@@ -36,16 +37,18 @@ inline int call_variant(const bsmm_args* a) {
 }
 inline void trace(const bsmm_args* a, int k) { if (a->trace) *a->trace = k; }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); the result is checked.  The latch is a cache of an
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); the result is checked.  The kernel is a template
+// ARGUMENT, so every kernel instantiation has its own latch (a latch per function TYPE would be shared by all kernels of one
+// signature, e.g. every xcol32_v3_kernel<...>: only the first of them would get the attribute).  The latch is a cache of an
 // idempotent driver call, not a switch: it never changes what a later call computes.
-template <class F>
-inline int ensure_lds(F* func, int bytes) {
-    static std::atomic<uint64_t> done{0};          // one instantiation (and one latch) per kernel
+template <auto Kernel>
+inline int ensure_lds(int bytes) {
+    static std::atomic<uint64_t> done{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     const uint64_t bit = 1ull << (dev & 63);
     if (done.load(std::memory_order_acquire) & bit) return 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(func), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return (int)e;
     done.fetch_or(bit, std::memory_order_release);
     return 0;
@@ -76,7 +79,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32 && a->axis == 1)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 16) return ((m == XC16PLAN_MAGIC || (m == X7PLAN_MAGIC && a->plan_width == X7_G)) && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return ((m == XCPLAN_MAGIC && a->plan_width == XS_G) || m == XFPLAN_MAGIC) ? BSMM_OK : BSMM_ERR_ARG;
-    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G)) ? BSMM_OK : BSMM_ERR_ARG;
+    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G) || (m == X3PLAN_MAGIC && a->plan_width == X3_G)) ? BSMM_OK : BSMM_ERR_ARG;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -151,7 +154,7 @@ int launch_xcol16_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
     constexpr int LDS = xc_lds_bytes(NW, PH);
-    if (int rc = ensure_lds(&xcol16_kernel<DT, AXIS, NW, PH>, LDS)) return rc;
+    if (int rc = ensure_lds<&xcol16_kernel<DT, AXIS, NW, PH>>(LDS)) return rc;
     trace(a, BSMM_K_XCOL16);
     xcol16_kernel<DT, AXIS, NW, PH><<<m.grid(), 64 * NW, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                    a->N, a->C, a->K);
@@ -168,7 +171,7 @@ int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* 
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds(&xcol16_v2_kernel<DT, AXIS>, X7_LDS)) return rc;
+    if (int rc = ensure_lds<&xcol16_v2_kernel<DT, AXIS>>(X7_LDS)) return rc;
     trace(a, BSMM_K_XCOL16_STAGED);
     xcol16_v2_kernel<DT, AXIS><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                               a->N, a->C, a->K);
@@ -194,7 +197,7 @@ int launch_xcol32f(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
     if (a->plan_magic != XFPLAN_MAGIC || a->plan_width != XC_G) return BSMM_ERR_ARG;
-    if (int rc = ensure_lds(&xcol32f_kernel<AXIS>, XF_LDS)) return rc;
+    if (int rc = ensure_lds<&xcol32f_kernel<AXIS>>(XF_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_F32MFMA);
     xcol32f_kernel<AXIS><<<m.grid(), 512, XF_LDS, st>>>(static_cast<const float*>(X), static_cast<const float*>(Wsel), static_cast<float*>(Y),
                                                         a->plan, m, a->N, a->C, a->K);
@@ -223,7 +226,7 @@ int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds(&xcol32s_kernel<AXIS>, XS_LDS)) return rc;
+    if (int rc = ensure_lds<&xcol32s_kernel<AXIS>>(XS_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_F32SPLIT);
     xcol32s_kernel<AXIS><<<m.grid(), 64 * XS_G, XS_LDS, st>>>(xp, wp, static_cast<float*>(Y), a->plan, m, a->N, a->C, a->K, a->blocks);
     return (int)hipGetLastError();
@@ -240,7 +243,7 @@ int launch_xcol0_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
     constexpr int LDS = 2 * PH * XC0_SLAB;
-    if (int rc = ensure_lds(&xcol32_a0_kernel<DT, TRANSW, G, PH>, LDS)) return rc;
+    if (int rc = ensure_lds<&xcol32_a0_kernel<DT, TRANSW, G, PH>>(LDS)) return rc;
     trace(a, BSMM_K_XCOL32);
     xcol32_a0_kernel<DT, TRANSW, G, PH><<<m.grid(), 64 * G, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                      a->N, a->C, a->K);
@@ -265,7 +268,7 @@ int launch_xcol_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, 
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
     constexpr int LDS = xc_lds_bytes(G, PH);
-    if (int rc = ensure_lds(&xcol32_a1_kernel<DT, TRANSW, G, PH>, LDS)) return rc;
+    if (int rc = ensure_lds<&xcol32_a1_kernel<DT, TRANSW, G, PH>>(LDS)) return rc;
     trace(a, BSMM_K_XCOL32);
     xcol32_a1_kernel<DT, TRANSW, G, PH><<<m.grid(), 64 * G, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                      a->N, a->C, a->K);
@@ -289,7 +292,7 @@ int launch_xcol_v2_ph(const void* X, const void* Wsel, void* Y, const bsmm_args*
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds(&xcol32_v2_kernel<DT, TRANSW, AXIS, GATED, PH>, X2_LDS)) return rc;
+    if (int rc = ensure_lds<&xcol32_v2_kernel<DT, TRANSW, AXIS, GATED, PH>>(X2_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_STAGED);
     xcol32_v2_kernel<DT, TRANSW, AXIS, GATED, PH><<<m.grid(), 64 * X2_G, X2_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                                  a->N, a->C, a->K, GATED ? a->gate : nullptr);
@@ -306,8 +309,39 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     return BSMM_ERR_ARG;
 }
 
+template <class DT, bool TRANSW, int AXIS, bool GATED, int PH>
+int launch_xcol_v3_ph(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    typedef typename DT::T T;
+    const int n_out = a->K / 32;
+    XMap m;
+    m.ntiles = (a->N + X3_R - 1) / X3_R;
+    m.segments = (n_out + X3_G - 1) / X3_G;
+    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+    if (m.P > m.segments) m.P = m.segments;
+    m.SP = (m.segments + m.P - 1) / m.P;
+    if (int rc = ensure_lds<&xcol32_v3_kernel<DT, TRANSW, AXIS, GATED, PH>>(X3_LDS)) return rc;
+    trace(a, BSMM_K_XCOL32_STAGED);
+    xcol32_v3_kernel<DT, TRANSW, AXIS, GATED, PH><<<m.grid(), 64 * X3_G, X3_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                                 a->N, a->C, a->K, GATED ? a->gate : nullptr);
+    return (int)hipGetLastError();
+}
+
+template <class DT, bool TRANSW, int AXIS, bool GATED = false>
+int launch_xcol_v3(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    switch (a->plan_inner) {     // steps per phase the plan was cut for
+        case 1: return launch_xcol_v3_ph<DT, TRANSW, AXIS, GATED, 1>(X, Wsel, Y, a, st);
+        case 2: return launch_xcol_v3_ph<DT, TRANSW, AXIS, GATED, 2>(X, Wsel, Y, a, st);
+    }
+    return BSMM_ERR_ARG;
+}
+
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
+    if (a->plan_magic == X3PLAN_MAGIC) {
+        if (a->plan_width != X3_G) return BSMM_ERR_ARG;
+        if (a->gate) return transw ? launch_xcol_v3<DT, true, AXIS, true>(X, Wsel, Y, a, st) : launch_xcol_v3<DT, false, AXIS, true>(X, Wsel, Y, a, st);
+        return transw ? launch_xcol_v3<DT, true, AXIS>(X, Wsel, Y, a, st) : launch_xcol_v3<DT, false, AXIS>(X, Wsel, Y, a, st);
+    }
     if (a->plan_magic == X2PLAN_MAGIC) {
         if (a->plan_width != X2_G) return BSMM_ERR_ARG;
         if (a->gate) return transw ? launch_xcol_v2<DT, true, AXIS, true>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false, AXIS, true>(X, Wsel, Y, a, st);
@@ -345,7 +379,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     const int variant = call_variant(a);
     const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
     // gated calls: only the staged bsize-32 kernel applies gates (exactly, bsmm_xcol_v2.h); everything else runs the per-segment kernels
-    const bool gate_ok = a->gate == nullptr || (BS == 32 && DT::is16 && a->plan_magic == X2PLAN_MAGIC);
+    const bool gate_ok = a->gate == nullptr || (BS == 32 && DT::is16 && (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC));
     const bool plan_ok = a->plan != nullptr && gate_ok && vec_ok && (variant == 0 || variant == 3);
     const bool force = variant == 3;
     if constexpr (BS == 8) {
@@ -379,7 +413,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     if constexpr (BS == 32 && DT::is16) {
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // axis-0 xcol needs 16-byte aligned row pieces
         // staged kernel: 32-bit per-lane byte offsets inside a slab's source (128 rows of C elements / 64 rows of N elements)
-        if (a->plan_magic == X2PLAN_MAGIC && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;
+        if ((a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC) && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;
         if (force) return XP_XCOL32;
         // Cost model fitted to the measurements in profiles/r01_sweeps.md (4096^2 / 20 % and 8192^2 / 5 %, N = 512 .. 8192):
         // the grouped kernel pays ~0.48 us per pair step of a group plus ~0.045 us per block, once per round of 256
@@ -392,7 +426,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         const double steps = std::ceil(CB / 2.0) * (1.0 - std::pow(1.0 - dens, 2.0 * G));
         double t_group = rounds * (0.48 * steps + 0.045 * a->blocks / ngroups) + 8.0;
         double t_segment = 17.0 + 1.04e-5 * (double)a->blocks * a->N;
-        if (a->plan_magic == X2PLAN_MAGIC) {
+        if (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC) {
             // staged kernel, refit (scripts/gpu_xprop_sweep.py, 4096^2 20 % / 5 %, 8192^2 5 %, 2048^2 20 %, N = 128 .. 8192): a round
             // costs 0.28 us per pair step + 0.040 us per block of the group, up to 20 % more when the round fills all CUs
             const double fill = std::min(1.0, ntiles * ngroups / rounds / 256.0);
@@ -432,7 +466,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     float* yacc = nullptr;
     size_t off = 0;
     const void* Wsel = W;
-    const bool staged = path == XP_XCOL32 && a->plan_magic == X2PLAN_MAGIC;   // transposes the staged blocks itself
+    const bool staged = path == XP_XCOL32 && (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC);   // transposes the staged blocks itself
     if (fprop && path != XP_VALU && !staged) {
         if constexpr (BS != 8) {
             if (!a->workspace || a->workspace_bytes < wt_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
@@ -527,10 +561,10 @@ int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const b
     const bool wide_win = a->plan_width == 16, waves16 = a->plan_waves == 16;
     if (!((a->plan_width == 8 && a->plan_waves == 8) || (AXIS == 1 && wide_win && (a->plan_waves == 8 || waves16)))) return BSMM_ERR_ARG;
     int rc_attr = 0;
-    if constexpr (AXIS == 0) rc_attr = ensure_lds(&updat32_a0_win_kernel<DT>, UW0_LDS);
-    else if (waves16)        rc_attr = ensure_lds(&updat32_a1_win_kernel<DT, 16, 16>, UWN_LDS);
-    else if (wide_win)       rc_attr = ensure_lds(&updat32_a1_win_kernel<DT, 16>, UWN_LDS);
-    else                     rc_attr = ensure_lds(&updat32_a1_win_kernel<DT, 8>, UWN_LDS);
+    if constexpr (AXIS == 0) rc_attr = ensure_lds<&updat32_a0_win_kernel<DT>>(UW0_LDS);
+    else if (waves16)        rc_attr = ensure_lds<&updat32_a1_win_kernel<DT, 16, 16>>(UWN_LDS);
+    else if (wide_win)       rc_attr = ensure_lds<&updat32_a1_win_kernel<DT, 16>>(UWN_LDS);
+    else                     rc_attr = ensure_lds<&updat32_a1_win_kernel<DT, 8>>(UWN_LDS);
     if (rc_attr) return rc_attr;
     const int nchunks = wide_win ? (N + 31) / 32 : (N + 63) / 64;
     const int split = updat_split(a, nitems, nchunks);
@@ -613,11 +647,11 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     }
     trace(a, BSMM_K_UPDAT_STREAM);
     if (a->plan_width == 16) {
-        if (int rc = ensure_lds(&updat32_a1_v2_kernel<DT, 16>, u2_lds_bytes(16))) return rc;
+        if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 16>>(u2_lds_bytes(16))) return rc;
         updat32_a1_v2_kernel<DT, 16><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(16), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
                                                                                      a->pcount, a->alpha, a->beta, L.flat);
     } else {
-        if (int rc = ensure_lds(&updat32_a1_v2_kernel<DT, 8>, u2_lds_bytes(8))) return rc;
+        if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 8>>(u2_lds_bytes(8))) return rc;
         updat32_a1_v2_kernel<DT, 8><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(8), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
                                                                                    a->pcount, a->alpha, a->beta, L.flat);
     }
@@ -728,7 +762,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         bool al = aligned16(DW);
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
         if (!use_valu && !gated && al && variant != 1) {   // LDS-DMA + transposing-read kernel
-            if (int rc = ensure_lds(&updat32_a1_tr_kernel<DT>, UT_LDS)) return rc;
+            if (int rc = ensure_lds<&updat32_a1_tr_kernel<DT>>(UT_LDS)) return rc;
             trace(a, BSMM_K_UPDAT_BLOCK_TR);
             const int grid = 8 * ((a->blocks + 7) / 8);
             updat32_a1_tr_kernel<DT><<<grid, 256, UT_LDS, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K, a->pcount,
@@ -741,7 +775,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         for (int p = 0; p < a->pcount; ++p) al16 = al16 && aligned16(xs.p[p]) && aligned16(es.p[p]);
         if (!use_valu && !gated && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed, 16x16 blocks
             if (a->plan_magic != UPLAN_MAGIC || a->plan_width != UW16 || a->plan_waves != UP_WAVES) return BSMM_ERR_ARG;
-            if (int rc = ensure_lds(&updat16_win_kernel<DT, AXIS>, 2 * UWN_SLOT)) return rc;
+            if (int rc = ensure_lds<&updat16_win_kernel<DT, AXIS>>(2 * UWN_SLOT)) return rc;
             trace(a, BSMM_K_UPDAT16_WIN);
             const int nitems = a->plan_items;
             const int nchunks = (N + 63) / 64;
@@ -765,7 +799,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         bool al = aligned16(DW);
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
         if (!use_valu && !gated && al && variant != 1) {   // LDS-DMA + transposing-read kernel, 16x16 blocks
-            if (int rc = ensure_lds(&updat16_a1_tr_kernel<DT>, UT16_LDS)) return rc;
+            if (int rc = ensure_lds<&updat16_a1_tr_kernel<DT>>(UT16_LDS)) return rc;
             trace(a, BSMM_K_UPDAT_BLOCK_TR);
             const int grid = 8 * ((a->blocks + 7) / 8);
             updat16_a1_tr_kernel<DT><<<grid, 256, UT16_LDS, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K, a->pcount,
@@ -965,6 +999,9 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
     return (int)hipGetLastError();
 }
 
+#ifdef BSMM_X3_TRACE
+int bsmm_debug_x3_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x3_trace), sizeof(bsmm::g_x3_trace)); }
+#endif
 #ifdef BSMM_XC_TRACE
 int bsmm_debug_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_xc_trace), sizeof(bsmm::g_xc_trace)); }
 #endif
@@ -1011,7 +1048,10 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
         return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
     }
     if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel (either feature axis)
-        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out, (options >> 8) & 7);   // bits 8..10: steps per phase (experiments)
+        const int ph = (options >> BSMM_PLAN_XPROP_PH_SHIFT) & 7;
+        const long n = (options & BSMM_PLAN_XCOL_R2) ? build_xcol2_plan(lut, segments, blocks, n_out, out, ph)
+                                                     : build_xcol3_plan(lut, segments, blocks, n_out, out, ph, (options >> BSMM_PLAN_XPROP_DUTY_SHIFT) & 7,
+                                                                        (options >> BSMM_PLAN_XPROP_PERM_SHIFT) & 3);
         if (n != 0) return n;                                            // 0: the layout does not fit the table fields
     }
     return build_xcol_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));
@@ -1052,7 +1092,7 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
         // slack for the rows that do not pack: <= 56 on average), 8x8 windows for denser layouts
         const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);
         const int ws = force == BSMM_PLAN_STREAM_16 ? 16 : (force == BSMM_PLAN_STREAM_8 ? 8 : (blocks <= 56.0 * windows ? 16 : 8));
-        return build_updat2_plan(lut, blocks, CB, KB, ws, out, (options >> 8) & 15);      // bits 8..11: item sets (experiments)
+        return build_updat2_plan(lut, blocks, CB, KB, ws, out, (options >> BSMM_PLAN_UPDAT_SETS_SHIFT) & 15);
     }
     const int w = updat_window(blocks, CB, KB, axis, options);
     return build_updat_plan(lut, blocks, CB, KB, w == 8 ? 8 : 16, UP_MAXB, out, w == 1616 ? 16 : 8);
@@ -1077,6 +1117,7 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
     switch (p[0]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR || p[11] < 2 || p[11] > 4) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
+        case X3PLAN_MAGIC:   if (p[1] != X3PLAN_VERSION || words < X3_HDR || p[11] < 1 || p[11] > 2) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
         case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;
