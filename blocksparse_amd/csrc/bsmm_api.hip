@@ -18,7 +18,6 @@
 #include "bsmm_xcols.h"
 #include "bsmm_xcol.h"
 #include "bsmm_xcol_v2.h"
-#include "bsmm_xcol_v3.h"
 #include "bsmm_xcol16.h"
 #include "bsmm_xcol16_v2.h"
 #include "bsmm_xprop.h"
@@ -79,7 +78,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32 && a->axis == 1)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 16) return ((m == XC16PLAN_MAGIC || (m == X7PLAN_MAGIC && a->plan_width == X7_G)) && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return ((m == XCPLAN_MAGIC && a->plan_width == XS_G) || m == XFPLAN_MAGIC) ? BSMM_OK : BSMM_ERR_ARG;
-    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G) || (m == X3PLAN_MAGIC && a->plan_width == X3_G)) ? BSMM_OK : BSMM_ERR_ARG;
+    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G)) ? BSMM_OK : BSMM_ERR_ARG;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -309,39 +308,8 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     return BSMM_ERR_ARG;
 }
 
-template <class DT, bool TRANSW, int AXIS, bool GATED, int PH>
-int launch_xcol_v3_ph(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    typedef typename DT::T T;
-    const int n_out = a->K / 32;
-    XMap m;
-    m.ntiles = (a->N + X3_R - 1) / X3_R;
-    m.segments = (n_out + X3_G - 1) / X3_G;
-    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
-    if (m.P > m.segments) m.P = m.segments;
-    m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds<&xcol32_v3_kernel<DT, TRANSW, AXIS, GATED, PH>>(X3_LDS)) return rc;
-    trace(a, BSMM_K_XCOL32_STAGED);
-    xcol32_v3_kernel<DT, TRANSW, AXIS, GATED, PH><<<m.grid(), 64 * X3_G, X3_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                                                 a->N, a->C, a->K, GATED ? a->gate : nullptr);
-    return (int)hipGetLastError();
-}
-
-template <class DT, bool TRANSW, int AXIS, bool GATED = false>
-int launch_xcol_v3(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    switch (a->plan_inner) {     // steps per phase the plan was cut for
-        case 1: return launch_xcol_v3_ph<DT, TRANSW, AXIS, GATED, 1>(X, Wsel, Y, a, st);
-        case 2: return launch_xcol_v3_ph<DT, TRANSW, AXIS, GATED, 2>(X, Wsel, Y, a, st);
-    }
-    return BSMM_ERR_ARG;
-}
-
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
-    if (a->plan_magic == X3PLAN_MAGIC) {
-        if (a->plan_width != X3_G) return BSMM_ERR_ARG;
-        if (a->gate) return transw ? launch_xcol_v3<DT, true, AXIS, true>(X, Wsel, Y, a, st) : launch_xcol_v3<DT, false, AXIS, true>(X, Wsel, Y, a, st);
-        return transw ? launch_xcol_v3<DT, true, AXIS>(X, Wsel, Y, a, st) : launch_xcol_v3<DT, false, AXIS>(X, Wsel, Y, a, st);
-    }
     if (a->plan_magic == X2PLAN_MAGIC) {
         if (a->plan_width != X2_G) return BSMM_ERR_ARG;
         if (a->gate) return transw ? launch_xcol_v2<DT, true, AXIS, true>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false, AXIS, true>(X, Wsel, Y, a, st);
@@ -379,7 +347,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     const int variant = call_variant(a);
     const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
     // gated calls: only the staged bsize-32 kernel applies gates (exactly, bsmm_xcol_v2.h); everything else runs the per-segment kernels
-    const bool gate_ok = a->gate == nullptr || (BS == 32 && DT::is16 && (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC));
+    const bool gate_ok = a->gate == nullptr || (BS == 32 && DT::is16 && a->plan_magic == X2PLAN_MAGIC);
     const bool plan_ok = a->plan != nullptr && gate_ok && vec_ok && (variant == 0 || variant == 3);
     const bool force = variant == 3;
     if constexpr (BS == 8) {
@@ -413,7 +381,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     if constexpr (BS == 32 && DT::is16) {
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // axis-0 xcol needs 16-byte aligned row pieces
         // staged kernel: 32-bit per-lane byte offsets inside a slab's source (128 rows of C elements / 64 rows of N elements)
-        if ((a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC) && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;
+        if (a->plan_magic == X2PLAN_MAGIC && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;
         if (force) return XP_XCOL32;
         // Cost model fitted to the measurements in profiles/r01_sweeps.md (4096^2 / 20 % and 8192^2 / 5 %, N = 512 .. 8192):
         // the grouped kernel pays ~0.48 us per pair step of a group plus ~0.045 us per block, once per round of 256
@@ -426,7 +394,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         const double steps = std::ceil(CB / 2.0) * (1.0 - std::pow(1.0 - dens, 2.0 * G));
         double t_group = rounds * (0.48 * steps + 0.045 * a->blocks / ngroups) + 8.0;
         double t_segment = 17.0 + 1.04e-5 * (double)a->blocks * a->N;
-        if (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC) {
+        if (a->plan_magic == X2PLAN_MAGIC) {
             // staged kernel, refit (scripts/gpu_xprop_sweep.py, 4096^2 20 % / 5 %, 8192^2 5 %, 2048^2 20 %, N = 128 .. 8192): a round
             // costs 0.28 us per pair step + 0.040 us per block of the group, up to 20 % more when the round fills all CUs
             const double fill = std::min(1.0, ntiles * ngroups / rounds / 256.0);
@@ -466,7 +434,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     float* yacc = nullptr;
     size_t off = 0;
     const void* Wsel = W;
-    const bool staged = path == XP_XCOL32 && (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X3PLAN_MAGIC);   // transposes the staged blocks itself
+    const bool staged = path == XP_XCOL32 && a->plan_magic == X2PLAN_MAGIC;   // transposes the staged blocks itself
     if (fprop && path != XP_VALU && !staged) {
         if constexpr (BS != 8) {
             if (!a->workspace || a->workspace_bytes < wt_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
@@ -999,9 +967,6 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
     return (int)hipGetLastError();
 }
 
-#ifdef BSMM_X3_TRACE
-int bsmm_debug_x3_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x3_trace), sizeof(bsmm::g_x3_trace)); }
-#endif
 #ifdef BSMM_XC_TRACE
 int bsmm_debug_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_xc_trace), sizeof(bsmm::g_xc_trace)); }
 #endif
@@ -1048,10 +1013,7 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
         return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
     }
     if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel (either feature axis)
-        const int ph = (options >> BSMM_PLAN_XPROP_PH_SHIFT) & 7;
-        const long n = (options & BSMM_PLAN_XCOL_R2) ? build_xcol2_plan(lut, segments, blocks, n_out, out, ph)
-                                                     : build_xcol3_plan(lut, segments, blocks, n_out, out, ph, (options >> BSMM_PLAN_XPROP_DUTY_SHIFT) & 7,
-                                                                        (options >> BSMM_PLAN_XPROP_PERM_SHIFT) & 3);
+        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out, (options >> BSMM_PLAN_XPROP_PH_SHIFT) & 7);
         if (n != 0) return n;                                            // 0: the layout does not fit the table fields
     }
     return build_xcol_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));
@@ -1117,7 +1079,6 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
     switch (p[0]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR || p[11] < 2 || p[11] > 4) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
-        case X3PLAN_MAGIC:   if (p[1] != X3PLAN_VERSION || words < X3_HDR || p[11] < 1 || p[11] > 2) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
         case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
         case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
         case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;

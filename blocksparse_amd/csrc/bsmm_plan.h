@@ -306,216 +306,6 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
 }  // namespace bsmm
 
 // =================================================================================================
-// staged xcol plan, round 3 ('BSX3'): the 'BSX2' scheme (groups of 16 output blocks, one per wave; the pair walk of a group cut
-// into phases; everything a phase needs staged through LDS by DMA) with the activation slabs requested TWO phases ahead.
-// What bounded 'BSX2' (profiles/r03_xcol_ab.md): a phase lasted "last request + ~1500 cycles until it has landed" -- the requests
-// for phase p+1 could only be made behind barrier p (their LDS half was being read until then) and had to have landed at barrier
-// p+1.  The LDS is now cut differently: a ring of THREE phases of activation slabs (3 * PH slabs of 16 KiB) and ONE pool of
-// weight slots (2 KiB each) in which consecutive phases get disjoint slot ranges handed out by this builder:
-//   PH = 2: 96 KiB of slabs + 31 slots (+ 1 for the gate table);  PH = 1 (dense layouts): 48 KiB + 55 slots (+ 1).
-// Behind barrier p a wave requests the weight blocks of phase p+1 (<= X3_WD half blocks per wave), multiplies its blocks of
-// phase p and then requests its share of the slabs of phase p+2 (they overwrite phase p-1's).  Its wait at the top of the next
-// phase is `vmcnt(PH)`: the slab requests -- always exactly PH per wave, the youngest -- stay in flight across the barrier.
-// Phase rule: a (sub)step holds <= SCAP blocks, a phase <= POOL - SCAP blocks and <= POOL - (blocks of the previous phase), so
-// two consecutive phases always fit the pool and the next phase's first step always fits.
-// The builder also decides which wave owns which column (local search on the sum over phases of the busiest SIMD's blocks; waves
-// v, v+4, v+8, v+12 share a SIMD) and, optionally, deals the weight requests to the waves with the least matrix work.
-// Accumulation order inside a column is unchanged: results are bit-identical to the 'BSX2' / round-1 kernels.
-// Layout (int32): [0] magic 'BSX3' [1] version [2] X3_G [3] ngroups [4] nphases_total [5] off_groups [6] off_px
-//                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] POOL [10] max phases of a group [11] PH
-//   groups[ngroups][8] = (phase_off, nphases, first_out_block, n_out_blocks_in_group, colw_lo, colw_hi, 0, 0)
-//        colw: 16 nibbles, nibble v = the column (output block - first) that wave v owns
-//   px [nphases_total]           pair of step 0 | pair of step 1 << 16   (0xffff = no such step)
-//   tab[nphases_total][16][8]    per phase and wave:
-//        [0]    pool slots this wave multiplies: byte 2*u + half = slot of (step u, half of the pair), 0xff = none
-//        [1]    0
-//        [2..5] weight requests: (2 * weight block + hb) | (2 * slot + hb) << 25, or -1       [6..7] 0
-// =================================================================================================
-namespace bsmm {
-
-constexpr int32_t X3PLAN_MAGIC = 0x42535833;
-constexpr int32_t X3PLAN_VERSION = 2;
-constexpr int X3_G = 16;
-constexpr int X3_HDR = 12;
-constexpr int X3_GROUPW = 8;                                         // words per group header
-constexpr int X3_ROW = 8;                                            // words per (phase, wave)
-constexpr int X3_WD = 4;                                             // weight requests per (phase, wave)
-constexpr int x3_pool(int ph) { return (163840 - 3 * ph * 16384) / 2048 - 1; }   // 31 (PH = 2), 55 (PH = 1)
-constexpr int x3_scap(int ph) { return ph == 2 ? 12 : 27; }          // blocks per (sub)step
-
-// duty_policy: 0 = weight requests round robin over the waves, 1 = to the waves with the least matrix work in the issuing phase
-// perm_policy: 0 = default (local search), 1 = identity
-inline long build_xcol3_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int force_ph = 0,
-                             int duty_policy = 0, int perm_policy = 0) {
-    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
-    if (blocks >= (1 << 24)) return 0;                                       // field widths of the tables
-    const int G = X3_G, ngroups = (n_out_blocks + G - 1) / G;
-    struct E { int p, col, half, w; };
-    std::vector<std::vector<E>> per_group(ngroups);
-    for (int s = 0; s < segments; ++s) {
-        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
-        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
-        for (int e = 0; e < cnt; ++e) {
-            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
-            if (w < 0 || w >= blocks || c < 0) return -1;
-            if (c >= 2 * 0xffff) return 0;
-            per_group[ob / G].push_back({c >> 1, ob % G, c & 1, w});
-        }
-    }
-    // one step per phase when two steps would not fit the pool most of the time (mean blocks per (group, pair) step > ~9)
-    size_t nsteps_all = 0;
-    for (int g = 0; g < ngroups; ++g) {
-        auto& v = per_group[g];
-        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : (a.col != b.col ? a.col < b.col : a.half < b.half); });
-        for (size_t i = 0; i < v.size(); ++i) nsteps_all += (i == 0 || v[i].p != v[i - 1].p);
-    }
-    const double mean = nsteps_all ? (double)blocks / (double)nsteps_all : 0.0;
-    const int PH = (force_ph == 1 || force_ph == 2) ? force_ph : (mean > 9.0 ? 1 : 2);
-    const int POOL = x3_pool(PH), SCAP = x3_scap(PH), PCAP = POOL - SCAP;
-    std::vector<int32_t> groups, px, tab;
-    int max_ph = 0, nphases_total = 0;
-    for (int g = 0; g < ngroups; ++g) {
-        auto& v = per_group[g];
-        // steps: runs of equal pair, at most SCAP entries each (a column's two halves stay in one step)
-        struct Step { int p; size_t lo, hi; };
-        std::vector<Step> steps;
-        for (size_t i = 0; i < v.size();) {
-            size_t j = i;
-            while (j < v.size() && v[j].p == v[i].p) ++j;
-            size_t lo = i;
-            while (lo < j) {
-                size_t hi = std::min(j, lo + SCAP);
-                if (hi < j && hi - lo > 1 && v[hi].col == v[hi - 1].col) --hi;
-                steps.push_back({v[i].p, lo, hi});
-                lo = hi;
-            }
-            i = j;
-        }
-        struct Phase { size_t s0; int nst; int n; };
-        std::vector<Phase> phases;
-        int prev_n = 0;
-        for (size_t s = 0; s < steps.size();) {
-            int nst = 1;
-            int n = (int)(steps[s].hi - steps[s].lo);
-            const int room = std::min(PCAP, POOL - prev_n);
-            while (nst < PH && s + nst < steps.size() && n + (int)(steps[s + nst].hi - steps[s + nst].lo) <= room) {
-                n += (int)(steps[s + nst].hi - steps[s + nst].lo);
-                ++nst;
-            }
-            if (n + prev_n > POOL) return -1;                        // cannot happen: prev_n <= PCAP, first step <= SCAP
-            phases.push_back({s, nst, n});
-            prev_n = n;
-            s += nst;
-        }
-        const int nph = (int)phases.size();
-        // blocks per (phase, column)
-        std::vector<int> L((size_t)nph * G, 0);
-        for (int ph = 0; ph < nph; ++ph)
-            for (int u = 0; u < phases[ph].nst; ++u)
-                for (size_t i = steps[phases[ph].s0 + u].lo; i < steps[phases[ph].s0 + u].hi; ++i) ++L[(size_t)ph * G + v[i].col];
-        // column -> wave: minimise the sum over phases of the busiest SIMD (waves v, v+4, v+8, v+12 share one)
-        int wave_of[G];
-        for (int c = 0; c < G; ++c) wave_of[c] = c;
-        if (perm_policy != 1 && nph > 0) {
-            auto cost = [&](const int* wo) {
-                long tot = 0;
-                for (int ph = 0; ph < nph; ++ph) {
-                    int sl[4] = {0, 0, 0, 0};
-                    for (int c = 0; c < G; ++c) sl[wo[c] & 3] += L[(size_t)ph * G + c];
-                    tot += std::max(std::max(sl[0], sl[1]), std::max(sl[2], sl[3]));
-                }
-                return tot;
-            };
-            long best = cost(wave_of);
-            uint32_t rng = 0x9e3779b9u + (uint32_t)g * 0x85ebca6bu;
-            const int iters = std::min(4000, 200000 / std::max(1, nph));
-            for (int it = 0; it < iters; ++it) {
-                rng = rng * 1664525u + 1013904223u;
-                const int a = (rng >> 8) & 15, b = (rng >> 16) & 15;
-                if ((wave_of[a] & 3) == (wave_of[b] & 3)) continue;
-                std::swap(wave_of[a], wave_of[b]);
-                const long c2 = cost(wave_of);
-                if (c2 <= best) best = c2; else std::swap(wave_of[a], wave_of[b]);
-            }
-        }
-        uint32_t colw[2] = {0, 0};
-        for (int c = 0; c < G; ++c) colw[wave_of[c] >> 3] |= (uint32_t)c << (4 * (wave_of[c] & 7));
-        int pool_pos = 0;                                            // next free pool slot (circular)
-        for (int ph = 0; ph < nph; ++ph) {
-            const Phase& P = phases[ph];
-            uint32_t pw = 0xffffffffu;
-            for (int u = 0; u < P.nst; ++u) pw = (pw & ~(0xffffu << (16 * u))) | ((uint32_t)steps[P.s0 + u].p << (16 * u));
-            px.push_back((int32_t)pw);
-            std::vector<int32_t> row((size_t)G * X3_ROW, 0);
-            for (int wv = 0; wv < G; ++wv) {
-                row[(size_t)wv * X3_ROW] = -1;
-                for (int k = 0; k < X3_WD; ++k) row[(size_t)wv * X3_ROW + 2 + k] = -1;
-            }
-            std::vector<int32_t> duties;
-            for (int u = 0; u < P.nst; ++u) {
-                const Step& st = steps[P.s0 + u];
-                for (size_t i = st.lo; i < st.hi; ++i) {
-                    const E& e = v[i];
-                    const int slot = pool_pos;
-                    pool_pos = (pool_pos + 1) % POOL;
-                    const int wv = wave_of[e.col], byte = 2 * u + e.half;
-                    uint32_t& cw = reinterpret_cast<uint32_t&>(row[(size_t)wv * X3_ROW]);
-                    cw = (cw & ~(0xffu << (8 * byte))) | ((uint32_t)slot << (8 * byte));
-                    for (int hb = 0; hb < 2; ++hb) duties.push_back((int32_t)((uint32_t)(2 * e.w + hb) | ((uint32_t)(2 * slot + hb) << 25)));
-                }
-            }
-            // the requests for THIS phase's weights are issued behind the barrier of the PREVIOUS phase (phase 0's in the prologue)
-            int prev_blk[G] = {0};
-            if (ph > 0 && duty_policy == 1)
-                for (int c = 0; c < G; ++c) prev_blk[wave_of[c]] = L[(size_t)(ph - 1) * G + c];
-            int nd[G] = {0};
-            int rr = (nphases_total + ph) * 5 % G;
-            for (int32_t d : duties) {
-                int pick = -1;
-                long bestc = 0;
-                for (int t = 0; t < G; ++t) {
-                    const int wv = (rr + t) % G;
-                    if (nd[wv] >= X3_WD) continue;
-                    const long c = 4L * prev_blk[wv] + nd[wv];
-                    if (pick < 0 || c < bestc) { pick = wv; bestc = c; }
-                }
-                rr = (rr + 1) % G;
-                if (pick < 0) return -1;                             // cannot happen: 16 * X3_WD >= 2 * PCAP
-                row[(size_t)pick * X3_ROW + 2 + nd[pick]++] = d;
-            }
-            tab.insert(tab.end(), row.begin(), row.end());
-        }
-        max_ph = std::max(max_ph, nph);
-        groups.insert(groups.end(), {nphases_total, nph, g * G, std::min(G, n_out_blocks - g * G), (int32_t)colw[0], (int32_t)colw[1], 0, 0});
-        nphases_total += nph;
-    }
-    // longest groups first (see the 'BSX2' builder)
-    {
-        std::vector<int> order(ngroups);
-        for (int g = 0; g < ngroups; ++g) order[g] = g;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[X3_GROUPW * a + 1] > groups[X3_GROUPW * b + 1]; });
-        std::vector<int32_t> sorted;
-        for (int g : order) sorted.insert(sorted.end(), groups.begin() + X3_GROUPW * g, groups.begin() + X3_GROUPW * (g + 1));
-        groups.swap(sorted);
-    }
-    const int off_groups = X3_HDR, off_px = off_groups + (int)groups.size();
-    const int off_tab = (off_px + (int)px.size() + 3) & ~3;
-    const long total = off_tab + (long)tab.size();
-    if (out) {
-        std::fill(out, out + off_tab, 0);
-        const int32_t hdr[X3_HDR] = {X3PLAN_MAGIC, X3PLAN_VERSION, G, ngroups, nphases_total, off_groups, off_px, off_tab,
-                                     n_out_blocks, POOL, max_ph, PH};
-        std::copy(hdr, hdr + X3_HDR, out);
-        std::copy(groups.begin(), groups.end(), out + off_groups);
-        std::copy(px.begin(), px.end(), out + off_px);
-        std::copy(tab.begin(), tab.end(), out + off_tab);
-    }
-    return total;
-}
-
-}  // namespace bsmm
-
-// =================================================================================================
 // staged xcol16 plan ('BSX7', bsize 16): the staged scheme of the 'BSX2' plan for 16x16 blocks (bsmm_xcol16_v2.h).  Groups of
 // X7_G = 32 consecutive output blocks, wave v of 16 owns blocks 2v and 2v+1; a step is a QUAD of input blocks (64 features);
 // a phase = up to two steps and up to X7_WCAP weight blocks = one half of the LDS ring (2 activation slabs of 16 KiB + X7_WCAP

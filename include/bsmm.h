@@ -71,22 +71,16 @@ enum {
     BSMM_PLAN_XCOL_NARROW = 1,      /* xprop bsize 32 / 16: 8 (16) output blocks per workgroup instead of 16 (32)            */
     BSMM_PLAN_F32_MFMA = 2,         /* xprop fp32 bsize 32: schedule for the fp32 matrix-core kernel instead of the bf16 split */
     BSMM_PLAN_XCOL_UNSTAGED = 4,    /* xprop bsize 32 / 16, 16-bit: the round-1 kernel (weights by register loads, bsmm_xcol.h)
-                                       instead of the staged one (weights through LDS as well, bsmm_xcol_v3.h)                */
+                                       instead of the staged one (weights through LDS as well, bsmm_xcol_v2.h)                */
     BSMM_PLAN_WINDOW_8 = 0x10,      /* updat bsize 32: round-1 windowed kernel, 8x8-block windows, 8 waves                  */
     BSMM_PLAN_WINDOW_16 = 0x20,     /*                 round-1 windowed kernel, 16x16-block windows, 8 waves                */
     BSMM_PLAN_WINDOW_16W = 0x30,    /*                 round-1 windowed kernel, 16x16-block windows, 16 waves               */
     BSMM_PLAN_STREAM_16 = 0x40,     /*                 streaming kernel (bsmm_updat_v2.h, axis 1), 16x16-block windows      */
     BSMM_PLAN_STREAM_8 = 0x50,      /*                 streaming kernel, 8x8-block windows (dense layouts)                  */
     BSMM_PLAN_WINDOW_MASK = 0xf0,   /* (0: axis 1 -> streaming kernel, window side by density; axis 0 -> 8x8 windows)       */
-    BSMM_PLAN_XCOL_R2 = 8,          /* xprop bsize 32, 16-bit: the round-2 staged schedule ('BSX2', bsmm_xcol_v2.h: two ring halves,
-                                       every request one phase ahead) instead of the 'BSX3' one (activation slabs two phases
-                                       ahead, weight pool); kept for A/B measurements                                          */
     /* experiment knobs of the builders (0 = the builder's own choice); disjoint bit ranges, one meaning each: */
-    BSMM_PLAN_XPROP_PH_SHIFT = 8,   /* bits  8..10  xprop staged plans: steps per phase ('BSX3': 1, 2; 'BSX2': 2, 3, 4)        */
-    BSMM_PLAN_UPDAT_SETS_SHIFT = 12,/* bits 12..15  updat streaming plan: item sets (1, 2, 4, 8)                               */
-    BSMM_PLAN_XPROP_DUTY_SHIFT = 16,/* bits 16..18  'BSX3': 1 = weight requests to the waves with the least matrix work in the
-                                                    issuing phase (default: round robin)                                      */
-    BSMM_PLAN_XPROP_PERM_SHIFT = 20 /* bits 20..21  'BSX3': 1 = wave v owns column v (no balancing over the SIMDs)            */
+    BSMM_PLAN_XPROP_PH_SHIFT = 8,   /* bits  8..10  xprop staged plans ('BSX2'): steps per phase (2, 3, 4)                      */
+    BSMM_PLAN_UPDAT_SETS_SHIFT = 12 /* bits 12..15  updat streaming plan ('BSU2'): item sets (1, 2, 4, 8)                       */
 };
 
 enum {

@@ -165,110 +165,65 @@ def test_plan_builder_covers_every_block_once(lib):
 
 
 def test_staged_xcol_plan(lib):
-    """'BSX3' plans (the default for bsize 32, 16-bit; bsmm_xcol_v3.h): every lut entry is multiplied exactly once, by the wave that
-    owns its output block (the group header says which wave owns which column: a permutation), from a pool slot that exactly one
-    pair of weight requests of that phase fills with that weight block; the pool slots of two CONSECUTIVE phases are disjoint
-    (phase p+1's weights land while phase p's are read); phases hold <= PH steps (PH = 2, dense layouts 1), waves <= 4 requests."""
+    """'BSX2' plans (the default for bsize 32, 16-bit; bsmm_xcol_v2.h): every lut entry is multiplied exactly once, by the wave that
+    owns its output block, from a slot of the phase's ring half that exactly one pair of DMA duties fills with that weight block;
+    phases hold <= PH steps and <= WCAP blocks (PH = 2 / 3 / 4 by density: WCAP 23 / 15 / 7), waves <= 3 duties."""
     import numpy as np
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_plan
     rng = np.random.default_rng(5)
-    D, P = lib.PLAN_XPROP_DUTY_SHIFT, lib.PLAN_XPROP_PERM_SHIFT
-    for CB, KB, dens, ph, extra in ((128, 128, 0.2, 2, 0), (128, 128, 0.2, 2, 1 << D), (128, 128, 0.2, 2, (1 << D) | (1 << P)), (128, 128, 0.08, 2, 0),
-                                    (128, 128, 0.02, 2, 0), (40, 52, 0.3, None, 0), (9, 35, 1.0, 1, 0), (1, 1, 1.0, None, 0), (64, 16, 0.6, 1, 1 << D),
-                                    (64, 48, 0.5, (1 << 8), 0), (64, 48, 0.5, (2 << 8), 0), (128, 128, 0.5, 1, 0), (33, 32, 1.0, (2 << 8), 0)):
+    for CB, KB, dens, ph in ((128, 128, 0.2, 2), (128, 128, 0.08, 3), (128, 128, 0.02, 4), (40, 52, 0.3, 2), (9, 35, 1.0, 2), (1, 1, 1.0, None),
+                             (64, 16, 0.6, 2), (64, 48, 0.5, (3 << 8)), (64, 48, 0.5, (4 << 8))):
         lay = rng.random((CB, KB)) < dens
         lay[0, :] = True
         t = L.build_tables(lay)
-        opt = (ph if (ph is not None and ph >= 256) else 0) | extra
+        opt = ph if (ph is not None and ph >= 256) else 0
         for side, n_out in (("fprop", KB), ("bprop", CB)):
             f = t[side]
             plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, 1, opt)
-            assert plan[0] == 0x42535833 and int(plan[2]) == 16 and plan[8] == n_out and plan[7] % 4 == 0 and plan[5] % 4 == 0
-            POOL, PH = int(plan[9]), int(plan[11])
-            assert (PH, POOL) in ((2, 31), (1, 55))
-            if opt & 0x700:
-                assert PH == (opt >> 8) & 7
-            elif ph is not None and CB == 128:
-                assert PH == ph, (dens, PH)
-            nph_total = int(plan[4])
-            groups = plan[plan[5]:plan[5] + 8 * int(plan[3])].reshape(-1, 8)
-            px = plan[plan[6]:plan[6] + nph_total]
-            tab = plan[plan[7]:plan[7] + nph_total * 128].reshape(-1, 16, 8)
-            got = set()
-            assert sorted(int(x) for x in groups[:, 2]) == [16 * g for g in range(len(groups))]      # every group once ...
-            assert all(groups[i, 1] >= groups[i + 1, 1] for i in range(len(groups) - 1))              # ... longest first
-            for g, (po, nph, ob0, nob, c_lo, c_hi, z0, z1) in enumerate(groups):
-                assert nob == min(16, n_out - ob0) and z0 == 0 and z1 == 0
-                colw = [((int(c_lo) & 0xffffffff) >> (4 * v)) & 15 for v in range(8)] + [((int(c_hi) & 0xffffffff) >> (4 * v)) & 15 for v in range(8)]
-                assert sorted(colw) == list(range(16))
-                if (opt >> P) & 3 == 1:
-                    assert colw == list(range(16))
-                prev_slots = set()
-                for phs in range(po, po + nph):
-                    pw = int(px[phs]) & 0xffffffff
-                    pairs = [pw & 0xffff, pw >> 16]
-                    assert pairs[0] != 0xffff and (PH == 2 or pairs[1] == 0xffff)
-                    slots = {}
-                    for wave in range(16):
-                        assert tab[phs, wave, 1] == 0 and (tab[phs, wave, 6:] == 0).all()
-                        for d in (int(x) & 0xffffffff for x in tab[phs, wave, 2:6] if x != -1):
-                            blk2, slot2 = d & 0x1ffffff, d >> 25
-                            assert blk2 & 1 == slot2 & 1 and slot2 < 2 * POOL
-                            slots.setdefault(slot2 >> 1, []).append(blk2)
-                    for sl, halves in slots.items():
-                        assert sorted(halves) == [2 * (halves[0] >> 1), 2 * (halves[0] >> 1) + 1]
-                    assert not (set(slots) & prev_slots)                    # disjoint from the phase that is read while these land
-                    used = set()
-                    for wave in range(16):
-                        for byte in range(4):
-                            sl = (int(tab[phs, wave, 0]) >> (8 * byte)) & 0xff
-                            if sl == 0xff:
-                                continue
-                            u, half = byte >> 1, byte & 1
-                            assert u < PH and pairs[u] != 0xffff and colw[wave] < nob and sl in slots and sl not in used
-                            used.add(sl)
-                            got.add((ob0 + colw[wave], 2 * pairs[u] + half, slots[sl][0] >> 1))
-                    assert used == set(slots) and len(used) + len(prev_slots) <= POOL
-                    prev_slots = used
-            want = {(ob, c, w) for ob, col in f["cols"] for c, w in col}
-            assert got == want
-
-
-def test_round2_staged_xcol_plan(lib):
-    """'BSX2' plans (BSMM_PLAN_XCOL_R2, bsmm_xcol_v2.h; kept for A/B): same invariants with the fixed shares of round 2 (waves <= 3 duties)."""
-    import numpy as np
-    from blocksparse_amd import lut as L
-    from blocksparse_amd.matmul import _host_plan
-    rng = np.random.default_rng(5)
-    for CB, KB, dens in ((128, 128, 0.2), (40, 52, 0.3), (1, 1, 1.0)):
-        lay = rng.random((CB, KB)) < dens
-        lay[0, :] = True
-        t = L.build_tables(lay)
-        for side, n_out in (("fprop", KB), ("bprop", CB)):
-            f = t[side]
-            plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, 1, lib.PLAN_XCOL_R2)
             assert plan[0] == 0x42535832 and int(plan[2]) == 16 and plan[8] == n_out and plan[7] % 4 == 0
             WCAP, PH = int(plan[9]), int(plan[11])
+            assert (PH, WCAP) in ((2, 23), (3, 15), (4, 7))
+            if opt:
+                assert PH == opt >> 8
+            elif ph is not None and CB == 128:
+                assert (PH == 2) if ph == 2 else (PH >= 3), (dens, PH)      # sparse layouts get longer phases
             nph_total = int(plan[4])
             groups = plan[plan[5]:plan[5] + 4 * int(plan[3])].reshape(-1, 4)
             px = plan[plan[6]:plan[6] + 2 * nph_total].reshape(-1, 2)
             tab = plan[plan[7]:plan[7] + nph_total * 128].reshape(-1, 16, 8)
             got = set()
+            assert sorted(int(x) for x in groups[:, 2]) == [16 * g for g in range(len(groups))]      # every group once ...
+            assert all(groups[i, 1] >= groups[i + 1, 1] for i in range(len(groups) - 1))              # ... longest first
             for g, (po, nph, ob0, nob) in enumerate(groups):
+                assert nob == min(16, n_out - ob0)
                 for phs in range(po, po + nph):
                     pw = [int(px[phs, 0]) & 0xffffffff, int(px[phs, 1]) & 0xffffffff]
                     pairs = [(pw[u >> 1] >> (16 * (u & 1))) & 0xffff for u in range(4)]
+                    assert pairs[0] != 0xffff and all(p == 0xffff for p in pairs[PH:])
                     slots = {}
                     for wave in range(16):
-                        for d in (int(d) & 0xffffffff for d in tab[phs, wave, 2:5] if d != -1):
-                            slots.setdefault((d >> 26) >> 1, []).append(d & 0x3ffffff)
+                        duties = [int(d) & 0xffffffff for d in tab[phs, wave, 2:5] if d != -1]
+                        assert (tab[phs, wave, 5:] == 0).all()
+                        for d in duties:
+                            blk2, slot2 = d & 0x3ffffff, d >> 26
+                            assert blk2 & 1 == slot2 & 1 and slot2 < 2 * WCAP
+                            slots.setdefault(slot2 >> 1, []).append(blk2)
+                    for sl, halves in slots.items():
+                        assert sorted(halves) == [2 * (halves[0] >> 1), 2 * (halves[0] >> 1) + 1]
+                    used = set()
                     for wave in range(16):
                         for byte in range(8):
                             sl = (int(tab[phs, wave, byte >> 2]) >> (8 * (byte & 3))) & 0xff
-                            if sl != 0xff:
-                                got.add((ob0 + wave, 2 * pairs[byte >> 1] + (byte & 1), slots[sl][0] >> 1))
-            assert got == {(ob, c, w) for ob, col in f["cols"] for c, w in col}
+                            if sl == 0xff:
+                                continue
+                            u, half = byte >> 1, byte & 1
+                            assert u < PH and wave < nob and pairs[u] != 0xffff and sl in slots and sl not in used
+                            used.add(sl)
+                            got.add((ob0 + wave, 2 * pairs[u] + half, slots[sl][0] >> 1))
+                    assert used == set(slots) and len(used) <= WCAP
+            want = {(ob, c, w) for ob, col in f["cols"] for c, w in col}
+            assert got == want
 
 
 def test_staged_xcol16_plan(lib):
@@ -511,13 +466,11 @@ def test_plan_attach_descriptor_and_host_side_rejection(lib):
         return a
     xp = _host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1)
     a = attach(xp)                                  # default for bsize 32 / 16-bit / axis 1: the staged kernel's 'BSX2' plan
-    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items) == (0x42535833, 16, 16, 0) and a.plan_inner in (2, 3, 4) and a.plan == 4096   # plan_inner: steps per phase
+    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items) == (0x42535832, 16, 16, 0) and a.plan_inner in (2, 3, 4) and a.plan == 4096   # plan_inner: steps per phase
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_UNSTAGED))
     assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items, a.plan_inner) == (0x42535843, 16, 16, 0, 0)
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 0))
-    assert a.plan_magic == 0x42535833               # feature_axis 0: the same staged plan
-    a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_R2))
-    assert (a.plan_magic, a.plan_width) == (0x42535832, 16)     # the round-2 schedule, on request
+    assert a.plan_magic == 0x42535832               # feature_axis 0: the same staged plan
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_NARROW))
     assert (a.plan_width, a.plan_waves) == (8, 8)
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.F32, 1, lib.PLAN_F32_MFMA))
