@@ -7,14 +7,16 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 OUT = os.path.join(_HERE, "libbsmm_hip.so")
 SOURCES = ["bsmm_api.hip", "bst_api.hip", "bsmm_dist.hip"]
-HEADERS = ["bsmm_common.h", "bsmm_xprop.h", "bsmm_updat.h", "bsmm_plan.h", "bsmm_updat_tr.h", "bsmm_updat_win.h", "bsmm_updat_v2.h", "bsmm_xcol.h", "bsmm_xcol16.h", "bsmm_super8.h", "bsmm_xcols.h", "bst_kernels.h", "bsmm_l2norm.h", "bsmm_sparse_proj.h"]
+def _headers():
+    """every header under csrc/ (a hand-kept list once missed the bench-path kernel: edit it and build() kept the old .so)"""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
 
 
 def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "bsmm.h"), os.path.join(INCLUDE, "bst.h"), os.path.join(INCLUDE, "bsmm_dist.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + _headers()] + [os.path.join(INCLUDE, "bsmm.h"), os.path.join(INCLUDE, "bst.h"), os.path.join(INCLUDE, "bsmm_dist.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -55,6 +55,20 @@ inline int ensure_lds(int bytes) {
 
 inline size_t elem_size(int dtype) { return dtype == BSMM_F32 ? 4 : 2; }
 
+// compute units of the current device (the kernel-choice cost models and the streaming updat grid scale with it); the driver is
+// asked once per device -- a cache of a constant, not a switch
+inline int device_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    const int slot = dev & 63;
+    int cus = cached[slot].load(std::memory_order_relaxed);
+    if (cus > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[slot].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
 int check_common(const bsmm_args* a) {
     if (!a || !a->lut) return BSMM_ERR_ARG;
     if (a->blocks <= 0 || a->N <= 0 || a->C <= 0 || a->K <= 0) return BSMM_ERR_ARG;
@@ -354,7 +368,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         if constexpr (DT::is16) {
             // bsize 8 on the matrix cores: expand W into the 32x32 super-blocks of the 'BSS8' plan and run the bsize-32 kernel
             const bool shape_ok = a->C % 32 == 0 && a->K % 32 == 0 && !(AXIS == 0 && (a->N % 8 != 0));
-            const bool fill = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
+            const bool fill = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= device_cus() * 7 / 8;
             if (plan_ok && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && shape_ok && (fill || force)) return XP_SUPER8;
         }
         return XP_VALU;
@@ -367,14 +381,14 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         if constexpr (!DT::is16) return XP_SEGMENT;
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // 16-byte aligned row pieces
         if (a->plan_magic == X7PLAN_MAGIC && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;   // 32-bit lane offsets
-        const bool enough = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 16 + XC16_G - 1) / XC16_G) >= 224;
+        const bool enough = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 16 + XC16_G - 1) / XC16_G) >= device_cus() * 7 / 8;
         return (enough || force) ? XP_XCOL16 : XP_SEGMENT;
     }
     if constexpr (BS == 32 && !DT::is16) {
         const bool split = a->plan_magic == XCPLAN_MAGIC;               // 'BSXC' (G = 16): exact bf16 split; 'BSXF': fp32 MFMA
         if (AXIS == 0 && (a->N % (split ? 8 : 4) != 0)) return XP_SEGMENT;
         if (split && a->C % 32 != 0) return XP_SEGMENT;
-        const bool enough = (long)((a->N + XF_R - 1) / XF_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= 224;
+        const bool enough = (long)((a->N + XF_R - 1) / XF_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= device_cus() * 7 / 8;
         if (!(enough || force)) return XP_SEGMENT;
         return split ? XP_F32SPLIT : XP_F32MFMA;
     }
@@ -389,7 +403,8 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         const int G = a->plan_width > 0 ? a->plan_width : 16;
         const double CB = a->C / 32.0, KB = a->K / 32.0;
         const double ngroups = (double)((a->K / 32 + G - 1) / G), ntiles = (double)((a->N + XC_R - 1) / XC_R);
-        const double rounds = std::max(1.0, std::ceil(ntiles * ngroups / 256.0));
+        const double cus = (double)device_cus();
+        const double rounds = std::max(1.0, std::ceil(ntiles * ngroups / cus));
         const double dens = std::min(1.0, a->blocks / std::max(1.0, CB * KB));
         const double steps = std::ceil(CB / 2.0) * (1.0 - std::pow(1.0 - dens, 2.0 * G));
         double t_group = rounds * (0.48 * steps + 0.045 * a->blocks / ngroups) + 8.0;
@@ -397,7 +412,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         if (a->plan_magic == X2PLAN_MAGIC) {
             // staged kernel, refit (scripts/gpu_xprop_sweep.py, 4096^2 20 % / 5 %, 8192^2 5 %, 2048^2 20 %, N = 128 .. 8192): a round
             // costs 0.28 us per pair step + 0.040 us per block of the group, up to 20 % more when the round fills all CUs
-            const double fill = std::min(1.0, ntiles * ngroups / rounds / 256.0);
+            const double fill = std::min(1.0, ntiles * ngroups / rounds / cus);
             t_group = rounds * (0.28 * steps + 0.040 * a->blocks / ngroups) * (1.0 + 0.2 * fill) + 4.0;
             t_segment = std::max(14.4, 10.0 + 1.04e-5 * (double)a->blocks * a->N);
         }
@@ -513,7 +528,8 @@ int xprop(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a)
 inline int updat_split(const bsmm_args* a, int nitems, int nchunks) {
     if (a->split > 0) return std::min(a->split, std::max(1, nchunks));
     int split = 1;
-    while (nitems * split < 256 && split * 2 <= nchunks / 8 && split < 8) split *= 2;
+    const int cus = device_cus();
+    while (nitems * split < cus && split * 2 <= nchunks / 8 && split < 8) split *= 2;
     return split;
 }
 
@@ -562,12 +578,6 @@ int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const b
         updat_finalize_kernel<DT><<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), n, a->alpha, a->beta);
     }
     return (int)hipGetLastError();
-}
-
-inline int device_cus() {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return cus;
 }
 
 // Streaming kernel (bsmm_updat_v2.h, 'BSU2' plans).  Default grid: 8 x U workgroups (U = CUs / 8) in the XCD-aware schedule of
@@ -696,7 +706,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                     } else if (L.scratch) {
                         t_stream += 8.0;
                     }
-                    const double rounds_b = std::max(1.0, std::ceil(a->blocks / 512.0));
+                    const double rounds_b = std::max(1.0, std::ceil(a->blocks / (2.0 * device_cus())));
                     const double foot = (double)N * a->pcount * (a->C + a->K) * 2.0 / 1048576.0;                 // MiB of X and DY
                     const double rate = std::min(0.0105, std::max(0.004, 0.004 + 0.0065 * (foot - 16.0) / 112.0));
                     const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * rate;
@@ -716,10 +726,10 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                 const bool w16 = a->plan_width == 16;
                 const double chunks = std::ceil(N / 64.0) * a->pcount;                 // 64-row units per window
                 const int split = updat_split(a, a->plan_items, w16 ? (N + 31) / 32 : (N + 63) / 64);   // as launch_updat32_win chooses it
-                const double rounds = std::max(1.0, std::ceil(a->plan_items * (double)split / 256.0));
+                const double rounds = std::max(1.0, std::ceil(a->plan_items * (double)split / (double)device_cus()));
                 const double t_win = 8.0 + rounds * (chunks / split) * 0.9 * (w16 ? 1.8 : 1.0) + (split > 1 ? 6.0 : 0.0);
                 // per-block kernel: two workgroups per CU, each walks the whole minibatch for ONE block
-                const double rounds_b = std::max(1.0, std::ceil(a->blocks / 512.0));
+                const double rounds_b = std::max(1.0, std::ceil(a->blocks / (2.0 * device_cus())));
                 const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * (N > 1024 ? 0.0105 : 0.0065);
                 windowed = t_win <= t_blk;
             }

@@ -13,14 +13,16 @@ PyTorch is used for device memory, streams and autograd plumbing only; all arith
 
 Differences from the reference that a user can observe:
   * (axis, block_size) combinations: the reference admits axis 0 x {8,16,32} and axis 1 x {32,64}
-    (matmul.py:84-89); we admit {8,16,32} on both axes (north_star), not 64.
+    (matmul.py:84-89); we admit {8,16,32} on both axes (north_star) and 64 on axis 1 (a 64x64 block is
+    addressed as four 32x32 blocks of the layout kron(layout, ones(2,2)); see ``_split64``).
   * By default the device walks an *unsegmented* lookup table (one segment per output block, no locks:
     deterministic, fp32-accumulated, single rounding).  ``segmented=True`` feeds the device the
-    reference-policy tables; output blocks shared by several segments are then accumulated with atomics
-    in the storage type, like the reference's locked path.  The public attributes ``fprop_lut`` etc.
-    always hold the reference-policy tables (bit-identical to the reference builder).
-  * ``gate=`` / ``gate_grad`` / ``dw_gated`` follow the reference (matmul.py:455-527); gated calls run the per-segment /
-    per-block kernels (the plan kernels do not take gates).
+    reference-policy tables; output blocks shared by several segments then meet in an fp32 image of the
+    output and are rounded ONCE (the reference rounds every partial sum to the storage type).  The public
+    attributes ``fprop_lut`` etc. always hold the reference-policy tables (bit-identical to the reference builder).
+  * ``gate=`` / ``gate_grad`` / ``dw_gated`` follow the reference (matmul.py:455-527).  Gated calls run the plan
+    kernels for block_size 32 with 16-bit types (staged xprop kernel: exact two-piece split of gate * w; streaming
+    updat kernel: the gate is applied in its summing pass), the per-segment / per-block kernels otherwise.
 """
 import ctypes
 

@@ -373,6 +373,42 @@ def test_cfg1_fp32_axis1(env):
     _check_sampled(torch, lib, b, layout, 8192, "f32", seed=51, expect={"xprop": lib.K_XCOL32_F32SPLIT}, ctx="cfg1", passes=("Y", "DX"))
 
 
+# ---- (g) bsize 8 at the BASELINE scale (north_star names bsize 8 on both axes) -----------------------------------------------
+@pytest.mark.parametrize("axis", [0, 1])
+def test_bench_shape_bsize8(env, axis):
+    """4096^2, bsize 8 (512 x 512 blocks), 10 %, bf16, N = 8192, through the 'BSS8' super-block path (the 8x8 blocks grouped into
+    32x32 super-blocks on the bsize-32 matrix-core kernels): sampled output block columns / rows / weight blocks vs the float64
+    oracle (blocksparse/matmul.py:353-419), the kernel family asserted."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(512, 512, 0.1, seed=1234)
+    b = BSMM(layout, block_size=8, feature_axis=axis)
+    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=71, expect={"xprop": lib.K_XPROP_SUPER8, "updat": lib.K_UPDAT_SUPER8},
+                   ctx="bs8 a%d" % axis, n_cols=16, n_blocks=128)
+
+
+# ---- (h) the kernel-choice cost models at measured points (profiles/r02_sweeps.md: the faster kernel wins by > 15 % there) ----
+@pytest.mark.parametrize("CB,dens,N,xk,uk", [(128, 0.2, 256, "K_XPROP_SEGMENT", "K_UPDAT_BLOCK_TR"), (128, 0.2, 2048, "K_XCOL32_STAGED", "K_UPDAT_STREAM"),
+                                             (128, 0.05, 2048, None, "K_UPDAT_STREAM"), (128, 0.05, 512, "K_XPROP_SEGMENT", "K_UPDAT_BLOCK_TR"),
+                                             (256, 0.05, 512, "K_XPROP_SEGMENT", "K_UPDAT_STREAM"), (256, 0.05, 2048, "K_XCOL32_STAGED", "K_UPDAT_STREAM"),
+                                             (64, 0.2, 512, "K_XPROP_SEGMENT", "K_UPDAT_BLOCK_TR"), (64, 0.2, 8192, "K_XCOL32_STAGED", None)])
+def test_cost_models_pick_the_measured_winner(env, CB, dens, N, xk, uk):
+    """Production dispatch (no flags) on a 256-CU part: at these (layout, minibatch) points of the sweeps one kernel family is clearly
+    faster; (128, 5 %, N = 2048) is the updat point the model once got wrong (auto 33.6 us on the per-block kernel, plan 25.2)."""
+    torch, BSMM, lib = env
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the measured points are those of a 256-CU part")
+    layout = P.random_layout(CB, CB, dens, seed=1234)
+    b = BSMM(layout, block_size=32, feature_axis=1)
+    w, x, e = _inputs(torch, b, N, "bf16", 3)
+    b.bprop(e, w)
+    if xk is not None:
+        assert lib.last_kernel() == getattr(lib, xk), ("bprop", CB, dens, N, lib.last_kernel())
+    b.updat(x, e)
+    if uk is not None:
+        assert lib.last_kernel() == getattr(lib, uk), ("updat", CB, dens, N, lib.last_kernel())
+    torch.cuda.synchronize()
+
+
 # ---- boundary: a plan that does not belong to the call is refused, not silently ignored -------------------------------
 def test_mismatched_plan_is_rejected(env):
     import ctypes
