@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- block-sparse matmul hot path on MI355X: effective TFLOP/s (+ GB/s, roofline, CPU baseline).
 
-    python bench.py [--gpus N --steps K --warmup W] [--config headline|cfg3]
+    python bench.py [--gpus N --steps K --warmup W] [--config headline|cfg2|cfg3]
 
 `--gpus N` with N > 1 spawns the N ranks itself (re-exec under torch.distributed.run, one process per GPU, rendezvous on
 127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set), so both `python bench.py --gpus 8` and the driver's
@@ -10,13 +10,18 @@
 Workloads
   headline (BASELINE.json metric): bsmm 4096x4096 bs=32 @ {10, 20, 50} % density, bf16 storage / fp32 accumulate, one STEP =
       fprop + bprop + updat of a minibatch of 8192 rows per GPU (weak scaling).  `value` is the 20 % figure; the three
-      densities sit side by side in "densities".
+      densities sit side by side in "densities".  On one GPU the default line also carries BASELINE configs[2] ("cfg2"),
+      configs[3] on one GPU ("cfg3"), configs[1] ("fp32_fprop_axis1") and configs[4] ("attention").
+  cfg2 (BASELINE configs[2]): 4096x4096 bs=16 feature_axis=0 @ 10 %, bf16, minibatch 8192 per GPU.
   cfg3 (BASELINE configs[3]): 8192x8192 bs=32 @ 5 %, GLOBAL minibatch 4096 sharded over the ranks (strong scaling; the
       N = 1 line is the whole minibatch on one GPU).
-Multi-GPU = data parallel: tables and W replicated, minibatch sharded, ONE all-reduce of dw per step over RCCL/xGMI,
-overlapped with bprop.  Synthetic inputs are resident in HBM before the timed region.
-Effective FLOPs per pass = 2 * blocks * bs^2 * N (nonzero blocks only; the reference's own definition,
+Multi-GPU = data parallel: tables and W replicated, minibatch sharded, the weight gradient reduced once per step by the LIBRARY's
+own RCCL communicator (include/bsmm_dist.h: reduce-scatter of the fp32 sums, finalize of 1 / world of the blocks per rank,
+all-gather of the finished shards) on a side stream, overlapped with bprop AND the next step's fprop; torch.distributed (gloo)
+only carries the bootstrap id, the barriers and the max-over-ranks of the timings.  Synthetic inputs are resident in HBM before
+the timed region.  Effective FLOPs per pass = 2 * blocks * bs^2 * N (nonzero blocks only; the reference's own definition,
 src/gpu_types.cc:48, src/blocksparse_matmul_op.cc:102,182).
+The CPU legs run FIRST, the GPU legs to the end of the process.
 """
 import argparse
 import json
@@ -32,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                                            # GB/s (spec)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def random_layout(CB, KB, density, seed):
@@ -51,23 +56,25 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--config", default="headline", choices=["headline", "cfg3"])
+    p.add_argument("--config", default="headline", choices=["headline", "cfg2", "cfg3"])
     p.add_argument("--prewarm-seconds", type=float, default=0.5,
                    help="untimed steps run for this long before the warmup steps: the GPU needs a few hundred ms of sustained load "
                         "to reach its boost clock")
     p.add_argument("--hidden", type=int, default=None)
-    p.add_argument("--bsize", type=int, default=32)
+    p.add_argument("--bsize", type=int, default=None)
     p.add_argument("--density", type=float, default=None, help="headline density (default 0.2; cfg3: 0.05)")
-    p.add_argument("--axis", type=int, default=1)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    p.add_argument("--axis", type=int, default=None)
+    p.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"])
     p.add_argument("--n-local", type=int, default=None, help="minibatch rows per GPU (headline; default 8192)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--cpu-seconds", type=float, default=6.0)
     p.add_argument("--no-attention", action="store_true", help="skip the BASELINE configs[4] (block-sparse attention) extra")
     p.add_argument("--no-densities", action="store_true", help="skip the 10 % / 50 % runs of the headline metric")
     p.add_argument("--no-extras", action="store_true", help="headline line only (no fp32 / attention / other densities / CPU baseline)")
     p.add_argument("--master-port", type=int, default=29533)
-    return p.parse_args()
+    a = p.parse_args()
+    a.bsize_given, a.axis_given, a.dtype_given = a.bsize is not None, a.axis is not None, a.dtype is not None
+    return a
 
 
 def respawn_under_launcher(a):
@@ -289,6 +296,22 @@ def parity_check(torch, b, layout, w, x, dy, dtype):
             "parity_sample": "fprop 3 block columns, bprop 3 block rows, updat 16 blocks vs oracle/bsmm_oracle.py (float64)"}
 
 
+CONFIGS = {
+    # name: (hidden, bsize, axis, density, dtype, minibatch per GPU or None = global 4096 split over the ranks)
+    "headline": (4096, 32, 1, 0.20, "bf16", 8192),     # BASELINE.json metric: 4096^2 bs 32 @ 20 % (10 / 50 % ride along)
+    "cfg2": (4096, 16, 0, 0.10, "bf16", 8192),         # BASELINE configs[2]
+    "cfg3": (8192, 32, 1, 0.05, "bf16", None),         # BASELINE configs[3]: global minibatch 4096, strong scaling
+}
+
+
+def measured_counters():
+    """per-density MFMA busy / measured HBM GB/s / HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_counters.json")))
+    except Exception:
+        return {}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -296,7 +319,7 @@ def main():
     import torch
     import torch.distributed as dist
     from blocksparse_amd import BlocksparseMatMul, _lib
-    from blocksparse_amd.dist import DwAllReduce
+    from blocksparse_amd.dist import DwReduce, DwAllReduce
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -305,191 +328,261 @@ def main():
     if a.gpus != world and rank == 0:
         print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
     torch.cuda.set_device(local)
-    use_dist = world > 1 or os.environ.get("BSMM_FORCE_DIST") == "1"   # the env forces the RCCL path at world_size 1 (self-test)
+    force_dist = os.environ.get("BSMM_FORCE_DIST") == "1"             # run the RCCL path at world size 1 (self-test)
+    use_dist = world > 1 or force_dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # gloo carries the bootstrap (the 128-byte RCCL id), the barriers and the max-over-ranks of the timings; the ONLY RCCL
+        # instance on the devices is the library's own communicator (include/bsmm_dist.h), which moves the gradients
+        dist.init_process_group("gloo")
     _lib.load()
 
-    cfg3 = a.config == "cfg3"
-    hidden = a.hidden or (8192 if cfg3 else 4096)
-    density = a.density if a.density is not None else (0.05 if cfg3 else 0.2)
-    if cfg3:
-        n_global = 4096
-        assert n_global % world == 0, "cfg3: the 4096-row minibatch must divide over the ranks"
-        n_local = n_global // world
-    else:
-        n_local = a.n_local or 8192
-        n_global = n_local * world
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
     if a.no_extras:
         a.no_densities = a.no_attention = a.no_cpu_baseline = True
-    td = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
-    s = 4 if a.dtype == "f32" else 2
-    CB = hidden // a.bsize
+    td_of = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
-    def setup(dens):
+    # ---- CPU legs first: the GPU legs then run to the end of the process (a utilisation sampler next to this run sees them) ----
+    cpu_out = None
+    hidden0, bsize0, axis0, dens0, dtype0, nloc0 = CONFIGS[a.config]
+    hidden0 = a.hidden or hidden0
+    bsize0 = a.bsize if a.bsize_given else bsize0
+    axis0 = a.axis if a.axis_given else axis0
+    dens0 = a.density if a.density is not None else dens0
+    dtype0 = a.dtype if a.dtype_given else dtype0
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        n_cpu = min(a.n_local or nloc0 or 4096, 8192)
+        cpu_out = cpu_baseline(random_layout(hidden0 // bsize0, hidden0 // bsize0, dens0, seed=1234), bsize0, axis0, n_cpu, a.cpu_seconds)
+
+    def setup(hidden, bsize, axis, dens, dtype, n_local):
+        td = td_of[dtype]
+        CB = hidden // bsize
         layout = random_layout(CB, CB, dens, seed=1234)
-        b = BlocksparseMatMul(layout, block_size=a.bsize, feature_axis=a.axis)
+        b = BlocksparseMatMul(layout, block_size=bsize, feature_axis=axis)
         g = torch.Generator(device="cuda").manual_seed(1 + rank)
         w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.01).to(td)
         x = (torch.randn(b.i_shape(n_local), device="cuda", generator=g) * 0.1).to(td)
         dy = (torch.randn(b.o_shape(n_local), device="cuda", generator=g) * 0.1).to(td)
         return layout, b, w, x, dy
 
-    def run(b, w, x, dy, steps, warmup):
-        """(seconds for `steps` steps [max over ranks], mean ms of fprop / updat / bprop from HIP events on the launch stream)"""
-        red = DwAllReduce(accumulate_fp32=True, force=use_dist)
-        dw = torch.empty(b.w_shape, dtype=td, device="cuda")
-        fused = use_dist and a.bsize == 32 and a.axis == 1 and a.dtype != "f32"   # the streaming updat kernel can hand over fp32 sums
+    def run(b, w, x, dy, steps, warmup, prewarm):
+        """(seconds for `steps` steps [max over ranks], mean ms of fprop / updat / bprop from HIP events on the launch stream).
+        Data-parallel step: fprop | wait for the PREVIOUS step's dw | updat -> raw fp32 sums | start their reduction (library RCCL
+        handle, side stream) | bprop -- the reduction of step i overlaps with bprop(i) and fprop(i + 1); dw is not needed before the
+        optimiser, which would sit where the wait is."""
+        td = w.dtype
+        fused = use_dist and b.bsize == 32 and b.axis == 1 and td != torch.float32   # the streaming updat kernel hands over fp32 sums
+        dws = [torch.empty(b.w_shape, dtype=td, device="cuda") for _ in range(2)]
+        red = DwReduce(b, force=use_dist) if fused else DwAllReduce(accumulate_fp32=True, force=use_dist)
+        state = {"i": 0, "pending": False}
 
         def step(ev=None):
+            i = state["i"]
             if ev: ev[0].record()
             y = b.fprop(x, w)
             if ev: ev[1].record()
+            if state["pending"]:
+                red.wait()                                 # dw of the previous step is complete here
+                state["pending"] = False
             if fused:
-                sums = b.updat(x, dy, sums_only=True)      # raw fp32 sums of this rank's minibatch shard
+                sums = b.updat(x, dy, sums_only=True, slot=i & 1)
                 if ev: ev[2].record()
-                red.start(sums)                            # RCCL all-reduce in fp32, in place, on the library's side stream
-                dx = b.bprop(dy, w)                        # ... overlaps with bprop
-                if ev: ev[3].record()
-                red.wait()
-                b.updat_finalize(sums, dw=dw)              # one rounding, after the cross-rank sum
+                red.start(sums, dws[i & 1])                # reduce-scatter f32 -> finalize 1/world -> all-gather, side stream
             else:
-                b.updat(x, dy, dw=dw)
+                b.updat(x, dy, dw=dws[i & 1])
                 if ev: ev[2].record()
-                red.start(dw)                              # (fp32 copy inside: accumulate_fp32)
-                dx = b.bprop(dy, w)
-                if ev: ev[3].record()
-                red.wait()
+                if use_dist:
+                    red.start(dws[i & 1])                  # generic path: all-reduce through an fp32 copy
+            state["pending"] = use_dist
+            dx = b.bprop(dy, w)
+            if ev: ev[3].record()
+            state["i"] = i + 1
             return y, dx
 
-        if a.prewarm_seconds > 0:
+        def drain():
+            if state["pending"]:
+                red.wait()
+                state["pending"] = False
+
+        if prewarm > 0:
             t_pre = time.perf_counter()
-            while time.perf_counter() - t_pre < a.prewarm_seconds:
+            while time.perf_counter() - t_pre < prewarm:
                 for _ in range(10):
                     step()
                 torch.cuda.synchronize()
         for _ in range(warmup):
             step()
+        drain()
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             step(evs[i])
+        drain()                                            # the last step's gradient belongs to the timed region
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         per = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in evs])) for i in range(3)]   # ms: fprop, updat, bprop
-        return el, per
+        via = red.via if use_dist else None
+        return el, per, via
 
-    def summarize(b, el, per, steps):
-        """metrics of one density: whole-job TFLOP/s, per-pass times, roofline of the dominant kernel"""
-        N = n_local
-        flops_pass = 2.0 * b.blocks * a.bsize ** 2 * N
+    def summarize(b, n_local, dtype, el, per, steps):
+        """metrics of one workload: whole-job TFLOP/s, per-pass times, roofline of the dominant kernel"""
+        s = 4 if dtype == "f32" else 2
+        flops_pass = 2.0 * b.blocks * b.bsize ** 2 * n_local
         f_ms, u_ms, b_ms = per
-        # bprop is ONE launch of the xprop kernel (fprop = the same kernel + a small weight-transpose launch); updat is one
-        # launch of the updat kernel (+ a finalize launch when the minibatch is split).  HIP events on the launch stream.
-        cand = {"bsmm_xprop(bprop)": (b_ms, flops_pass, alg_bytes_xprop(b, N, s)), "bsmm_updat": (u_ms, flops_pass, alg_bytes_updat(b, N, s))}
+        # bprop is ONE launch of the xprop kernel (fprop = the same kernel, for some kernel families + a small weight-transpose
+        # launch); updat is one launch of the updat kernel (+ a summing pass when the minibatch is split).  HIP events on the
+        # launch stream.
+        cand = {"bsmm_xprop(bprop)": (b_ms, flops_pass, alg_bytes_xprop(b, n_local, s)), "bsmm_updat": (u_ms, flops_pass, alg_bytes_updat(b, n_local, s))}
         dom = max(cand, key=lambda k: cand[k][0])
-        roof = roofline_of(dom, *cand[dom], a.dtype)
+        roof = roofline_of(dom, *cand[dom], dtype)
         return {"blocks": int(b.blocks), "value": round(3 * flops_pass * world * steps / el / 1e12, 3), "ms_per_step": round(el / steps * 1e3, 4),
                 "pass_ms": {"fprop": round(f_ms, 4), "bprop": round(b_ms, 4), "updat": round(u_ms, 4)},
                 "pass_tflops": {"fprop": round(flops_pass / f_ms / 1e9, 2), "bprop": round(flops_pass / b_ms / 1e9, 2),
                                 "updat": round(flops_pass / u_ms / 1e9, 2)},
-                "gbps_algorithmic": round((2 * alg_bytes_xprop(b, N, s) + alg_bytes_updat(b, N, s)) / (el / steps) / 1e9, 1),
+                "gbps_algorithmic": round((2 * alg_bytes_xprop(b, n_local, s) + alg_bytes_updat(b, n_local, s)) / (el / steps) / 1e9, 1),
                 "roofline": roof}
 
-    layout, b, w, x, dy = setup(density)
-    el, per = run(b, w, x, dy, a.steps, a.warmup)
-    head = summarize(b, el, per, a.steps)
-    dname = "d%d" % round(density * 100)
-    workload_name = ("bsmm fprop+bprop+updat %dx%d block_size=%d density=%.0f%% feature_axis=%d, minibatch %d per GPU, "
-                     "layout default_rng(1234)" % (hidden, hidden, a.bsize, density * 100, a.axis, n_local))
-    roof = head["roofline"]
-    # HBM bytes per launch of that kernel, from the committed rocprofv3 PMC passes (separate runs; gfx950-corrected):
-    # only quoted when the profile was taken on exactly this workload
-    traffic = {}
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")))
-        if traffic.get("workload") == workload_name and roof["kernel"] in traffic and world == 1:
-            roof["traffic"] = traffic[roof["kernel"]]["hbm_bytes"]
-    except Exception:
-        traffic = {}
+    def workload_string(hidden, bsize, axis, dens, n_local):
+        return ("bsmm fprop+bprop+updat %dx%d block_size=%d density=%.0f%% feature_axis=%d, minibatch %d per GPU, "
+                "layout default_rng(1234)" % (hidden, hidden, bsize, dens * 100, axis, n_local))
 
+    counters = measured_counters()
+
+    def attach_counters(rec, workload):
+        """measured HBM bytes / GB/s and MFMA busy of the dominant kernel, when the committed PMC passes are of exactly this workload"""
+        c = counters.get(workload)
+        if not c or world != 1:
+            return
+        k = c.get(rec["roofline"]["kernel"])
+        if k:
+            rec["roofline"]["traffic"] = k.get("hbm_bytes")
+            rec["measured"] = {"source": "profiles/%s_counters.json (rocprofv3 --pmc, separate passes)" % PROFILE_ROUND,
+                               "hbm_gbps_measured": k.get("hbm_gbps"), "mfma_busy": k.get("mfma_busy"), "kernel_us_profiled": k.get("time_us")}
+
+    # ---- the main workload of this run ----
+    cfg3 = a.config == "cfg3"
+    if nloc0 is None:
+        n_global = 4096
+        assert n_global % world == 0, "cfg3: the 4096-row minibatch must divide over the ranks"
+        n_local = a.n_local or n_global // world
+    else:
+        n_local = a.n_local or nloc0
+    n_global = n_local * world
+    layout, b, w, x, dy = setup(hidden0, bsize0, axis0, dens0, dtype0, n_local)
+    el, per, via = run(b, w, x, dy, a.steps, a.warmup, a.prewarm_seconds)
+    head = summarize(b, n_local, dtype0, el, per, a.steps)
+    dname = "d%d" % round(dens0 * 100)
+    workload_name = workload_string(hidden0, bsize0, axis0, dens0, n_local)
+    attach_counters(head, workload_name)
+    roof = head["roofline"]
     out = {
-        "metric": "bsmm_effective_tflops_%dx%d_bs%d_%s" % (hidden, hidden, a.bsize, dname),
+        "metric": "bsmm_effective_tflops_%dx%d_bs%d_%s" % (hidden0, hidden0, bsize0, dname),
         "value": head["value"], "unit": "TFLOP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if cfg3 else "weak", "vs_baseline": None,
-        "dtype": a.dtype, "data": "synthetic",
+        "dtype": dtype0, "data": "synthetic",
         "config": {"workload": workload_name, "blocks": int(b.blocks), "global_minibatch": n_global,
-                   "parallelism": "dp%d (minibatch sharded, dw all-reduce over RCCL, fp32 accumulation)" % world if world > 1 else "single GPU"},
+                   "parallelism": ("dp%d (minibatch sharded; dw: reduce-scatter of fp32 sums + shard finalize + all-gather over RCCL, "
+                                   "overlapped with bprop and the next fprop)" % world) if world > 1 else "single GPU"},
         "gbps_algorithmic": head["gbps_algorithmic"],
         # what a dense GEMM of the same shapes would have to sustain to take the same time (SURVEY 8d: reported alongside,
         # never the headline)
-        "dense_equivalent_tflops": round(3 * 2.0 * hidden * hidden * n_global * a.steps / el / 1e12, 1),
+        "dense_equivalent_tflops": round(3 * 2.0 * hidden0 * hidden0 * n_global * a.steps / el / 1e12, 1),
         "pass_ms": head["pass_ms"], "pass_tflops": head["pass_tflops"],
         "roofline": roof,
     }
+    if "measured" in head:
+        out["measured"] = head["measured"]
     if rank == 0:
-        out.update(parity_check(torch, b, layout, w, x, dy, a.dtype))
+        out.update(parity_check(torch, b, layout, w, x, dy, dtype0))
     if use_dist:
-        # the dw all-reduce on its own (it overlaps with bprop inside the step): time alone, and how much of it the step hides
-        red = DwAllReduce(accumulate_fp32=True, force=True)
-        dw_t = torch.zeros(b.w_shape, dtype=torch.float32, device="cuda")
+        # the gradient reduction on its own (inside the step it overlaps with bprop and the next fprop): time alone, and how much
+        # of it the step does not hide
+        fused = b.bsize == 32 and b.axis == 1 and dtype0 != "f32"
+        sums_t = b.updat(x, dy, sums_only=True) if fused else torch.zeros(b.w_shape, dtype=torch.float32, device="cuda")
+        dw_t = torch.empty(b.w_shape, dtype=td_of[dtype0], device="cuda")
+        red = DwReduce(b, force=True) if fused else DwAllReduce(accumulate_fp32=True, force=True)
+
+        def once():
+            if fused:
+                red.start(sums_t, dw_t)
+            else:
+                red.start(sums_t)
+            red.wait()
         for _ in range(5):
-            red.start(dw_t); red.wait()
+            once()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        barrier()
         t_ar = time.perf_counter()
         for _ in range(20):
-            red.start(dw_t); red.wait()
+            once()
         torch.cuda.synchronize()
         ar_ms = (time.perf_counter() - t_ar) / 20 * 1e3
         if world > 1:
-            tt = torch.tensor([ar_ms], device="cuda", dtype=torch.float64)
+            tt = torch.tensor([ar_ms], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             ar_ms = float(tt.item())
         compute_ms = sum(per)
         ms_step = head["ms_per_step"]
-        out["allreduce"] = {"bytes": int(dw_t.numel() * 4), "dtype": "f32", "via": red.via, "ms_alone": round(ar_ms, 4),
-                            "compute_ms": round(compute_ms, 4),
+        shard = int(b.blocks * b.bsize ** 2 / max(1, world))
+        out["allreduce"] = {"via": via, "wire_bytes_per_rank": int((world - 1) * shard * (4 + (2 if dtype0 != "f32" else 4))) if fused
+                            else int(2 * (world - 1) * shard * 4),
+                            "sums_dtype": "f32", "ms_alone": round(ar_ms, 4), "compute_ms": round(compute_ms, 4),
                             "exposed_ms": round(max(0.0, ms_step - compute_ms), 4),
-                            "hidden_frac": round(max(0.0, min(1.0, 1.0 - max(0.0, ms_step - compute_ms) / max(ar_ms, 1e-9))), 3)}
+                            "hidden_frac": round(max(0.0, min(1.0, 1.0 - max(0.0, ms_step - compute_ms) / max(ar_ms, 1e-9))), 3),
+                            "scaling_curve": "unmeasured on hardware until a multi-GPU node runs this (1-GPU leases only so far)"}
+    extras = rank == 0 and world == 1 and not a.no_extras and a.config == "headline"
     # the other densities of the BASELINE metric (10 % and 50 %; the headline run above is the 20 % one), same shape and minibatch
-    if not cfg3 and not a.no_densities:
+    if a.config == "headline" and not a.no_densities:
         dens = {dname: {k: head[k] for k in ("blocks", "value", "ms_per_step", "pass_ms", "pass_tflops", "roofline")}}
         dens[dname]["roofline"] = dict(roof)
+        if "measured" in head:
+            dens[dname]["measured"] = head["measured"]
         for d in (0.1, 0.5):
-            if abs(d - density) < 1e-9:
+            if abs(d - dens0) < 1e-9:
                 continue
-            _, b2, w2, x2, dy2 = setup(d)
+            _, b2, w2, x2, dy2 = setup(hidden0, bsize0, axis0, d, dtype0, n_local)
             st2 = max(10, a.steps // 2)
-            el2, per2 = run(b2, w2, x2, dy2, st2, max(3, a.warmup // 2))
-            r = summarize(b2, el2, per2, st2)
+            el2, per2, _ = run(b2, w2, x2, dy2, st2, max(3, a.warmup // 2), min(a.prewarm_seconds, 0.2))
+            r = summarize(b2, n_local, dtype0, el2, per2, st2)
+            attach_counters(r, workload_string(hidden0, bsize0, axis0, d, n_local))
             key = "d%d" % round(d * 100)
-            dens[key] = {k: r[k] for k in ("blocks", "value", "ms_per_step", "pass_ms", "pass_tflops", "roofline")}
-            wl2 = workload_name.replace("density=%.0f%%" % (density * 100), "density=%.0f%%" % (d * 100))
-            tr = traffic.get("densities", {}).get(key, {})
-            if tr.get("workload") == wl2 and world == 1 and r["roofline"]["kernel"] in tr:
-                dens[key]["roofline"]["traffic"] = tr[r["roofline"]["kernel"]]["hbm_bytes"]
+            dens[key] = {k: r[k] for k in ("blocks", "value", "ms_per_step", "pass_ms", "pass_tflops", "roofline") }
+            if "measured" in r:
+                dens[key]["measured"] = r["measured"]
             del b2, w2, x2, dy2
         out["densities"] = dens
+    # the other BASELINE configurations that fit one GPU, measured by the same machinery (fewer steps): configs[2] and configs[3]
+    if extras:
+        for name in ("cfg2", "cfg3"):
+            hid, bsz, ax, dn, dt, nl = CONFIGS[name]
+            nl = nl or 4096
+            lay2, b2, w2, x2, dy2 = setup(hid, bsz, ax, dn, dt, nl)
+            st2 = max(10, a.steps // 4)
+            el2, per2, _ = run(b2, w2, x2, dy2, st2, 5, 0.2)
+            r = summarize(b2, nl, dt, el2, per2, st2)
+            wl = workload_string(hid, bsz, ax, dn, nl)
+            attach_counters(r, wl)
+            r["workload"] = "BASELINE configs[%s]: %s%s" % (name[3], wl, " (the whole global minibatch on one GPU)" if name == "cfg3" else "")
+            r.update(parity_check(torch, b2, lay2, w2, x2, dy2, dt))
+            out[name] = r
+            del b2, w2, x2, dy2
     # BASELINE.json configs[1]: same layout, fp32, feature_axis=1, fprop only.  Priced against the fp32 matrix-core peak
     # (157.3 TF; AI 195 > ridge 20) although the kernel computes the fp32 result exactly from bf16 pieces on the 16-bit
     # matrix cores (six MFMAs per product, bsmm_xcols.h), whose ceiling for this formulation is 2500 / 6 = 417 TF.
-    if rank == 0 and world == 1 and not cfg3 and not a.no_extras:
+    if extras:
         N = n_local
-        b32 = BlocksparseMatMul(layout, block_size=a.bsize, feature_axis=1)
+        b32 = BlocksparseMatMul(layout, block_size=bsize0, feature_axis=1)
         g32 = torch.Generator(device="cuda").manual_seed(7)
         w32 = torch.randn(b32.w_shape, device="cuda", generator=g32) * 0.01
         x32 = torch.randn(b32.i_shape(N), device="cuda", generator=g32) * 0.1
@@ -503,21 +596,18 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms32 = e0.elapsed_time(e1) / 50
-        tf32 = 2.0 * b32.blocks * a.bsize ** 2 * N / ms32 / 1e9
+        tf32 = 2.0 * b32.blocks * bsize0 ** 2 * N / ms32 / 1e9
         out["fp32_fprop_axis1"] = {"workload": "BASELINE configs[1]: %dx%d bs%d d%.0f%% fp32 feature_axis=1 fprop, minibatch %d" %
-                                               (hidden, hidden, a.bsize, density * 100, N),
+                                               (hidden0, hidden0, bsize0, dens0 * 100, N),
                                    "kernel": "exact three-piece bf16 split on v_mfma_f32_32x32x16_bf16 (incl. the split pre-passes)",
                                    "ms": round(ms32, 4), "tflops": round(tf32, 2), "peak": PEAK_MFMA["f32"],
                                    "frac": round(tf32 / PEAK_MFMA["f32"], 4),
                                    "peak_bf16_six_products": round(PEAK_MFMA["bf16"] / 6, 1),
                                    "frac_bf16_six_products": round(tf32 / (PEAK_MFMA["bf16"] / 6), 4)}
         del b32, w32, x32
-    if rank == 0 and world == 1 and not cfg3 and not a.no_attention:
+    if rank == 0 and world == 1 and a.config == "headline" and not a.no_attention:
         out["attention"] = attention_extra(a)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(layout, a.bsize, a.axis, min(n_local, 8192), a.cpu_seconds)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    out["cpu_baseline"] = cpu_out
     # The JSON line must be the LAST thing on stdout.  RCCL's version banner (NCCL_DEBUG=VERSION) sits in every rank's C stdio
     # buffer and would otherwise be flushed at process exit, after Python's own output: push it out on ALL ranks first, meet at
     # a barrier, and only then let rank 0 print.

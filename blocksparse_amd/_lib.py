@@ -27,7 +27,7 @@ SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_updat_finalize", "bsm
            "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
            "bsmm_plan_attach", "bsmm_error_string", "bsmm_version")
 DIST_SYMBOLS = ("bsmm_dist_unique_id", "bsmm_dist_create", "bsmm_dist_allreduce_begin", "bsmm_dist_allreduce_end", "bsmm_dist_stream",
-                "bsmm_dist_world", "bsmm_dist_destroy")
+                "bsmm_dist_world", "bsmm_dist_destroy", "bsmm_dist_dw_shard_elems", "bsmm_dist_dw_begin", "bsmm_dist_dw_end")
 BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask")
 
 
@@ -120,6 +120,12 @@ def load():
     lib.bsmm_dist_world.restype = ctypes.c_int
     lib.bsmm_dist_destroy.argtypes = [vp]
     lib.bsmm_dist_destroy.restype = ctypes.c_int
+    lib.bsmm_dist_dw_shard_elems.argtypes = [i32, i32, i32]
+    lib.bsmm_dist_dw_shard_elems.restype = ctypes.c_size_t
+    lib.bsmm_dist_dw_begin.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp]
+    lib.bsmm_dist_dw_begin.restype = ctypes.c_int
+    lib.bsmm_dist_dw_end.argtypes = [vp, vp]
+    lib.bsmm_dist_dw_end.restype = ctypes.c_int
     lib.bsmm_identity_init.argtypes = [vp, vp, i32, i32, i32, i32, f32, i32, vp]
     lib.bsmm_identity_init.restype = ctypes.c_int
     lib.bsmm_gate_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]

@@ -587,7 +587,8 @@ int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const b
 // partial-sum path of the streaming kernel: the workspace holds the fp32 sums [blocks][1024] (only written for
 // BSMM_FLAG_DW_SUMS) and behind them one region of 64 accumulator slots x 4 KiB per (round, workgroup)
 struct U2Launch { int grid; bool scratch; int flat; int rounds; };
-inline size_t u2_sums_bytes(const bsmm_args* a) { return round16((size_t)a->blocks * 1024 * sizeof(float)); }
+// (+ 2 KiB: the fused data-parallel reduction reads / writes the sums in `world` 32-byte aligned shards, include/bsmm_dist.h)
+inline size_t u2_sums_bytes(const bsmm_args* a) { return round16((size_t)a->blocks * 1024 * sizeof(float)) + 2048; }
 inline size_t u2_region_bytes() { return (size_t)U2_WAVES * U2_SLOTS * 4096; }
 inline U2Launch updat2_shape(const bsmm_args* a, bool gated) {
     const int cus = device_cus();

@@ -2,6 +2,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "bsmm.h"
@@ -9,12 +10,14 @@
 
 namespace {
 
-// the five RCCL entry points this path needs (rccl.h: ncclResult_t = int, 0 = success; ncclSum = 0;
+// the RCCL entry points this path needs (rccl.h: ncclResult_t = int, 0 = success; ncclSum = 0;
 // ncclFloat16 = 6, ncclFloat32 = 7, ncclBfloat16 = 9)
 struct Rccl {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, const void*, int) = nullptr;      // NOTE: real signature takes ncclUniqueId BY VALUE (128 bytes)
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     void* lib = nullptr;
     bool ok = false;
@@ -35,13 +38,42 @@ Rccl& rccl() {
         r.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(r.lib, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<int (*)(void**, int, const void*, int)>(dlsym(r.lib, "ncclCommInitRank"));
         r.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(r.lib, "ncclAllReduce"));
+        r.ReduceScatter = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(r.lib, "ncclReduceScatter"));
+        r.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(r.lib, "ncclAllGather"));
         r.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(r.lib, "ncclCommDestroy"));
-        r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
+        r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.ReduceScatter && r.AllGather && r.CommDestroy;
     });
     return r;
 }
 
 inline int nccl_type(int dtype) { return dtype == BSMM_F32 ? 7 : (dtype == BSMM_F16 ? 6 : (dtype == BSMM_BF16 ? 9 : -1)); }
+inline size_t dw_elem_size(int dtype) { return dtype == BSMM_F32 ? 4 : 2; }
+
+// out[i] = alpha * [gate[(i0 + i) / bsq] *] sums[i] + beta * dw_old[i], rounded once, for the elements [i0, i0 + n) of DW that this
+// rank owns after the reduce-scatter (the finalize of bsmm_updat_finalize, restricted to a shard).  T16: 0 fp32, 1 fp16, 2 bf16.
+template <int T16>
+__global__ void __launch_bounds__(256)
+dw_shard_finalize_kernel(const float* __restrict__ sums, const void* __restrict__ dw_old, void* __restrict__ out, size_t n, size_t i0, int bsq,
+                         float alpha, float beta, const float* __restrict__ gate) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i + e >= n) break;
+        const float a = gate ? alpha * gate[(i0 + i + e) / bsq] : alpha;
+        float v = a * sums[i + e];
+        if constexpr (T16 == 0) {
+            if (beta != 0.f) v += beta * static_cast<const float*>(dw_old)[i + e];
+            static_cast<float*>(out)[i + e] = v;
+        } else if constexpr (T16 == 1) {
+            if (beta != 0.f) v += beta * (float)static_cast<const _Float16*>(dw_old)[i + e];
+            static_cast<_Float16*>(out)[i + e] = (_Float16)v;
+        } else {
+            if (beta != 0.f) v += beta * (float)static_cast<const __bf16*>(dw_old)[i + e];
+            static_cast<__bf16*>(out)[i + e] = (__bf16)v;
+        }
+    }
+}
 
 }  // namespace
 
@@ -99,6 +131,46 @@ int bsmm_dist_allreduce_end(bsmm_dist* h, void* consumer_stream) {
     if (!h) return BSMM_ERR_ARG;
     return (int)hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), h->reduced, 0);
 }
+
+size_t bsmm_dist_dw_shard_elems(int32_t world, int32_t blocks, int32_t bsize) {
+    if (world < 1 || blocks <= 0 || bsize <= 0) return 0;
+    const size_t total = (size_t)blocks * bsize * bsize;
+    return ((total + world - 1) / world + 7) & ~(size_t)7;          // 16-byte aligned shards for every dtype
+}
+
+int bsmm_dist_dw_begin(bsmm_dist* h, float* sums, void* dw, void* staging, const float* gate, int32_t blocks, int32_t bsize, int32_t dtype,
+                       float alpha, float beta, void* producer_stream) {
+    if (!h || !h->comm || !sums || !dw || !staging || blocks <= 0 || nccl_type(dtype) < 0) return BSMM_ERR_ARG;
+    if (bsize != 8 && bsize != 16 && bsize != 32) return BSMM_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(sums) & 15) || (reinterpret_cast<uintptr_t>(staging) & 15)) return BSMM_ERR_ARG;
+    const size_t total = (size_t)blocks * bsize * bsize, shard = bsmm_dist_dw_shard_elems(h->world, blocks, bsize);
+    const size_t lo = std::min(total, (size_t)h->rank * shard), hi = std::min(total, lo + shard), es = dw_elem_size(dtype);
+    hipError_t e = hipEventRecord(h->produced, static_cast<hipStream_t>(producer_stream));
+    if (e != hipSuccess) return (int)e;
+    if ((e = hipStreamWaitEvent(h->stream, h->produced, 0)) != hipSuccess) return (int)e;
+    Rccl& r = rccl();
+    // 1. every rank receives the cross-rank fp32 sum of ITS shard (in place: recv = send + rank * shard)
+    if (r.ReduceScatter(sums, sums + (size_t)h->rank * shard, shard, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream) != 0) return BSMM_ERR_ARG;
+    // 2. alpha / beta / gate and the ONE rounding, on 1 / world of the elements
+    if (hi > lo) {
+        const size_t n = hi - lo;
+        const unsigned grid = (unsigned)((n / 4 + 255) / 256 + 1);
+        const void* old = static_cast<const char*>(dw) + lo * es;
+        void* out = static_cast<char*>(staging) + lo * es;
+        const int bsq = bsize * bsize;
+        if (dtype == BSMM_F32)      dw_shard_finalize_kernel<0><<<grid, 256, 0, h->stream>>>(sums + lo, old, out, n, lo, bsq, alpha, beta, gate);
+        else if (dtype == BSMM_F16) dw_shard_finalize_kernel<1><<<grid, 256, 0, h->stream>>>(sums + lo, old, out, n, lo, bsq, alpha, beta, gate);
+        else                        dw_shard_finalize_kernel<2><<<grid, 256, 0, h->stream>>>(sums + lo, old, out, n, lo, bsq, alpha, beta, gate);
+        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    }
+    // 3. the finished shards travel in the storage type (half the bytes of the sums), in place in the staging buffer
+    if (r.AllGather(static_cast<const char*>(staging) + (size_t)h->rank * shard * es, staging, shard, nccl_type(dtype), h->comm, h->stream) != 0) return BSMM_ERR_ARG;
+    if ((e = hipMemcpyAsync(dw, staging, total * es, hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return (int)e;
+    e = hipEventRecord(h->reduced, h->stream);
+    return (int)e;
+}
+
+int bsmm_dist_dw_end(bsmm_dist* h, void* consumer_stream) { return bsmm_dist_allreduce_end(h, consumer_stream); }
 
 void* bsmm_dist_stream(bsmm_dist* h) { return h ? h->stream : nullptr; }
 int bsmm_dist_world(const bsmm_dist* h) { return h ? h->world : 0; }

@@ -47,12 +47,17 @@ class RcclComm(object):
         else:
             self.rank, self.world = 0, 1
         ident = ctypes.create_string_buffer(128)
+        rc = 0
         if self.rank == 0:
-            _lib.check(self._lib.bsmm_dist_unique_id(ident), "bsmm_dist_unique_id")
+            rc = self._lib.bsmm_dist_unique_id(ident)
         if self.world > 1:
-            box = [ident.raw]
+            # every rank takes part in the broadcast whatever happened on rank 0 (a rank that raised before it would leave the
+            # others blocked in a collective nobody matches); rank 0's verdict travels with the id
+            box = [(rc, ident.raw)]
             dist.broadcast_object_list(box, src=0, group=group)
-            ident = ctypes.create_string_buffer(box[0], 128)
+            rc, raw = box[0]
+            ident = ctypes.create_string_buffer(raw, 128)
+        _lib.check(rc, "bsmm_dist_unique_id (rank 0)")
         h = ctypes.c_void_p()
         _lib.check(self._lib.bsmm_dist_create(ctypes.byref(h), ident, self.rank, self.world, self.device.index or 0), "bsmm_dist_create")
         self._h = h
@@ -68,6 +73,18 @@ class RcclComm(object):
         """make the current stream wait for the collective"""
         st = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self._lib.bsmm_dist_allreduce_end(self._h, st), "bsmm_dist_allreduce_end")
+
+    def shard_elems(self, blocks, bsize):
+        return int(self._lib.bsmm_dist_dw_shard_elems(self.world, blocks, bsize))
+
+    def dw_begin(self, sums, dw, staging, gate, blocks, bsize, alpha, beta):
+        """fused reduction of the weight gradient (bsmm_dist_dw_begin): reduce-scatter of the fp32 sums, finalize of this rank's
+        shard, all-gather of the finished shards into ``dw`` -- all on the handle's stream, ordered after the current stream"""
+        from .matmul import _dtype_code
+        st = torch.cuda.current_stream(dw.device).cuda_stream
+        self._check(self._lib.bsmm_dist_dw_begin(self._h, sums.data_ptr(), dw.data_ptr(), staging.data_ptr(),
+                                                 gate.data_ptr() if gate is not None else None, blocks, bsize, _dtype_code(dw.dtype),
+                                                 alpha, beta, st), "bsmm_dist_dw_begin")
 
     def close(self):
         if self._h:
@@ -141,6 +158,7 @@ class DwAllReduce(object):
                 self.comm.begin(self._buf)
             else:
                 self._dst = None
+                self._buf = t                      # keep the tensor alive until wait(): the collective runs on another stream
                 self.comm.begin(t)
             self._direct = True
             return t
@@ -158,7 +176,9 @@ class DwAllReduce(object):
             self.comm.end()
             if self._dst is not None:
                 self._dst.copy_(self._buf)
-            self._dst = None
+                self._dst = None
+            else:
+                self._buf = None
             self._direct = False
             return
         if self._work is not None:
@@ -168,3 +188,64 @@ class DwAllReduce(object):
                 self._dst.copy_(self._buf)
         self._buf = None
         self._dst = None
+
+
+class DwReduce(object):
+    """The data-parallel weight-gradient reduction of one ``BlocksparseMatMul`` (bsize-32 streaming updat), fused:
+
+        sums = bsmm.updat(x, dy, sums_only=True)        # this rank's raw fp32 sums
+        red.start(sums, dw, alpha, beta, gate)          # reduce-scatter(fp32) -> finalize 1/world -> all-gather(storage type) -> dw
+        ... bprop, the next step's fprop ...            # dw is not needed before the optimiser
+        red.wait()
+
+    25 % fewer bytes on the wire than an fp32 all-reduce, 1 / world of the finalize per rank, ONE rounding after the cross-rank
+    sum (the reference all-reduces fp16 gradients, src/nccl_op.cc:166-201).  CUDA tensors go through the library's RCCL handle
+    (include/bsmm_dist.h) -- the collectives are issued from C on the handle's own stream; CPU tensors (gloo tests) through
+    torch.distributed with the same arithmetic.  ``force`` runs the RCCL path at world size 1 too (self-test)."""
+
+    def __init__(self, bsmm, group=None, comm=None, force=False):
+        self.bsmm, self.group, self.comm, self.force = bsmm, group, comm, force
+        self._staging = None
+        self._hold = None
+        self._cpu = None
+
+    @property
+    def via(self):
+        return "bsmm_dist_dw (library RCCL handle: reduce-scatter f32 + shard finalize + all-gather)"
+
+    def _active(self):
+        return self.force or (dist.is_initialized() and dist.get_world_size(self.group) > 1)
+
+    def start(self, sums, dw, alpha=1.0, beta=0.0, gate=None):
+        b = self.bsmm
+        if not self._active():
+            b.updat_finalize(sums, alpha=alpha, beta=beta, dw=dw, gate=gate)
+            return dw
+        if not sums.is_cuda:          # gloo: same arithmetic through torch.distributed
+            tot = sums.clone()
+            work = dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._cpu = (work, tot, dw, alpha, beta, gate)
+            return dw
+        if self.comm is None:
+            self.comm = RcclComm(sums.device, self.group)      # raises on every rank alike if rank 0 could not make an id
+        shard = self.comm.shard_elems(b.blocks, b.bsize)
+        need = self.comm.world * shard
+        if self._staging is None or self._staging.numel() < need or self._staging.dtype != dw.dtype:
+            self._staging = torch.empty(need, dtype=dw.dtype, device=dw.device)
+        self._hold = (sums, dw, gate)                           # alive until wait(): the work runs on the handle's stream
+        self.comm.dw_begin(sums, dw, self._staging, gate, b.blocks, b.bsize, alpha, beta)
+        return dw
+
+    def wait(self):
+        if self._cpu is not None:
+            work, tot, dw, alpha, beta, gate = self._cpu
+            work.wait()
+            v = tot * alpha if gate is None else tot * (alpha * gate.reshape(-1, 1, 1))
+            if beta != 0.0:
+                v = v + beta * dw.float()
+            dw.copy_(v.to(dw.dtype))
+            self._cpu = None
+            return
+        if self._hold is not None:
+            self.comm.end()
+            self._hold = None

@@ -253,13 +253,13 @@ class BlocksparseMatMul(object):
         a.stream = torch.cuda.current_stream(lut_t.device).cuda_stream
         return a
 
-    def _workspace(self, a, op, device):
+    def _workspace(self, a, op, device, slot=0):
         """Device scratch for one call, kept per (device, stream, op) and grown on demand: the entry points never allocate, and
         consecutive calls on a stream reuse the same bytes in stream order (nothing inside the timed region of a step)."""
         need = _lib.load().bsmm_workspace_bytes(op, ctypes.byref(a))
         if not need:
             return None
-        key = (device.index, a.stream, op)
+        key = (device.index, a.stream, op, slot)
         ws = self._workspaces.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
@@ -326,14 +326,17 @@ class BlocksparseMatMul(object):
         _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
         return dx
 
-    def updat(self, xs, dys, alpha=1.0, beta=0.0, dw=None, gate=None, sums_only=False):
+    def updat(self, xs, dys, alpha=1.0, beta=0.0, dw=None, gate=None, sums_only=False, slot=0):
         """DW = alpha * sum_p updat(X_p, DY_p) + beta * DW  (ops BlocksparseMatmulDW / ...DWA).
 
         ``xs``/``dys``: one tensor each or equally long lists of up to 8 tensors (the reference's Plist).
         ``gate``: gated dw (op attr gated_dw): the sum of block w is scaled by gate[w].
         ``sums_only``: return the raw fp32 sums [blocks, bs, bs] (a view of the call's workspace, valid until the next updat on
-        this stream) instead of DW -- the data-parallel path all-reduces them in fp32 and calls ``updat_finalize``; only the
-        streaming kernel (bsize 32, feature axis 1, 16-bit types) can, other configurations raise BsmmError(-2)."""
+        this stream with the same ``slot``) instead of DW -- the data-parallel path reduces them over the ranks in fp32
+        (``dist.DwReduce``) or calls ``updat_finalize``; only the streaming kernel (bsize 32, feature axis 1, 16-bit types) can,
+        other configurations raise BsmmError(-2).  ``gate`` is NOT applied to the sums: pass it to the finalize step.
+        ``slot``: which of the op's workspaces to use -- alternate 0 / 1 when the sums of one step are still being reduced while
+        the next step's updat runs."""
         if isinstance(xs, torch.Tensor):
             xs, dys = [xs], [dys]
         if len(xs) != len(dys) or not 1 <= len(xs) <= 8:
@@ -380,7 +383,9 @@ class BlocksparseMatMul(object):
             a.gate, a.flags = gate.data_ptr(), a.flags | _lib.FLAG_GATED_DW
         if sums_only:
             a.flags |= _lib.FLAG_DW_SUMS
-        ws = self._workspace(a, _lib.OP_UPDAT, dev)
+        if sums_only and gate is not None:
+            raise ValueError("updat(sums_only=True) returns the ungated sums: pass the gate to updat_finalize / DwReduce.start")
+        ws = self._workspace(a, _lib.OP_UPDAT, dev, slot)
         arr = ctypes.c_void_p * len(xs)
         xp = arr(*[t.data_ptr() for t in xs])
         ep = arr(*[t.data_ptr() for t in dys])

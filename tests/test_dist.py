@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from blocksparse_amd.dist import DwAllReduce, shard_bounds, shard_minibatch
+from blocksparse_amd.dist import DwAllReduce, DwReduce, shard_bounds, shard_minibatch
 from oracle import bsmm_oracle as orc
 
 
@@ -68,7 +68,20 @@ def _worker(rank, world, port, axis, out_q):
         red2.wait()
         full = torch.from_numpy(orc.updat(t, X, E, axis).astype(np.float32))
         ok_bf = torch.allclose(dwb.float(), full, rtol=2e-2, atol=2e-2)
-        out_q.put((rank, ok_y, ok_dw, ok_dx, bool(ok_bf)))
+        # the fused reduction (reduce the raw fp32 sums over the ranks, THEN alpha / beta / gate and one rounding): same object the
+        # GPU path uses, CPU tensors go through torch.distributed with the same arithmetic
+        class _B(object):                 # what DwReduce needs of a BlocksparseMatMul
+            blocks, bsize = t["blocks"], bs
+        gate = torch.from_numpy(rng.random(t["blocks"]).astype(np.float32))
+        dw_old = torch.from_numpy(rng.normal(size=(t["blocks"], bs, bs)).astype(np.float32)).bfloat16()
+        sums = torch.from_numpy(orc.updat(t, xs, es, axis).astype(np.float32))
+        dwf = dw_old.clone()
+        red3 = DwReduce(_B())
+        red3.start(sums, dwf, alpha=0.5, beta=2.0, gate=gate)
+        red3.wait()
+        want = (0.5 * gate.reshape(-1, 1, 1) * full + 2.0 * dw_old.float()).bfloat16()
+        ok_fused = torch.equal(dwf, want) or torch.allclose(dwf.float(), want.float(), rtol=1e-2, atol=1e-2)
+        out_q.put((rank, ok_y, ok_dw, ok_dx, bool(ok_bf), bool(ok_fused)))
     finally:
         dist.destroy_process_group()
 

@@ -75,13 +75,46 @@ def test_rccl_handle_world_size_one(env):
     comm.close()
 
 
+def test_fused_dw_reduce_world_size_one(env):
+    """bsmm_dist_dw_begin / _end on one GPU (reduce-scatter over one rank, shard finalize, all-gather, copy into dw): equals
+    updat_finalize of the same sums bit for bit, with alpha / beta / gate, for a block count that does not divide into shards."""
+    torch, BSMM, lib = env
+    from blocksparse_amd.dist import DwReduce, RcclComm
+    layout = P.random_layout(40, 40, 0.15, seed=2)
+    b = BSMM(layout, block_size=32, feature_axis=1)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N = 1000
+    x = (torch.randn(b.i_shape(N), device="cuda", generator=g) * 0.1).bfloat16()
+    dy = (torch.randn(b.o_shape(N), device="cuda", generator=g) * 0.1).bfloat16()
+    gate = torch.rand(b.blocks, device="cuda", generator=g)
+    dw0 = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.1).bfloat16()
+    comm = RcclComm()
+    red = DwReduce(b, comm=comm, force=True)
+    try:
+        lib.set_kernel_variant(3)
+        for slot, (alpha, beta, gt) in enumerate(((1.0, 0.0, None), (0.5, 2.0, gate))):
+            sums = b.updat(x, dy, sums_only=True, slot=slot)
+            want = b.updat_finalize(sums, alpha=alpha, beta=beta, dw=dw0.clone(), gate=gt)
+            got = dw0.clone()
+            red.start(sums, got, alpha=alpha, beta=beta, gate=gt)
+            y = b.bprop(dy, dw0)                                   # something to overlap with
+            red.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (alpha, beta)
+        with pytest.raises(ValueError):
+            b.updat(x, dy, sums_only=True, gate=gate)              # the sums are ungated: the gate belongs to the finalize step
+    finally:
+        lib.set_kernel_variant(0)
+        comm.close()
+
+
 _WORKER = r"""
 import os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
 import numpy as np, torch, torch.distributed as dist
 import _parity as P
 from blocksparse_amd import BlocksparseMatMul
-from blocksparse_amd.dist import DwAllReduce, shard_minibatch
+from blocksparse_amd.dist import DwAllReduce, DwReduce, shard_minibatch
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
 dist.init_process_group("gloo")                                 # bootstrap channel only: the data goes through the library's RCCL handle
@@ -101,7 +134,17 @@ dw = b.updat_finalize(sums)
 ref = b.updat(X.cuda(), E.cuda())                               # the whole minibatch on this GPU
 l2 = ((dw.float() - ref.float()).norm() / ref.float().norm()).item()
 assert l2 < 1e-3, l2
-print("rank", rank, "ok", l2, flush=True)
+# the fused form: reduce-scatter of the fp32 sums, finalize of this rank's shard, all-gather of the finished shards
+red2 = DwReduce(b)
+sums2 = b.updat(x, e, sums_only=True, slot=1)
+dw2 = torch.empty(b.w_shape, dtype=torch.bfloat16, device="cuda")
+red2.start(sums2, dw2)
+dx = b.bprop(e, dw2 * 0)
+red2.wait()
+torch.cuda.synchronize()
+l2b = ((dw2.float() - ref.float()).norm() / ref.float().norm()).item()
+assert l2b < 1e-3, l2b
+print("rank", rank, "ok", l2, l2b, flush=True)
 dist.destroy_process_group()
 """
 
