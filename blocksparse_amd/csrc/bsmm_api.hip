@@ -184,10 +184,16 @@ int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* 
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds<&xcol16_v2_kernel<DT, AXIS>>(X7_LDS)) return rc;
     trace(a, BSMM_K_XCOL16_STAGED);
-    xcol16_v2_kernel<DT, AXIS><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                              a->N, a->C, a->K);
+    if (a->gate) {
+        if (int rc = ensure_lds<&xcol16_v2_kernel<DT, AXIS, true>>(X7_LDS)) return rc;
+        xcol16_v2_kernel<DT, AXIS, true><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                         a->N, a->C, a->K, a->gate);
+    } else {
+        if (int rc = ensure_lds<&xcol16_v2_kernel<DT, AXIS, false>>(X7_LDS)) return rc;
+        xcol16_v2_kernel<DT, AXIS, false><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                          a->N, a->C, a->K, nullptr);
+    }
     return (int)hipGetLastError();
 }
 
@@ -360,8 +366,9 @@ template <class DT, int BS, int AXIS>
 XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a) {
     const int variant = call_variant(a);
     const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
-    // gated calls: only the staged bsize-32 kernel applies gates (exactly, bsmm_xcol_v2.h); everything else runs the per-segment kernels
-    const bool gate_ok = a->gate == nullptr || (BS == 32 && DT::is16 && a->plan_magic == X2PLAN_MAGIC);
+    // gated calls: the staged bsize-32 / bsize-16 kernels apply gates (exactly: bsmm_xcol_v2.h, bsmm_xcol16_v2.h); everything else runs
+    // the per-segment kernels
+    const bool gate_ok = a->gate == nullptr || (DT::is16 && ((BS == 32 && a->plan_magic == X2PLAN_MAGIC) || (BS == 16 && a->plan_magic == X7PLAN_MAGIC)));
     const bool plan_ok = a->plan != nullptr && gate_ok && vec_ok && (variant == 0 || variant == 3);
     const bool force = variant == 3;
     if constexpr (BS == 8) {

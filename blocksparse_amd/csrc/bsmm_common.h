@@ -22,6 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4v __attribute__((ext_vector_type(4)));
 
 struct DTf32 {
     typedef float T;
@@ -43,6 +45,10 @@ struct DTf16 {
     static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
+    // K = 16: lane (r, q) holds k = 4q .. 4q+3 (8 bytes); same time as the K = 32 instruction, half the products
+    static __device__ __forceinline__ f32x4 mfma16k16(uint2 a, uint2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+    }
 };
 
 struct DTbf16 {
@@ -57,6 +63,9 @@ struct DTbf16 {
     }
     static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16k16(uint2 a, uint2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4v, a), __builtin_bit_cast(s16x4v, b), c, 0, 0, 0);
     }
 };
 

@@ -7,9 +7,14 @@
 //   workgroup = 32 output blocks (512 features) x 128 minibatch rows, 16 waves, wave v owns output blocks 2v, 2v+1 for all rows
 //   (2 x 8 row tiles of 16 x 4 accumulator registers); step = QUAD of input blocks (64 features), the activation slab is
 //   byte-for-byte the slab of a bsize-32 pair step; phase = up to two steps and up to X7_WCAP weight blocks;
-//   LDS = 2 halves x (2 slabs of 16 KiB + 96 slots of 512 B) = 160 KiB; slot X7_WCAP of each half is zero: the fragment of a
-//   block that does not exist (v_mfma_f32_16x16x32 K-concatenates two input blocks: lane (o, q) takes its 8 weights from
-//   block 2 * ks + (q >> 1) of the quad).
+//   LDS = 2 halves x (2 slabs of 16 KiB + 96 slots of 512 B) = 160 KiB.
+//   A K-step is a PAIR of input blocks (32 features).  When a column has both blocks of the pair, one v_mfma_f32_16x16x32
+//   K-concatenates them (lane (o, q) takes its 8 weights from block 2 * ks + (q >> 1), its 8 activations from the same 16
+//   features); when it has only one -- 18 % of the pairs against 1 % at 10 % density -- the block is multiplied on its own by
+//   v_mfma_f32_16x16x16 (same issue time, lane (o, q) holds k = 4q .. 4q+3) from 8-byte fragment reads of exactly its 16
+//   features: half the LDS fragment bytes of a zero-padded K = 32 instruction, and the activations of the ABSENT partner are
+//   never touched (round 2 multiplied a zero weight fragment against them: 0 * Inf = NaN where the reference never reads
+//   that feature, blocksparse/matmul.py:353-392).
 //   Weight DMA: one instruction = two blocks (lanes 0..31 / 32..63), slots 2j and 2j+1.
 #pragma once
 #include "bsmm_common.h"
@@ -27,10 +32,15 @@ constexpr int X7_WBASE = 2 * X7_XHALF;
 constexpr int X7_LDS = X7_WBASE + 2 * X7_WHALF;        // 160 KiB
 static_assert(X7_LDS <= 163840 && XC_R * X7_G * 32 <= X7_LDS && X7_WCAP % 2 == 0, "ring and epilogue tile must fit the LDS");
 
-template <class DT, int AXIS>
+// GATED: per-block fp32 gates (the reference gates all three tensor-core block sizes, src/blocksparse_hgemm_cn_64_op_gpu.cu:256-717).
+// The wave that requests a pair of weight blocks also fetches their gates into the ring half's gate table (the two spare slots);
+// a block with gate 0 is treated as absent, gate 1 takes the plain path, otherwise g * w is formed per fragment element in fp32 and
+// split into TWO 16-bit pieces that are both multiplied (exact to ~2^-17; see bsmm_xcol_v2.h).
+template <class DT, int AXIS, bool GATED = false>
 __global__ void __launch_bounds__(1024, 4)
 xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
-                 typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
+                 typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout,
+                 const float* __restrict__ gate = nullptr) {
     typedef typename DT::T T;
     static_assert(DT::is16, "xcol16 v2 kernel: 16-bit storage types");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -47,10 +57,6 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     const int n_tile = tile * XC_R;
     const uint32_t base_addr = lds_addr_of(smem);
     const int nquads_full = Cin / 64;
-
-    // the zero slots (before anyone can read them: the first barrier of the phase loop orders this)
-    if (threadIdx.x < 64) *reinterpret_cast<uint4*>(smem + X7_WBASE + (lane >> 5) * X7_WHALF + X7_WCAP * 512 + (lane & 31) * 16) = zero_u4();
-    __syncthreads();
 
     // activation DMA: wave v issues instruction v of each slab (16 x 1 KiB), geometry of bsmm_xcol_v2.h
     uint32_t xvoff, xvoff_tail;
@@ -88,14 +94,59 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             return make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
     };
-    // A (W) fragment: row o16 of the block, 8 weights at 8 * (q & 1); the block is slot s_lo (q < 2) or s_hi (q >= 2)
+    // ... of ONE block of the K-step (hf = 0 / 1: features 32 ks + 16 hf .. + 16) for the K = 16 instruction: lane (n, q) holds
+    // features 4q .. 4q+3 of the block
+    auto xfrag16 = [&](const unsigned char* slab, int tt, int ks, int hf) -> uint2 {
+        if constexpr (AXIS == 1) {
+            const int row = 16 * tt + o16;
+            return *reinterpret_cast<const uint2*>(slab + row * 128 + (((4 * ks + 2 * hf + (q >> 1)) ^ ((row >> 1) & 7)) << 4) + (q & 1) * 8);
+        } else {
+            const int row0 = 32 * ks + 16 * hf + 4 * q + trow;
+            const int byte = (16 * tt + 4 * (t16 & 3)) * 2;
+            const int sw = (((byte >> 4) ^ (4 * (row0 & 3))) << 4) | (byte & 15);
+            return ds_tr16(slab + row0 * XC0_ROWB + sw);
+        }
+    };
+    // A (W) fragment: row o16 of the block.  K = 32: 8 weights at 8 * (q & 1) of slot s_lo (q < 2) or s_hi (q >= 2); K = 16: 4 weights at 4q
     const uint32_t wfrag_lane = (uint32_t)(o16 * 32 + (q & 1) * 16);
+    const uint32_t wfrag16_lane = (uint32_t)(o16 * 32 + q * 8);
 
     f32x4 acc[2][8];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // gated calls: lanes 0..5 fetch the gates of the (up to) six blocks my three duties request; the values are written into the
+    // ring half's gate table (fp32 per slot, in the two spare slots behind the weight slots) at the top of the next phase, behind
+    // the same wait as the DMAs
+    constexpr int GTAB = X7_WCAP * 512;                // byte offset of the gate table inside a weight ring half
+    float gpend = 0.f;
+    uint32_t gaddr = X7_WBASE + GTAB + 255 * 4;        // entry 255: nobody's
+    // (a macro over scalars: an array passed to a lambda by reference ends up in scratch memory)
+#define X7_FETCH_GATES(d0_, d1_, d2_, d3_, d4_, d5_, hbn_)                                                                          \
+    do {                                                                                                                             \
+        if constexpr (GATED) {                                                                                                       \
+            const int i_ = lane >> 1;                                            /* duty of this lane (lanes 0..5) */                \
+            const int da_ = i_ == 0 ? (d0_) : (i_ == 1 ? (d2_) : (d4_)), db_ = i_ == 0 ? (d1_) : (i_ == 1 ? (d3_) : (d5_));          \
+            const bool valid_ = lane < 6 && da_ != -1;                                                                               \
+            const int blk_ = (lane & 1) ? db_ : (da_ & 0x3ffffff);                                                                   \
+            const uint32_t slot_ = 2u * ((uint32_t)da_ >> 26) + (lane & 1);                                                          \
+            gpend = valid_ ? gate[blk_] : 0.f;                                                                                       \
+            gaddr = X7_WBASE + (hbn_) * X7_WHALF + GTAB + (valid_ ? slot_ : 255u) * 4;                                               \
+        }                                                                                                                            \
+    } while (0)
+    auto gate_of = [&](int hbc, uint32_t slot) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint32_t*>(smem + X7_WBASE + hbc * X7_WHALF + GTAB + slot * 4)));
+    };
+    // (hi, lo) 16-bit pieces of g * w per element: hi = round(g w), lo = round(g w - hi)
+    auto split2 = [&](uint32_t src, float g, uint32_t& hi, uint32_t& lo) {
+        const float p0f = g * DT::to_f32((uint16_t)(src & 0xffffu)), p1f = g * DT::to_f32((uint16_t)(src >> 16));
+        const uint16_t h0 = DT::from_f32(p0f), h1 = DT::from_f32(p1f);
+        const uint16_t l0 = DT::from_f32(p0f - DT::to_f32(h0)), l1 = DT::from_f32(p1f - DT::to_f32(h1));
+        hi = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        lo = (uint32_t)l0 | ((uint32_t)l1 << 16);
+    };
 
 #define X7_WDUTY(a_, b_)                                                                                                   \
     if ((a_) != -1) {                                                                                                       \
@@ -119,6 +170,7 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             const int d[6] = {__builtin_amdgcn_readfirstlane(da.x), __builtin_amdgcn_readfirstlane(da.y), __builtin_amdgcn_readfirstlane(da.z),
                               __builtin_amdgcn_readfirstlane(da.w), __builtin_amdgcn_readfirstlane(db.x), __builtin_amdgcn_readfirstlane(db.y)};
             X7_ISSUE(px0, d, 0);
+            X7_FETCH_GATES(d[0], d[1], d[2], d[3], d[4], d[5], 0);
         }
         int hb = 0;
         for (int tb = 0; tb < nph; tb += 64) {       // lane-indexed tables for phases [tb, tb + 64)
@@ -133,47 +185,100 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             const int tend = min(64, nph - tb);
             for (int qi = 0; qi < tend; ++qi) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA shares of this phase have landed
+                if constexpr (GATED) {                               // ... and the gates I fetched with them: into this half's table
+                    *reinterpret_cast<float*>(smem + gaddr) = gpend;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_s_barrier();                        // everyone's have; everyone left the previous phase
                 if (tb + qi + 1 < nph) {
                     const int px1 = __builtin_amdgcn_readlane(pxv, qi);
                     const int d[6] = {__builtin_amdgcn_readlane(d0, qi), __builtin_amdgcn_readlane(d1, qi), __builtin_amdgcn_readlane(d2, qi),
                                       __builtin_amdgcn_readlane(d3, qi), __builtin_amdgcn_readlane(d4, qi), __builtin_amdgcn_readlane(d5, qi)};
                     X7_ISSUE(px1, d, hb ^ 1);
+                    X7_FETCH_GATES(d[0], d[1], d[2], d[3], d[4], d[5], hb ^ 1);
+                } else if constexpr (GATED) {
+                    gaddr = X7_WBASE + GTAB + 255 * 4;
                 }
                 const uint32_t cw[4] = {(uint32_t)__builtin_amdgcn_readlane(cw0, qi), (uint32_t)__builtin_amdgcn_readlane(cw1, qi),
                                         (uint32_t)__builtin_amdgcn_readlane(cw2, qi), (uint32_t)__builtin_amdgcn_readlane(cw3, qi)};
-                const unsigned char* wring = smem + X7_WBASE + hb * X7_WHALF + wfrag_lane;
+                const unsigned char* wring = smem + X7_WBASE + hb * X7_WHALF;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if ((cw[2 * u] & cw[2 * u + 1]) == 0xffffffffu) continue;        // nothing of mine in this step
                     const unsigned char* slab = smem + hb * X7_XHALF + u * X7_SLAB;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        uint4 wf[2];
-                        bool act[2];
+                        // One column at a time.  Per column: 0 = no block in this pair, 1 = only the first, 2 = only the second, 3 = both.
+                        // A lone block is multiplied by the K = 16 instruction from 8-byte fragments of exactly its features: TH16 row
+                        // tiles' reads are issued together (one LDS latency per block, not per pair of MFMAs).
+                        constexpr int TH32 = GATED ? 1 : (AXIS == 1 ? BSMM_XC16_TH_A1 : BSMM_XC16_TH_A0);
+                        constexpr int TH16 = GATED ? (AXIS == 1 ? 4 : 2) : (AXIS == 1 ? 8 : 4);
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             const uint32_t pairb = (cw[2 * u + c] >> (16 * ks)) & 0xffffu;    // slots of sub-blocks 2ks, 2ks+1
-                            act[c] = pairb != 0xffffu;
-                            if (act[c]) {
-                                const uint32_t lo = pairb & 0xff, hi = pairb >> 8;
-                                const uint32_t s_lo = (lo == 0xff ? (uint32_t)X7_WCAP : lo) << 9, s_hi = (hi == 0xff ? (uint32_t)X7_WCAP : hi) << 9;
-                                wf[c] = *reinterpret_cast<const uint4*>(wring + ((q >> 1) ? s_hi : s_lo));
+                            if (pairb == 0xffffu) continue;
+                            const uint32_t lo = pairb & 0xff, hi = pairb >> 8;
+                            int pat = (lo != 0xff ? 1 : 0) | (hi != 0xff ? 2 : 0);
+                            float g_lo = 1.f, g_hi = 1.f;
+                            if constexpr (GATED) {
+                                if (pat & 1) { g_lo = gate_of(hb, lo); if (g_lo == 0.f) pat &= ~1; }   // gate 0: the block is skipped
+                                if (pat & 2) { g_hi = gate_of(hb, hi); if (g_hi == 0.f) pat &= ~2; }
+                                if (pat == 0) continue;
                             }
-                        }
-                        if (!(act[0] || act[1])) continue;
-                        constexpr int TH = AXIS == 1 ? BSMM_XC16_TH_A1 : BSMM_XC16_TH_A0;
-#pragma unroll
-                        for (int t0 = 0; t0 < 8; t0 += TH) {
-                            uint4 xf[TH];
-#pragma unroll
-                            for (int tt = 0; tt < TH; ++tt) xf[tt] = xfrag(slab, t0 + tt, ks);
-#pragma unroll
-                            for (int c = 0; c < 2; ++c)
-                                if (act[c]) {
-#pragma unroll
-                                    for (int tt = 0; tt < TH; ++tt) acc[c][t0 + tt] = DT::mfma16(wf[c], xf[tt], acc[c][t0 + tt]);
+                            if (pat == 3) {
+                                uint4 w4 = *reinterpret_cast<const uint4*>(wring + wfrag_lane + (((q >> 1) ? hi : lo) << 9)), l4 = zero_u4();
+                                bool two = false;
+                                if constexpr (GATED) {
+                                    two = g_lo != 1.f || g_hi != 1.f;
+                                    if (two) {
+                                        const float g = (q >> 1) ? g_hi : g_lo;
+                                        uint4 h4;
+                                        split2(w4.x, g, h4.x, l4.x); split2(w4.y, g, h4.y, l4.y); split2(w4.z, g, h4.z, l4.z); split2(w4.w, g, h4.w, l4.w);
+                                        w4 = h4;
+                                    }
                                 }
+#pragma unroll
+                                for (int t0 = 0; t0 < 8; t0 += TH32) {
+                                    uint4 xf[TH32];
+#pragma unroll
+                                    for (int tt = 0; tt < TH32; ++tt) xf[tt] = xfrag(slab, t0 + tt, ks);
+#pragma unroll
+                                    for (int tt = 0; tt < TH32; ++tt) acc[c][t0 + tt] = DT::mfma16(w4, xf[tt], acc[c][t0 + tt]);
+                                    if constexpr (GATED) {
+                                        if (two) {
+#pragma unroll
+                                            for (int tt = 0; tt < TH32; ++tt) acc[c][t0 + tt] = DT::mfma16(l4, xf[tt], acc[c][t0 + tt]);
+                                        }
+                                    }
+                                }
+                            } else {
+                                const int hf = pat - 1;
+                                uint2 w2 = *reinterpret_cast<const uint2*>(wring + wfrag16_lane + ((hf ? hi : lo) << 9)), l2 = make_uint2(0u, 0u);
+                                bool two = false;
+                                if constexpr (GATED) {
+                                    const float g = hf ? g_hi : g_lo;
+                                    two = g != 1.f;
+                                    if (two) {
+                                        uint2 h2;
+                                        split2(w2.x, g, h2.x, l2.x); split2(w2.y, g, h2.y, l2.y);
+                                        w2 = h2;
+                                    }
+                                }
+#pragma unroll
+                                for (int t0 = 0; t0 < 8; t0 += TH16) {
+                                    uint2 xh[TH16];
+#pragma unroll
+                                    for (int tt = 0; tt < TH16; ++tt) xh[tt] = xfrag16(slab, t0 + tt, ks, hf);
+#pragma unroll
+                                    for (int tt = 0; tt < TH16; ++tt) acc[c][t0 + tt] = DT::mfma16k16(w2, xh[tt], acc[c][t0 + tt]);
+                                    if constexpr (GATED) {
+                                        if (two) {
+#pragma unroll
+                                            for (int tt = 0; tt < TH16; ++tt) acc[c][t0 + tt] = DT::mfma16k16(l2, xh[tt], acc[c][t0 + tt]);
+                                        }
+                                    }
+                                }
+                            }
                         }
                     }
                 }
@@ -182,6 +287,7 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
         }
     }
 #undef X7_ISSUE
+#undef X7_FETCH_GATES
 #undef X7_WDUTY
 
     const bool own0 = 2 * wave < nob, own1 = 2 * wave + 1 < nob;

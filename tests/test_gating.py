@@ -103,6 +103,50 @@ def test_gated_passes_match_oracle(env, bs, axis, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("axis", [1, 0])
+def test_gated_staged_plan_kernel_bsize16(env, axis, dtype):
+    """Gates on the bsize-16 plan kernel (bsmm_xcol16_v2.h, GATED; the reference gates all of its tensor-core block sizes,
+    src/blocksparse_hgemm_cn_64_op_gpu.cu:256-717): forced on small layouts -- gates 0 (block skipped: both of a K-concatenated pair,
+    one of them), 1, negative, > 1 -- and at BASELINE configs[2]'s shape, against the oracle, which gates the fp32 block product."""
+    torch, BSMM = env
+    from blocksparse_amd import _lib
+    cases = [(P.random_layout(18, 14, 0.4, seed=8), (72, 200)), (np.ones((6, 40), dtype=bool), (128,)), (P.ba_layout(60, 3, seed=1), (264,))]
+    try:
+        _lib.set_kernel_variant(3)
+        for li, (lay, Ns) in enumerate(cases):
+            b = BSMM(lay, block_size=16, feature_axis=axis)
+            t = O.build_layout_luts(lay, 16)
+            for N in Ns:
+                W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=60 + N)
+                g = MG.gate_inputs(b.blocks, 70 + li)
+                tg = torch.from_numpy(g).cuda()
+                tw, tx, te = _t(torch, W, dtype), _t(torch, X, dtype), _t(torch, E, dtype)
+                y = b.fprop(tx, tw, gate=tg)
+                assert _lib.last_kernel() == _lib.K_XCOL16_STAGED
+                dx = b.bprop(te, tw, gate=tg)
+                assert _lib.last_kernel() == _lib.K_XCOL16_STAGED
+                for name, got, ref in (("Y", y, O.fprop(t, X, W, axis, gate=g)), ("DX", dx, O.bprop(t, E, W, axis, gate=g))):
+                    l2, _ = P.errors(got.float().cpu().numpy(), O.round_to(ref, dtype))
+                    assert l2 <= P.L2_BAR[dtype], (axis, dtype, li, N, name, l2)
+    finally:
+        _lib.set_kernel_variant(0)
+    lay = P.random_layout(256, 256, 0.1, seed=1234)
+    b = BSMM(lay, block_size=16, feature_axis=axis)
+    t = O.build_layout_luts(lay, 16)
+    N = 4096
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=7)
+    g = MG.gate_inputs(b.blocks, 9)
+    y = b.fprop(_t(torch, X, dtype), _t(torch, W, dtype), gate=torch.from_numpy(g).cuda())
+    assert _lib.last_kernel() == _lib.K_XCOL16_STAGED
+    yh = y.float().cpu().numpy()
+    for k, ref in O.fprop_cols(t, X * 1.0, np.asarray(W, dtype=np.float64) * g[:, None, None], axis, [0, 77, 255]).items():
+        got = yh[:, k * 16:(k + 1) * 16] if axis else yh[k * 16:(k + 1) * 16, :]
+        l2, _ = P.errors(got, O.round_to(ref, dtype))
+        assert l2 <= P.L2_BAR[dtype], (axis, dtype, k, l2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("axis", [1, 0])
 def test_gated_staged_plan_kernel(env, axis, dtype):
     """Gates on the bsize-32 plan kernel (bsmm_xcol_v2.h, GATED): forced on small layouts (gates 0, negative, > 1; dense phases; N not a
     multiple of the row tile) and at the bench shape, fprop and bprop against the oracle, which gates the fp32 block product."""

@@ -480,3 +480,45 @@ def test_step_is_capturable_in_a_hip_graph(env):
     y_e, dx_e = step()
     torch.cuda.synchronize()
     assert torch.equal(y_g, y_e) and torch.equal(dx_g, dx_e) and torch.equal(dw_g, dw)
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("bs", [32, 16, 8])
+def test_inf_in_an_unconnected_feature_does_not_reach_the_output(env, bs, axis):
+    """The reference never reads an input feature block that the layout does not connect to an output block
+    (blocksparse/matmul.py:353-392 walks only the lut entries): an Inf / NaN there leaves that output finite.  The plan kernels
+    that K-concatenate blocks (bsize 16: two input blocks per v_mfma_f32_16x16x32) mask the ACTIVATIONS of an absent partner,
+    not only its weights, so the same holds for them -- forced here with BSMM_FLAG_FORCE_PLAN.  bsize 8 with a plan multiplies
+    zero-filled 32x32 super-blocks (a documented deviation: 0 * Inf inside a super-block that holds another block of that
+    feature); BSMM_FLAG_NO_PLAN is the exact path and is what is checked for it."""
+    torch, BSMM, lib = env
+    rng = np.random.default_rng(3 + bs + axis)
+    CB = KB = 48 if bs != 8 else 64
+    lay = (rng.random((CB, KB)) < 0.12).astype(np.int32)
+    lay[np.arange(CB), rng.integers(0, KB, CB)] = 1
+    lay[rng.integers(0, CB, KB), np.arange(KB)] = 1
+    N = 256
+    b = BSMM(lay, block_size=bs, feature_axis=axis)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.05).bfloat16()
+    x = (torch.randn(b.i_shape(N), device="cuda", generator=g) * 0.1).bfloat16()
+    dy = (torch.randn(b.o_shape(N), device="cuda", generator=g) * 0.1).bfloat16()
+    c_bad, k_bad = 5, 7
+    xs = x.clone()
+    (xs[:, c_bad * bs:(c_bad + 1) * bs] if axis else xs[c_bad * bs:(c_bad + 1) * bs, :]).fill_(float("inf"))
+    es = dy.clone()
+    (es[:, k_bad * bs:(k_bad + 1) * bs] if axis else es[k_bad * bs:(k_bad + 1) * bs, :]).fill_(float("nan"))
+    lib.set_kernel_variant(2 if bs == 8 else 3)
+    try:
+        y = b.fprop(xs, w).float()
+        dx = b.bprop(es, w).float()
+        if bs != 8:
+            assert lib.last_kernel() in (lib.K_XCOL32_STAGED, lib.K_XCOL16_STAGED)
+    finally:
+        lib.set_kernel_variant(0)
+    for k in range(KB):
+        blk = y[:, k * bs:(k + 1) * bs] if axis else y[k * bs:(k + 1) * bs, :]
+        assert bool(torch.isfinite(blk).all()) == (lay[c_bad, k] == 0), ("fprop", bs, axis, k)
+    for c in range(CB):
+        blk = dx[:, c * bs:(c + 1) * bs] if axis else dx[c * bs:(c + 1) * bs, :]
+        assert bool(torch.isfinite(blk).all()) == (lay[c, k_bad] == 0), ("bprop", bs, axis, c)
