@@ -853,7 +853,7 @@ int bsmm_bprop(const void* DY, const void* W, void* DX, const bsmm_args* args) {
 int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
     int rc = check_common(a);
     if (rc) return rc;
-    if (!X || !DY || !DW) return BSMM_ERR_ARG;
+    if (!X || !DY || (!DW && !(a->flags & BSMM_FLAG_DW_SUMS))) return BSMM_ERR_ARG;      // (DW is not written in sums mode)
     if (a->pcount < 1 || a->pcount > 8) return BSMM_ERR_ARG;
     if ((rc = check_plan(true, a))) return rc;
     if ((a->flags & BSMM_FLAG_DW_SUMS) && !(a->bsize == 32 && a->axis == 1 && a->dtype != BSMM_F32 && a->plan && a->plan_magic == U2PLAN_MAGIC))

@@ -389,7 +389,7 @@ class BlocksparseMatMul(object):
         arr = ctypes.c_void_p * len(xs)
         xp = arr(*[t.data_ptr() for t in xs])
         ep = arr(*[t.data_ptr() for t in dys])
-        _lib.check(lib.bsmm_updat(xp, ep, dw.data_ptr() if dw is not None else 16, ctypes.byref(a)), "bsmm_updat")
+        _lib.check(lib.bsmm_updat(xp, ep, dw.data_ptr() if dw is not None else None, ctypes.byref(a)), "bsmm_updat")
         if sums_only:
             n = self.blocks * self.bsize * self.bsize
             return ws[:4 * n].view(torch.float32).view(self.w_shape)
