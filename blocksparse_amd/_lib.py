@@ -25,7 +25,7 @@ PLAN_XCOL_NARROW, PLAN_F32_MFMA, PLAN_WINDOW_8, PLAN_WINDOW_16, PLAN_WINDOW_16W,
 
 SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_updat_finalize", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_sparse_op", "bsmm_sparse_mul_grad", "bsmm_workspace_bytes",
            "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
-           "bsmm_plan_attach", "bsmm_error_string", "bsmm_version")
+           "bsmm_plan_attach", "bsmm_error_string", "bsmm_version", "bsmm_prepared_bytes", "bsmm_prepare_weights")
 DIST_SYMBOLS = ("bsmm_dist_unique_id", "bsmm_dist_create", "bsmm_dist_allreduce_begin", "bsmm_dist_allreduce_end", "bsmm_dist_stream",
                 "bsmm_dist_world", "bsmm_dist_destroy", "bsmm_dist_dw_shard_elems", "bsmm_dist_dw_begin", "bsmm_dist_dw_end")
 BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask")
@@ -42,7 +42,7 @@ class BsmmArgs(ctypes.Structure):
         ("locks", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
         ("shared", ctypes.c_int32), ("pcount", ctypes.c_int32), ("axis", ctypes.c_int32),
         ("dtype", ctypes.c_int32), ("alpha", ctypes.c_float), ("beta", ctypes.c_float),
-        ("stream", ctypes.c_void_p), ("trace", ctypes.POINTER(ctypes.c_int32)),
+        ("stream", ctypes.c_void_p), ("trace", ctypes.POINTER(ctypes.c_int32)), ("prepared_w", ctypes.c_void_p),
     ]
 
 
@@ -140,6 +140,10 @@ def load():
     lib.bsmm_sparse_mul_grad.restype = ctypes.c_int
     lib.bsmm_workspace_bytes.argtypes = [ctypes.c_int, pargs]
     lib.bsmm_workspace_bytes.restype = ctypes.c_size_t
+    lib.bsmm_prepared_bytes.argtypes = [ctypes.c_int, pargs]
+    lib.bsmm_prepared_bytes.restype = ctypes.c_size_t
+    lib.bsmm_prepare_weights.argtypes = [ctypes.c_int, vp, vp, pargs]
+    lib.bsmm_prepare_weights.restype = ctypes.c_int
     ip = ctypes.POINTER(ctypes.c_int32)
     lib.bsmm_xprop_plan_words.argtypes = [ip, i32, i32, i32, i32, i32, i32, i32]
     lib.bsmm_xprop_plan_words.restype = ctypes.c_long

@@ -225,19 +225,25 @@ int launch_xcol32f(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
 
 // fp32 on the bf16 matrix cores: split pre-passes into the workspace ([3][N*C] activation pieces, then [3][blocks*1024]
 // weight pieces), then the wide xcol kernel with three slabs per step.
+inline size_t xcols_w_bytes(const bsmm_args* a) { return 6 * (size_t)a->blocks * 1024; }
 inline size_t xcols_workspace_bytes(const bsmm_args* a) {
-    return 6 * ((size_t)a->N * a->C + (size_t)a->blocks * 1024);
+    return 6 * (size_t)a->N * a->C + (a->prepared_w ? 0 : xcols_w_bytes(a));
 }
 template <int AXIS>
 int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a, hipStream_t st) {
     const size_t nx = (size_t)a->N * a->C;
     if (a->plan_magic != XCPLAN_MAGIC || a->plan_width != XS_G) return BSMM_ERR_ARG;
     if (!a->workspace || a->workspace_bytes < xcols_workspace_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+    if (a->prepared_w && !aligned16(a->prepared_w)) return BSMM_ERR_ARG;
     uint16_t* xp = static_cast<uint16_t*>(a->workspace);
-    uint16_t* wp = xp + 3 * nx;
+    const uint16_t* wp = static_cast<const uint16_t*>(a->prepared_w);
     split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X), xp, nx);
-    if (fprop) split3_w_kernel<true><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), wp, a->blocks);
-    else       split3_w_kernel<false><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), wp, a->blocks);
+    if (!wp) {      // W's pieces are a constant of the pass: a caller that holds them (bsmm_prepare_weights) skips this launch
+        uint16_t* wq = xp + 3 * nx;
+        if (fprop) split3_w_kernel<true><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), wq, a->blocks);
+        else       split3_w_kernel<false><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), wq, a->blocks);
+        wp = wq;
+    }
     const int n_out = a->K / 32;
     XMap m;
     m.ntiles = (a->N + XC_R - 1) / XC_R;
@@ -870,6 +876,22 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
         case BSMM_BF16: return updat_dt<DTbf16>(xs, es, DW, a);
     }
     return BSMM_ERR_UNSUPPORTED;
+}
+
+size_t bsmm_prepared_bytes(int op, const bsmm_args* a) {
+    if (!a || (op != BSMM_OP_FPROP && op != BSMM_OP_BPROP)) return 0;
+    if (a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && a->plan_magic == XCPLAN_MAGIC && a->plan_width == XS_G && a->blocks > 0) return xcols_w_bytes(a);
+    return 0;
+}
+
+int bsmm_prepare_weights(int op, const void* W, void* prepared, const bsmm_args* a) {
+    if (!a || !W || !prepared || (op != BSMM_OP_FPROP && op != BSMM_OP_BPROP)) return BSMM_ERR_ARG;
+    if (bsmm_prepared_bytes(op, a) == 0) return BSMM_ERR_UNSUPPORTED;
+    if (!aligned16(W) || !aligned16(prepared)) return BSMM_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    if (op == BSMM_OP_FPROP) split3_w_kernel<true><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), static_cast<uint16_t*>(prepared), a->blocks);
+    else                     split3_w_kernel<false><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), static_cast<uint16_t*>(prepared), a->blocks);
+    return (int)hipGetLastError();
 }
 
 int bsmm_updat_finalize(const float* sums, void* DW, const float* gate, int32_t blocks, int32_t bsize, int32_t dtype, float alpha, float beta,

@@ -169,6 +169,7 @@ class BlocksparseMatMul(object):
         self.layout = ref["layout"]
         self._device_cache = {}
         self._workspaces = {}
+        self._prepared_w = {}             # op -> ((op, w.data_ptr, w._version, stream), buffer): bsmm_prepare_weights results
         self._inner = None
         if block_size == 64:
             # same weights, cut into 32x32 blocks: inner block n is quadrant (i, j) of outer block b
@@ -267,6 +268,23 @@ class BlocksparseMatMul(object):
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         return ws
 
+    def _prepared(self, a, op, w):
+        """The per-weights preparation of the library (bsmm_prepare_weights: fp32 / bsize 32 with a plan = the bf16 pieces of W), made
+        once per (op, parameter tensor, version) and handed to the call in ``a.prepared_w`` -- W is constant across the calls of a
+        pass, only an in-place update (optimizer step: ``w._version`` changes) invalidates it."""
+        lib = _lib.load()
+        need = lib.bsmm_prepared_bytes(op, ctypes.byref(a))
+        if not need:
+            return
+        key = (op, w.data_ptr(), w._version, a.stream)
+        hit = self._prepared_w.get(op)
+        if hit is None or hit[0] != key:
+            buf = hit[1] if (hit is not None and hit[1].numel() >= need) else torch.empty(need, dtype=torch.uint8, device=w.device)
+            _lib.check(lib.bsmm_prepare_weights(op, w.data_ptr(), buf.data_ptr(), ctypes.byref(a)), "bsmm_prepare_weights")
+            self._prepared_w[op] = (key, buf)
+            hit = self._prepared_w[op]
+        a.prepared_w = hit[1].data_ptr()
+
     def _out_shape(self, x, feat_out):
         shp = list(x.shape)
         if self.axis == 0:
@@ -302,6 +320,7 @@ class BlocksparseMatMul(object):
         a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype,
                        plan=tabs.fprop_plan_f32 if x.dtype == torch.float32 else tabs.fprop_plan)
         a.gate = gate.data_ptr() if gate is not None else None
+        self._prepared(a, _lib.OP_FPROP, w)
         self._workspace(a, _lib.OP_FPROP, x.device)
         _lib.check(lib.bsmm_fprop(x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(a)), "bsmm_fprop")
         return y
@@ -322,6 +341,7 @@ class BlocksparseMatMul(object):
         a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype,
                        plan=tabs.bprop_plan_f32 if dy.dtype == torch.float32 else tabs.bprop_plan)
         a.gate = gate.data_ptr() if gate is not None else None
+        self._prepared(a, _lib.OP_BPROP, w)
         self._workspace(a, _lib.OP_BPROP, dy.device)
         _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
         return dx

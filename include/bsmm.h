@@ -131,6 +131,9 @@ typedef struct bsmm_args {
     float beta;
     void* stream;           /* hipStream_t                                                                           */
     int32_t* trace;         /* optional HOST pointer: receives the BSMM_K_* code of the kernel this call dispatched to  */
+    const void* prepared_w; /* optional: the result of bsmm_prepare_weights() for THIS op, W and plan (fp32 / bsize 32 with a plan:
+                               the bf16 pieces of W).  W is constant across the calls of a forward / backward pass; without this
+                               pointer every fprop / bprop re-splits it (one extra launch) into the workspace.  NULL = do that. */
 } bsmm_args;
 
 /* Y = fprop(X, W).  args->lut = fprop_lut.  Workspace: a transposed copy of W (not read by the staged bsize-32 kernel, which
@@ -145,6 +148,13 @@ int bsmm_bprop(const void* DY, const void* W, void* DX, const bsmm_args* args);
 /* DW = alpha * sum_{p<pcount} updat(X[p], DY[p]) + beta * DW.  args->lut = updat_lut.
  * X and DY are HOST arrays of pcount device pointers. */
 int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm_args* args);
+
+/* Per-weights preparation that the xprop kernels would otherwise repeat on every call (fp32, bsize 32, with a plan: the exact
+ * three-piece bf16 split of W, transposed per block for fprop).  bsmm_prepared_bytes() > 0 means: allocate that many bytes, call
+ * bsmm_prepare_weights() once whenever W changes, and pass the buffer in args->prepared_w of the fprop (op BSMM_OP_FPROP) or bprop
+ * (BSMM_OP_BPROP) calls; their workspace then holds only the pieces of the activations.  0 = nothing to prepare for these args. */
+size_t bsmm_prepared_bytes(int op, const bsmm_args* args);
+int bsmm_prepare_weights(int op, const void* W, void* prepared, const bsmm_args* args);
 
 /* Second half of an updat issued with BSMM_FLAG_DW_SUMS: DW[w] = alpha * [gate[w] *] sums[w] + beta * DW[w], one rounding.
  * sums: fp32 [blocks][bsize][bsize] (the workspace of that call, possibly all-reduced in between); gate may be NULL. */

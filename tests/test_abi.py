@@ -46,7 +46,38 @@ def test_struct_layout_matches_header(lib):
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = [re.search(r"(\w+)\s*;", ln).group(1) for ln in body.splitlines() if ";" in ln]
     assert names == [f[0] for f in lib.BsmmArgs._fields_]
-    assert ctypes.sizeof(lib.BsmmArgs) == 5 * 8 + 18 * 4 + 2 * 4 + 2 * 8   # 4 ptr + size_t, 18 int32, 2 float, 2 ptr
+    assert ctypes.sizeof(lib.BsmmArgs) == 5 * 8 + 18 * 4 + 2 * 4 + 3 * 8   # 4 ptr + size_t, 18 int32, 2 float, 3 ptr
+
+
+def test_prepared_weights_entry_points_without_gpu(lib):
+    """bsmm_prepared_bytes / bsmm_prepare_weights (the cached split of constant fp32 weights): only fp32 / bsize 32 with the 16-wide
+    'BSXC' plan has something to prepare; everything else answers 0 / BSMM_ERR_UNSUPPORTED; bad arguments are refused."""
+    import numpy as np
+    from blocksparse_amd import lut as LT
+    from blocksparse_amd.matmul import _host_plan
+    L = lib.load()
+    ip = ctypes.POINTER(ctypes.c_int32)
+    lay = np.random.default_rng(1).random((8, 8)) < 0.4
+    lay[0, :] = True
+    t = LT.build_tables(lay)
+    f = t["fprop"]
+    a = lib.BsmmArgs()
+    a.blocks, a.bsize, a.dtype, a.N, a.C, a.K, a.axis = t["blocks"], 32, lib.F32, 256, 256, 256, 1
+    assert L.bsmm_prepared_bytes(lib.OP_FPROP, ctypes.byref(a)) == 0                      # no plan
+    words = _host_plan(f["lut"], f["segments"], t["blocks"], 8, 32, lib.F32, 1)
+    assert L.bsmm_plan_attach(ctypes.byref(a), words.ctypes.data_as(ip), words.size, ctypes.c_void_p(4096)) == 0
+    assert L.bsmm_prepared_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * t["blocks"] * 1024   # three bf16 pieces of every weight
+    assert L.bsmm_prepared_bytes(lib.OP_BPROP, ctypes.byref(a)) == 6 * t["blocks"] * 1024
+    assert L.bsmm_prepared_bytes(lib.OP_UPDAT, ctypes.byref(a)) == 0
+    ws_without = L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a))
+    a.prepared_w = 8192
+    assert ws_without - L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * t["blocks"] * 1024   # the call no longer splits W
+    one = ctypes.c_void_p(256)
+    assert L.bsmm_prepare_weights(lib.OP_UPDAT, one, one, ctypes.byref(a)) == -1
+    assert L.bsmm_prepare_weights(lib.OP_FPROP, None, one, ctypes.byref(a)) == -1
+    a.dtype = lib.BF16
+    assert L.bsmm_prepared_bytes(lib.OP_FPROP, ctypes.byref(a)) == 0
+    assert L.bsmm_prepare_weights(lib.OP_FPROP, one, one, ctypes.byref(a)) == -2
 
 
 def test_argument_validation_without_gpu(lib):

@@ -522,3 +522,41 @@ def test_inf_in_an_unconnected_feature_does_not_reach_the_output(env, bs, axis):
     for c in range(CB):
         blk = dx[:, c * bs:(c + 1) * bs] if axis else dx[c * bs:(c + 1) * bs, :]
         assert bool(torch.isfinite(blk).all()) == (lay[c, k_bad] == 0), ("bprop", bs, axis, c)
+
+
+def test_prepared_weights_cache_fp32(env):
+    """bsmm_prepare_weights: the bf16 pieces of constant fp32 weights are made once per parameter version; fprop / bprop with the
+    cached pieces give the same bits as a call that splits W itself, and an in-place update of W refreshes them."""
+    import ctypes
+    torch, BSMM, lib = env
+    lay = P.random_layout(40, 40, 0.2, seed=5)
+    b = BSMM(lay, block_size=32, feature_axis=1)
+    N = 4096
+    g = torch.Generator(device="cuda").manual_seed(2)
+    w = torch.randn(b.w_shape, device="cuda", generator=g) * 0.05
+    x = torch.randn(b.i_shape(N), device="cuda", generator=g) * 0.1
+    dy = torch.randn(b.o_shape(N), device="cuda", generator=g) * 0.1
+    lib.set_kernel_variant(3)
+    try:
+        y1, dx1 = b.fprop(x, w), b.bprop(dy, w)
+        assert lib.last_kernel() == lib.K_XCOL32_F32SPLIT and set(b._prepared_w) == {lib.OP_FPROP, lib.OP_BPROP}
+        keys = {k: v[0] for k, v in b._prepared_w.items()}
+        y2 = b.fprop(x, w)
+        assert torch.equal(y1, y2) and b._prepared_w[lib.OP_FPROP][0] == keys[lib.OP_FPROP]            # cache hit
+        # the uncached call (prepared_w = NULL: the library splits W into the workspace) gives the same bits
+        L = lib.load()
+        tabs = b._tables_on(x.device)
+        a = b._args(tabs.fprop, b._dev_tables["fprop"], N, b.C, b.K, x.dtype, plan=tabs.fprop_plan_f32)
+        ws = torch.empty(L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)), dtype=torch.uint8, device="cuda")
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        y3 = torch.empty_like(y1)
+        assert L.bsmm_fprop(x.data_ptr(), w.data_ptr(), y3.data_ptr(), ctypes.byref(a)) == 0
+        assert torch.equal(y1, y3)
+        w.mul_(2.0)                                                                                   # optimizer step: version changes
+        y4 = b.fprop(x, w)
+        assert b._prepared_w[lib.OP_FPROP][0] != keys[lib.OP_FPROP]
+        assert torch.allclose(y4, 2.0 * y1, rtol=1e-6, atol=1e-6)
+        dx2 = b.bprop(dy, w)
+        assert torch.allclose(dx2, 2.0 * dx1, rtol=1e-6, atol=1e-6)
+    finally:
+        lib.set_kernel_variant(0)
