@@ -1,5 +1,6 @@
 #!/bin/bash
-# rocprofv3 evidence for profiles/: kernel trace of the default bench run + PMC passes of the headline step at 10 / 20 / 50 %.
+# rocprofv3 evidence for profiles/ (round 3): per WORKLOAD (headline at 10 / 20 / 50 %, BASELINE configs[2], configs[3]) one kernel trace
+# and the PMC passes (separate runs: TCC has 4 slots, FETCH_SIZE costs 3, WRITE_SIZE 2), plus the unprofiled default bench line.
 # Runs on the GPU box (gpurun); every profiler invocation sits under its own `timeout`.  Output: gpurun_out/prof/*.
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
@@ -14,17 +15,20 @@ run_prof() {   # $1 = tag, $2.. = rocprofv3 options ; then -- command
   DB=$(find /tmp/rp_$tag -name "*results.db" | head -1)
   echo "$DB"
 }
-: > $OUT/status.txt
-# 1. kernel trace of a bench run with the extras (shorter than the default 200 steps; the averages do not depend on it)
-DB=$(run_prof trace --kernel-trace --stats -- python $REPO/bench.py --steps 60 --warmup 10 --no-cpu-baseline)
-[ -n "$DB" ] && python $REPO/scripts/rocpd_stats.py $DB $OUT/kernel_trace.md > /dev/null
-tail -1 /tmp/rp_trace/log.txt > $OUT/bench_line_profiled.json
-# 2. PMC passes per density (separate passes: TCC has 4 slots, FETCH_SIZE costs 3, WRITE_SIZE 2)
-for D in 0.1 0.2 0.5; do
+: > $OUT/status.txt; : > $OUT/pmc.txt
+python $REPO/bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+WORKLOADS=("d10|--density 0.1" "d20|--density 0.2" "d50|--density 0.5" "cfg2|--config cfg2" "cfg3|--config cfg3")
+for W in "${WORKLOADS[@]}"; do
+  KEY=${W%%|*}; ARGS=${W#*|}
+  # 1. kernel trace of this workload alone (so that "avg us" is one density's, not a mix)
+  DB=$(run_prof trace_$KEY --kernel-trace --stats -- python $REPO/bench.py $ARGS --no-extras --steps 100 --warmup 20)
+  [ -n "$DB" ] && python $REPO/scripts/rocpd_stats.py $DB $OUT/kernel_trace_$KEY.md > /dev/null
+  tail -1 /tmp/rp_trace_$KEY/log.txt > $OUT/bench_line_profiled_$KEY.json
+  # 2. PMC passes
   for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
-    tag="pmc_d${D}_$(echo $P | cut -d' ' -f1)"
-    DB=$(run_prof $tag --kernel-trace --pmc $P -- python $REPO/bench.py --density $D --steps 8 --warmup 2 --prewarm-seconds 0 --no-extras --no-cpu-baseline)
-    echo "## density $D pass: $P" >> $OUT/pmc.txt
+    tag="pmc_${KEY}_$(echo $P | cut -d' ' -f1)"
+    DB=$(run_prof $tag --kernel-trace --pmc $P -- python $REPO/bench.py $ARGS --steps 8 --warmup 2 --prewarm-seconds 0 --no-extras)
+    echo "## workload $KEY pass: $P" >> $OUT/pmc.txt
     [ -n "$DB" ] && python $REPO/scripts/rocpd_pmc.py $DB bsmm >> $OUT/pmc.txt 2>&1
   done
 done
