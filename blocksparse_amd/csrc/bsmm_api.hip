@@ -175,7 +175,7 @@ int launch_xcol16_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a
 }
 
 template <class DT, int AXIS>
-int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
     typedef typename DT::T T;
     const int n_out = a->K / 16;
     XMap m;
@@ -190,16 +190,28 @@ int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* 
         xcol16_v2_kernel<DT, AXIS, true><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                          a->N, a->C, a->K, a->gate);
     } else {
+#ifdef X7_POSITIONAL      // experiment builds: the round-2 inner loop (position tests instead of the plan's block lists)
         if (int rc = ensure_lds<&xcol16_v2_kernel<DT, AXIS, false>>(X7_LDS)) return rc;
         xcol16_v2_kernel<DT, AXIS, false><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                           a->N, a->C, a->K, nullptr);
+#else
+        if (transw) {
+            if (int rc = ensure_lds<&xcol16_list_kernel<DT, AXIS, true>>(X7_LDS)) return rc;
+            xcol16_list_kernel<DT, AXIS, true><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                              a->N, a->C, a->K);
+        } else {
+            if (int rc = ensure_lds<&xcol16_list_kernel<DT, AXIS, false>>(X7_LDS)) return rc;
+            xcol16_list_kernel<DT, AXIS, false><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                               a->N, a->C, a->K);
+        }
+#endif
     }
     return (int)hipGetLastError();
 }
 
 template <class DT, int AXIS>
-int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    if (a->plan_magic == X7PLAN_MAGIC) return a->plan_width == X7_G ? launch_xcol16_v2<DT, AXIS>(X, Wsel, Y, a, st) : BSMM_ERR_ARG;
+int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
+    if (a->plan_magic == X7PLAN_MAGIC) return a->plan_width == X7_G ? launch_xcol16_v2<DT, AXIS>(X, Wsel, Y, a, st, transw) : BSMM_ERR_ARG;
     if (a->plan_magic != XC16PLAN_MAGIC) return BSMM_ERR_ARG;
     if (a->plan_width == 32) return launch_xcol16_g<DT, AXIS, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
     if (a->plan_width == XC16_G) return launch_xcol16_g<DT, AXIS, 8, XC_PH>(X, Wsel, Y, a, st);
@@ -463,7 +475,12 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     size_t off = 0;
     const void* Wsel = W;
     const bool staged = path == XP_XCOL32 && a->plan_magic == X2PLAN_MAGIC;   // transposes the staged blocks itself
-    if (fprop && path != XP_VALU && !staged) {
+#ifdef X7_POSITIONAL
+    const bool staged16 = false;
+#else
+    const bool staged16 = path == XP_XCOL16 && a->plan_magic == X7PLAN_MAGIC && !a->gate;   // the list kernel reads them transposed
+#endif
+    if (fprop && path != XP_VALU && !staged && !staged16) {
         if constexpr (BS != 8) {
             if (!a->workspace || a->workspace_bytes < wt_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
             const int rc = launch_transpose<DT, BS>(W, a->workspace, a->blocks, st);
@@ -496,7 +513,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
             if constexpr (BS == 32 && DT::is16) rc = launch_xgroup32<DT, AXIS>(X, Wsel, Y, a, st, staged && fprop);
             break;
         case XP_XCOL16:
-            if constexpr (BS == 16 && DT::is16) rc = launch_xcol16<DT, AXIS>(X, Wsel, Y, a, st);
+            if constexpr (BS == 16 && DT::is16) rc = launch_xcol16<DT, AXIS>(X, Wsel, Y, a, st, staged16 && fprop);
             break;
         case XP_F32MFMA:
             if constexpr (BS == 32 && !DT::is16) rc = launch_xcol32f<AXIS>(X, Wsel, Y, a, st);
@@ -1010,6 +1027,9 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
 #ifdef BSMM_XC_TRACE
 int bsmm_debug_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_xc_trace), sizeof(bsmm::g_xc_trace)); }
 #endif
+#ifdef X7L_TRACE
+int bsmm_debug_x7_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x7_trace), sizeof(bsmm::g_x7_trace)); }
+#endif
 
 int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB, int32_t blocks, int32_t bsize,
                        float scale, int32_t dtype, void* stream) {
@@ -1170,8 +1190,9 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
         }
         return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float);   // fp32 partial sums of the split-minibatch path
     }
-    if (xprop_op && a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && a->plan_magic == XCPLAN_MAGIC)
-        return xcols_workspace_bytes(a);   // bf16 pieces of the activations and the weights (bsmm_xcols.h)
+    if (xprop_op && a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && a->plan_magic == XCPLAN_MAGIC)   // bf16 pieces of the activations and
+        return std::max(xcols_workspace_bytes(a), (op == BSMM_OP_FPROP ? wt_bytes(a) : 0) + lock);          // (unless prepared) the weights -- or what
+                                                                                                           // the kernels without a plan need, if the cost model sends the call there
     // fprop keeps a transposed copy of W (the matrix-core operand wants the contraction index contiguous)
     if (op == BSMM_OP_FPROP) return wt_bytes(a) + lock;
     if (op == BSMM_OP_BPROP) return lock;

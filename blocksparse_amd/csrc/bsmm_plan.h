@@ -312,21 +312,31 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
 // slots of 512 B).  Weight blocks are fetched two at a time (one 1 KiB DMA instruction = slots 2j and 2j+1), the instructions
 // dealt evenly over the 16 waves (<= 3 each).
 // Layout (int32): [0] magic 'BSX7' [1] version [2] X7_G [3] ngroups [4] nphases_total [5] off_groups [6] off_px
-//                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] X7_WCAP [10] max phases of a group
+//                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] X7_WCAP [10] max phases of a group [11] off_lists
 //   groups[ngroups][4] = (phase_off, nphases, first_out_block, n_out_blocks_in_group)
 //   px [nphases_total]           quad of step 0 | quad of step 1 << 16   (0xffff = no such step)
 //   tab[nphases_total][16][12]   per phase and wave:
 //        [0..3]  16 slot bytes: byte 8 * u + 4 * c + sub = slot of (step u, my output block c, input block sub of the quad), 0xff = none
 //        [4..9]  three DMA duties (A, B): A = first weight block | slot pair << 26 (or -1: no duty), B = second weight block
-//        [10..11] 0
+//        [10]    blocks of my column 0 in this phase | blocks of my column 1 << 8 | (i + 1) << 16 if I am issuer i (0..3) of the NEXT
+//                phase's requests during this phase  (version 2)
+//        [11]    0
+//   list section (version 2, at [11] off_lists), X7_PHW = 768 words per phase:
+//     [16][40] per wave: word 38 = tab word [10] of this phase, word 39 = tab word [10] of the next phase (0 behind the group's last), 32..37 zero; words 0..31 the blocks of column 0, then of column 1, in (step, input block) order, two words each:
+//        activation position bits = sub << 5 | sub << 12 | step << 14 (the kernel keeps the field of its feature axis: byte offset bits
+//        of the block's 16 features inside the slab pair), weight slot * 512
+//     [64][2]  the phase's requests as ONE lane-indexed table (xcol16_list_kernel: four waves issue all requests of a phase):
+//        entry k < npairs: byte offsets of the weight blocks of slots 2k and 2k+1 inside W;  entry 48: (px of the phase, npairs)
 // =================================================================================================
 namespace bsmm {
 
 constexpr int32_t X7PLAN_MAGIC = 0x42535837;
-constexpr int32_t X7PLAN_VERSION = 1;
+constexpr int32_t X7PLAN_VERSION = 2;
 constexpr int X7_G = 32;
 constexpr int X7_WCAP = 94;            // even; slot X7_WCAP of each ring half stays zero (the fragment of an absent block)
 constexpr int X7_ROW = 12;             // words per (phase, wave)
+constexpr int X7_LIST = 40;            // words of a (phase, wave) block list: 16 entries of two words, words 0..31 entries, 38 = counts | role, 39 = the same of the next phase
+constexpr int X7_PHW = 16 * X7_LIST + 128;   // words of a phase in the list section: 16 block lists, then the request table
 
 inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
@@ -344,7 +354,7 @@ inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int
             per_group[ob / G].push_back({c >> 2, ob % G, c & 3, w});
         }
     }
-    std::vector<int32_t> groups, px, tab;
+    std::vector<int32_t> groups, px, tab, lists;
     int max_ph = 0;
     for (int g = 0; g < ngroups; ++g) {
         auto& v = per_group[g];
@@ -367,6 +377,8 @@ inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int
             for (int wv = 0; wv < 16; ++wv)
                 for (int k = 0; k < 10; ++k) row[(size_t)wv * X7_ROW + k] = -1;
             std::vector<int32_t> ws;                 // weight block of every slot, in slot order
+            std::vector<int32_t> lrow((size_t)16 * X7_LIST, 0);
+            std::vector<int32_t> pend[32];           // list words per column of the group
             for (int u = 0; u < nst; ++u)
                 for (size_t i = steps[s + u].lo; i < steps[s + u].hi; ++i) {
                     const E& e = v[i];
@@ -375,7 +387,44 @@ inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int
                     const int byte = 8 * u + 4 * (e.col & 1) + e.sub;
                     uint32_t& word = reinterpret_cast<uint32_t&>(row[(size_t)(e.col >> 1) * X7_ROW + (byte >> 2)]);
                     word = (word & ~(0xffu << (8 * (byte & 3)))) | ((uint32_t)slot << (8 * (byte & 3)));
+                    pend[e.col].push_back((e.sub << 5) | (e.sub << 12) | (u << 14));
+                    pend[e.col].push_back(slot * 512);
                 }
+            for (int wv = 0; wv < 16; ++wv) {
+                const std::vector<int32_t>&c0 = pend[2 * wv], &c1 = pend[2 * wv + 1];       // <= 8 entries each (2 steps x 4 input blocks)
+                std::copy(c0.begin(), c0.end(), lrow.begin() + (size_t)wv * X7_LIST);
+                std::copy(c1.begin(), c1.end(), lrow.begin() + (size_t)wv * X7_LIST + c0.size());
+                row[(size_t)wv * X7_ROW + 10] = (int32_t)(c0.size() / 2) | ((int32_t)(c1.size() / 2) << 8);
+                row[(size_t)wv * X7_ROW + 11] = 0;
+            }
+            {   // the four waves that issue the requests of the NEXT phase during this one: a wave that issues is held for as long as the
+                // memory system takes to deliver the phase (~1500 cycles), so the job goes to the waves with the fewest blocks here
+                // (ties: rotate with the phase, so that no SIMD's waves are picked every time)
+                int order[16];
+                const int rot = (int)(px.size() * 5) % 16;
+                for (int i = 0; i < 16; ++i) order[i] = (i + rot) % 16;
+                std::stable_sort(order, order + 16, [&](int a, int b) {
+                    return pend[2 * a].size() + pend[2 * a + 1].size() < pend[2 * b].size() + pend[2 * b + 1].size(); });
+                for (int i = 0; i < 4; ++i) row[(size_t)order[i] * X7_ROW + 10] |= (i + 1) << 16;
+            }
+            {   // the same words inside the list rows (what xcol16_list_kernel reads): mine into word 38, and into word 39 of the previous phase
+                int32_t* mine = lrow.data();
+                for (int wv = 0; wv < 16; ++wv) mine[(size_t)wv * X7_LIST + 38] = row[(size_t)wv * X7_ROW + 10];
+                if ((int)px.size() - 1 > phase_off)
+                    for (int wv = 0; wv < 16; ++wv) (lists.data() + lists.size() - X7_PHW)[(size_t)wv * X7_LIST + 39] = row[(size_t)wv * X7_ROW + 10];
+            }
+            lists.insert(lists.end(), lrow.begin(), lrow.end());
+            {
+                std::vector<int32_t> req(128, 0);
+                const int npairs = (int)(ws.size() + 1) / 2;                     // <= X7_WCAP / 2 = 47
+                for (int k = 0; k < npairs; ++k) {
+                    req[2 * k] = (int32_t)((uint32_t)ws[2 * k] * 512u);
+                    req[2 * k + 1] = (int32_t)((uint32_t)((size_t)(2 * k + 1) < ws.size() ? ws[2 * k + 1] : ws[2 * k]) * 512u);
+                }
+                req[96] = px.back();
+                req[97] = npairs;
+                lists.insert(lists.end(), req.begin(), req.end());
+            }
             int duty = (int)(px.size() * 5) % 16;
             std::vector<int> nduty(16, 0);
             for (size_t pair = 0; 2 * pair < ws.size(); ++pair) {
@@ -394,15 +443,18 @@ inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int
     }
     const int off_groups = XC_HDR, off_px = off_groups + (int)groups.size();
     const int off_tab = (off_px + (int)px.size() + 3) & ~3;
-    const long total = off_tab + (long)tab.size();
+    const long off_lists = off_tab + (long)tab.size();
+    const long total = off_lists + (long)lists.size();
+    if (total >= (1L << 31)) return 0;
     if (out) {
         std::fill(out, out + off_tab, 0);
         const int32_t hdr[XC_HDR] = {X7PLAN_MAGIC, X7PLAN_VERSION, G, ngroups, (int32_t)px.size(), off_groups, off_px, off_tab,
-                                     n_out_blocks, X7_WCAP, max_ph, 0};
+                                     n_out_blocks, X7_WCAP, max_ph, (int32_t)off_lists};
         std::copy(hdr, hdr + XC_HDR, out);
         std::copy(groups.begin(), groups.end(), out + off_groups);
         std::copy(px.begin(), px.end(), out + off_px);
         std::copy(tab.begin(), tab.end(), out + off_tab);
+        std::copy(lists.begin(), lists.end(), out + off_lists);
     }
     return total;
 }

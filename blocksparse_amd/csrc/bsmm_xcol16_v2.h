@@ -32,6 +32,55 @@ constexpr int X7_WBASE = 2 * X7_XHALF;
 constexpr int X7_LDS = X7_WBASE + 2 * X7_WHALF;        // 160 KiB
 static_assert(X7_LDS <= 163840 && XC_R * X7_G * 32 <= X7_LDS && X7_WCAP % 2 == 0, "ring and epilogue tile must fit the LDS");
 
+// D[o][n] of a wave's 2 x 8 accumulator tiles: col = n = lane & 15 (row of tile tt), rows o = 4q + reg
+template <class DT, int AXIS>
+__device__ __forceinline__ void x7_epilogue(f32x4 (&acc)[2][8], unsigned char* smem, typename DT::T* __restrict__ Y, int lane, int wave, int n_tile,
+                                            int ob0, int nob, int N, int Kout) {
+    typedef typename DT::T T;
+    const int o16 = lane & 15, q = lane >> 4;
+    const bool own0 = 2 * wave < nob, own1 = 2 * wave + 1 < nob;
+    if constexpr (AXIS == 1) {
+        constexpr int ROWB = X7_G * 32;       // staged through LDS and stored as full rows (see xcol32_a1_kernel)
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (!((c == 0) ? own0 : own1)) continue;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int n = 16 * tt + o16;
+                const uint32_t lo = (uint32_t)DT::from_f32(acc[c][tt][0]) | ((uint32_t)DT::from_f32(acc[c][tt][1]) << 16);
+                const uint32_t hi = (uint32_t)DT::from_f32(acc[c][tt][2]) | ((uint32_t)DT::from_f32(acc[c][tt][3]) << 16);
+                const int piece = (2 * wave + c) * 2 + (q >> 1);
+                *reinterpret_cast<uint2*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4) + 8 * (q & 1)) = make_uint2(lo, hi);
+            }
+        }
+        __syncthreads();
+        const int rowbytes = nob * 32;
+        T* ybase = Y + (size_t)ob0 * 16;
+        constexpr int PPR = ROWB / 16;
+        for (int i = threadIdx.x; i < XC_R * PPR; i += 1024) {
+            const int n = i / PPR, piece = i % PPR;
+            if (n_tile + n < N && piece * 16 < rowbytes) {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)(n_tile + n) * Kout) + piece * 16) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (!((c == 0) ? own0 : own1)) continue;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int n = n_tile + 16 * tt + o16;
+                if (n >= N) continue;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    Y[(size_t)((ob0 + 2 * wave + c) * 16 + 4 * q + reg) * N + n] = DT::from_f32(acc[c][tt][reg]);
+            }
+        }
+    }
+}
+
 // GATED: per-block fp32 gates (the reference gates all three tensor-core block sizes, src/blocksparse_hgemm_cn_64_op_gpu.cu:256-717).
 // The wave that requests a pair of weight blocks also fetches their gates into the ring half's gate table (the two spare slots);
 // a block with gate 0 is treated as absent, gate 1 takes the plain path, otherwise g * w is formed per fragment element in fp32 and
@@ -151,15 +200,20 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
 #define X7_WDUTY(a_, b_)                                                                                                   \
     if ((a_) != -1) {                                                                                                       \
         const uint32_t oa = ((uint32_t)(a_) & 0x3ffffffu) << 9, ob = (uint32_t)(b_) << 9;                                   \
-        glds16_saddr(wsel, (lane < 32 ? oa : ob) + wlane, wdst + (((uint32_t)(a_) >> 26) << 10));                           \
+        X7_DMA(wsel, (lane < 32 ? oa : ob) + wlane, wdst + (((uint32_t)(a_) >> 26) << 10));                           \
     }
+#ifdef X7_NO_DMA        // ablation builds (scripts/build_variants.py): what is left without the DMA / without the matrix work
+#define X7_DMA(b_, v_, d_) asm volatile("" ::"s"(b_), "v"(v_), "s"(d_))
+#else
+#define X7_DMA(b_, v_, d_) glds16_saddr(b_, v_, d_)
+#endif
 #define X7_ISSUE(px_, d_, hb_)                                                                                              \
     do {                                                                                                                    \
         const uint32_t xdst = base_addr + (hb_) * X7_XHALF + wave * 1024;                                                   \
         const uint32_t wdst = base_addr + X7_WBASE + (hb_) * X7_WHALF;                                                      \
         const int p0 = (px_) & 0xffff, p1 = (int)((uint32_t)(px_) >> 16);                                                   \
-        glds16_saddr(xtile + (size_t)p0 * xstep, p0 < nquads_full ? xvoff : xvoff_tail, xdst);                              \
-        if (p1 != 0xffff) glds16_saddr(xtile + (size_t)p1 * xstep, p1 < nquads_full ? xvoff : xvoff_tail, xdst + X7_SLAB);  \
+        X7_DMA(xtile + (size_t)p0 * xstep, p0 < nquads_full ? xvoff : xvoff_tail, xdst);                              \
+        if (p1 != 0xffff) X7_DMA(xtile + (size_t)p1 * xstep, p1 < nquads_full ? xvoff : xvoff_tail, xdst + X7_SLAB);  \
         X7_WDUTY(d_[0], d_[1]) X7_WDUTY(d_[2], d_[3]) X7_WDUTY(d_[4], d_[5])                                                \
     } while (0)
 
@@ -204,6 +258,9 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
                 const unsigned char* wring = smem + X7_WBASE + hb * X7_WHALF;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
+#ifdef X7_NO_COMPUTE
+                    if (N != 12345) continue;
+#endif
                     if ((cw[2 * u] & cw[2 * u + 1]) == 0xffffffffu) continue;        // nothing of mine in this step
                     const unsigned char* slab = smem + hb * X7_XHALF + u * X7_SLAB;
 #pragma unroll
@@ -286,52 +343,295 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             }
         }
     }
-#undef X7_ISSUE
-#undef X7_FETCH_GATES
-#undef X7_WDUTY
+    x7_epilogue<DT, AXIS>(acc, smem, Y, lane, wave, n_tile, ob0, nob, N, Kout);
+}
 
-    const bool own0 = 2 * wave < nob, own1 = 2 * wave + 1 < nob;
-    // D[o][n]: col = n = lane & 15 (row of tile tt), rows o = 4q + reg
-    if constexpr (AXIS == 1) {
-        constexpr int ROWB = X7_G * 32;       // staged through LDS and stored as full rows (see xcol32_a1_kernel)
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (!((c == 0) ? own0 : own1)) continue;
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const int n = 16 * tt + o16;
-                const uint32_t lo = (uint32_t)DT::from_f32(acc[c][tt][0]) | ((uint32_t)DT::from_f32(acc[c][tt][1]) << 16);
-                const uint32_t hi = (uint32_t)DT::from_f32(acc[c][tt][2]) | ((uint32_t)DT::from_f32(acc[c][tt][3]) << 16);
-                const int piece = (2 * wave + c) * 2 + (q >> 1);
-                *reinterpret_cast<uint2*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4) + 8 * (q & 1)) = make_uint2(lo, hi);
-            }
+// ------------------------------------------------------------------------------------------------------------------
+// List-driven variant ('BSX7' plans of version 2 carry, per phase and wave, the blocks of the wave's two columns as a LIST, and per
+// phase ONE request table).  What the ablation builds and cycle stamps of the kernel above said (profiles/r03_x7_*.txt, 4096^2 /
+// 10 % / N = 8192): without the DMAs the pass still takes 106-117 of its 114-128 us, without the matrix work 62-71 -- the pass
+// is bound by how a wave gets through a phase, not by delivery:
+//   * per block one dependent chain  scalar position test -> weight fragment read -> 8 fragment reads -> 8 MFMAs, nothing of the
+//     next block in flight, 16 position tests per phase for 1.6 blocks;
+//   * the request section in front of it: every wave issues 2-5 LDS-DMA instructions behind ~60 scalar instructions; with 16 waves
+//     issuing at once an instruction holds its wave ~120 cycles (scripts/micro/dma_issue2.hip) and a SIMD issues one scalar
+//     instruction per four cycles: 700-1900 cycles per phase in which the wave multiplies nothing.
+// Here:
+//   * a wave that issues requests is HELD by them: the memory pipeline takes them only as fast as it delivers (a phase's 45 KB at
+//     ~30 B/clk = ~1500 cycles).  So FOUR waves issue ALL requests of the next phase from one lane-indexed table -- the four with
+//     the fewest blocks in the current phase, named by the plan (one in five (wave, phase) pairs has no block at all at 10 %) --
+//     and the other twelve go from the barrier straight to their blocks;
+//   * the plan lists a wave's blocks per column (words: activation-slab bits, weight slot offset), the row of the NEXT phase is
+//     fetched lane-indexed with one load during the current one, a visit costs two v_readlane and a handful of vector ops;
+//   * a visit is software-pipelined in halves of 4 row tiles: [reads tiles 4-7 of e] [4 MFMAs tiles 0-3] [reads weights and
+//     tiles 0-3 of e + 1] [4 MFMAs tiles 4-7];
+//   * every block is multiplied on its own by the K = 16 instruction (a pair of blocks = two visits).
+// Activation fragment address: lane part XOR (position bits | slab bit | ring-half bit) -- the swizzles of both slab layouts are
+// XORs of disjoint bit fields, see xfrag16 above; tile tt: + 2048 tt (axis 1) / XOR 32 tt (axis 0).
+// ------------------------------------------------------------------------------------------------------------------
+#ifdef X7L_TRACE
+// cycle stamps of the first 8 workgroups: [wg][wave][phase < 40][5] = top, after the wait, after the barrier, after the requests,
+// after the list (s_memtime); read back with bsmm_debug_x7_trace_copy().  Debug builds only.
+__device__ unsigned long long g_x7_trace[8 * 16 * 40 * 5];
+#define X7L_STAMP(k) do { if (blockIdx.x < 8 && ph < 40 && lane == 0) g_x7_trace[((blockIdx.x * 16 + wave) * 40 + ph) * 5 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define X7L_STAMP(k) do { } while (0)
+#endif
+#ifdef X7_NO_DMA
+#define X7L_DMA4(b_, v0_, v1_, v2_, v3_, d_) asm volatile("" ::"s"(b_), "v"(v0_), "v"(v1_), "v"(v2_), "v"(v3_), "s"(d_))
+#else
+#define X7L_DMA4(b_, v0_, v1_, v2_, v3_, d_) glds16_saddr_x4(b_, v0_, v1_, v2_, v3_, d_)
+#endif
+// TRANSW: the staged blocks are W's own (fprop multiplies by the transpose): the weight fragment is then read with the transposing
+// read -- 16-lane group q points at rows 4q .. 4q+3 of the 16 x 16 block, lane t receives column t -- instead of from a transposed
+// copy of W that a pre-pass wrote (5.5 us and a launch per fprop at BASELINE configs[2]).
+template <class DT, int AXIS, bool TRANSW>
+__global__ void __launch_bounds__(1024, 4)
+xcol16_list_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel,
+                   typename DT::T* __restrict__ Y, const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "xcol16 list kernel: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile, grp;
+    if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
+    const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
+    const int ph_off = __builtin_amdgcn_readfirstlane(gh.x), nph = __builtin_amdgcn_readfirstlane(gh.y);
+    const int ob0 = __builtin_amdgcn_readfirstlane(gh.z), nob = __builtin_amdgcn_readfirstlane(gh.w);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // list section of my group: per phase X7_PHW words = [16 waves][X7_LIST] block lists, [64][2] request table
+    const unsigned char* sect = static_cast<const unsigned char*>(uniform_ptr(plan + plan[11] + (size_t)ph_off * X7_PHW));
+    const uint32_t llane = (uint32_t)(wave * X7_LIST + min(lane, X7_LIST - 1)) * 4u;    // my word of my list row (lanes 0..39 are read)
+    const uint32_t rlane = (uint32_t)(16 * X7_LIST + 2 * lane) * 4u;                     // my entry of the request table
+    const int o16 = lane & 15, q = lane >> 4;
+    const int n_tile = tile * XC_R;
+    const uint32_t base_addr = lds_addr_of(smem);
+    const int nquads_full = Cin / 64;
+
+    // activation requests: issuer iss fetches pieces 4 iss .. 4 iss + 3 (1 KiB each) of every slab of the phase; geometry of a piece
+    // as in xcol16_v2_kernel (there: piece = wave)
+    const uint32_t xrow_bytes = AXIS == 1 ? (uint32_t)Cin * 2u : (uint32_t)N * 2u;
+    auto x_offset = [&](int iss, int e, bool tail) -> uint32_t {
+        const int j = 4 * iss + e;
+        if constexpr (AXIS == 1) {
+            const int row = 8 * j + (lane >> 3);
+            const int xr = min(n_tile + row, N - 1) - n_tile;
+            const int piece = (lane & 7) ^ ((row >> 1) & 7);
+            const uint32_t v = (uint32_t)xr * xrow_bytes + piece * 16;
+            // a trailing quad may lack blocks (Cin % 64 != 0): pieces past the row end re-read the row's last 16 bytes
+            return tail ? v - 2u * (uint32_t)max(0, nquads_full * 64 + piece * 8 + 8 - Cin) : v;
+        } else {
+            const int row = 4 * j + (lane >> 4);
+            const int piece = (lane & 15) ^ (4 * (row & 3));
+            const int col = min(n_tile + piece * 8, N - 8) - n_tile;
+            return (uint32_t)(tail ? min(row, max(0, Cin - nquads_full * 64 - 1)) : row) * xrow_bytes + (uint32_t)col * 2u;
         }
-        __syncthreads();
-        const int rowbytes = nob * 32;
-        T* ybase = Y + (size_t)ob0 * 16;
-        constexpr int PPR = ROWB / 16;
-        for (int i = threadIdx.x; i < XC_R * PPR; i += 1024) {
-            const int n = i / PPR, piece = i % PPR;
-            if (n_tile + n < N && piece * 16 < rowbytes) {
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4));
-                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)(n_tile + n) * Kout) + piece * 16) = v;
+    };
+    const size_t xstep = AXIS == 1 ? (size_t)128 : (size_t)N * 128;
+    const unsigned char* xtile = static_cast<const unsigned char*>(
+        uniform_ptr(reinterpret_cast<const unsigned char*>(X) + (AXIS == 1 ? (size_t)n_tile * Cin * 2 : (size_t)n_tile * 2)));
+    const unsigned char* wsel = static_cast<const unsigned char*>(uniform_ptr(Wsel));
+    const uint32_t wlane = (uint32_t)(lane & 31) * 16u;
+
+    // fragment addressing (LDS byte addresses; the ring half is folded into the lane parts once per phase)
+    const int t16 = lane & 15, trow = t16 >> 2;
+    uint32_t xl;          // lane part of the activation fragment address, tile 0
+    if constexpr (AXIS == 1) xl = (uint32_t)(o16 * 128 + ((((q >> 1) ^ ((o16 >> 1) & 7))) << 4) + (q & 1) * 8);
+    else                     xl = (uint32_t)((4 * q + trow) * XC0_ROWB + (((((t16 & 3) >> 1) ^ (4 * trow))) << 4) + 8 * (t16 & 1));
+    const uint32_t wl = (uint32_t)(X7_WBASE + (TRANSW ? (4 * q + trow) * 32 + (t16 & 3) * 8 : o16 * 32 + q * 8));
+    auto wread = [&](uint32_t wa) -> uint2 {
+        if constexpr (TRANSW) return ds_tr16(smem + wa);
+        else                  return *reinterpret_cast<const uint2*>(smem + wa);
+    };
+    constexpr uint32_t XMASK = AXIS == 1 ? ((3u << 5) | (1u << 14)) : ((3u << 12) | (1u << 14));
+    auto xread = [&](uint32_t xa, int tt) -> uint2 {
+        if constexpr (AXIS == 1) return *reinterpret_cast<const uint2*>(smem + xa + 2048 * tt);
+        else                     return ds_tr16(smem + (xa ^ (uint32_t)(tt << 5)));
+    };
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // all requests of one phase (table row in rA / rB: lane k = byte offsets of the blocks of slots 2k, 2k+1; lane 48 = px, npairs)
+    // into ring half hb_: my four pieces of each activation slab, and every fourth pair of weight blocks
+#define X7L_REQUESTS(rA_, rB_, hb_, iss_)                                                                                        \
+    do {                                                                                                                         \
+        const uint32_t px_ = (uint32_t)__builtin_amdgcn_readlane(rA_, 48);                                                       \
+        const int np_ = __builtin_amdgcn_readlane(rB_, 48);                                                                      \
+        const int p0_ = px_ & 0xffff, p1_ = (int)(px_ >> 16);                                                                    \
+        const uint32_t xdst_ = base_addr + (hb_) * X7_XHALF + (iss_) * 4096;                                                     \
+        {                                                                                                                        \
+            const bool t_ = p0_ >= nquads_full;                                                                                  \
+            X7L_DMA4(xtile + (size_t)p0_ * xstep, x_offset(iss_, 0, t_), x_offset(iss_, 1, t_), x_offset(iss_, 2, t_), x_offset(iss_, 3, t_), xdst_); \
+        }                                                                                                                        \
+        if (p1_ != 0xffff) {                                                                                                     \
+            const bool t_ = p1_ >= nquads_full;                                                                                  \
+            X7L_DMA4(xtile + (size_t)p1_ * xstep, x_offset(iss_, 0, t_), x_offset(iss_, 1, t_), x_offset(iss_, 2, t_), x_offset(iss_, 3, t_), xdst_ + X7_SLAB); \
+        }                                                                                                                        \
+        const uint32_t wdst_ = base_addr + X7_WBASE + (hb_) * X7_WHALF;                                                          \
+        for (int k_ = (iss_); k_ < np_; k_ += 4) {                                                                               \
+            const uint32_t oa_ = (uint32_t)__builtin_amdgcn_readlane(rA_, k_), ob_ = (uint32_t)__builtin_amdgcn_readlane(rB_, k_); \
+            X7_DMA(wsel, (lane < 32 ? oa_ : ob_) + wlane, wdst_ + (uint32_t)k_ * 1024u);                                         \
+        }                                                                                                                        \
+    } while (0)
+    // (plain loads between asm statements with memory clobbers: they stay where they are written, and their first use is the copy at
+    //  the loop's back edge, i.e. the compiler's own wait lands next to the vmcnt(0) at the top of the next phase.  Loading through
+    //  inline asm instead lets the compiler copy the destination register while the data is still in flight.
+    //  The pointers are cast to the global address space: a FLAT load would also count on lgkmcnt and stall the fragment reads.)
+    typedef const uint32_t __attribute__((address_space(1))) * gptr1_t;
+    typedef const unsigned long long __attribute__((address_space(1))) * gptr2_t;
+#define X7L_LOAD1(dst_, voff_, base_) dst_ = *reinterpret_cast<gptr1_t>(reinterpret_cast<uintptr_t>((base_) + (voff_)))
+#define X7L_LOAD2(dst_, voff_, base_)                                                                                             \
+    do {                                                                                                                         \
+        const unsigned long long t_ = *reinterpret_cast<gptr2_t>(reinterpret_cast<uintptr_t>((base_) + (voff_)));                \
+        dst_ = make_uint2((uint32_t)t_, (uint32_t)(t_ >> 32));                                                                   \
+    } while (0)
+#ifdef X7L_NO_PHASES
+    if (nph > 0 && N == 12345) {
+#else
+    if (nph > 0) {
+#endif
+        uint32_t lnext;                 // my words of my list row of the next phase (lane-indexed)
+        uint2 rnext = make_uint2(0u, 0u);   // request table of the phase after the next, if its requests will be mine
+        {   // prologue: the requests of phase 0 (by waves 12..15) into ring half 0; the issuers of phase 0 fetch the table of phase 1
+            if (wave >= 12) {
+                uint2 r0;
+                X7L_LOAD2(r0, rlane, sect);
+                X7L_REQUESTS(r0.x, r0.y, 0, wave & 3);
             }
+            if (((uint32_t)reinterpret_cast<const int32_t*>(sect)[wave * X7_LIST + 38] >> 16) != 0 && nph > 1) {
+                const unsigned char* nrow = static_cast<const unsigned char*>(uniform_ptr(sect + (size_t)X7_PHW * 4));
+                X7L_LOAD2(rnext, rlane, nrow);
+            }
+            X7L_LOAD1(lnext, llane, sect);
         }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (!((c == 0) ? own0 : own1)) continue;
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const int n = n_tile + 16 * tt + o16;
-                if (n >= N) continue;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    Y[(size_t)((ob0 + 2 * wave + c) * 16 + 4 * q + reg) * N + n] = DT::from_f32(acc[c][tt][reg]);
+        int hb = 0;
+#pragma unroll 1
+        for (int ph = 0; ph < nph; ++ph) {
+            X7L_STAMP(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my requests for this phase have landed (my list row and request table too)
+            const uint32_t lcur = lnext;
+            X7L_STAMP(1);
+            __builtin_amdgcn_s_barrier();                        // everyone's have; everyone left the previous phase
+            X7L_STAMP(2);
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane(lcur, 38);   // blocks of my columns | my role in this phase
+            if (ph + 1 < nph) {
+                const unsigned char* nrow = static_cast<const unsigned char*>(uniform_ptr(sect + (size_t)(ph + 1) * (X7_PHW * 4)));
+                const int my_iss = (int)((cnt >> 16) & 0xff);
+                if (my_iss != 0) X7L_REQUESTS(rnext.x, rnext.y, hb ^ 1, my_iss - 1);
+                // (after my requests: a wave that issues in two consecutive phases reads the old table first)
+                if ((((uint32_t)__builtin_amdgcn_readlane(lcur, 39) >> 16) & 0xff) != 0 && ph + 2 < nph) X7L_LOAD2(rnext, rlane, nrow + X7_PHW * 4);
+                X7L_LOAD1(lnext, llane, nrow);
             }
+                X7L_STAMP(3);
+#ifdef X7_NO_COMPUTE
+                const int n0 = N != 12345 ? 0 : (cnt & 0xff), n1 = N != 12345 ? 0 : ((cnt >> 8) & 0xff);
+#else
+                const int n0 = cnt & 0xff, n1 = (cnt >> 8) & 0xff;
+#endif
+                if (n0 + n1 > 0) {
+#ifdef X7L_FULL_AHEAD
+                    // one block ahead: the 9 fragment reads of block e + 1 are issued before the 8 MFMAs of block e, two register sets
+                    const uint32_t xlh = xl ^ (uint32_t)(hb << 15), wlh = wl + (uint32_t)(hb * X7_WHALF);
+                    uint2 wA, wB, fA[8], fB[8];
+#define X7_FETCH(W_, F_, e_)                                                                                                     \
+    do {                                                                                                                         \
+        const uint32_t sx_ = (uint32_t)__builtin_amdgcn_readlane(lcur, 2 * (e_)) & XMASK, sw_ = (uint32_t)__builtin_amdgcn_readlane(lcur, 2 * (e_) + 1); \
+        const uint32_t xa_ = xlh ^ sx_;                                                                                          \
+        W_ = wread(wlh + sw_);                                                                  \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t) F_[t] = xread(xa_, t);                                                     \
+    } while (0)
+#define X7_VISIT(C)                                                                                                              \
+    do {                                                                                                                         \
+        ++e;                                                                                                                     \
+        X7_FETCH(wB, fB, e);                  /* (past the end: zero words of the row's tail -- a valid address, not used) */     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t) acc[C][t] = DT::mfma16k16(wA, fA[t], acc[C][t]);                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        wA = wB;                                                                                                                 \
+        _Pragma("unroll") for (int t = 0; t < 8; ++t) fA[t] = fB[t];                                                             \
+    } while (0)
+                    X7_FETCH(wA, fA, 0);
+                    int e = 0;
+#pragma unroll 1
+                    for (int k = 0; k < n0; ++k) X7_VISIT(0);
+#pragma unroll 1
+                    for (int k = 0; k < n1; ++k) X7_VISIT(1);
+#undef X7_VISIT
+#undef X7_FETCH
+#else
+                    // software pipeline in halves of 4 row tiles: [reads tiles 4-7 of e] [4 MFMAs tiles 0-3] [reads weights and tiles 0-3 of
+                    // e + 1] [4 MFMAs tiles 4-7].  (Measured: fetching the whole next block ahead -- X7L_FULL_AHEAD, two register sets and 9
+                    // 64-bit moves per block -- is slower, 91 against 81 us.)
+                    const uint32_t xlh = xl ^ (uint32_t)(hb << 15), wlh = wl + (uint32_t)(hb * X7_WHALF);
+                    int e = 0;
+                    uint2 w, xA[4], xB[4];
+                    uint32_t xa;
+                    {
+                        const uint32_t sx = (uint32_t)__builtin_amdgcn_readlane(lcur, 0) & XMASK, sw = (uint32_t)__builtin_amdgcn_readlane(lcur, 1);
+                        xa = xlh ^ sx;
+                        w = wread(wlh + sw);
+#ifndef X7L_NO_READS
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) xA[t] = xread(xa, t);
+#else
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) xA[t] = make_uint2(xa, xa + t);
+#endif
+                    }
+#ifndef X7L_NO_READS
+#define X7L_XREAD(a_, t_) xread(a_, t_)
+#else
+#define X7L_XREAD(a_, t_) make_uint2(a_, a_ + t_)
+#endif
+#ifndef X7L_NO_MFMA
+#define X7L_MFMA(w_, x_, c_) c_ = DT::mfma16k16(w_, x_, c_)
+#else
+#define X7L_MFMA(w_, x_, c_) asm volatile("" : "+v"(c_) : "v"(w_), "v"(x_))
+#endif
+#define X7_VISIT(C)                                                                                                              \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) xB[t] = X7L_XREAD(xa, 4 + t);                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) X7L_MFMA(w, xA[t], acc[C][t]);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        ++e;                                                                                                                     \
+        const uint32_t sx_ = (uint32_t)__builtin_amdgcn_readlane(lcur, 2 * e) & XMASK, sw_ = (uint32_t)__builtin_amdgcn_readlane(lcur, 2 * e + 1); \
+        xa = xlh ^ sx_;                                                                                                          \
+        const uint2 wn_ = wread(wlh + sw_);                                                     \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) xA[t] = X7L_XREAD(xa, t);                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) X7L_MFMA(w, xB[t], acc[C][4 + t]);                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        w = wn_;                                                                                                                 \
+    } while (0)
+#pragma unroll 1
+                    for (int k = 0; k < n0; ++k) X7_VISIT(0);
+#pragma unroll 1
+                    for (int k = 0; k < n1; ++k) X7_VISIT(1);
+#undef X7_VISIT
+#undef X7L_XREAD
+#undef X7L_MFMA
+#endif
+                }
+            X7L_STAMP(4);
+            hb ^= 1;
         }
     }
+#undef X7L_REQUESTS
+#undef X7L_LOAD1
+#undef X7L_LOAD2
+    x7_epilogue<DT, AXIS>(acc, smem, Y, lane, wave, n_tile, ob0, nob, N, Kout);
 }
+
+#undef X7L_DMA4
+#undef X7L_STAMP
+#undef X7_ISSUE
+#undef X7_DMA
+#undef X7_FETCH_GATES
+#undef X7_WDUTY
 
 }  // namespace bsmm

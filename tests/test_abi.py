@@ -260,7 +260,9 @@ def test_staged_xcol_plan(lib):
 def test_staged_xcol16_plan(lib):
     """'BSX7' plans (default for bsize 16, 16-bit; bsmm_xcol16_v2.h): every lut entry is multiplied exactly once, by the wave that
     owns its output block, from a slot of the phase's ring half that exactly one DMA duty fills with that weight block (a duty
-    fetches two blocks into slots 2j, 2j+1); phases hold <= 2 steps and <= WCAP blocks, waves <= 3 duties."""
+    fetches two blocks into slots 2j, 2j+1); phases hold <= 2 steps and <= WCAP blocks, waves <= 3 duties.  Version 2: the block
+    LIST of every (phase, wave) -- what xcol16_list_kernel walks -- names the same (position, slot) set as the slot bytes, column 0
+    first, with the counts in word 10; the phase's request table (what four waves issue for everyone) repeats the duties' slot map."""
     import numpy as np
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_plan
@@ -273,7 +275,10 @@ def test_staged_xcol16_plan(lib):
             for side, n_out in (("fprop", KB), ("bprop", CB)):
                 f = t[side]
                 plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis)
-                assert plan[0] == 0x42535837 and int(plan[2]) == 32 and plan[8] == n_out and plan[7] % 4 == 0
+                assert plan[0] == 0x42535837 and int(plan[1]) == 2 and int(plan[2]) == 32 and plan[8] == n_out and plan[7] % 4 == 0
+                sect = plan[plan[11]:plan[11] + int(plan[4]) * 768].reshape(-1, 768)
+                assert int(plan[11]) + sect.size == plan.size
+                lists, reqs = sect[:, :640].reshape(-1, 16, 40), sect[:, 640:].reshape(-1, 64, 2)
                 WCAP = int(plan[9])
                 groups = plan[plan[5]:plan[5] + 4 * int(plan[3])].reshape(-1, 4)
                 px = plan[plan[6]:plan[6] + int(plan[4])]
@@ -294,9 +299,10 @@ def test_staged_xcol16_plan(lib):
                                 pair = a >> 26
                                 assert 2 * pair + 1 < WCAP and 2 * pair not in slots
                                 slots[2 * pair], slots[2 * pair + 1] = a & 0x3ffffff, b
-                            assert (tab[ph, wave, 10:] == 0).all()
+                            assert tab[ph, wave, 11] == 0
                         used = set()
                         for wave in range(16):
+                            by_bytes = [[], []]
                             for byte in range(16):
                                 sl = (int(tab[ph, wave, byte >> 2]) >> (8 * (byte & 3))) & 0xff
                                 if sl == 0xff:
@@ -306,7 +312,29 @@ def test_staged_xcol16_plan(lib):
                                 assert col < nob and quads[u] != 0xffff and sl in slots and sl not in used
                                 used.add(sl)
                                 got.add((ob0 + col, 4 * quads[u] + sub, slots[sl]))
+                                by_bytes[c].append((u, sub, sl))
+                            n0, n1 = int(tab[ph, wave, 10]) & 0xff, (int(tab[ph, wave, 10]) >> 8) & 0xff
+                            assert (n0, n1) == (len(by_bytes[0]), len(by_bytes[1])) and int(tab[ph, wave, 10]) >> 19 == 0
+                            words = lists[ph, wave]
+                            ent = [((int(words[2 * e]) >> 14) & 1, (int(words[2 * e]) >> 5) & 3, int(words[2 * e + 1]) // 512) for e in range(n0 + n1)]
+                            for e in range(n0 + n1):
+                                sub = (int(words[2 * e]) >> 5) & 3
+                                assert int(words[2 * e]) == (sub << 5 | sub << 12 | ent[e][0] << 14) and int(words[2 * e + 1]) % 512 == 0
+                            assert ent[:n0] == sorted(by_bytes[0]) and ent[n0:] == sorted(by_bytes[1]) and (words[2 * (n0 + n1):38] == 0).all()
+                            # the row carries the wave's counts | role word of this phase and of the next one of the group
+                            assert words[38] == tab[ph, wave, 10] and words[39] == (tab[ph + 1, wave, 10] if ph + 1 < po + nph else 0)
                         assert len(used) <= WCAP and set(slots) - used <= {max(slots)}      # at most the padded partner of the last pair
+                        # four waves issue the next phase's requests: issuers 0..3, each once, none busier than a wave that does not issue
+                        load = [(int(tab[ph, w_, 10]) & 0xff) + ((int(tab[ph, w_, 10]) >> 8) & 0xff) for w_ in range(16)]
+                        role = [(int(tab[ph, w_, 10]) >> 16) & 0xff for w_ in range(16)]
+                        assert sorted(r for r in role if r) == [1, 2, 3, 4]
+                        assert max(l for l, r in zip(load, role) if r) <= min(l for l, r in zip(load, role) if not r)
+                        # the request table names the same (slot -> weight block) map, pairs in slot order, and the phase's quads
+                        npairs = int(reqs[ph, 48, 1])
+                        assert int(reqs[ph, 48, 0]) == int(px[ph]) and npairs == (len(slots) + 1) // 2 and npairs <= 47
+                        for k in range(npairs):
+                            assert int(reqs[ph, k, 0]) == slots[2 * k] * 512 and int(reqs[ph, k, 1]) == slots[2 * k + 1] * 512
+                        assert (reqs[ph, npairs:48] == 0).all() and (reqs[ph, 49:] == 0).all()
                 want = {(ob, c, w) for ob, col in f["cols"] for c, w in col}
                 assert got == want
 
