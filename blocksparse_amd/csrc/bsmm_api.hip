@@ -89,7 +89,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (reinterpret_cast<uintptr_t>(a->plan) & 15) return BSMM_ERR_ARG;
     const int32_t m = a->plan_magic;
     if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
-    if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32 && a->axis == 1)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
+    if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 16) return ((m == XC16PLAN_MAGIC || (m == X7PLAN_MAGIC && a->plan_width == X7_G)) && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return ((m == XCPLAN_MAGIC && a->plan_width == XS_G) || m == XFPLAN_MAGIC) ? BSMM_OK : BSMM_ERR_ARG;
     return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G)) ? BSMM_OK : BSMM_ERR_ARG;
@@ -620,12 +620,13 @@ struct U2Launch { int grid; bool scratch; int flat; int rounds; };
 // (+ 2 KiB: the fused data-parallel reduction reads / writes the sums in `world` 32-byte aligned shards, include/bsmm_dist.h)
 inline size_t u2_sums_bytes(const bsmm_args* a) { return round16((size_t)a->blocks * 1024 * sizeof(float)) + 2048; }
 inline size_t u2_region_bytes() { return (size_t)U2_WAVES * U2_SLOTS * 4096; }
+inline int u2_chunk(const bsmm_args* a) { return a->axis == 1 ? U2_CH : U2_CH0; }   // minibatch entries per chunk of the streaming kernel
 inline U2Launch updat2_shape(const bsmm_args* a, bool gated) {
     const int cus = device_cus();
     const int nsets = a->plan_inner & 15, longest = a->plan_inner >> 8, common = (a->plan_inner & 16) ? longest : 0;
     U2Launch L;
     if (a->split >= 1) {
-        const long nchunks = (long)a->pcount * ((a->N + U2_CH - 1) / U2_CH);
+        const long nchunks = (long)a->pcount * ((a->N + u2_chunk(a) - 1) / u2_chunk(a));
         const long sp = std::max<long>(1, std::min<long>(a->split, nchunks));
         L.grid = (int)(a->plan_items * sp); L.scratch = sp > 1 || gated; L.flat = 1;
         L.rounds = (a->plan_items + L.grid - 1) / L.grid;
@@ -638,7 +639,7 @@ inline U2Launch updat2_shape(const bsmm_args* a, bool gated) {
     return L;
 }
 
-template <class DT>
+template <class DT, int AXIS>
 int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a, const float* gate) {
     typedef typename DT::T T;
     hipStream_t st = static_cast<hipStream_t>(a->stream);
@@ -655,17 +656,18 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
         scratch = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + u2_sums_bytes(a));
     }
     trace(a, BSMM_K_UPDAT_STREAM);
+    constexpr int LDS16 = AXIS == 1 ? u2_lds_bytes(16) : u2_lds_bytes0(16), LDS8 = AXIS == 1 ? u2_lds_bytes(8) : u2_lds_bytes0(8);
     if (a->plan_width == 16) {
-        if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 16>>(u2_lds_bytes(16))) return rc;
-        updat32_a1_v2_kernel<DT, 16><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(16), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                                     a->pcount, a->alpha, a->beta, L.flat);
+        if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 16, AXIS>>(LDS16)) return rc;
+        updat32_a1_v2_kernel<DT, 16, AXIS><<<L.grid, 64 * U2_WAVES, LDS16, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
+                                                                                a->pcount, a->alpha, a->beta, L.flat);
     } else {
-        if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 8>>(u2_lds_bytes(8))) return rc;
-        updat32_a1_v2_kernel<DT, 8><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(8), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                                   a->pcount, a->alpha, a->beta, L.flat);
+        if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 8, AXIS>>(LDS8)) return rc;
+        updat32_a1_v2_kernel<DT, 8, AXIS><<<L.grid, 64 * U2_WAVES, LDS8, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
+                                                                              a->pcount, a->alpha, a->beta, L.flat);
     }
     if (scratch) {
-        const int CPI = a->pcount * ((a->N + U2_CH - 1) / U2_CH);
+        const int CPI = a->pcount * ((a->N + u2_chunk(a) - 1) / u2_chunk(a));
         const int32_t* bmap = a->plan + U2_HDR + (size_t)a->plan_items * U2_ITEM;     // behind the items (bsmm_plan.h)
         if (sums_only) updat2_reduce_kernel<DT, true><<<a->blocks, 128, 0, st>>>(scratch, nullptr, sums, a->plan, bmap, nullptr, L.grid, L.flat, CPI, 1.f, 0.f);
         else           updat2_reduce_kernel<DT, false><<<a->blocks, 128, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, bmap, gate, L.grid, L.flat, CPI, a->alpha, a->beta);
@@ -714,19 +716,19 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             al = aligned16(DW);
             for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
         }
-        if constexpr (AXIS == 1) {
-            // streaming kernel ('BSU2' plan): 32-bit element offsets inside an operand
+        {
+            // streaming kernel ('BSU2' plan): 32-bit byte offsets inside an operand
             if (!use_valu && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_magic == U2PLAN_MAGIC &&
                 (long)N * std::max(a->C, a->K) < (1L << 30)) {
                 bool stream = true;
-                if (variant == 0) {
+                if (variant == 0 && AXIS == 1) {      // (axis 0 has no per-block kernel of that kind to fall back to)
                     // Fitted to scripts/gpu_updat_sweep.py (4096^2 20 % / 5 %, 8192^2 5 %, 2048^2 20 %, N = 128 .. 8192, us):
                     // streaming kernel: 6 + 0.40 per 16-row chunk of a workgroup's share + 0.45 per MiB of partial sums (written by the
                     // kernel, read back by the reduce pass; a block has nparts partial sums, times the slices of the last round);
                     // per-block transposing-read kernel: 8 + rounds of 512 blocks * N * r, r = 0.004 while X and DY are small
                     // (16 MiB), rising to 0.0105 at 128 MiB.
                     const U2Launch L = updat2_shape(a, gated);
-                    const double chunks = (double)a->plan_items * a->pcount * ((N + U2_CH - 1) / U2_CH);
+                    const double chunks = (double)a->plan_items * a->pcount * ((N + 15) / 16);      // (the fit is per 16 minibatch entries)
                     double t_stream = 6.0 + chunks / L.grid * 0.40;
                     if (L.scratch && !L.flat) {
                         const int nsets = a->plan_inner & 15, longest = a->plan_inner >> 8, U = std::max(1, L.grid / 8);
@@ -743,7 +745,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                     const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * rate;
                     stream = t_stream <= t_blk || sums_only;
                 }
-                if (stream) return launch_updat2<DT>(xs, es, DW, a, ug);
+                if (stream) return launch_updat2<DT, AXIS>(xs, es, DW, a, ug);
             }
         }
         if (sums_only) return BSMM_ERR_UNSUPPORTED;
@@ -879,7 +881,7 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
     if (!X || !DY || (!DW && !(a->flags & BSMM_FLAG_DW_SUMS))) return BSMM_ERR_ARG;      // (DW is not written in sums mode)
     if (a->pcount < 1 || a->pcount > 8) return BSMM_ERR_ARG;
     if ((rc = check_plan(true, a))) return rc;
-    if ((a->flags & BSMM_FLAG_DW_SUMS) && !(a->bsize == 32 && a->axis == 1 && a->dtype != BSMM_F32 && a->plan && a->plan_magic == U2PLAN_MAGIC))
+    if ((a->flags & BSMM_FLAG_DW_SUMS) && !(a->bsize == 32 && a->dtype != BSMM_F32 && a->plan && a->plan_magic == U2PLAN_MAGIC))
         return BSMM_ERR_UNSUPPORTED;
     PtrList8 xs, es;
     for (int p = 0; p < 8; ++p) {
@@ -1109,7 +1111,7 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
     if (bsize == 16) return build_updat_plan(lut, blocks, CB, KB, UW16, UP16_MAXB, out);
     if (bsize != 32) return 0;
     const int force = options & BSMM_PLAN_WINDOW_MASK;
-    if (axis == 1 && (force == 0 || force == BSMM_PLAN_STREAM_16 || force == BSMM_PLAN_STREAM_8)) {
+    if (force == 0 || force == BSMM_PLAN_STREAM_16 || force == BSMM_PLAN_STREAM_8) {     // either feature axis
         // streaming kernel: 16x16 windows while a window's blocks fit the 64 accumulator slots of a workgroup (with some
         // slack for the rows that do not pack: <= 56 on average), 8x8 windows for denser layouts
         const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);

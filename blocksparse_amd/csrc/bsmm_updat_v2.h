@@ -53,6 +53,19 @@ constexpr int U2_D = 64 / U2_CH;           // ring slots (128 KiB with 16x16 win
 constexpr int U2_AHEAD = U2_D / 2;         // prefetch distance in chunks (see the ring protocol at the chunk loop)
 static_assert(U2_CH == 16 || U2_CH == 32, "chunk = 1 or 2 K-steps");
 constexpr int u2_lds_bytes(int ws) { return U2_D * 2 * U2_CH * ws * 64; }
+// feature_axis 0 (activations (C, N): slab rows are FEATURES, a chunk is 32 minibatch columns = 64 B per row -- a piece length the
+// L2 -> LDS path delivers at the rate of 128-byte pieces, scripts/micro/seg_bw.hip; 16 columns = 32 B deliver at half of it):
+constexpr int U2_CH0 = 32;                 // minibatch columns per chunk
+// Ring: two slots of 64 KiB (16x16 windows) / four of 32 KiB.  Measured at 4096^2, N = 8192 (profiles/r03_updat_a0_stream*.txt): 111 / 125 / 180 us
+// at 10 / 20 / 50 % against 120 / 129 / 270 for the windowed kernel of round 1 -- and 71 / 95 / 174 on feature axis 1 for the same bytes.  The
+// counters say why (profiles/r03_pmc_updat_a0_a1.txt): the L1 sends one L2 request per 64 contiguous bytes, 17.7 M requests against 8.7 M, and
+// the per-CU request rate is what bounds these kernels; 128-byte row pieces (64 columns) would need 128 KiB per chunk of a 512 x 512 window.
+// -DU2_RING5=1: FIVE half slots (X of chunk k in half slot 2k mod 5, DY in 2k + 1 mod 5; X requested two chunks ahead, DY one: 1.5 chunks
+// always in flight) -- measured 109 / 129 / 192: more data in flight does not help a request-rate bound.
+#ifndef U2_RING5
+#define U2_RING5 0
+#endif
+constexpr int u2_lds_bytes0(int ws) { return U2_RING5 ? 5 * ws * 32 * (U2_CH0 * 2) : 131072; }
 
 // a wave-uniform pointer, provably so for the compiler (an "s" asm operand fed from a value it regards as divergent is
 // emitted as a VGPR and does not assemble)
@@ -102,27 +115,35 @@ __device__ __forceinline__ const unsigned char* pick_ptr(const PtrList8& l, int 
     return static_cast<const unsigned char*>(p);
 }
 
-template <class DT, int WS>
+// AXIS = 0: the same schedule, ring protocol, partial-sum regions and epilogue over slabs whose ROWS are the window's features
+// ([WS*32 rows][64 B] per operand and chunk; the 16-byte pieces of row r XOR-swizzled with (r >> 2) & 3, conflict-free for the plain
+// ds_read_b128 fragment reads: lane (row, k-half) takes 8 consecutive minibatch columns of its feature).  Needs N % 8 == 0.
+template <class DT, int WS, int AXIS = 1>
 __global__ void __launch_bounds__(64 * U2_WAVES, 4)
 updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
                      const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta, int flat) {
     typedef typename DT::T T;
     static_assert(DT::is16 && (WS == 8 || WS == 16), "updat v2: 16-bit storage types, 8x8 or 16x16 windows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int ROWB = WS * 64;                 // bytes per slab row
-    constexpr int SLAB = U2_CH * ROWB;            // one operand, one chunk
+    constexpr int CH = AXIS == 1 ? U2_CH : U2_CH0;                // minibatch entries per chunk
+    constexpr int KS = CH / 16;                                   // MFMA K-steps per chunk
+    constexpr bool FIVE = AXIS == 0 && U2_RING5;                  // axis 0, experiment: five HALF slots instead (see u2_lds_bytes0)
+    constexpr int D = AXIS == 1 ? U2_D : (WS == 16 ? 2 : 4);      // ring slots (axis 0: 64 / 32 KiB each)
+    constexpr int AHEAD = D / 2;                                  // prefetch distance in chunks
+    constexpr int ROWB = AXIS == 1 ? WS * 64 : CH * 2;            // bytes per slab row
+    constexpr int SLAB = AXIS == 1 ? CH * ROWB : WS * 32 * ROWB;  // one operand, one chunk
     constexpr int SLOT = 2 * SLAB;
     constexpr int PPR = ROWB / 16;                // 16-byte pieces per row
     constexpr int RPI = 1024 / ROWB;              // rows per DMA instruction
-    constexpr int IPO = U2_CH / RPI;              // DMA instructions per operand and chunk
+    constexpr int IPO = SLAB / 1024;              // DMA instructions per operand and chunk
     constexpr int NI = 2 * IPO / U2_WAVES;        // DMA instructions per wave and chunk (consecutive pieces of ONE operand)
     static_assert((NI == 1 || NI == 2 || NI == 4) && NI * U2_WAVES == 2 * IPO && IPO % NI == 0, "the chunk must split evenly over the waves");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t* items = plan + plan[6];
-    const int nchunks = (N + U2_CH - 1) / U2_CH;
-    const int nfull = N / U2_CH;                                              // chunks of a pair with all U2_CH rows
+    const int nchunks = (N + CH - 1) / CH;
+    const int nfull = N / CH;                                                 // chunks of a pair with all CH rows / columns
     const int CPI = pcount * nchunks;                                         // chunks per item (pairs back to back)
     // ---- schedule (see bsmm_plan.h): XCD x = blockIdx.x % 8 owns item set x / nparts and minibatch part x % nparts; its
     //      U = gridDim.x / 8 workgroups take the set's items in rounds of U, one item each over the whole part; a last
@@ -145,14 +166,18 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     //      operand's slab; instruction q covers slab rows d_row0 + q*RPI (+ lane / PPR), this lane's 16-byte piece lane % PPR ----
     const int opE = (NI * wave) / IPO;                                        // 0: X slab, 1: DY slab (wave-uniform)
     const int d_row0 = ((NI * wave) % IPO) * RPI + lane / PPR;
-    const uint32_t wave_off = opE * SLAB + ((NI * wave) % IPO) * 1024;        // my first piece inside a ring slot
-    const int F = opE ? Kf : Cf;                                              // row length of my operand
-    // ---- fragment geometry (see bsmm_updat_tr.h): 16-lane group g16 -> features 16*(g16&1).., K half h ----
+    const uint32_t sub_off = ((NI * wave) % IPO) * 1024;                      // my first piece inside my operand's slab
+    const uint32_t wave_off = (!FIVE ? opE * SLAB : 0) + sub_off;         // ... inside a ring slot (five half slots: the half slot carries the operand)
+    constexpr uint32_t HS = SLAB, RING0 = 5 * SLAB;                           // axis 0: half slot, ring
+    const int F = opE ? Kf : Cf;                                              // row length (axis 1) / row count (axis 0) of my operand
+    const int my_piece0 = (lane % PPR) ^ ((d_row0 >> 2) & 3);                 // axis 0: the source piece of my 16 bytes (the same for all my instructions: RPI = 16)
+    // ---- fragment geometry.  axis 1 (see bsmm_updat_tr.h): 16-lane group g16 -> features 16*(g16&1).., K half h.
+    //      axis 0: lane (row r = lane & 31, K half h = lane >> 5) reads 16 bytes = 8 columns of feature row r of the block ----
     const int g16 = lane >> 4, t16 = lane & 15;
-    const int h = g16 >> 1;
+    const int h = AXIS == 1 ? g16 >> 1 : lane >> 5;
     const int trow = t16 >> 2;
     const int tsub = (2 * (g16 & 1) + ((t16 & 3) >> 1)) * 16 + (t16 & 1) * 8;
-    const int frag_row = (8 * h + trow) * ROWB + tsub;
+    const int frag_row = AXIS == 1 ? (8 * h + trow) * ROWB + tsub : (lane & 31) * ROWB + ((h ^ (((lane & 31) >> 2) & 3)) << 4);
 #ifdef U2_NO_PINGPONG
     const bool setb = false;
 #else
@@ -185,17 +210,30 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
         // (plain scalars, not arrays: with NI == 1 hipcc left a one-element array that lambdas capture by reference in scratch memory)
         auto piece_off = [&](int q) {
             const int row = d_row0 + q * RPI;
-            const int piece = (lane % PPR) ^ (4 * (row & 3));                 // source piece of the LDS piece lane % PPR
-            const int col = min((opE ? k0 : c0) * 32 + piece * 8, F - 8);
-            return (uint32_t)(row * F + col) * 2u;
+            if constexpr (AXIS == 1) {
+                const int piece = (lane % PPR) ^ (4 * (row & 3));                 // source piece of the LDS piece lane % PPR
+                const int col = min((opE ? k0 : c0) * 32 + piece * 8, F - 8);
+                return (uint32_t)(row * F + col) * 2u;
+            } else {                                                          // row = feature row of the window (clamped inside the matrix)
+                const int piece = (lane % PPR) ^ ((row >> 2) & 3);
+                const int feat = min((opE ? k0 : c0) * 32 + row, F - 1);
+                return ((uint32_t)feat * (uint32_t)N + (uint32_t)piece * 8u) * 2u;
+            }
         };
         const uint32_t voff0 = piece_off(0), voff1 = NI > 1 ? piece_off(1) : 0u, voff2 = NI > 2 ? piece_off(2) : 0u, voff3 = NI > 2 ? piece_off(3) : 0u;
         // fragment offsets inside a ring slot
         int aoff[2], boff[U2_SLOTS];
-        aoff[0] = frag_row + ((((meta >> 8) & 15) ^ trow) << 6);
-        aoff[1] = frag_row + ((((meta >> 12) & 15) ^ trow) << 6);
+        if constexpr (AXIS == 1) {
+            aoff[0] = frag_row + ((((meta >> 8) & 15) ^ trow) << 6);
+            aoff[1] = frag_row + ((((meta >> 12) & 15) ^ trow) << 6);
 #pragma unroll
-        for (int j = 0; j < U2_SLOTS; ++j) boff[j] = SLAB + frag_row + ((((meta >> (16 + 4 * j)) & 15) ^ trow) << 6);
+            for (int j = 0; j < U2_SLOTS; ++j) boff[j] = SLAB + frag_row + ((((meta >> (16 + 4 * j)) & 15) ^ trow) << 6);
+        } else {                                  // block index * 32 rows
+            aoff[0] = frag_row + (int)((meta >> 8) & 15) * (32 * ROWB);
+            aoff[1] = frag_row + (int)((meta >> 12) & 15) * (32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < U2_SLOTS; ++j) boff[j] = (FIVE ? 0 : SLAB) + frag_row + (int)((meta >> (16 + 4 * j)) & 15) * (32 * ROWB);
+        }
 
         f32x16 acc[U2_SLOTS];
 #pragma unroll
@@ -210,7 +248,7 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
         //      offsets just advance by one chunk (vector ALU), `reg_left` counts how many such issues lie ahead.  Everything
         //      else (first chunk, ragged last chunk of a pair: rows past N re-read row N - 1 and are zeroed in LDS before use,
         //      pair boundary, past the end) goes through issue_slow, which recomputes the cursor from k.
-        const uint32_t fstride = (uint32_t)(U2_CH * F) * 2u;
+        const uint32_t fstride = AXIS == 1 ? (uint32_t)(CH * F) * 2u : (uint32_t)CH * 2u;
         // Two wave sets per SIMD (waves v, v+4 | v+8, v+12), half an interval out of phase: set A reads the fragments of
         // chunk i and multiplies them; set B multiplies the fragments it read during the PREVIOUS interval and then reads
         // chunk i's.  While one set's transposing reads are in flight the other set feeds the matrix pipe, with one barrier
@@ -225,23 +263,31 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
             uint4 a0 = zero_u4(), a1 = zero_u4(), b[(N0 + N1) ? (N0 + N1) : 1];
 #pragma unroll
             for (int j = 0; j < N0 + N1; ++j) b[j] = zero_u4();   // set B multiplies "the previous fragments" from interval 0 on
-            auto read_frags = [&](const unsigned char* slot) {
+            auto read_frags = [&](const unsigned char* slot, const unsigned char* slot_y, int ks) {
 #ifdef U2_NO_READS
                 asm volatile("" ::"s"(slot));
                 return;
 #endif
-                {
-                    const uint2 lo = ds_tr16(slot + aoff[0]), hi = ds_tr16(slot + aoff[0] + 4 * ROWB);
-                    a0 = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
-                if constexpr (N1 > 0) {
-                    const uint2 lo = ds_tr16(slot + aoff[1]), hi = ds_tr16(slot + aoff[1] + 4 * ROWB);
-                    a1 = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
+                if constexpr (AXIS == 1) {
+                    slot += ks * 16 * ROWB;
+                    {
+                        const uint2 lo = ds_tr16(slot + aoff[0]), hi = ds_tr16(slot + aoff[0] + 4 * ROWB);
+                        a0 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    }
+                    if constexpr (N1 > 0) {
+                        const uint2 lo = ds_tr16(slot + aoff[1]), hi = ds_tr16(slot + aoff[1] + 4 * ROWB);
+                        a1 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    }
 #pragma unroll
-                for (int j = 0; j < N0 + N1; ++j) {
-                    const uint2 lo = ds_tr16(slot + boff[j]), hi = ds_tr16(slot + boff[j] + 4 * ROWB);
-                    b[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    for (int j = 0; j < N0 + N1; ++j) {
+                        const uint2 lo = ds_tr16(slot + boff[j]), hi = ds_tr16(slot + boff[j] + 4 * ROWB);
+                        b[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    }
+                } else {                          // K-step ks = pieces 2 ks + h of the row: the swizzled offset XOR 32 ks
+                    a0 = *reinterpret_cast<const uint4*>(slot + (aoff[0] ^ (ks << 5)));
+                    if constexpr (N1 > 0) a1 = *reinterpret_cast<const uint4*>(slot + (aoff[1] ^ (ks << 5)));
+#pragma unroll
+                    for (int j = 0; j < N0 + N1; ++j) b[j] = *reinterpret_cast<const uint4*>(slot_y + (boff[j] ^ (ks << 5)));
                 }
             };
             auto multiply = [&]() {
@@ -269,14 +315,22 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
         const int kk_ = min(k_issue, cnt - 1);                                                                               \
         const int g_ = r0 + kk_, p_ = __builtin_amdgcn_readfirstlane(g_ / nchunks), q_ = g_ - p_ * nchunks;                  \
         fb = static_cast<const unsigned char*>(uniform_ptr(opE ? pick_ptr(Es, p_) : pick_ptr(Xs, p_)));                      \
-        const uint32_t dst_ = __builtin_amdgcn_readfirstlane(base_addr + wave_off + (uint32_t)(k_issue & (U2_D - 1)) * SLOT); \
-        const uint32_t row_off_ = (uint32_t)(q_ * U2_CH * F) * 2u;                                                           \
-        const int over0_ = max(0, q_ * U2_CH + d_row0 - (N - 1)), over1_ = max(0, q_ * U2_CH + d_row0 + RPI - (N - 1));     \
-        const int over2_ = max(0, q_ * U2_CH + d_row0 + 2 * RPI - (N - 1)), over3_ = max(0, q_ * U2_CH + d_row0 + 3 * RPI - (N - 1)); \
-        U2_DMA1(fb, voff0 + row_off_ - (uint32_t)(over0_ * F) * 2u, dst_);                                                   \
-        if constexpr (NI >= 2) U2_DMA1(fb, voff1 + row_off_ - (uint32_t)(over1_ * F) * 2u, dst_ + 1024);                     \
-        if constexpr (NI == 4) U2_DMA1(fb, voff2 + row_off_ - (uint32_t)(over2_ * F) * 2u, dst_ + 2048);                     \
-        if constexpr (NI == 4) U2_DMA1(fb, voff3 + row_off_ - (uint32_t)(over3_ * F) * 2u, dst_ + 3072);                     \
+        const uint32_t dst_ = __builtin_amdgcn_readfirstlane(base_addr + wave_off + (!FIVE ? (uint32_t)(k_issue & (D - 1)) * SLOT : (uint32_t)((2 * k_issue + opE) % 5) * HS)); \
+        uint32_t row_off_, sub0_, sub1_, sub2_, sub3_;                                                                       \
+        if constexpr (AXIS == 1) {      /* rows past N re-read row N - 1 */                                                  \
+            row_off_ = (uint32_t)(q_ * CH * F) * 2u;                                                                         \
+            sub0_ = (uint32_t)(max(0, q_ * CH + d_row0 - (N - 1)) * F) * 2u;                                                 \
+            sub1_ = (uint32_t)(max(0, q_ * CH + d_row0 + RPI - (N - 1)) * F) * 2u;                                           \
+            sub2_ = (uint32_t)(max(0, q_ * CH + d_row0 + 2 * RPI - (N - 1)) * F) * 2u;                                       \
+            sub3_ = (uint32_t)(max(0, q_ * CH + d_row0 + 3 * RPI - (N - 1)) * F) * 2u;                                       \
+        } else {                        /* 8-column pieces past N re-read the row's last piece (N % 8 == 0) */               \
+            row_off_ = (uint32_t)(q_ * CH) * 2u;                                                                             \
+            sub0_ = sub1_ = sub2_ = sub3_ = (uint32_t)max(0, q_ * CH + my_piece0 * 8 + 8 - N) * 2u;                          \
+        }                                                                                                                    \
+        U2_DMA1(fb, voff0 + row_off_ - sub0_, dst_);                                                                         \
+        if constexpr (NI >= 2) U2_DMA1(fb, voff1 + row_off_ - sub1_, dst_ + 1024);                                           \
+        if constexpr (NI == 4) U2_DMA1(fb, voff2 + row_off_ - sub2_, dst_ + 2048);                                           \
+        if constexpr (NI == 4) U2_DMA1(fb, voff3 + row_off_ - sub3_, dst_ + 3072);                                           \
         rv0 = voff0 + row_off_ + fstride;                                                                                    \
         rv1 = voff1 + row_off_ + fstride;                                                                                    \
         rv2 = voff2 + row_off_ + fstride;                                                                                    \
@@ -307,53 +361,71 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
         } else {                                                                                                             \
             U2_ISSUE_SLOW();                                                                                                 \
         }                                                                                                                    \
-        doff = (doff + SLOT) & (U2_D * SLOT - 1);                                                                            \
+        if constexpr (!FIVE) doff = (doff + SLOT) & (D * SLOT - 1);                                                      \
+        else { doff += 2 * HS; if (doff >= RING0) doff -= RING0; }                                                           \
     } while (0)
             k_issue = 0; reg_left = 0;
+            if constexpr (!FIVE) {
 #pragma unroll
-            for (int d = 0; d < U2_AHEAD; ++d) U2_ISSUE_SLOW();
-            uint32_t vslot = 0;
-            asm volatile("" : "+v"(vslot));                     // the ring offset of the fragment reads lives on the vector ALU
-            uint32_t doff = (uint32_t)U2_AHEAD * SLOT;          // ring offset of the next DMA destination
+                for (int d = 0; d < AHEAD; ++d) U2_ISSUE_SLOW();
+            } else {                                                // X runs two chunks ahead, DY one
+                U2_ISSUE_SLOW();
+                if (!opE) U2_ISSUE_SLOW();
+            }
+            uint32_t vslot = !FIVE ? 0u : (uint32_t)HS;         // axis 1: ring offset of the chunk; axis 0: of its DY slab (vslot0: its X slab)
+            uint32_t vslot0 = 0;
+            asm volatile("" : "+v"(vslot), "+v"(vslot0));           // the ring offsets of the fragment reads live on the vector ALU
+            uint32_t doff = !FIVE ? (uint32_t)AHEAD * SLOT : (uint32_t)((2 * k_issue + opE) % 5) * HS;   // ring offset of the next DMA destination
             const uint32_t ring_base = __builtin_amdgcn_readfirstlane(base_addr + wave_off);
             int cq = __builtin_amdgcn_readfirstlane(r0 - (r0 / nchunks) * nchunks);   // chunk-in-pair index of the compute cursor (ragged N only)
 #pragma unroll 1
             for (int i = 0; i < cnt; ++i) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * U2_AHEAD - NI) : "memory");   // my share of chunk i has landed
-                if (nfull != nchunks) {            // N % 16 != 0: is chunk i the ragged last chunk of its pair?  zero its rows >= N
+                if constexpr (!FIVE) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * AHEAD - NI) : "memory");  // my share of chunk i has landed
+                } else {                           // (an X wave's latest request is chunk i + 1's)
+                    if (opE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+                }
+                if (nfull != nchunks) {            // ragged N: is chunk i the last chunk of its pair?  zero its rows / columns >= N
                     if (cq == nfull) {
 #pragma unroll
                         for (int e = 0; e < NI; ++e)
-                            if (cq * U2_CH + d_row0 + e * RPI >= N)
-                                *reinterpret_cast<uint4*>(smem + (i & (U2_D - 1)) * SLOT + wave_off + e * 1024 + lane * 16) = zero_u4();
+                            if (AXIS == 1 ? (cq * CH + d_row0 + e * RPI >= N) : (cq * CH + my_piece0 * 8 >= N))
+                                *reinterpret_cast<uint4*>(smem + (!FIVE ? (uint32_t)(i & (D - 1)) * SLOT : (uint32_t)((2 * i + opE) % 5) * HS) + wave_off + e * 1024 + lane * 16) = zero_u4();
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                     if (++cq == nchunks) cq = 0;
                 }
                 // (two-slot ring: the slot refilled in this interval is the one set B read at the END of the previous interval --
                 //  those reads must have returned before anyone may request the refill)
-                if constexpr (U2_D == 2 && SETB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr ((D == 2 || FIVE) && SETB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef U2_NO_BARRIER
                 __builtin_amdgcn_s_barrier();                                               // everyone's has
 #endif
-                const unsigned char* slot = smem + vslot;
+                const unsigned char* slot = smem + (!FIVE ? vslot : vslot0);      // X fragments
+                const unsigned char* slot_y = smem + vslot;                           // DY fragments (axis 1: boff holds the slab offset)
                 if constexpr (N0 == 0) {
                     U2_ISSUE();
                 } else if constexpr (!SETB) {
-                    read_frags(slot);
+                    read_frags(slot, slot_y, 0);
                     U2_ISSUE();
                     multiply();
 #pragma unroll
-                    for (int ks = 1; ks < U2_KS; ++ks) { read_frags(slot + ks * 16 * ROWB); multiply(); }
+                    for (int ks = 1; ks < KS; ++ks) { read_frags(slot, slot_y, ks); multiply(); }
                 } else {
                     multiply();
                     __builtin_amdgcn_sched_barrier(0);
                     U2_ISSUE();
 #pragma unroll
-                    for (int ks = 0; ks < U2_KS - 1; ++ks) { read_frags(slot + ks * 16 * ROWB); multiply(); }
-                    read_frags(slot + (U2_KS - 1) * 16 * ROWB);
+                    for (int ks = 0; ks < KS - 1; ++ks) { read_frags(slot, slot_y, ks); multiply(); }
+                    read_frags(slot, slot_y, KS - 1);
                 }
-                vslot = (vslot + SLOT) & (U2_D * SLOT - 1);
+                if constexpr (!FIVE) {
+                    vslot = (vslot + SLOT) & (D * SLOT - 1);
+                } else {
+                    vslot += 2 * HS;  vslot = vslot >= RING0 ? vslot - RING0 : vslot;
+                    vslot0 += 2 * HS; vslot0 = vslot0 >= RING0 ? vslot0 - RING0 : vslot0;
+                }
             }
 #undef U2_ISSUE
 #undef U2_ISSUE_SLOW

@@ -1,4 +1,4 @@
-"""time updat (bsize 32, axis 1, bf16, N = 8192) for the library selected by BSMM_LIB: density x plan option"""
+"""time updat (bsize 32, bf16, N = 8192; AXIS=0|1 in the environment, default 1) for the library selected by BSMM_LIB: density x plan option"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -24,11 +24,12 @@ out = []
 for c in cases:
     d, o = c.split(":")
     lay = P.random_layout(128, 128, int(d[1:]) / 100.0, 1234)
-    b = BlocksparseMatMul(lay, block_size=32, feature_axis=1, plan_options=OPT[o])
+    b = BlocksparseMatMul(lay, block_size=32, feature_axis=int(os.environ.get("AXIS", "1")), plan_options=OPT[o])
     g = torch.Generator(device="cuda").manual_seed(1)
     x = (torch.randn(b.i_shape(8192), device="cuda", generator=g) * 0.1).bfloat16()
     dy = (torch.randn(b.o_shape(8192), device="cuda", generator=g) * 0.1).bfloat16()
     dw = torch.empty(b.w_shape, dtype=torch.bfloat16, device="cuda")
+    b.updat(x, dy, dw=dw); k = _lib.last_kernel()
     us = timeit(lambda: b.updat(x, dy, dw=dw))
-    out.append("%s %.1f" % (c, us))
+    out.append("%s %.1f (k%d)" % (c, us, k))
 print("%-28s %s" % (tag, "  ".join(out)), flush=True)

@@ -340,7 +340,7 @@ def test_staged_xcol16_plan(lib):
 
 
 def test_updat_plan_covers_every_block_once(lib):
-    """bsmm_updat_plan_build, round-1 windowed formats ('BSUP': axis 0, bsize 16, or BSMM_PLAN_WINDOW_* on axis 1): every weight
+    """bsmm_updat_plan_build, round-1 windowed formats ('BSUP': bsize 16, or BSMM_PLAN_WINDOW_* at bsize 32): every weight
     block appears in exactly one (item, wave, slot), inside its window, items are padded to a multiple of 8 (one list per XCD),
     every wave of an item has at most `nslots` blocks."""
     import numpy as np
@@ -351,7 +351,7 @@ def test_updat_plan_covers_every_block_once(lib):
         lay = rng.random((CB, KB)) < dens
         lay[0, 0] = True
         t = L.build_tables(lay)
-        for bsize, axis, opt in ((32, 0, 0), (32, 1, lib.PLAN_WINDOW_8), (32, 1, lib.PLAN_WINDOW_16), (32, 1, lib.PLAN_WINDOW_16W), (16, 1, 0), (16, 0, 0)):
+        for bsize, axis, opt in ((32, 0, lib.PLAN_WINDOW_8), (32, 1, lib.PLAN_WINDOW_8), (32, 1, lib.PLAN_WINDOW_16), (32, 1, lib.PLAN_WINDOW_16W), (16, 1, 0), (16, 0, 0)):
             plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, bsize, lib.BF16, axis, opt)
             assert plan[0] == 0x42535550 and plan[5] == t["blocks"]
             want_w = {0: 8 if bsize == 32 else 16, lib.PLAN_WINDOW_8: 8, lib.PLAN_WINDOW_16: 16, lib.PLAN_WINDOW_16W: 16}[opt]
@@ -397,7 +397,7 @@ def test_updat_plan_covers_every_block_once(lib):
 
 
 def test_streaming_updat_plan(lib):
-    """'BSU2' plans (bsize 32, axis 1: the default): every block in exactly one (item, wave, slot); a wave holds <= 4 blocks from
+    """'BSU2' plans (bsize 32, either feature axis: the default): every block in exactly one (item, wave, slot); a wave holds <= 4 blocks from
     <= 2 rows of the window, group 0 first; a window side of 16 for layouts up to ~22 % density, 8 above; hub rows split over waves;
     the two halves of the block rows alternate in the item list."""
     import numpy as np
@@ -413,6 +413,7 @@ def test_streaming_updat_plan(lib):
         t = L.build_tables(lay)
         for opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8):
             plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, opt)
+            assert (plan == _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 0, opt)).all()    # the same items on feature axis 0
             assert plan[0] == 0x42535532 and plan[1] == 2 and plan[3] == 4 and plan[5] == t["blocks"] and plan[7] == 16
             WS, nitems = int(plan[2]), int(plan[4])
             if opt == 0:

@@ -29,8 +29,8 @@ def env():
 
 
 def _updat_kernel(lib, axis, opt=0):
-    """which bsize-32 updat kernel a plan built with `opt` runs: axis 1 defaults to the streaming kernel (bsmm_updat_v2.h)"""
-    if axis == 1 and opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8):
+    """which bsize-32 updat kernel a plan built with `opt` runs: both axes default to the streaming kernel (bsmm_updat_v2.h)"""
+    if opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8):
         return lib.K_UPDAT_STREAM
     return lib.K_UPDAT_WIN
 
