@@ -171,6 +171,7 @@ class BlocksparseMatMul(object):
         self._workspaces = {}
         self._prepared_w = {}             # op -> ((op, w.data_ptr, w._version, stream), buffer): bsmm_prepare_weights results
         self._inner = None
+        self._split64_hit = None
         if block_size == 64:
             # same weights, cut into 32x32 blocks: inner block n is quadrant (i, j) of outer block b
             self._inner = BlocksparseMatMul(np.kron(self.layout, np.ones((2, 2), dtype=self.layout.dtype)), block_size=32, feature_axis=feature_axis,
@@ -190,6 +191,17 @@ class BlocksparseMatMul(object):
     def _split64(self, w):
         perm, _ = self._idx64(w.device)
         return w.contiguous().view(self.blocks, 2, 32, 2, 32).permute(0, 1, 3, 2, 4).reshape(4 * self.blocks, 32, 32).index_select(0, perm)
+
+    def _split64_cached(self, w):
+        """The quadrant view of a weight tensor for fprop / bprop, made once per (storage, version): W is constant across the calls
+        of a pass; an in-place update (``w._version``) or another tensor invalidates it.  Not used under autograd (the gather is
+        part of the graph there)."""
+        if w.requires_grad and torch.is_grad_enabled():
+            return self._split64(w)
+        key = (w.data_ptr(), w._version, w.dtype, w.device)
+        if self._split64_hit is None or self._split64_hit[0] != key:
+            self._split64_hit = (key, self._split64(w))
+        return self._split64_hit[1]
 
     def _merge64(self, w32):
         _, inv = self._idx64(w32.device)
@@ -311,7 +323,7 @@ class BlocksparseMatMul(object):
         if x.dtype != w.dtype:
             raise TypeError("x and w must have the same dtype")
         if self._inner is not None:
-            return self._inner.fprop(x, self._split64(w), gate=self._gate64(gate))
+            return self._inner.fprop(x, self._split64_cached(w), gate=self._gate64(gate))
         x = x.contiguous(); w = w.contiguous()
         N = self._n_of(x, self.C)
         lib = _lib.load()
@@ -332,7 +344,7 @@ class BlocksparseMatMul(object):
         if dy.dtype != w.dtype:
             raise TypeError("dy and w must have the same dtype")
         if self._inner is not None:
-            return self._inner.bprop(dy, self._split64(w), gate=self._gate64(gate))
+            return self._inner.bprop(dy, self._split64_cached(w), gate=self._gate64(gate))
         dy = dy.contiguous(); w = w.contiguous()
         N = self._n_of(dy, self.K)
         lib = _lib.load()
@@ -372,8 +384,10 @@ class BlocksparseMatMul(object):
             if self._n_of(x, self.C) != N or self._n_of(dy, self.K) != N:
                 raise ValueError("all pairs must share the minibatch size")
         if self._inner is not None:      # bsize 64: the gradient of the four 32x32 quadrants, put back together
-            if sums_only:
-                raise _lib.BsmmError(-2, "bsmm_updat(sums_only) with bsize 64")
+            if sums_only:                # the fp32 sums of the quadrants (a view of the inner call's workspace), put together as a copy
+                if gate is not None:
+                    raise ValueError("updat(sums_only=True) returns the ungated sums: pass the gate to updat_finalize / DwReduce.start")
+                return self._merge64(self._inner.updat(xs, dys, sums_only=True, slot=slot))
             if beta != 0.0 and dw is None:
                 raise ValueError("beta != 0 needs dw")
             dw32 = self._inner.updat(xs, dys, alpha=alpha, beta=beta, dw=self._split64(dw) if (dw is not None and beta != 0.0) else None,
@@ -426,8 +440,12 @@ class BlocksparseMatMul(object):
             dw = torch.empty(self.w_shape, dtype=dtype or torch.bfloat16, device=sums.device)
         gate = self._check_gate(gate, sums.device)
         st = torch.cuda.current_stream(sums.device).cuda_stream
-        _lib.check(_lib.load().bsmm_updat_finalize(sums.data_ptr(), dw.data_ptr(), gate.data_ptr() if gate is not None else None, self.blocks,
-                                                   self.bsize, _dtype_code(dw.dtype), alpha, beta, st), "bsmm_updat_finalize")
+        blocks, bsize = self.blocks, self.bsize
+        if bsize == 64:      # elementwise: a 64x64 block is four contiguous quarters of 1024 elements with the block's gate
+            blocks, bsize = 4 * blocks, 32
+            gate = gate.repeat_interleave(4) if gate is not None else None
+        _lib.check(_lib.load().bsmm_updat_finalize(sums.data_ptr(), dw.data_ptr(), gate.data_ptr() if gate is not None else None, blocks,
+                                                   bsize, _dtype_code(dw.dtype), alpha, beta, st), "bsmm_updat_finalize")
         return dw
 
     def updat_grouped(self, xs, dys, group_size=8, dw=None, alpha=1.0):
@@ -460,6 +478,11 @@ class BlocksparseMatMul(object):
         gate = self._check_gate(gate, dw.device)
         if dw.dtype != w.dtype or tuple(dw.shape) != self.w_shape or tuple(w.shape) != self.w_shape:
             raise ValueError("dw and w must be %s tensors of one dtype" % (self.w_shape,))
+        if self._inner is not None:      # bsize 64: per quadrant, dg summed over the four quadrants of a block
+            o32, dg32 = self._inner.gate_grad(self._split64(dw), self._split64(w), self._gate64(gate))
+            perm, _ = self._idx64(dw.device)
+            dg = torch.zeros(self.blocks, dtype=torch.float32, device=dw.device).index_add_(0, perm // 4, dg32)
+            return self._merge64(o32), dg
         dw = dw.contiguous(); w = w.contiguous()
         out = torch.empty_like(dw)
         dg = torch.empty(self.blocks, dtype=torch.float32, device=dw.device)
@@ -472,6 +495,8 @@ class BlocksparseMatMul(object):
     def l2_normalize(self, W, gain=None, epsilon=1e-12, dtype=None):
         """y = gain * W / sqrt(max(sum of W^2 over each output feature, epsilon)) on the device, differentiable
         (ops L2NormalizeCK / L2NormalizeGainCK and their registered gradients, blocksparse/matmul.py:447-453,529-553)."""
+        if self._inner is not None:      # bsize 64: the quadrant view keeps every output feature's column
+            return self._merge64(self._inner.l2_normalize(self._split64(W), gain=gain, epsilon=epsilon, dtype=dtype))
         return _L2NormFunction.apply(W, gain, self, float(epsilon), dtype or W.dtype)
 
     def _l2_tables(self, device):
@@ -565,6 +590,8 @@ class BlocksparseMatMul(object):
             dtype = dtype or torch.float32
             if shape is not None:
                 assert tuple(shape) == self.w_shape
+            if self._inner is not None:  # bsize 64: the identity of a diagonal block is the identity of its two diagonal quadrants
+                return self._merge64(self._inner.identity_init(scale)(dtype=dtype, device=device))
             dev = torch.device(device)
             if dev.type != "cuda":
                 raise RuntimeError("blocksparse_amd: identity_init runs on a ROCm device only")

@@ -335,6 +335,53 @@ def test_bsize64_axis1(env):
         BSMM(layout, block_size=64, feature_axis=0)
 
 
+def test_bsize64_axis1_helper_ops(env):
+    """bsize 64: the ops around the matmul run on the quadrant view too -- gate gradient (and with it the gated autograd
+    path), identity init, L2 weight norm, raw fp32 sums + finalize; each against the same op at bsize 32 on the four-quadrant layout or
+    against NumPy.  The quadrant view of a constant W is made once per tensor version."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(12, 12, 0.3, seed=19)
+    layout[np.arange(12), np.arange(12)] = 1
+    b = BSMM(layout, block_size=64, feature_axis=1)
+    rng = np.random.default_rng(5)
+    W = torch.from_numpy(rng.normal(size=b.w_shape).astype(np.float32) * 0.05).cuda().bfloat16()
+    DW = torch.from_numpy(rng.normal(size=b.w_shape).astype(np.float32) * 0.05).cuda().bfloat16()
+    g = torch.from_numpy(rng.random(b.blocks).astype(np.float32)).cuda()
+    out, dg = b.gate_grad(DW, W, g)
+    want_dg = (DW.float() * W.float()).sum(dim=(1, 2))
+    assert torch.allclose(dg, want_dg, rtol=1e-4, atol=1e-5)
+    assert torch.equal(out, (DW.float() * g[:, None, None]).to(torch.bfloat16))
+    # identity init
+    I = b.identity_init(0.5)(dtype=torch.float32)
+    eye = torch.zeros(b.w_shape)
+    for w_, (c, k) in enumerate(b.updat_list):
+        if c == k:
+            eye[w_] = 0.5 * torch.eye(64)
+    assert torch.equal(I.cpu(), eye)
+    # L2 norm against the NumPy restatement of the class
+    Wf = W.float()
+    y = b.l2_normalize(Wf)
+    assert np.allclose(y.cpu().numpy(), b.l2_normalize_test(Wf.cpu().numpy()), rtol=1e-5, atol=1e-6)
+    # sums + finalize == updat (one rounding each)
+    x = (torch.randn(b.i_shape(256), device="cuda") * 0.1).bfloat16()
+    dy = (torch.randn(b.o_shape(256), device="cuda") * 0.1).bfloat16()
+    sums = b.updat(x, dy, sums_only=True)
+    assert sums.dtype == torch.float32 and tuple(sums.shape) == b.w_shape
+    fin = b.updat_finalize(sums, alpha=0.5, beta=2.0, dw=DW.clone(), gate=g)
+    ref = b.updat(x, dy, alpha=0.5, beta=2.0, dw=DW.clone(), gate=g)
+    d = (fin.float() - ref.float()).abs()
+    assert (d.norm() / ref.float().norm()).item() < 1e-3
+    # gated autograd path
+    xg = x.float().requires_grad_(True); wg = W.float().requires_grad_(True); gg = g.clone().requires_grad_(True)
+    yv = b(xg, wg, gate=gg, gate_grad=True)
+    yv.backward(torch.ones_like(yv))
+    assert xg.grad is not None and wg.grad is not None and gg.grad is not None and torch.isfinite(gg.grad).all()
+    # the split of a constant W is cached: same storage and version -> the same tensor object
+    b.fprop(x, W); first = b._split64_hit[1]
+    b.bprop(dy, W); assert b._split64_hit[1] is first
+    W.add_(0.0); b.fprop(x, W); assert b._split64_hit[1] is not first
+
+
 # ---- (e) the reference's own test matrix ------------------------------------------------------------------------------
 @pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("bs", [32, 16, 8])
