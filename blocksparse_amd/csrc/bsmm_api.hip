@@ -174,6 +174,20 @@ int launch_xcol16_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a
     return (int)hipGetLastError();
 }
 
+// bsize 16, 'BSX7' plan: which inner loop.  The list-driven kernel multiplies every block on its own with the K = 16 instruction; where most
+// blocks have their pair partner (dense layouts) the round-2 kernel's K = 32 instruction per PAIR wins on feature axis 1 -- measured at 4096^2,
+// N = 8192 (profiles/r03_x7_density.txt): 20 % 152 / 145 against 166 / 149 us, 30 % 201 / 193 against 210 / 184, 50 % 315 / 319 against 284 / 263;
+// on feature axis 0 the list kernel wins at every density (50 %: 251 / 237 against 321 / 301).  Gated calls: the round-2 kernel.
+inline bool x7_use_list(const bsmm_args* a) {
+#ifdef X7_POSITIONAL
+    return false;
+#else
+    if (a->gate) return false;
+    const double dens = (double)a->blocks / std::max(1.0, (a->C / 16.0) * (a->K / 16.0));
+    return a->axis == 0 || dens < 0.4;
+#endif
+}
+
 template <class DT, int AXIS>
 int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
     typedef typename DT::T T;
@@ -189,22 +203,18 @@ int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* 
         if (int rc = ensure_lds<&xcol16_v2_kernel<DT, AXIS, true>>(X7_LDS)) return rc;
         xcol16_v2_kernel<DT, AXIS, true><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                          a->N, a->C, a->K, a->gate);
-    } else {
-#ifdef X7_POSITIONAL      // experiment builds: the round-2 inner loop (position tests instead of the plan's block lists)
+    } else if (!x7_use_list(a)) {
         if (int rc = ensure_lds<&xcol16_v2_kernel<DT, AXIS, false>>(X7_LDS)) return rc;
         xcol16_v2_kernel<DT, AXIS, false><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                           a->N, a->C, a->K, nullptr);
-#else
-        if (transw) {
-            if (int rc = ensure_lds<&xcol16_list_kernel<DT, AXIS, true>>(X7_LDS)) return rc;
-            xcol16_list_kernel<DT, AXIS, true><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                                              a->N, a->C, a->K);
-        } else {
-            if (int rc = ensure_lds<&xcol16_list_kernel<DT, AXIS, false>>(X7_LDS)) return rc;
-            xcol16_list_kernel<DT, AXIS, false><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                                               a->N, a->C, a->K);
-        }
-#endif
+    } else if (transw) {
+        if (int rc = ensure_lds<&xcol16_list_kernel<DT, AXIS, true>>(X7_LDS)) return rc;
+        xcol16_list_kernel<DT, AXIS, true><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                          a->N, a->C, a->K);
+    } else {
+        if (int rc = ensure_lds<&xcol16_list_kernel<DT, AXIS, false>>(X7_LDS)) return rc;
+        xcol16_list_kernel<DT, AXIS, false><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                           a->N, a->C, a->K);
     }
     return (int)hipGetLastError();
 }
@@ -475,11 +485,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     size_t off = 0;
     const void* Wsel = W;
     const bool staged = path == XP_XCOL32 && a->plan_magic == X2PLAN_MAGIC;   // transposes the staged blocks itself
-#ifdef X7_POSITIONAL
-    const bool staged16 = false;
-#else
-    const bool staged16 = path == XP_XCOL16 && a->plan_magic == X7PLAN_MAGIC && !a->gate;   // the list kernel reads them transposed
-#endif
+    const bool staged16 = path == XP_XCOL16 && a->plan_magic == X7PLAN_MAGIC && x7_use_list(a);   // the list kernel reads them transposed
     if (fprop && path != XP_VALU && !staged && !staged16) {
         if constexpr (BS != 8) {
             if (!a->workspace || a->workspace_bytes < wt_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;

@@ -16,7 +16,8 @@ def timeit(fn, reps=100, warm=30):
     return e0.elapsed_time(e1) / reps * 1e3
 
 opts = [int(a, 0) for a in sys.argv[1:]] or [0]
-lay = P.random_layout(256, 256, 0.1, 1234)
+dens = float(os.environ.get("DENS", "0.1"))      # BASELINE configs[2] is 10 %
+lay = P.random_layout(256, 256, dens, 1234)
 for axis in (1, 0):
     outs = {}
     for o in opts:
@@ -30,8 +31,8 @@ for axis in (1, 0):
         outs[o] = (y, dx)
         tf, tb, tu = timeit(lambda: b.fprop(x, w)), timeit(lambda: b.bprop(dy, w)), timeit(lambda: b.updat(x, dy, dw=dw))
         fl = 2.0 * b.blocks * 256 * 8192
-        print("axis %d opt %#x blocks %d: fprop %.1f us (k%d, %.0f TF)  bprop %.1f (%.0f TF)  updat %.1f (k%d, %.0f TF)" %
-              (axis, o, b.blocks, tf, kf, fl / tf / 1e6, tb, fl / tb / 1e6, tu, ku, fl / tu / 1e6), flush=True)
+        print("d%.0f%% axis %d opt %#x blocks %d: fprop %.1f us (k%d, %.0f TF)  bprop %.1f (%.0f TF)  updat %.1f (k%d, %.0f TF)" %
+              (dens * 100, axis, o, b.blocks, tf, kf, fl / tf / 1e6, tb, fl / tb / 1e6, tu, ku, fl / tu / 1e6), flush=True)
     if len(opts) > 1:
         a, c = outs[opts[0]], outs[opts[1]]
         print("   same bits: fprop %s bprop %s" % (torch.equal(a[0], c[0]), torch.equal(a[1], c[1])), flush=True)
