@@ -20,6 +20,7 @@
 #include "bsmm_xcol_v2.h"
 #include "bsmm_xcol16.h"
 #include "bsmm_xcol16_v2.h"
+#include "bsmm_b64.h"
 #include "bsmm_xprop.h"
 
 using namespace bsmm;
@@ -72,7 +73,7 @@ inline int device_cus() {
 int check_common(const bsmm_args* a) {
     if (!a || !a->lut) return BSMM_ERR_ARG;
     if (a->blocks <= 0 || a->N <= 0 || a->C <= 0 || a->K <= 0) return BSMM_ERR_ARG;
-    if (a->bsize != 8 && a->bsize != 16 && a->bsize != 32) return BSMM_ERR_UNSUPPORTED;
+    if (a->bsize != 8 && a->bsize != 16 && a->bsize != 32 && !(a->bsize == 64 && a->axis == 1)) return BSMM_ERR_UNSUPPORTED;   // 64: axis 1 only, as the reference
     if (a->axis != 0 && a->axis != 1) return BSMM_ERR_UNSUPPORTED;
     if (a->dtype != BSMM_F32 && a->dtype != BSMM_F16 && a->dtype != BSMM_BF16) return BSMM_ERR_UNSUPPORTED;
     if (a->C % a->bsize || a->K % a->bsize) return BSMM_ERR_ARG;
@@ -88,6 +89,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (!a->plan) return BSMM_OK;
     if (reinterpret_cast<uintptr_t>(a->plan) & 15) return BSMM_ERR_ARG;
     const int32_t m = a->plan_magic;
+    if (a->bsize == 64) return (m == B64PLAN_MAGIC && a->plan_inner == (updat ? 1 : 0)) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 16) return ((m == XC16PLAN_MAGIC || (m == X7PLAN_MAGIC && a->plan_width == X7_G)) && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
@@ -543,11 +545,60 @@ int xprop_dt(bool fprop, const void* X, const void* W, void* Y, const bsmm_args*
     return BSMM_ERR_UNSUPPORTED;
 }
 
+// ---- bsize 64 (feature axis 1): the quadrant view on the bsize-32 path ('BS64' plans, bsmm_plan.h / bsmm_b64.h) ----
+// descriptor of a 'BS64' plan in bsmm_args (bsmm_plan_attach): plan_width / plan_items = the nested plan's, plan_waves = the nested plan's
+// waves (5 bits) | code of its format << 5 | its `inner` word << 8, plan_inner = 0 (xprop) / 1 (updat)
+const int32_t kNestedMagic[8] = {0, XCPLAN_MAGIC, X2PLAN_MAGIC, XFPLAN_MAGIC, UPLAN_MAGIC, U2PLAN_MAGIC, 0, 0};
+inline int nested_code(int32_t magic) { for (int i = 1; i < 8; ++i) if (kNestedMagic[i] == magic) return i; return 0; }
+inline size_t b64_w_bytes(const bsmm_args* a) { return round16((size_t)a->blocks * 4096 * elem_size(a->dtype)); }
+inline size_t b64_gate_bytes(const bsmm_args* a) { return a->gate ? round16((size_t)a->blocks * 4 * sizeof(float)) : 0; }
+// the bsize-32 call behind a bsize-64 one (workspace fields left to the caller)
+inline bsmm_args b64_inner(const bsmm_args* a, bool updat) {
+    bsmm_args b = *a;
+    b.bsize = 32; b.blocks = 4 * a->blocks; b.prepared_w = nullptr;
+    b.lut = a->plan + B64_HDR;
+    if (!updat) { b.segments = 2 * a->segments; b.locks = 2 * a->locks; }
+    b.plan = a->plan + b64_off_nested(updat ? 1 : 0, updat ? 0 : a->segments, a->blocks);
+    b.plan_magic = kNestedMagic[(a->plan_waves >> 5) & 7];
+    b.plan_waves = a->plan_waves & 31;
+    b.plan_inner = (int32_t)((uint32_t)a->plan_waves >> 8);
+    if (b.plan_magic == 0) { b.plan = nullptr; b.plan_width = b.plan_waves = b.plan_items = b.plan_inner = 0; }
+    return b;
+}
+
+int xprop(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a);
+
+int xprop64(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    if (!a->plan || !aligned16(W)) return BSMM_ERR_ARG;       // (check_plan: a 'BS64' xprop plan)
+    bsmm_args b = b64_inner(a, false);
+    // workspace: [quadrant copy of W, unless the caller prepared one][gates of the quadrants][the inner call's]
+    const size_t wq = a->prepared_w ? 0 : b64_w_bytes(a), gq = b64_gate_bytes(a);
+    const size_t inner = bsmm_workspace_bytes(fprop ? BSMM_OP_FPROP : BSMM_OP_BPROP, &b);
+    if (wq + gq + inner > 0 && (!a->workspace || a->workspace_bytes < wq + gq + inner || !aligned16(a->workspace))) return BSMM_ERR_WORKSPACE;
+    char* ws = static_cast<char*>(a->workspace);
+    const void* Wq = a->prepared_w;
+    if (!Wq) {
+        if (elem_size(a->dtype) == 4) b64_split_kernel<4><<<a->blocks, 256, 0, st>>>(static_cast<const unsigned char*>(W), reinterpret_cast<unsigned char*>(ws), a->blocks, fprop ? 0 : 1);
+        else                          b64_split_kernel<2><<<a->blocks, 256, 0, st>>>(static_cast<const unsigned char*>(W), reinterpret_cast<unsigned char*>(ws), a->blocks, fprop ? 0 : 1);
+        Wq = ws;
+    } else if (!aligned16(Wq)) return BSMM_ERR_ARG;
+    if (a->gate) {
+        b64_gate_kernel<<<(4 * a->blocks + 255) / 256, 256, 0, st>>>(a->gate, reinterpret_cast<float*>(ws + wq), a->blocks);
+        b.gate = reinterpret_cast<const float*>(ws + wq);
+    }
+    b.workspace = inner ? ws + wq + gq : nullptr;
+    b.workspace_bytes = inner ? a->workspace_bytes - wq - gq : 0;
+    return xprop(fprop, X, Wq, Y, &b);
+}
+
 int xprop(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
     int rc = check_common(a);
     if (rc) return rc;
     if (!X || !W || !Y || a->segments <= 0) return BSMM_ERR_ARG;
+    if (a->bsize == 64 && !a->plan) return BSMM_ERR_UNSUPPORTED;      // bsize 64 runs through its plan only
     if ((rc = check_plan(false, a))) return rc;
+    if (a->bsize == 64) return xprop64(fprop, X, W, Y, a);
     switch (a->dtype) {
         case BSMM_F32:  return xprop_dt<DTf32>(fprop, X, W, Y, a);
         case BSMM_F16:  return xprop_dt<DTf16>(fprop, X, W, Y, a);
@@ -849,6 +900,28 @@ int updat_dt(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* 
     return BSMM_ERR_UNSUPPORTED;
 }
 
+int updat64(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
+    // the streaming bsize-32 kernel leaves the fp32 sums of the quadrants in the workspace; one pass puts them together with alpha /
+    // beta / gate and ONE rounding.  16-bit types with the streaming plan only (what the reference runs bsize 64 in: fp16 tensor cores).
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    if (!a->plan) return BSMM_ERR_UNSUPPORTED;
+    bsmm_args b = b64_inner(a, true);
+    if (a->dtype == BSMM_F32 || b.plan_magic != U2PLAN_MAGIC) return BSMM_ERR_UNSUPPORTED;
+    const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;
+    if (sums_only) return BSMM_ERR_UNSUPPORTED;                  // (the raw sums of a bsize-64 call would be in quadrant order)
+    b.flags = (a->flags & ~BSMM_FLAG_GATED_DW) | BSMM_FLAG_DW_SUMS;
+    b.gate = nullptr; b.alpha = 1.f; b.beta = 0.f;
+    b.workspace = a->workspace; b.workspace_bytes = a->workspace_bytes;
+    if (!a->workspace || a->workspace_bytes < bsmm_workspace_bytes(BSMM_OP_UPDAT, &b)) return BSMM_ERR_WORKSPACE;
+    const int rc = bsmm_updat(X, DY, nullptr, &b);
+    if (rc) return rc;
+    const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;
+    const float* sums = static_cast<const float*>(a->workspace);
+    if (a->dtype == BSMM_F16) b64_finalize_kernel<DTf16><<<a->blocks, 256, 0, st>>>(sums, static_cast<uint16_t*>(DW), ug, a->blocks, a->alpha, a->beta);
+    else                      b64_finalize_kernel<DTbf16><<<a->blocks, 256, 0, st>>>(sums, static_cast<uint16_t*>(DW), ug, a->blocks, a->alpha, a->beta);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 namespace {
@@ -886,7 +959,9 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
     if (rc) return rc;
     if (!X || !DY || (!DW && !(a->flags & BSMM_FLAG_DW_SUMS))) return BSMM_ERR_ARG;      // (DW is not written in sums mode)
     if (a->pcount < 1 || a->pcount > 8) return BSMM_ERR_ARG;
+    if (a->bsize == 64 && !a->plan) return BSMM_ERR_UNSUPPORTED;
     if ((rc = check_plan(true, a))) return rc;
+    if (a->bsize == 64) return DW ? updat64(X, DY, DW, a) : (int)BSMM_ERR_ARG;
     if ((a->flags & BSMM_FLAG_DW_SUMS) && !(a->bsize == 32 && a->dtype != BSMM_F32 && a->plan && a->plan_magic == U2PLAN_MAGIC))
         return BSMM_ERR_UNSUPPORTED;
     PtrList8 xs, es;
@@ -905,6 +980,7 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
 
 size_t bsmm_prepared_bytes(int op, const bsmm_args* a) {
     if (!a || (op != BSMM_OP_FPROP && op != BSMM_OP_BPROP)) return 0;
+    if (a->bsize == 64) return (a->axis == 1 && a->blocks > 0 && a->plan && a->plan_magic == B64PLAN_MAGIC) ? b64_w_bytes(a) : 0;   // the quadrant copy of W
     if (a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && a->plan_magic == XCPLAN_MAGIC && a->plan_width == XS_G && a->blocks > 0) return xcols_w_bytes(a);
     return 0;
 }
@@ -914,6 +990,12 @@ int bsmm_prepare_weights(int op, const void* W, void* prepared, const bsmm_args*
     if (bsmm_prepared_bytes(op, a) == 0) return BSMM_ERR_UNSUPPORTED;
     if (!aligned16(W) || !aligned16(prepared)) return BSMM_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(a->stream);
+    if (a->bsize == 64) {      // (one image per op: bprop numbers the quadrants the other way round, see bsmm_b64.h)
+        const int swap = op == BSMM_OP_BPROP;
+        if (elem_size(a->dtype) == 4) b64_split_kernel<4><<<a->blocks, 256, 0, st>>>(static_cast<const unsigned char*>(W), static_cast<unsigned char*>(prepared), a->blocks, swap);
+        else                          b64_split_kernel<2><<<a->blocks, 256, 0, st>>>(static_cast<const unsigned char*>(W), static_cast<unsigned char*>(prepared), a->blocks, swap);
+        return (int)hipGetLastError();
+    }
     if (op == BSMM_OP_FPROP) split3_w_kernel<true><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), static_cast<uint16_t*>(prepared), a->blocks);
     else                     split3_w_kernel<false><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), static_cast<uint16_t*>(prepared), a->blocks);
     return (int)hipGetLastError();
@@ -1066,6 +1148,16 @@ static inline int opt_xc16_group(int32_t options) { return (options & BSMM_PLAN_
 static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int32_t n_out, int32_t bsize, int32_t dtype, int32_t axis,
                        int32_t options, int32_t* out) {
     if (axis != 0 && axis != 1) return 0;
+    if (bsize == 64) {      // 'BS64': the quadrant view's lut + the bsize-32 plan built from it (feature axis 1 only)
+        if (axis != 1 || !lut || segments <= 0 || blocks <= 0 || blocks >= (1 << 28)) return axis != 1 ? 0 : -1;
+        std::vector<int32_t> lut32, nested;
+        if (!b64_expand_xprop_lut(lut, segments, blocks, lut32)) return -1;
+        const long nw = xprop_plan(lut32.data(), 2 * segments, 4 * blocks, 2 * n_out, 32, dtype, axis, options, nullptr);
+        if (nw < 0) return -1;
+        nested.resize((size_t)nw);
+        if (nw > 0 && out) xprop_plan(lut32.data(), 2 * segments, 4 * blocks, 2 * n_out, 32, dtype, axis, options, nested.data());
+        return b64_emit(0, blocks, segments, lut32, nested, out);
+    }
     if (bsize == 8) return dtype == BSMM_F32 ? 0 : build_super8_xprop_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));   // 'BSS8'
     if (bsize != 32 && bsize != 16) return 0;   // plan kernels: bsize 32 (any dtype) / 16 and 8 (16-bit)
     if (dtype == BSMM_F32) {
@@ -1113,6 +1205,20 @@ static int updat_window(int32_t blocks, int32_t CB, int32_t KB, int32_t axis, in
 static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype, int32_t axis, int32_t options,
                        int32_t* out) {
     if (dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: 16-bit types
+    if (bsize == 64) {      // 'BS64': the quadrant view's updat lut + the bsize-32 (streaming) plan built from it
+        if (axis != 1 || !lut || blocks <= 0 || blocks >= (1 << 28)) return axis != 1 ? 0 : -1;
+        std::vector<int32_t> lut32((size_t)8 * blocks), nested;
+        for (int w = 0; w < blocks; ++w)
+            for (int q = 0; q < 4; ++q) {
+                lut32[(size_t)2 * (4 * w + q)] = 2 * lut[2 * w] + (q >> 1);
+                lut32[(size_t)2 * (4 * w + q) + 1] = 2 * lut[2 * w + 1] + (q & 1);
+            }
+        const long nw = updat_plan(lut32.data(), 4 * blocks, 2 * CB, 2 * KB, 32, dtype, axis, options, nullptr);
+        if (nw < 0) return -1;
+        nested.resize((size_t)nw);
+        if (nw > 0 && out) updat_plan(lut32.data(), 4 * blocks, 2 * CB, 2 * KB, 32, dtype, axis, options, nested.data());
+        return b64_emit(1, blocks, 0, lut32, nested, out);
+    }
     if (bsize == 8) return build_super8_updat_plan(lut, blocks, CB, KB, out);   // 'BSS8'
     if (bsize == 16) return build_updat_plan(lut, blocks, CB, KB, UW16, UP16_MAXB, out);
     if (bsize != 32) return 0;
@@ -1172,6 +1278,16 @@ int bsmm_plan_attach(bsmm_args* a, const int32_t* host_plan, long words, const i
         if (off < S8_HDR || off >= words || !describe_flat(host_plan + off, words - off, d)) return BSMM_ERR_ARG;
         if (d[0] != (host_plan[7] ? UPLAN_MAGIC : XCPLAN_MAGIC)) return BSMM_ERR_ARG;     // word [7]: 0 = xprop, 1 = updat
         a->plan_magic = S8PLAN_MAGIC; a->plan_width = host_plan[2]; a->plan_waves = d[2]; a->plan_items = d[3]; a->plan_inner = d[1];
+    } else if (host_plan[0] == B64PLAN_MAGIC) {
+        if (host_plan[1] != B64PLAN_VERSION || host_plan[2] <= 0 || host_plan[6] != words || (host_plan[3] != 0 && host_plan[3] != 1)) return BSMM_ERR_ARG;
+        const int32_t off = host_plan[5];
+        if (off != b64_off_nested(host_plan[3], host_plan[7], host_plan[2]) || off > words) return BSMM_ERR_ARG;
+        a->plan_magic = B64PLAN_MAGIC; a->plan_inner = host_plan[3];
+        if (off < words) {      // a nested bsize-32 plan (none: the nested call runs the kernels without a plan)
+            if (!describe_flat(host_plan + off, words - off, d) || nested_code(d[0]) == 0 || d[2] > 31 || (uint32_t)d[4] > 0xffffffu) return BSMM_ERR_ARG;
+            a->plan_width = d[1]; a->plan_items = d[3];
+            a->plan_waves = d[2] | (nested_code(d[0]) << 5) | (int32_t)((uint32_t)d[4] << 8);
+        }
     } else {
         if (!describe_flat(host_plan, words, d)) return BSMM_ERR_ARG;
         a->plan_magic = d[0]; a->plan_width = d[1]; a->plan_waves = d[2]; a->plan_items = d[3]; a->plan_inner = d[4];
@@ -1185,6 +1301,12 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     const bool xprop_op = op == BSMM_OP_FPROP || op == BSMM_OP_BPROP;
     // locked reference-policy tables on the per-segment kernels with a 16-bit type: fp32 image of the output (see xprop_typed);
     // asked for whenever the call COULD take that path (no plan, a gate, or the size heuristic)
+    if (a->bsize == 64) {   // 'BS64' plans: [the quadrant copy of W, unless prepared][the quadrants' gates][what the nested bsize-32 call needs]
+        if (a->axis != 1 || !a->plan || a->plan_magic != B64PLAN_MAGIC || a->plan_inner != (xprop_op ? 0 : 1)) return 0;
+        bsmm_args b = b64_inner(a, !xprop_op);
+        if (!xprop_op) { b.flags |= BSMM_FLAG_DW_SUMS; return bsmm_workspace_bytes(op, &b); }
+        return (a->prepared_w ? 0 : b64_w_bytes(a)) + b64_gate_bytes(a) + bsmm_workspace_bytes(op, &b);
+    }
     const size_t lock = xprop_op ? lock_acc_bytes(a) : 0;
     if (a->bsize == 8) {   // 'BSS8' plans: the expanded W (xprop) / the fp32 sums of the super-blocks (updat)
         if (!a->plan || a->plan_magic != S8PLAN_MAGIC || a->plan_width <= 0 || a->dtype == BSMM_F32) return lock;

@@ -724,6 +724,66 @@ inline long build_super8_updat_plan(const int32_t* updat_lut, int blocks, int CB
 }  // namespace bsmm
 
 // =================================================================================================
+// bsize 64 (feature axis 1 -- the reference's second axis-1 block size, blocksparse/matmul.py:84-89): a 64x64 block is four 32x32
+// QUADRANTS of the layout kron(layout, ones(2, 2)); a quadrant of weight block w is weight block 4 w + 2 i + j of the quadrant view,
+// i = which half of the CALL's input block, j = which half of its output block (fprop: (row half, column half) of W's block; bprop the
+// other way round -- the library stores the quadrant copy of W accordingly, bsmm_b64.h; updat: (row half, column half)).  The composite plan 'BS64' carries the lookup table
+// of the quadrant view (what the kernels without a plan read, device side) and the nested bsize-32 plan built from it; the library
+// repacks W into quadrant order (once per weights version when the caller keeps the result: bsmm_prepare_weights) and runs the
+// bsize-32 path.  Layout (int32): [0] magic 'BS64' [1] version [2] blocks (64x64) [3] kind: 0 = xprop, 1 = updat
+//   [4] off_lut32 (= B64_HDR) [5] off_nested (multiple of 4) [6] total words [7] segments of the 64-block lut (xprop) / 0
+//   lut32: xprop: 2 x segments headers (offset / 2, entries, output block, lock) + 8 x blocks entry words, the two halves of an
+//          output block column are consecutive segments (2 s, 2 s + 1), lock ids 2 l - 1 and 2 l;   updat: [4 x blocks][2] = (c, k)
+// =================================================================================================
+namespace bsmm {
+
+constexpr int32_t B64PLAN_MAGIC = 0x42533634;
+constexpr int32_t B64PLAN_VERSION = 1;
+constexpr int B64_HDR = 8;
+inline long b64_lut32_words(int kind, int segments64, int blocks64) { return kind == 0 ? 8L * segments64 + 8L * blocks64 : 8L * blocks64; }
+inline long b64_off_nested(int kind, int segments64, int blocks64) { return (B64_HDR + b64_lut32_words(kind, segments64, blocks64) + 3) & ~3L; }
+
+// quadrant view of an xprop lut: false = malformed
+inline bool b64_expand_xprop_lut(const int32_t* lut, int segments, int blocks, std::vector<int32_t>& out) {
+    out.assign((size_t)(8L * segments + 8L * blocks), 0);
+    long pos = 4L * segments;                   // entry pairs written so far (the 2 x segments headers take 4 x segments pairs)
+    for (int s = 0; s < segments; ++s) {
+        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2], lock = lut[4 * s + 3];
+        if (cnt < 0 || off < 0) return false;
+        for (int j = 0; j < 2; ++j) {
+            int32_t* h = &out[(size_t)4 * (2 * s + j)];
+            h[0] = (int32_t)pos; h[1] = 2 * cnt; h[2] = 2 * ob + j; h[3] = lock > 0 ? 2 * lock - 1 + j : lock;
+            for (int e = 0; e < cnt; ++e) {
+                const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
+                if (w < 0 || w >= blocks || c < 0) return false;
+                for (int i = 0; i < 2; ++i) {
+                    out[(size_t)2 * pos] = 2 * c + i;
+                    out[(size_t)2 * pos + 1] = 4 * w + 2 * i + j;
+                    ++pos;
+                }
+            }
+        }
+    }
+    return 2 * pos == (long)out.size();
+}
+
+inline long b64_emit(int kind, int blocks64, int segments64, const std::vector<int32_t>& lut32, const std::vector<int32_t>& nested, int32_t* out) {
+    const long off_nested = b64_off_nested(kind, segments64, blocks64);
+    const long total = off_nested + (long)nested.size();
+    if (total >= (1L << 31)) return 0;
+    if (out) {
+        std::fill(out, out + off_nested, 0);
+        const int32_t hdr[B64_HDR] = {B64PLAN_MAGIC, B64PLAN_VERSION, blocks64, kind, B64_HDR, (int32_t)off_nested, (int32_t)total, kind == 0 ? segments64 : 0};
+        std::copy(hdr, hdr + B64_HDR, out);
+        std::copy(lut32.begin(), lut32.end(), out + B64_HDR);
+        std::copy(nested.begin(), nested.end(), out + off_nested);
+    }
+    return total;
+}
+
+}  // namespace bsmm
+
+// =================================================================================================
 // updat v2 plan ('BSU2'): work items of the streaming weight-gradient kernel (bsmm_updat_v2.h), bsize 32, feature axis 1,
 // 16-bit types.  The block grid is cut into WS x WS windows (WS = 16 for layouts up to ~22 % density: a window then holds
 // up to 64 blocks = 16 waves x 4 accumulator slots; WS = 8 above).  Inside an item every wave owns up to U2_SLOTS blocks

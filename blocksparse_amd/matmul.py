@@ -172,6 +172,7 @@ class BlocksparseMatMul(object):
         self._prepared_w = {}             # op -> ((op, w.data_ptr, w._version, stream), buffer): bsmm_prepare_weights results
         self._inner = None
         self._split64_hit = None
+        self.native64 = True          # bsize 64: call the library with bsize = 64 (False: always the host-side quadrant view)
         if block_size == 64:
             # same weights, cut into 32x32 blocks: inner block n is quadrant (i, j) of outer block b
             self._inner = BlocksparseMatMul(np.kron(self.layout, np.ones((2, 2), dtype=self.layout.dtype)), block_size=32, feature_axis=feature_axis,
@@ -322,7 +323,7 @@ class BlocksparseMatMul(object):
         gate = self._check_gate(gate, x.device)
         if x.dtype != w.dtype:
             raise TypeError("x and w must have the same dtype")
-        if self._inner is not None:
+        if self._inner is not None and not self.native64:
             return self._inner.fprop(x, self._split64_cached(w), gate=self._gate64(gate))
         x = x.contiguous(); w = w.contiguous()
         N = self._n_of(x, self.C)
@@ -343,7 +344,7 @@ class BlocksparseMatMul(object):
         gate = self._check_gate(gate, dy.device)
         if dy.dtype != w.dtype:
             raise TypeError("dy and w must have the same dtype")
-        if self._inner is not None:
+        if self._inner is not None and not self.native64:
             return self._inner.bprop(dy, self._split64_cached(w), gate=self._gate64(gate))
         dy = dy.contiguous(); w = w.contiguous()
         N = self._n_of(dy, self.K)
@@ -383,7 +384,9 @@ class BlocksparseMatMul(object):
         for x, dy in zip(xs, dys):
             if self._n_of(x, self.C) != N or self._n_of(dy, self.K) != N:
                 raise ValueError("all pairs must share the minibatch size")
-        if self._inner is not None:      # bsize 64: the gradient of the four 32x32 quadrants, put back together
+        # bsize 64: the library takes it for 16-bit types (bsmm_args.bsize = 64 with a 'BS64' plan: quadrant sums + one finalize pass);
+        # fp32 and the raw-sums form go through the host-side quadrant view
+        if self._inner is not None and not (self.native64 and xs[0].dtype != torch.float32 and not sums_only):
             if sums_only:                # the fp32 sums of the quadrants (a view of the inner call's workspace), put together as a copy
                 if gate is not None:
                     raise ValueError("updat(sums_only=True) returns the ungated sums: pass the gate to updat_finalize / DwReduce.start")

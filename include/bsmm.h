@@ -117,7 +117,9 @@ typedef struct bsmm_args {
     int32_t split;          /* updat with a plan: workgroups per work item (each takes a slice of the minibatch; > 1 or a
                                gate: fp32 partial sums in the workspace + a summing pass); 0 = library chooses          */
     int32_t blocks;         /* nonzero blocks                                                                        */
-    int32_t bsize;          /* 8, 16 or 32                                                                           */
+    int32_t bsize;          /* 8, 16 or 32; 64 on feature axis 1 (the reference's second axis-1 block size, blocksparse/matmul.py:84-89,
+                               src/blocksparse_hgemm_nc_op_gpu.cu:38-281) WITH a plan built for bsize 64: the library runs the four 32x32
+                               quadrants of every block on the bsize-32 kernels (see bsmm_xprop_plan_build)                        */
     int32_t segments;       /* xprop: number of lut headers (incl. empty output blocks)                              */
     int32_t locks;          /* xprop: number of output blocks written by more than one segment                       */
     int32_t C;              /* input features  of this call (bprop: caller passes the layer's K here)                */
@@ -204,7 +206,11 @@ int bsmm_sparse_mul_grad(void* dx, void* dy, const void* dz, const void* x, cons
  * options: BSMM_PLAN_* (0 = default).
  * bsize 8 (16-bit types, n_out_blocks % 4 == 0): the result is a composite 'BSS8' plan -- the 8x8 blocks grouped into 32x32
  * super-blocks, the bsize-32 plan of that super layout nested at word [5]; fprop / bprop then need workspace
- * (bsmm_workspace_bytes). */
+ * (bsmm_workspace_bytes).
+ * bsize 64 (feature axis 1, any dtype; replaces hgemm_blocksparse_64x64x64_*, src/blocksparse_hgemm_nc_op_gpu.cu:38-281,949-1083): a composite
+ * 'BS64' plan -- the lookup table of the quadrant view (a 64x64 block = four 32x32 blocks of kron(layout, ones(2,2))) and the bsize-32
+ * plan built from it.  bsmm_fprop / bsmm_bprop with bsize = 64 REQUIRE this plan; they run the bsize-32 kernels on a quadrant-ordered copy
+ * of W, made per call into the workspace or, better, once per weights version by bsmm_prepare_weights (args->prepared_w; one image per op). */
 long bsmm_xprop_plan_words(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks,
                            int32_t bsize, int32_t dtype, int32_t axis, int32_t options);
 int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blocks, int32_t n_out_blocks,
@@ -214,7 +220,9 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
  * columns of the layout).  Same conventions as the xprop plan (options: BSMM_PLAN_WINDOW_* or 0).
  * With a plan, bsmm_updat needs workspace (the fp32 sums and, for the streaming kernel, one 256 KiB region of partial sums per
  * round and workgroup: 141 MB at 4096^2 / 20 % / N = 8192): ask bsmm_workspace_bytes(BSMM_OP_UPDAT, args).
- * bsize 8 (16-bit types, CB % 4 == 0 and KB % 4 == 0): composite 'BSS8' plan as above. */
+ * bsize 8 (16-bit types, CB % 4 == 0 and KB % 4 == 0): composite 'BSS8' plan as above.
+ * bsize 64 (feature axis 1, 16-bit types): composite 'BS64' plan around the streaming bsize-32 plan of the quadrant view; bsmm_updat then
+ * leaves the fp32 sums of the quadrants in the workspace and one pass writes DW (64x64 blocks) with alpha / beta / gate and ONE rounding. */
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize,
                            int32_t dtype, int32_t axis, int32_t options);
 int bsmm_updat_plan_build(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize,

@@ -49,6 +49,74 @@ def test_struct_layout_matches_header(lib):
     assert ctypes.sizeof(lib.BsmmArgs) == 5 * 8 + 18 * 4 + 2 * 4 + 3 * 8   # 4 ptr + size_t, 18 int32, 2 float, 3 ptr
 
 
+def test_bsize64_composite_plans_without_gpu(lib):
+    """bsize 64 at the C ABI (feature axis 1, the reference's second axis-1 block size, blocksparse/matmul.py:84-89): 'BS64' plans carry the
+    lookup table of the QUADRANT view -- weight block 4 w + 2 i + j for (input half i, output half j) of the call -- and the nested bsize-32 plan
+    built from it; bsmm_plan_attach describes the nested plan in the args, the workspace / prepared-weights queries answer for the
+    nested call plus the quadrant copy of W; other combinations are refused on the host."""
+    import numpy as np
+    from blocksparse_amd import lut as LT
+    from blocksparse_amd.matmul import _host_plan, _host_updat_plan
+    L = lib.load()
+    ip = ctypes.POINTER(ctypes.c_int32)
+    rng = np.random.default_rng(3)
+    for CB, KB, dens in ((6, 10, 0.4), (20, 20, 0.2), (1, 1, 1.0)):
+        lay = rng.random((CB, KB)) < dens
+        lay[0, :] = True
+        t = LT.build_tables(lay)
+        B = t["blocks"]
+        for side, n_out in (("fprop", KB), ("bprop", CB)):
+            f = t[side]
+            for dt in (lib.BF16, lib.F32):
+                plan = _host_plan(f["lut"], f["segments"], B, n_out, 64, dt, 1)
+                assert plan[0] == 0x42533634 and plan[1] == 1 and plan[2] == B and plan[3] == 0 and plan[4] == 8 and plan[6] == plan.size and plan[7] == f["segments"]
+                S = f["segments"]
+                lut32 = plan[8:8 + 8 * S + 8 * B]
+                assert plan[5] == (8 + lut32.size + 3) // 4 * 4
+                got = set()
+                for s32 in range(2 * S):
+                    off, cnt, ob, lock = (int(v) for v in lut32[4 * s32:4 * s32 + 4])
+                    lock64 = int(f["lut"][4 * (s32 // 2) + 3])                         # a locked column's halves get lock ids 2 l - 1 and 2 l
+                    assert lock == (2 * lock64 - 1 + (s32 & 1) if lock64 > 0 else 0) and ob == 2 * int(f["lut"][4 * (s32 // 2) + 2]) + (s32 & 1)
+                    for e in range(cnt):
+                        got.add((ob, int(lut32[2 * (off + e)]), int(lut32[2 * (off + e) + 1])))
+                want = set()
+                for ob, col in f["cols"]:
+                    for c, w in col:
+                        for i in range(2):
+                            for j in range(2):
+                                want.add((2 * ob + j, 2 * c + i, 4 * w + 2 * i + j))
+                assert got == want
+                nested = plan[plan[5]:]
+                assert nested[0] in ((0x42535832, 0x42535843) if dt == lib.BF16 else (0x42535843, 0x42535846))       # 'BSX2' / 'BSXC' / 'BSXF'
+                # the same plan the library builds for the quadrant lut directly
+                assert (nested == _host_plan(lut32, 2 * S, 4 * B, 2 * n_out, 32, dt, 1)).all()
+                a = lib.BsmmArgs()
+                a.blocks, a.bsize, a.dtype, a.N, a.axis, a.segments = B, 64, dt, 128, 1, S
+                a.C, a.K = (CB * 64, KB * 64) if side == "fprop" else (KB * 64, CB * 64)
+                assert L.bsmm_plan_attach(ctypes.byref(a), plan.ctypes.data_as(ip), plan.size, ctypes.c_void_p(4096)) == 0
+                assert a.plan_magic == 0x42533634 and a.plan_inner == 0
+                es = 2 if dt == lib.BF16 else 4
+                op = lib.OP_FPROP if side == "fprop" else lib.OP_BPROP
+                assert L.bsmm_prepared_bytes(op, ctypes.byref(a)) == B * 4096 * es
+                ws = L.bsmm_workspace_bytes(op, ctypes.byref(a))
+                assert ws >= B * 4096 * es
+                a.prepared_w = 8192
+                assert ws - L.bsmm_workspace_bytes(op, ctypes.byref(a)) == B * 4096 * es
+        up = _host_updat_plan(t["updat_lut"], B, CB, KB, 64, lib.BF16, 1)
+        assert up[0] == 0x42533634 and up[3] == 1 and up[2] == B and up[6] == up.size
+        q = up[8:8 + 8 * B].reshape(4 * B, 2)
+        for w, (c, k) in enumerate(t["updat_lut"]):
+            assert [tuple(r) for r in q[4 * w:4 * w + 4]] == [(2 * c, 2 * k), (2 * c, 2 * k + 1), (2 * c + 1, 2 * k), (2 * c + 1, 2 * k + 1)]
+        assert up[up[5]] == 0x42535532                                                          # nested: the streaming plan
+        a = lib.BsmmArgs()
+        a.blocks, a.bsize, a.dtype, a.N, a.axis, a.C, a.K = B, 64, lib.BF16, 128, 1, CB * 64, KB * 64
+        assert L.bsmm_plan_attach(ctypes.byref(a), up.ctypes.data_as(ip), up.size, ctypes.c_void_p(4096)) == 0 and a.plan_inner == 1
+        assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(a)) >= 4 * B * 4096                # the fp32 sums of the quadrants
+        assert _host_updat_plan(t["updat_lut"], B, CB, KB, 64, lib.F32, 1) is None
+        assert _host_plan(t["fprop"]["lut"], t["fprop"]["segments"], B, KB, 64, lib.BF16, 0) is None       # feature axis 0: not a reference configuration
+
+
 def test_prepared_weights_entry_points_without_gpu(lib):
     """bsmm_prepared_bytes / bsmm_prepare_weights (the cached split of constant fp32 weights): only fp32 / bsize 32 with the 16-wide
     'BSXC' plan has something to prepare; everything else answers 0 / BSMM_ERR_UNSUPPORTED; bad arguments are refused."""

@@ -333,6 +333,18 @@ def test_bsize64_axis1(env):
                 assert l2 <= P.L2_BAR[dtype], (dtype, N, k, l2)
     with pytest.raises(ValueError):
         BSMM(layout, block_size=64, feature_axis=0)
+    # round 3: the calls above went to the library with bsmm_args.bsize = 64 ('BS64' plans; fp32 updat excepted).  The host-side
+    # quadrant view (native64 = False) is the same arithmetic on the same kernels: bit-identical for xprop, and for the 16-bit updat
+    # up to the order in which the streaming kernel's partial sums meet
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(520), b.o_shape(520), "bf16", seed=77)
+    w, x, e = P.to_dev(W, "bf16", torch), P.to_dev(X, "bf16", torch), P.to_dev(E, "bf16", torch)
+    y1, dx1, dw1 = b.fprop(x, w), b.bprop(e, w), b.updat(x, e)
+    assert lib.last_kernel() == lib.K_UPDAT_STREAM
+    b.native64 = False
+    y0, dx0, dw0 = b.fprop(x, w), b.bprop(e, w), b.updat(x, e)
+    b.native64 = True
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    assert ((dw1.float() - dw0.float()).norm() / dw0.float().norm()).item() < 1e-3
 
 
 def test_bsize64_axis1_helper_ops(env):
@@ -376,7 +388,12 @@ def test_bsize64_axis1_helper_ops(env):
     yv = b(xg, wg, gate=gg, gate_grad=True)
     yv.backward(torch.ones_like(yv))
     assert xg.grad is not None and wg.grad is not None and gg.grad is not None and torch.isfinite(gg.grad).all()
-    # the split of a constant W is cached: same storage and version -> the same tensor object
+    # the quadrant copy of a constant W is made once per (op, storage, version): by the library call path (bsmm_prepare_weights) ...
+    b.fprop(x, W); key = b._prepared_w[lib.OP_FPROP][0]
+    b.fprop(x, W); assert b._prepared_w[lib.OP_FPROP][0] == key
+    W.add_(0.0); b.fprop(x, W); assert b._prepared_w[lib.OP_FPROP][0] != key
+    # ... and by the host-side quadrant view
+    b.native64 = False
     b.fprop(x, W); first = b._split64_hit[1]
     b.bprop(dy, W); assert b._split64_hit[1] is first
     W.add_(0.0); b.fprop(x, W); assert b._split64_hit[1] is not first
