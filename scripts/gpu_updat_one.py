@@ -18,8 +18,9 @@ def timeit(fn, reps=100, warm=30):
 tag = os.path.basename(os.environ.get("BSMM_LIB", "default"))
 cases = sys.argv[1:] or ["d10:stream16", "d20:stream16", "d50:stream8"]
 OPT = {"stream16": _lib.PLAN_STREAM_16, "stream8": _lib.PLAN_STREAM_8, "win8": _lib.PLAN_WINDOW_8, "auto": 0,
-       "s16x1": _lib.PLAN_STREAM_16 | 0x100, "s16x2": _lib.PLAN_STREAM_16 | 0x200, "s16x4": _lib.PLAN_STREAM_16 | 0x400, "s16x8": _lib.PLAN_STREAM_16 | 0x800,
-       "s8x4": _lib.PLAN_STREAM_8 | 0x400, "s8x2": _lib.PLAN_STREAM_8 | 0x200}
+       "s16x1": _lib.PLAN_STREAM_16 | (1 << _lib.PLAN_UPDAT_SETS_SHIFT), "s16x2": _lib.PLAN_STREAM_16 | (2 << _lib.PLAN_UPDAT_SETS_SHIFT),
+       "s16x4": _lib.PLAN_STREAM_16 | (4 << _lib.PLAN_UPDAT_SETS_SHIFT), "s16x8": _lib.PLAN_STREAM_16 | (8 << _lib.PLAN_UPDAT_SETS_SHIFT),
+       "s8x4": _lib.PLAN_STREAM_8 | (4 << _lib.PLAN_UPDAT_SETS_SHIFT), "s8x2": _lib.PLAN_STREAM_8 | (2 << _lib.PLAN_UPDAT_SETS_SHIFT)}
 out = []
 for c in cases:
     d, o = c.split(":")
