@@ -458,6 +458,18 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     return XP_SEGMENT;
 }
 
+// the bsize-32 call nested in a 'BSS8' plan: plan_inner = nested width | nested format << 8 (0: round-1 'BSXC' / 'BSUP', 1: staged 'BSX2',
+// 2: streaming 'BSU2') | the nested plan's own descriptor word << 11 (bsmm_plan_attach)
+inline bsmm_args s8_inner(const bsmm_args* a, bool updat) {
+    const int ns = a->plan_width, code = (a->plan_inner >> 8) & 7;
+    bsmm_args b = *a;
+    b.bsize = 32; b.blocks = ns; b.plan = a->plan + s8_off_nested(ns);
+    b.plan_width = a->plan_inner & 0xff;
+    b.plan_inner = (int32_t)((uint32_t)a->plan_inner >> 11);
+    b.plan_magic = updat ? (code == 2 ? U2PLAN_MAGIC : UPLAN_MAGIC) : (code == 1 ? X2PLAN_MAGIC : XCPLAN_MAGIC);
+    return b;
+}
+
 template <class DT, int BS, int AXIS>
 int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
     typedef typename DT::T T;
@@ -470,9 +482,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
             if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
             if (fprop) expand8_kernel<DT, true><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
             else       expand8_kernel<DT, false><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
-            bsmm_args b = *a;
-            b.bsize = 32; b.blocks = ns; b.plan = a->plan + s8_off_nested(ns);
-            b.plan_magic = XCPLAN_MAGIC; b.plan_width = a->plan_inner; b.plan_inner = 0;
+            bsmm_args b = s8_inner(a, false);
             const int rc = launch_xgroup32<DT, AXIS>(X, a->workspace, Y, &b, st, false);
             trace(a, BSMM_K_XPROP_SUPER8);
             return rc;
@@ -755,12 +765,17 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
         if (a->plan != nullptr && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && a->plan_items > 0 && !gated && al && (variant == 0 || variant == 3)) {
             const int ns = a->plan_width;
-            bsmm_args b = *a;
-            b.bsize = 32; b.blocks = ns; b.flags = 0; b.gate = nullptr; b.trace = nullptr;
+            bsmm_args b = s8_inner(a, true);
+            b.flags = 0; b.gate = nullptr; b.trace = nullptr;
             b.lut = a->plan + s8_off_lut32(ns);
-            b.plan = a->plan + s8_off_nested(ns);
-            b.plan_magic = UPLAN_MAGIC; b.plan_width = a->plan_inner; b.plan_inner = 0;
-            const int rc = launch_updat32_win<DT, AXIS>(xs, es, nullptr, &b, true);
+            int rc;
+            if (b.plan_magic == U2PLAN_MAGIC) {      // streaming kernel, raw fp32 sums of the super-blocks at the start of the workspace
+                b.flags = BSMM_FLAG_DW_SUMS; b.split = 0;
+                if ((long)N * std::max(a->C, a->K) >= (1L << 30)) return BSMM_ERR_UNSUPPORTED;
+                rc = launch_updat2<DT, AXIS>(xs, es, nullptr, &b, nullptr);
+            } else {
+                rc = launch_updat32_win<DT, AXIS>(xs, es, nullptr, &b, true);
+            }
             if (rc) return rc;
             trace(a, BSMM_K_UPDAT_SUPER8);
             gather8_kernel<DT><<<ns, 256, 0, st>>>(static_cast<const float*>(a->workspace), a->plan, static_cast<T*>(DW), a->alpha, a->beta);
@@ -1276,8 +1291,14 @@ int bsmm_plan_attach(bsmm_args* a, const int32_t* host_plan, long words, const i
         if (host_plan[1] != S8PLAN_VERSION || host_plan[2] <= 0 || host_plan[6] != words) return BSMM_ERR_ARG;
         const int32_t off = host_plan[5];
         if (off < S8_HDR || off >= words || !describe_flat(host_plan + off, words - off, d)) return BSMM_ERR_ARG;
-        if (d[0] != (host_plan[7] ? UPLAN_MAGIC : XCPLAN_MAGIC)) return BSMM_ERR_ARG;     // word [7]: 0 = xprop, 1 = updat
-        a->plan_magic = S8PLAN_MAGIC; a->plan_width = host_plan[2]; a->plan_waves = d[2]; a->plan_items = d[3]; a->plan_inner = d[1];
+        int code = -1;                                                                    // word [7]: 0 = xprop, 1 = updat
+        if (!host_plan[7] && d[0] == XCPLAN_MAGIC) code = 0;
+        if (!host_plan[7] && d[0] == X2PLAN_MAGIC) code = 1;
+        if (host_plan[7] && d[0] == UPLAN_MAGIC) code = 0;
+        if (host_plan[7] && d[0] == U2PLAN_MAGIC) code = 2;
+        if (code < 0 || d[1] > 255 || (uint32_t)d[4] >= (1u << 21)) return BSMM_ERR_ARG;
+        a->plan_magic = S8PLAN_MAGIC; a->plan_width = host_plan[2]; a->plan_waves = d[2]; a->plan_items = d[3];
+        a->plan_inner = d[1] | (code << 8) | (int32_t)((uint32_t)(code ? d[4] : 0) << 11);
     } else if (host_plan[0] == B64PLAN_MAGIC) {
         if (host_plan[1] != B64PLAN_VERSION || host_plan[2] <= 0 || host_plan[6] != words || (host_plan[3] != 0 && host_plan[3] != 1)) return BSMM_ERR_ARG;
         const int32_t off = host_plan[5];
@@ -1311,6 +1332,11 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     if (a->bsize == 8) {   // 'BSS8' plans: the expanded W (xprop) / the fp32 sums of the super-blocks (updat)
         if (!a->plan || a->plan_magic != S8PLAN_MAGIC || a->plan_width <= 0 || a->dtype == BSMM_F32) return lock;
         const size_t blk = (size_t)a->plan_width * 1024;
+        if (op == BSMM_OP_UPDAT && ((a->plan_inner >> 8) & 7) == 2) {      // nested streaming plan: its sums + partial-sum regions
+            bsmm_args b = s8_inner(a, true);
+            b.flags = BSMM_FLAG_DW_SUMS; b.split = 0;
+            return bsmm_workspace_bytes(op, &b);
+        }
         return op == BSMM_OP_UPDAT ? blk * sizeof(float) : std::max(blk * elem_size(a->dtype), lock);
     }
     if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32) {

@@ -663,7 +663,7 @@ inline long s8_emit(const std::vector<S8Super>& supers, const std::vector<int32_
 }
 
 // xprop: lut = the bsize-8 segment table of the pass (headers (offset, count, out block, lock), then (in block, w) pairs)
-inline long build_super8_xprop_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int G = XC_G) {
+inline long build_super8_xprop_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int G = XC_G, bool staged = false) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
     if (n_out_blocks % 4 != 0) return 0;                       // the super grid needs whole 32-feature blocks
     std::vector<int32_t> trip;
@@ -692,6 +692,17 @@ inline long build_super8_xprop_plan(const int32_t* lut, int segments, int blocks
         }
         lut32[4 * ob] = 2 * n_out32 + first; lut32[4 * ob + 1] = pos - first; lut32[4 * ob + 2] = ob; lut32[4 * ob + 3] = -1;
     }
+    // nested plan: the round-1 'BSXC' plan.  `staged`: the staged kernel's 'BSX2' plan instead -- measured SLOWER here (4096^2 bsize 8 10 %:
+    // 293 / 274 us against 220 / 200): the super layout of a 10 % bsize-8 layout is ~80 % dense, a pair step then holds more blocks than
+    // a ring half has weight slots and is cut into sub-steps that fetch the same activation slab twice
+    if (staged) {
+        const long n2 = build_xcol2_plan(lut32.data(), n_out32, ns, n_out32, nullptr, 0);
+        if (n2 > 0) {
+            std::vector<int32_t> nested((size_t)n2);
+            build_xcol2_plan(lut32.data(), n_out32, ns, n_out32, nested.data(), 0);
+            return s8_emit(supers, nested, 0, out);
+        }
+    }
     const long nw = build_xcol_plan(lut32.data(), n_out32, ns, n_out32, nullptr, G);
     if (nw <= 0) return -1;
     std::vector<int32_t> nested((size_t)nw);
@@ -699,7 +710,11 @@ inline long build_super8_xprop_plan(const int32_t* lut, int segments, int blocks
     return s8_emit(supers, nested, 0, out);
 }
 
-inline long build_super8_updat_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int32_t* out) {
+inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets);   // ('BSU2', below)
+
+// stream: nest the streaming kernel's 'BSU2' plan (round 3; the super layout of a 10 % bsize-8 layout is ~80 % dense: 8x8 windows) instead of the
+// round-1 windowed 'BSUP' plan; feature axis 1 and 0 alike (the streaming kernel serves both since round 3)
+inline long build_super8_updat_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int32_t* out, bool stream = true) {
     if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0) return -1;
     if (CB % 4 != 0 || KB % 4 != 0) return 0;
     std::vector<int32_t> trip;
@@ -714,6 +729,16 @@ inline long build_super8_updat_plan(const int32_t* updat_lut, int blocks, int CB
     const int ns = (int)supers.size();
     std::vector<int32_t> lut32((size_t)2 * ns);
     for (int s = 0; s < ns; ++s) { lut32[2 * s] = supers[s].a32; lut32[2 * s + 1] = supers[s].b32; }
+    if (stream) {
+        const double windows = (double)((CB / 4 + 15) / 16) * ((KB / 4 + 15) / 16);
+        const int ws = ns <= 56.0 * windows ? 16 : 8;            // as bsmm_api.hip chooses for a bsize-32 layout
+        const long n2 = build_updat2_plan(lut32.data(), ns, CB / 4, KB / 4, ws, nullptr, 0);
+        if (n2 > 0) {
+            std::vector<int32_t> nested((size_t)n2);
+            build_updat2_plan(lut32.data(), ns, CB / 4, KB / 4, ws, nested.data(), 0);
+            return s8_emit(supers, nested, 1, out);
+        }
+    }
     const long nw = build_updat_plan(lut32.data(), ns, CB / 4, KB / 4, UW, UP_MAXB, nullptr);
     if (nw <= 0) return -1;
     std::vector<int32_t> nested((size_t)nw);
@@ -816,7 +841,7 @@ constexpr int U2_WWORDS = 5;
 constexpr int U2_ITEM = 4 + U2_WAVES * U2_WWORDS;
 constexpr int U2_HDR = 28;   // 9 + 2 * 8 set descriptors, padded to a multiple of 4 words
 
-inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets = 0) {
+inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets) {
     if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || (ws != 8 && ws != 16)) return -1;
     const int WS = ws;
     const int wc = (CB + WS - 1) / WS, wk = (KB + WS - 1) / WS;

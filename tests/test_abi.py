@@ -610,7 +610,8 @@ def test_plan_attach_descriptor_and_host_side_rejection(lib):
     assert (a.plan_width, a.plan_waves) == (8, 8)
     s8 = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 8, lib.BF16, 0)
     a = attach(s8)
-    assert (a.plan_magic, a.plan_width, a.plan_inner, a.plan_waves) == (0x42535338, int(s8[2]), 8, 8) and a.plan_items > 0
+    # bsize 8: the nested plan's width | its format (2 = the streaming 'BSU2' plan, round 3) << 8 | its descriptor word << 11
+    assert (a.plan_magic, a.plan_width) == (0x42535338, int(s8[2])) and a.plan_inner & 0xff in (8, 16) and (a.plan_inner >> 8) & 7 == 2 and a.plan_waves == 16 and a.plan_items > 0
     # garbage / truncated / foreign-version words are not a plan
     bad = xp.copy(); bad[1] += 1
     b = lib.BsmmArgs()

@@ -10,7 +10,7 @@ from blocksparse_amd import lut as _lut
 from blocksparse_amd.matmul import _host_plan, _host_updat_plan
 from tests import _parity as P
 
-S8_MAGIC, XC_MAGIC, UP_MAGIC = 0x42535338, 0x42535843, 0x42535550
+S8_MAGIC, XC_MAGIC, UP_MAGIC, X2_MAGIC, U2_MAGIC = 0x42535338, 0x42535843, 0x42535550, 0x42535832, 0x42535532
 
 
 def _dense(layout, W, bs):
@@ -75,7 +75,7 @@ def test_updat_super_plan_covers_every_block_once(shape, density):
     B = t["blocks"]
     plan = _host_updat_plan(t["updat_lut"], B, t["CB"], t["KB"], 8, _lib.BF16, 1)
     ns, sub, lut32, nested = _parts(plan)
-    assert nested[0] == UP_MAGIC and nested[5] == ns
+    assert nested[0] == U2_MAGIC and nested[5] == ns       # round 3: the streaming kernel's plan of the super layout
     for w, (c, k) in enumerate(t["updat_lut"].tolist()):
         s = np.nonzero((lut32[:, 0] == c // 4) & (lut32[:, 1] == k // 4))[0]
         assert len(s) == 1 and sub[s[0], c % 4, k % 4] == w
