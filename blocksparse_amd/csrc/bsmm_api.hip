@@ -710,7 +710,7 @@ template <class DT, int AXIS>
 int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a, const float* gate) {
     typedef typename DT::T T;
     hipStream_t st = static_cast<hipStream_t>(a->stream);
-    if (a->plan_magic != U2PLAN_MAGIC || a->plan_waves != U2_WAVES || a->plan_items <= 0 || (a->plan_width != 16 && a->plan_width != 8)) return BSMM_ERR_ARG;
+    if (a->plan_magic != U2PLAN_MAGIC || a->plan_waves != U2_WAVES || a->plan_items <= 0 || (a->plan_width != 16 && a->plan_width != 8 && !(a->plan_width == 32 && AXIS == 1))) return BSMM_ERR_ARG;
     U2Launch L = updat2_shape(a, gate != nullptr);
     const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;
     if (sums_only) L.scratch = true;
@@ -724,7 +724,15 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     }
     trace(a, BSMM_K_UPDAT_STREAM);
     constexpr int LDS16 = AXIS == 1 ? u2_lds_bytes(16) : u2_lds_bytes0(16), LDS8 = AXIS == 1 ? u2_lds_bytes(8) : u2_lds_bytes0(8);
-    if (a->plan_width == 16) {
+    if (a->plan_width == 32) {
+        if constexpr (AXIS == 1) {
+            if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 32, 1>>(u2_lds_bytes(32))) return rc;
+            updat32_a1_v2_kernel<DT, 32, 1><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(32), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
+                                                                                            a->pcount, a->alpha, a->beta, L.flat);
+        } else {
+            return BSMM_ERR_ARG;
+        }
+    } else if (a->plan_width == 16) {
         if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 16, AXIS>>(LDS16)) return rc;
         updat32_a1_v2_kernel<DT, 16, AXIS><<<L.grid, 64 * U2_WAVES, LDS16, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
                                                                                 a->pcount, a->alpha, a->beta, L.flat);
@@ -1238,11 +1246,15 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
     if (bsize == 16) return build_updat_plan(lut, blocks, CB, KB, UW16, UP16_MAXB, out);
     if (bsize != 32) return 0;
     const int force = options & BSMM_PLAN_WINDOW_MASK;
-    if (force == 0 || force == BSMM_PLAN_STREAM_16 || force == BSMM_PLAN_STREAM_8) {     // either feature axis
+    if (force == 0 || force == BSMM_PLAN_STREAM_16 || force == BSMM_PLAN_STREAM_8 || force == BSMM_PLAN_STREAM_32) {     // either feature axis
         // streaming kernel: 16x16 windows while a window's blocks fit the 64 accumulator slots of a workgroup (with some
         // slack for the rows that do not pack: <= 56 on average), 8x8 windows for denser layouts
         const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);
-        const int ws = force == BSMM_PLAN_STREAM_16 ? 16 : (force == BSMM_PLAN_STREAM_8 ? 8 : (blocks <= 56.0 * windows ? 16 : 8));
+        int ws = force == BSMM_PLAN_STREAM_16 ? 16 : (force == BSMM_PLAN_STREAM_8 ? 8 : (blocks <= 56.0 * windows ? 16 : 8));
+        // very sparse layouts on feature axis 1: 32 x 32 windows (a 16 x 16 window then holds < 10 blocks for its 32 KiB per chunk).  Measured at
+        // 8192^2, N = 4096 (profiles/r03_updat_ws32.txt): 3 % 71 against 95 us; 5 % (BASELINE configs[3]) 102 against 96 -- so only below ~3.7 %
+        const double windows32 = (double)((CB + 31) / 32) * ((KB + 31) / 32);
+        if (force == BSMM_PLAN_STREAM_32 || (force == 0 && axis == 1 && windows32 >= 16 && blocks <= 38.0 * windows32)) ws = 32;
         return build_updat2_plan(lut, blocks, CB, KB, ws, out, (options >> BSMM_PLAN_UPDAT_SETS_SHIFT) & 15);
     }
     const int w = updat_window(blocks, CB, KB, axis, options);

@@ -842,7 +842,7 @@ constexpr int U2_ITEM = 4 + U2_WAVES * U2_WWORDS;
 constexpr int U2_HDR = 28;   // 9 + 2 * 8 set descriptors, padded to a multiple of 4 words
 
 inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets) {
-    if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || (ws != 8 && ws != 16)) return -1;
+    if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || (ws != 8 && ws != 16 && ws != 32) || blocks >= (1 << 29)) return -1;
     const int WS = ws;
     const int wc = (CB + WS - 1) / WS, wk = (KB + WS - 1) / WS;
     struct Ent { int c, k, w; };
@@ -875,16 +875,21 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
             wd[1] = wd[2] = wd[3] = wd[4] = -1;
             if (v >= (int)waves.size() || waves[v].p.empty()) continue;
             const Wave& W = waves[v];
+            // window-local indices: 4 bits each in word 0; with 32 x 32 windows their fifth bit rides in the id words: bit 30 of slot j's word
+            // = bit 4 of kidx[j], bit 29 of slot 0's / slot n0's word = bit 4 of cidx0 / cidx1
             const int n0 = (int)W.p[0].e.size(), n1 = W.p.size() > 1 ? (int)W.p[1].e.size() : 0;
-            uint32_t m = (uint32_t)n0 | ((uint32_t)n1 << 4) | ((uint32_t)(W.p[0].row - wi * WS) << 8);
-            if (n1) m |= (uint32_t)(W.p[1].row - wi * WS) << 12;
+            const int c0i = W.p[0].row - wi * WS, c1i = n1 ? W.p[1].row - wi * WS : 0;
+            uint32_t m = (uint32_t)n0 | ((uint32_t)n1 << 4) | ((uint32_t)(c0i & 15) << 8) | ((uint32_t)(c1i & 15) << 12);
             int j = 0;
             for (const Piece& pc : W.p)
                 for (const Ent& e : pc.e) {
-                    m |= (uint32_t)(e.k - wj * WS) << (16 + 4 * j);
-                    wd[1 + j] = e.w;
+                    const int ki = e.k - wj * WS;
+                    m |= (uint32_t)(ki & 15) << (16 + 4 * j);
+                    wd[1 + j] = e.w | ((ki >> 4) << 30);
                     ++j; ++n;
                 }
+            wd[1] |= (c0i >> 4) << 29;
+            if (n1) wd[1 + n0] |= (c1i >> 4) << 29;
             wd[0] = (int32_t)m;
         }
         it[0] = wi * WS; it[1] = wj * WS; it[2] = n;
@@ -1007,8 +1012,9 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
                 const int32_t* wd = ip + 4 + wv * U2_WWORDS;
                 const int n = (wd[0] & 15) + ((wd[0] >> 4) & 15);
                 for (int j = 0; j < n; ++j) {
-                    if (wd[1 + j] < 0 || wd[1 + j] >= blocks || bmap[wd[1 + j]] != -1) return -1;
-                    bmap[wd[1 + j]] = (int32_t)((it << 8) | (wv * U2_SLOTS + j));
+                    const int32_t wid = wd[1 + j] & 0x1fffffff;                 // (bits 29 / 30: fifth index bits of 32 x 32 windows)
+                    if (wd[1 + j] < 0 || wid >= blocks || bmap[wid] != -1) return -1;
+                    bmap[wid] = (int32_t)((it << 8) | (wv * U2_SLOTS + j));
                 }
             }
         }

@@ -52,7 +52,8 @@ constexpr int U2_KS = U2_CH / 16;          // MFMA K-steps per chunk
 constexpr int U2_D = 64 / U2_CH;           // ring slots (128 KiB with 16x16 windows)
 constexpr int U2_AHEAD = U2_D / 2;         // prefetch distance in chunks (see the ring protocol at the chunk loop)
 static_assert(U2_CH == 16 || U2_CH == 32, "chunk = 1 or 2 K-steps");
-constexpr int u2_lds_bytes(int ws) { return U2_D * 2 * U2_CH * ws * 64; }
+constexpr int u2_ring(int ws) { return ws == 32 ? 2 : U2_D; }          // 32 x 32 windows (sparse layouts): two slots of 64 KiB
+constexpr int u2_lds_bytes(int ws) { return u2_ring(ws) * 2 * U2_CH * ws * 64; }
 // feature_axis 0 (activations (C, N): slab rows are FEATURES, a chunk is 32 minibatch columns = 64 B per row -- a piece length the
 // L2 -> LDS path delivers at the rate of 128-byte pieces, scripts/micro/seg_bw.hip; 16 columns = 32 B deliver at half of it):
 constexpr int U2_CH0 = 32;                 // minibatch columns per chunk
@@ -123,18 +124,19 @@ __global__ void __launch_bounds__(64 * U2_WAVES, 4)
 updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
                      const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta, int flat) {
     typedef typename DT::T T;
-    static_assert(DT::is16 && (WS == 8 || WS == 16), "updat v2: 16-bit storage types, 8x8 or 16x16 windows");
+    static_assert(DT::is16 && (WS == 8 || WS == 16 || (WS == 32 && AXIS == 1)), "updat v2: 16-bit storage types, 8x8 / 16x16 windows (32x32: feature axis 1)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CH = AXIS == 1 ? U2_CH : U2_CH0;                // minibatch entries per chunk
     constexpr int KS = CH / 16;                                   // MFMA K-steps per chunk
     constexpr bool FIVE = AXIS == 0 && U2_RING5;                  // axis 0, experiment: five HALF slots instead (see u2_lds_bytes0)
-    constexpr int D = AXIS == 1 ? U2_D : (WS == 16 ? 2 : 4);      // ring slots (axis 0: 64 / 32 KiB each)
+    constexpr int D = AXIS == 1 ? u2_ring(WS) : (WS == 16 ? 2 : 4);   // ring slots (axis 0: 64 / 32 KiB each)
     constexpr int AHEAD = D / 2;                                  // prefetch distance in chunks
     constexpr int ROWB = AXIS == 1 ? WS * 64 : CH * 2;            // bytes per slab row
     constexpr int SLAB = AXIS == 1 ? CH * ROWB : WS * 32 * ROWB;  // one operand, one chunk
     constexpr int SLOT = 2 * SLAB;
     constexpr int PPR = ROWB / 16;                // 16-byte pieces per row
-    constexpr int RPI = 1024 / ROWB;              // rows per DMA instruction
+    constexpr int RPI = ROWB <= 1024 ? 1024 / ROWB : 1;   // rows per DMA instruction ...
+    constexpr int IPR = ROWB <= 1024 ? 1 : ROWB / 1024;   // ... or instructions per row (32 x 32 windows: a row is 2 KiB)
     constexpr int IPO = SLAB / 1024;              // DMA instructions per operand and chunk
     constexpr int NI = 2 * IPO / U2_WAVES;        // DMA instructions per wave and chunk (consecutive pieces of ONE operand)
     static_assert((NI == 1 || NI == 2 || NI == 4) && NI * U2_WAVES == 2 * IPO && IPO % NI == 0, "the chunk must split evenly over the waves");
@@ -165,8 +167,11 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     // ---- DMA geometry of this wave: instructions NI*wave .. NI*wave + NI-1 of a chunk = consecutive 1 KiB pieces of one
     //      operand's slab; instruction q covers slab rows d_row0 + q*RPI (+ lane / PPR), this lane's 16-byte piece lane % PPR ----
     const int opE = (NI * wave) / IPO;                                        // 0: X slab, 1: DY slab (wave-uniform)
-    const int d_row0 = ((NI * wave) % IPO) * RPI + lane / PPR;
-    const uint32_t sub_off = ((NI * wave) % IPO) * 1024;                      // my first piece inside my operand's slab
+    const int ii0 = (NI * wave) % IPO;                                        // my first instruction of the operand's slab
+    const int d_row0 = ROWB <= 1024 ? ii0 * RPI + lane / PPR : ii0 / IPR;     // its (this lane's) slab row
+    auto row_of = [&](int q) -> int { return ROWB <= 1024 ? d_row0 + q * RPI : (ii0 + q) / IPR; };          // slab row of my instruction q
+    auto pos_of = [&](int q) -> int { return ROWB <= 1024 ? lane % PPR : ((ii0 + q) % IPR) * 64 + lane; };  // LDS piece of the row this lane fills
+    const uint32_t sub_off = ii0 * 1024;                                      // my first piece inside my operand's slab
     const uint32_t wave_off = (!FIVE ? opE * SLAB : 0) + sub_off;         // ... inside a ring slot (five half slots: the half slot carries the operand)
     constexpr uint32_t HS = SLAB, RING0 = 5 * SLAB;                           // axis 0: half slot, ring
     const int F = opE ? Kf : Cf;                                              // row length (axis 1) / row count (axis 0) of my operand
@@ -209,9 +214,9 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
         // pieces belong to window columns no block of the item uses)
         // (plain scalars, not arrays: with NI == 1 hipcc left a one-element array that lambdas capture by reference in scratch memory)
         auto piece_off = [&](int q) {
-            const int row = d_row0 + q * RPI;
+            const int row = row_of(q);
             if constexpr (AXIS == 1) {
-                const int piece = (lane % PPR) ^ (4 * (row & 3));                 // source piece of the LDS piece lane % PPR
+                const int piece = pos_of(q) ^ (4 * (row & 3));                    // source piece of the LDS piece this lane fills
                 const int col = min((opE ? k0 : c0) * 32 + piece * 8, F - 8);
                 return (uint32_t)(row * F + col) * 2u;
             } else {                                                          // row = feature row of the window (clamped inside the matrix)
@@ -224,10 +229,20 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
         // fragment offsets inside a ring slot
         int aoff[2], boff[U2_SLOTS];
         if constexpr (AXIS == 1) {
-            aoff[0] = frag_row + ((((meta >> 8) & 15) ^ trow) << 6);
-            aoff[1] = frag_row + ((((meta >> 12) & 15) ^ trow) << 6);
+            // (32 x 32 windows: the fifth bit of an index rides in the id words, see the plan format)
+            int c0i = (meta >> 8) & 15, c1i = (meta >> 12) & 15;
+            if constexpr (WS == 32) {
+                c0i |= (__builtin_amdgcn_readfirstlane(wd[1]) >> 29 & 1) << 4;
+                c1i |= n1 > 0 ? (__builtin_amdgcn_readfirstlane(wd[1 + n0]) >> 29 & 1) << 4 : 0;
+            }
+            aoff[0] = frag_row + ((c0i ^ trow) << 6);
+            aoff[1] = frag_row + ((c1i ^ trow) << 6);
 #pragma unroll
-            for (int j = 0; j < U2_SLOTS; ++j) boff[j] = SLAB + frag_row + ((((meta >> (16 + 4 * j)) & 15) ^ trow) << 6);
+            for (int j = 0; j < U2_SLOTS; ++j) {
+                int ki = (meta >> (16 + 4 * j)) & 15;
+                if constexpr (WS == 32) ki |= (__builtin_amdgcn_readfirstlane(wd[1 + j]) >> 30 & 1) << 4;
+                boff[j] = SLAB + frag_row + ((ki ^ trow) << 6);
+            }
         } else {                                  // block index * 32 rows
             aoff[0] = frag_row + (int)((meta >> 8) & 15) * (32 * ROWB);
             aoff[1] = frag_row + (int)((meta >> 12) & 15) * (32 * ROWB);
@@ -319,10 +334,10 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
         uint32_t row_off_, sub0_, sub1_, sub2_, sub3_;                                                                       \
         if constexpr (AXIS == 1) {      /* rows past N re-read row N - 1 */                                                  \
             row_off_ = (uint32_t)(q_ * CH * F) * 2u;                                                                         \
-            sub0_ = (uint32_t)(max(0, q_ * CH + d_row0 - (N - 1)) * F) * 2u;                                                 \
-            sub1_ = (uint32_t)(max(0, q_ * CH + d_row0 + RPI - (N - 1)) * F) * 2u;                                           \
-            sub2_ = (uint32_t)(max(0, q_ * CH + d_row0 + 2 * RPI - (N - 1)) * F) * 2u;                                       \
-            sub3_ = (uint32_t)(max(0, q_ * CH + d_row0 + 3 * RPI - (N - 1)) * F) * 2u;                                       \
+            sub0_ = (uint32_t)(max(0, q_ * CH + row_of(0) - (N - 1)) * F) * 2u;                                              \
+            sub1_ = (uint32_t)(max(0, q_ * CH + row_of(1) - (N - 1)) * F) * 2u;                                              \
+            sub2_ = (uint32_t)(max(0, q_ * CH + row_of(2) - (N - 1)) * F) * 2u;                                              \
+            sub3_ = (uint32_t)(max(0, q_ * CH + row_of(3) - (N - 1)) * F) * 2u;                                              \
         } else {                        /* 8-column pieces past N re-read the row's last piece (N % 8 == 0) */               \
             row_off_ = (uint32_t)(q_ * CH) * 2u;                                                                             \
             sub0_ = sub1_ = sub2_ = sub3_ = (uint32_t)max(0, q_ * CH + my_piece0 * 8 + 8 - N) * 2u;                          \
@@ -390,7 +405,7 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
                     if (cq == nfull) {
 #pragma unroll
                         for (int e = 0; e < NI; ++e)
-                            if (AXIS == 1 ? (cq * CH + d_row0 + e * RPI >= N) : (cq * CH + my_piece0 * 8 >= N))
+                            if (AXIS == 1 ? (cq * CH + row_of(e) >= N) : (cq * CH + my_piece0 * 8 >= N))
                                 *reinterpret_cast<uint4*>(smem + (!FIVE ? (uint32_t)(i & (D - 1)) * SLOT : (uint32_t)((2 * i + opE) % 5) * HS) + wave_off + e * 1024 + lane * 16) = zero_u4();
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
@@ -486,7 +501,7 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
 #pragma unroll
             for (int j = 0; j < U2_SLOTS; ++j) {
                 if (j >= n0 + n1) break;
-                const int wid = __builtin_amdgcn_readfirstlane(wd[1 + j]);
+                const int wid = __builtin_amdgcn_readfirstlane(wd[1 + j]) & 0x1fffffff;
                 const size_t base = (size_t)wid * 1024 + (lane & 31);
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {

@@ -77,6 +77,7 @@ enum {
     BSMM_PLAN_WINDOW_16W = 0x30,    /*                 round-1 windowed kernel, 16x16-block windows, 16 waves               */
     BSMM_PLAN_STREAM_16 = 0x40,     /*                 streaming kernel (bsmm_updat_v2.h, axis 1), 16x16-block windows      */
     BSMM_PLAN_STREAM_8 = 0x50,      /*                 streaming kernel, 8x8-block windows (dense layouts)                  */
+    BSMM_PLAN_STREAM_32 = 0x60,     /*                 streaming kernel, 32x32-block windows (sparse layouts, feature axis 1)    */
     BSMM_PLAN_WINDOW_MASK = 0xf0,   /* (0: axis 1 -> streaming kernel, window side by density; axis 0 -> 8x8 windows)       */
     /* experiment knobs of the builders (0 = the builder's own choice); disjoint bit ranges, one meaning each: */
     BSMM_PLAN_XPROP_PH_SHIFT = 8,   /* bits  8..10  xprop staged plans ('BSX2'): steps per phase (2, 3, 4)                      */

@@ -17,18 +17,19 @@ def timeit(fn, reps=100, warm=30):
 
 tag = os.path.basename(os.environ.get("BSMM_LIB", "default"))
 cases = sys.argv[1:] or ["d10:stream16", "d20:stream16", "d50:stream8"]
-OPT = {"stream16": _lib.PLAN_STREAM_16, "stream8": _lib.PLAN_STREAM_8, "win8": _lib.PLAN_WINDOW_8, "auto": 0,
+OPT = {"stream32": _lib.PLAN_STREAM_32, "stream16": _lib.PLAN_STREAM_16, "stream8": _lib.PLAN_STREAM_8, "win8": _lib.PLAN_WINDOW_8, "auto": 0,
        "s16x1": _lib.PLAN_STREAM_16 | (1 << _lib.PLAN_UPDAT_SETS_SHIFT), "s16x2": _lib.PLAN_STREAM_16 | (2 << _lib.PLAN_UPDAT_SETS_SHIFT),
        "s16x4": _lib.PLAN_STREAM_16 | (4 << _lib.PLAN_UPDAT_SETS_SHIFT), "s16x8": _lib.PLAN_STREAM_16 | (8 << _lib.PLAN_UPDAT_SETS_SHIFT),
        "s8x4": _lib.PLAN_STREAM_8 | (4 << _lib.PLAN_UPDAT_SETS_SHIFT), "s8x2": _lib.PLAN_STREAM_8 | (2 << _lib.PLAN_UPDAT_SETS_SHIFT)}
 out = []
 for c in cases:
     d, o = c.split(":")
-    lay = P.random_layout(128, 128, int(d[1:]) / 100.0, 1234)
+    CBK, NN = int(os.environ.get("CB", "128")), int(os.environ.get("N", "8192"))
+    lay = P.random_layout(CBK, CBK, int(d[1:]) / 100.0, 1234)
     b = BlocksparseMatMul(lay, block_size=32, feature_axis=int(os.environ.get("AXIS", "1")), plan_options=OPT[o])
     g = torch.Generator(device="cuda").manual_seed(1)
-    x = (torch.randn(b.i_shape(8192), device="cuda", generator=g) * 0.1).bfloat16()
-    dy = (torch.randn(b.o_shape(8192), device="cuda", generator=g) * 0.1).bfloat16()
+    x = (torch.randn(b.i_shape(NN), device="cuda", generator=g) * 0.1).bfloat16()
+    dy = (torch.randn(b.o_shape(NN), device="cuda", generator=g) * 0.1).bfloat16()
     dw = torch.empty(b.w_shape, dtype=torch.bfloat16, device="cuda")
     b.updat(x, dy, dw=dw); k = _lib.last_kernel()
     us = timeit(lambda: b.updat(x, dy, dw=dw))

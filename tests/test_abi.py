@@ -485,6 +485,10 @@ def test_streaming_updat_plan(lib):
             assert plan[0] == 0x42535532 and plan[1] == 2 and plan[3] == 4 and plan[5] == t["blocks"] and plan[7] == 16
             WS, nitems = int(plan[2]), int(plan[4])
             if opt == 0:
+                w32 = (-(-CB // 32)) * (-(-KB // 32))
+                if w32 >= 16 and t["blocks"] <= 38 * w32:
+                    assert WS == 32                                    # very sparse layouts (round 3)
+                    continue                                           # (the fifth index bits ride in the id words: decoded by the GPU tests)
                 assert WS == (16 if t["blocks"] <= 56 * (-(-CB // 16)) * (-(-KB // 16)) else 8)
             else:
                 assert WS == (16 if opt == lib.PLAN_STREAM_16 else 8)

@@ -30,7 +30,7 @@ def env():
 
 def _updat_kernel(lib, axis, opt=0):
     """which bsize-32 updat kernel a plan built with `opt` runs: both axes default to the streaming kernel (bsmm_updat_v2.h)"""
-    if opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8):
+    if opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8, lib.PLAN_STREAM_32):
         return lib.K_UPDAT_STREAM
     return lib.K_UPDAT_WIN
 
@@ -147,7 +147,7 @@ def test_cfg3_8192_5pct(env, axis, N, force):
 
 
 # ---- (c) window variants ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("opt", ["PLAN_WINDOW_8", "PLAN_WINDOW_16", "PLAN_WINDOW_16W", "PLAN_STREAM_16", "PLAN_STREAM_8"])
+@pytest.mark.parametrize("opt", ["PLAN_WINDOW_8", "PLAN_WINDOW_16", "PLAN_WINDOW_16W", "PLAN_STREAM_16", "PLAN_STREAM_8", "PLAN_STREAM_32"])
 @pytest.mark.parametrize("density", [0.05, 0.2])
 def test_updat_window_variants(env, opt, density):
     torch, BSMM, lib = env
@@ -162,7 +162,7 @@ def test_updat_window_variants(env, opt, density):
 
 
 # ---- (d) small forced-plan layouts with several blocks per 16x16 window -----------------------------------------------
-@pytest.mark.parametrize("opt", [0, "PLAN_WINDOW_16", "PLAN_WINDOW_16W", "PLAN_STREAM_8"])
+@pytest.mark.parametrize("opt", [0, "PLAN_WINDOW_16", "PLAN_WINDOW_16W", "PLAN_STREAM_8", "PLAN_STREAM_32"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_small_layouts_multi_block_windows(env, opt, dtype):
     torch, BSMM, lib = env
