@@ -110,8 +110,10 @@ typedef struct bsmm_args {
     int32_t plan_width;     /*   output blocks per workgroup (xprop) / window side (updat); bsize 8: number of super-blocks */
     int32_t plan_waves;     /*   waves per workgroup the schedule was dealt for                                          */
     int32_t plan_items;     /*   updat: number of work items (= grid size)                                               */
-    int32_t plan_inner;     /*   bsize 8: width / window side of the nested bsize-32 plan; staged xprop plan: steps per phase;
-                                 streaming updat plan: item sets | 16 if all equally long | longest set << 8            */
+    int32_t plan_inner;     /*   staged xprop plan: steps per phase; streaming updat plan: item sets | 16 if all equally long | longest set << 8;
+                                 bsize 8: width / window side of the nested bsize-32 plan | its format << 8 | its own word of this kind << 11;
+                                 bsize 64: 0 = xprop plan, 1 = updat plan (the nested plan is described in plan_width / plan_items and
+                                 plan_waves = its waves | its format << 5 | its own word of this kind << 8)                       */
                             /* The launchers check the descriptor against the kernel they are about to launch and return
                                BSMM_ERR_ARG on a mismatch (a plan built with other options, or for another pass).        */
     int32_t flags;          /* BSMM_FLAG_* (0 = none)                                                                 */
