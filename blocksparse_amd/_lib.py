@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BSMM_LIB: load another build of the same library (kernel A/B experiments: scripts/build_variants.py); product = the default
 LIB_PATH = os.environ.get("BSMM_LIB") or os.path.join(_HERE, "libbsmm_hip.so")
 
+ABI_VERSION = 120        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
 FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN, FLAG_DW_SUMS = 1, 2, 4, 8, 16
@@ -27,7 +28,8 @@ SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_updat_finalize", "bsm
            "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
            "bsmm_plan_attach", "bsmm_error_string", "bsmm_version", "bsmm_prepared_bytes", "bsmm_prepare_weights")
 DIST_SYMBOLS = ("bsmm_dist_unique_id", "bsmm_dist_create", "bsmm_dist_allreduce_begin", "bsmm_dist_allreduce_end", "bsmm_dist_stream",
-                "bsmm_dist_world", "bsmm_dist_destroy", "bsmm_dist_dw_shard_elems", "bsmm_dist_dw_begin", "bsmm_dist_dw_end")
+                "bsmm_dist_world", "bsmm_dist_destroy", "bsmm_dist_dw_shard_elems", "bsmm_dist_dw_layout", "bsmm_dist_dw_begin", "bsmm_dist_dw_emulate",
+                "bsmm_dist_dw_end")
 BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask")
 
 
@@ -122,8 +124,14 @@ def load():
     lib.bsmm_dist_destroy.restype = ctypes.c_int
     lib.bsmm_dist_dw_shard_elems.argtypes = [i32, i32, i32]
     lib.bsmm_dist_dw_shard_elems.restype = ctypes.c_size_t
-    lib.bsmm_dist_dw_begin.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp]
+    psz = ctypes.POINTER(ctypes.c_size_t)
+    lib.bsmm_dist_dw_layout.argtypes = [i32, i32, i32, i32, psz, psz, psz, psz]
+    lib.bsmm_dist_dw_layout.restype = ctypes.c_int
+    lib.bsmm_dist_dw_begin.argtypes = [vp, vp, ctypes.c_size_t, vp, vp, vp, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp]
     lib.bsmm_dist_dw_begin.restype = ctypes.c_int
+    lib.bsmm_dist_dw_emulate.argtypes = [i32, ctypes.POINTER(vp), ctypes.c_size_t, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, i32, i32, i32,
+                                         ctypes.c_float, ctypes.c_float, vp]
+    lib.bsmm_dist_dw_emulate.restype = ctypes.c_int
     lib.bsmm_dist_dw_end.argtypes = [vp, vp]
     lib.bsmm_dist_dw_end.restype = ctypes.c_int
     lib.bsmm_identity_init.argtypes = [vp, vp, i32, i32, i32, i32, f32, i32, vp]
@@ -169,8 +177,19 @@ def load():
     lib.bst_softmax_grad.restype = ctypes.c_int
     lib.bst_partial_autoregressive_mask.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     lib.bst_partial_autoregressive_mask.restype = ctypes.c_int
+    if lib.bsmm_version() != ABI_VERSION:
+        raise RuntimeError("blocksparse_amd: %s reports ABI version %d, this binding expects %d -- rebuild the library "
+                           "(python -c 'import __graft_entry__ as g; g.build()')" % (LIB_PATH, lib.bsmm_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def dw_layout(world, rank, blocks, bsize):
+    """(shard, lo, hi, capacity) of the fused dw reduction for one rank (bsmm_dist_dw_layout: host arithmetic, no device needed)"""
+    sh, lo, hi, cap = (ctypes.c_size_t() for _ in range(4))
+    check(load().bsmm_dist_dw_layout(world, rank, blocks, bsize, ctypes.byref(sh), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(cap)),
+          "bsmm_dist_dw_layout")
+    return int(sh.value), int(lo.value), int(hi.value), int(cap.value)
 
 
 def error_string(code):

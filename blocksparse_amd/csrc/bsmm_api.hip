@@ -771,7 +771,10 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         // present 8x8 parts get alpha / beta and are rounded once
         bool al = aligned16(DW) && a->C % 32 == 0 && a->K % 32 == 0 && !(AXIS == 0 && (N % 8 != 0));
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
-        if (a->plan != nullptr && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && a->plan_items > 0 && !gated && al && (variant == 0 || variant == 3)) {
+        // (operands the streaming kernel's 32-bit byte offsets cannot address fall through to the generic kernels below: ADVICE r3)
+        const bool s8_big = (long)N * std::max(a->C, a->K) >= (1L << 30);
+        if (a->plan != nullptr && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && a->plan_items > 0 && !gated && al && (variant == 0 || variant == 3) &&
+            !(s8_inner(a, true).plan_magic == U2PLAN_MAGIC && s8_big)) {
             const int ns = a->plan_width;
             bsmm_args b = s8_inner(a, true);
             b.flags = 0; b.gate = nullptr; b.trace = nullptr;
@@ -779,7 +782,6 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             int rc;
             if (b.plan_magic == U2PLAN_MAGIC) {      // streaming kernel, raw fp32 sums of the super-blocks at the start of the workspace
                 b.flags = BSMM_FLAG_DW_SUMS; b.split = 0;
-                if ((long)N * std::max(a->C, a->K) >= (1L << 30)) return BSMM_ERR_UNSUPPORTED;
                 rc = launch_updat2<DT, AXIS>(xs, es, nullptr, &b, nullptr);
             } else {
                 rc = launch_updat32_win<DT, AXIS>(xs, es, nullptr, &b, true);

@@ -138,13 +138,58 @@ size_t bsmm_dist_dw_shard_elems(int32_t world, int32_t blocks, int32_t bsize) {
     return ((total + world - 1) / world + 7) & ~(size_t)7;          // 16-byte aligned shards for every dtype
 }
 
-int bsmm_dist_dw_begin(bsmm_dist* h, float* sums, void* dw, void* staging, const float* gate, int32_t blocks, int32_t bsize, int32_t dtype,
-                       float alpha, float beta, void* producer_stream) {
+int bsmm_dist_dw_layout(int32_t world, int32_t rank, int32_t blocks, int32_t bsize, size_t* shard, size_t* lo, size_t* hi, size_t* capacity) {
+    if (world < 1 || rank < 0 || rank >= world || blocks <= 0 || bsize <= 0) return BSMM_ERR_ARG;
+    const size_t total = (size_t)blocks * bsize * bsize, sh = bsmm_dist_dw_shard_elems(world, blocks, bsize);
+    const size_t l = std::min(total, (size_t)rank * sh), h = std::min(total, l + sh);
+    if (shard) *shard = sh;
+    if (lo) *lo = l;
+    if (hi) *hi = h;
+    if (capacity) *capacity = (size_t)world * sh;
+    return BSMM_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// step 2 of the fused reduction: alpha / beta / gate and the ONE rounding on the elements [lo, hi) of DW, from `sums_shard` (the fp32
+// sums of exactly those elements) into staging + lo.  Shared by the RCCL path and the single-device emulation.
+int dw_finalize_shard(const float* sums_shard, const void* dw, void* staging, const float* gate, size_t lo, size_t hi, int bsize, int dtype,
+                      float alpha, float beta, hipStream_t st) {
+    if (hi <= lo) return 0;
+    const size_t n = hi - lo, es = dw_elem_size(dtype);
+    const unsigned grid = (unsigned)((n / 4 + 255) / 256 + 1);
+    const void* old = static_cast<const char*>(dw) + lo * es;
+    void* out = static_cast<char*>(staging) + lo * es;
+    const int bsq = bsize * bsize;
+    if (dtype == BSMM_F32)      dw_shard_finalize_kernel<0><<<grid, 256, 0, st>>>(sums_shard, old, out, n, lo, bsq, alpha, beta, gate);
+    else if (dtype == BSMM_F16) dw_shard_finalize_kernel<1><<<grid, 256, 0, st>>>(sums_shard, old, out, n, lo, bsq, alpha, beta, gate);
+    else                        dw_shard_finalize_kernel<2><<<grid, 256, 0, st>>>(sums_shard, old, out, n, lo, bsq, alpha, beta, gate);
+    return (int)hipGetLastError();
+}
+
+// the emulation's stand-in for ncclReduceScatter(sum, fp32): dst[i] = sum over q of src[q][i], i < n (dst may be src[r])
+struct PtrList16 { const float* p[16]; };
+__global__ void __launch_bounds__(256) emu_sum_kernel(PtrList16 src, int world, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int q = 0; q < world; ++q) v += src.p[q][i];
+    dst[i] = v;
+}
+}  // namespace
+
+extern "C" {
+
+int bsmm_dist_dw_begin(bsmm_dist* h, float* sums, size_t sums_capacity, void* dw, void* staging, const float* gate, int32_t blocks, int32_t bsize,
+                       int32_t dtype, float alpha, float beta, void* producer_stream) {
     if (!h || !h->comm || !sums || !dw || !staging || blocks <= 0 || nccl_type(dtype) < 0) return BSMM_ERR_ARG;
     if (bsize != 8 && bsize != 16 && bsize != 32) return BSMM_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(sums) & 15) || (reinterpret_cast<uintptr_t>(staging) & 15)) return BSMM_ERR_ARG;
-    const size_t total = (size_t)blocks * bsize * bsize, shard = bsmm_dist_dw_shard_elems(h->world, blocks, bsize);
-    const size_t lo = std::min(total, (size_t)h->rank * shard), hi = std::min(total, lo + shard), es = dw_elem_size(dtype);
+    size_t shard, lo, hi, need;
+    if (int rc = bsmm_dist_dw_layout(h->world, h->rank, blocks, bsize, &shard, &lo, &hi, &need)) return rc;
+    if (sums_capacity < need) return BSMM_ERR_WORKSPACE;      // the reduce-scatter reads and writes world * shard floats of `sums`
+    const size_t total = (size_t)blocks * bsize * bsize, es = dw_elem_size(dtype);
     hipError_t e = hipEventRecord(h->produced, static_cast<hipStream_t>(producer_stream));
     if (e != hipSuccess) return (int)e;
     if ((e = hipStreamWaitEvent(h->stream, h->produced, 0)) != hipSuccess) return (int)e;
@@ -152,22 +197,52 @@ int bsmm_dist_dw_begin(bsmm_dist* h, float* sums, void* dw, void* staging, const
     // 1. every rank receives the cross-rank fp32 sum of ITS shard (in place: recv = send + rank * shard)
     if (r.ReduceScatter(sums, sums + (size_t)h->rank * shard, shard, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, h->stream) != 0) return BSMM_ERR_ARG;
     // 2. alpha / beta / gate and the ONE rounding, on 1 / world of the elements
-    if (hi > lo) {
-        const size_t n = hi - lo;
-        const unsigned grid = (unsigned)((n / 4 + 255) / 256 + 1);
-        const void* old = static_cast<const char*>(dw) + lo * es;
-        void* out = static_cast<char*>(staging) + lo * es;
-        const int bsq = bsize * bsize;
-        if (dtype == BSMM_F32)      dw_shard_finalize_kernel<0><<<grid, 256, 0, h->stream>>>(sums + lo, old, out, n, lo, bsq, alpha, beta, gate);
-        else if (dtype == BSMM_F16) dw_shard_finalize_kernel<1><<<grid, 256, 0, h->stream>>>(sums + lo, old, out, n, lo, bsq, alpha, beta, gate);
-        else                        dw_shard_finalize_kernel<2><<<grid, 256, 0, h->stream>>>(sums + lo, old, out, n, lo, bsq, alpha, beta, gate);
-        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    }
+    if (int rc = dw_finalize_shard(sums + lo, dw, staging, gate, lo, hi, bsize, dtype, alpha, beta, h->stream)) return rc;
     // 3. the finished shards travel in the storage type (half the bytes of the sums), in place in the staging buffer
     if (r.AllGather(static_cast<const char*>(staging) + (size_t)h->rank * shard * es, staging, shard, nccl_type(dtype), h->comm, h->stream) != 0) return BSMM_ERR_ARG;
     if ((e = hipMemcpyAsync(dw, staging, total * es, hipMemcpyDeviceToDevice, h->stream)) != hipSuccess) return (int)e;
     e = hipEventRecord(h->reduced, h->stream);
     return (int)e;
+}
+
+int bsmm_dist_dw_emulate(int32_t world, float* const* sums, size_t sums_capacity, void* const* dw, void* const* staging, const float* gate,
+                         int32_t blocks, int32_t bsize, int32_t dtype, float alpha, float beta, void* stream) {
+    if (world < 1 || world > 16 || !sums || !dw || !staging || blocks <= 0 || nccl_type(dtype) < 0) return BSMM_ERR_ARG;
+    if (bsize != 8 && bsize != 16 && bsize != 32) return BSMM_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t total = (size_t)blocks * bsize * bsize, es = dw_elem_size(dtype);
+    size_t shard, lo, hi, need;
+    if (int rc = bsmm_dist_dw_layout(world, 0, blocks, bsize, &shard, &lo, &hi, &need)) return rc;
+    if (sums_capacity < need) return BSMM_ERR_WORKSPACE;
+    PtrList16 src;
+    for (int q = 0; q < 16; ++q) src.p[q] = nullptr;
+    for (int q = 0; q < world; ++q) {
+        if (!sums[q] || !dw[q] || !staging[q] || (reinterpret_cast<uintptr_t>(sums[q]) & 15) || (reinterpret_cast<uintptr_t>(staging[q]) & 15)) return BSMM_ERR_ARG;
+    }
+    // 1. "reduce-scatter": rank r's shard region of ITS OWN sums buffer receives the sum of that region over all ranks -- the same
+    //    world * shard floats of every buffer are read (padding past `total` included) and the same region is written as in the RCCL call
+    for (int r = 0; r < world; ++r) {
+        for (int q = 0; q < world; ++q) src.p[q] = sums[q] + (size_t)r * shard;
+        emu_sum_kernel<<<(unsigned)((shard + 255) / 256), 256, 0, st>>>(src, world, sums[r] + (size_t)r * shard, shard);
+    }
+    // 2. every rank finalizes its shard with ITS rank's bounds
+    for (int r = 0; r < world; ++r) {
+        if (int rc = bsmm_dist_dw_layout(world, r, blocks, bsize, &shard, &lo, &hi, nullptr)) return rc;
+        if (int rc = dw_finalize_shard(sums[r] + lo, dw[r], staging[r], gate, lo, hi, bsize, dtype, alpha, beta, st)) return rc;
+    }
+    // 3. "all-gather" of shard-sized pieces (padding included, as the RCCL call moves it), then the copy into dw
+    for (int r = 0; r < world; ++r)
+        for (int q = 0; q < world; ++q)
+            if (q != r) {
+                hipError_t e = hipMemcpyAsync(static_cast<char*>(staging[q]) + (size_t)r * shard * es, static_cast<const char*>(staging[r]) + (size_t)r * shard * es,
+                                              shard * es, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return (int)e;
+            }
+    for (int q = 0; q < world; ++q) {
+        hipError_t e = hipMemcpyAsync(dw[q], staging[q], total * es, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return (int)hipGetLastError();
 }
 
 int bsmm_dist_dw_end(bsmm_dist* h, void* consumer_stream) { return bsmm_dist_allreduce_end(h, consumer_stream); }

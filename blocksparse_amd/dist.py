@@ -32,6 +32,12 @@ def shard_minibatch(t, feature_axis, rank, world):
     return flat[lo:hi].contiguous()
 
 
+def sums_capacity(sums):
+    """floats the storage of ``sums`` holds from its first element on (a view of an updat workspace has the padding the fused
+    reduction needs behind it; a clone or an accumulated tensor is exactly sized)"""
+    return int((sums.untyped_storage().nbytes() - sums.storage_offset() * sums.element_size()) // 4)
+
+
 class RcclComm(object):
     """One RCCL communicator of the library (bsmm_dist_*) for this process' device.  world == 1 needs no bootstrap;
     otherwise torch.distributed (already initialised, any backend) broadcasts rank 0's id."""
@@ -79,10 +85,12 @@ class RcclComm(object):
 
     def dw_begin(self, sums, dw, staging, gate, blocks, bsize, alpha, beta):
         """fused reduction of the weight gradient (bsmm_dist_dw_begin): reduce-scatter of the fp32 sums, finalize of this rank's
-        shard, all-gather of the finished shards into ``dw`` -- all on the handle's stream, ordered after the current stream"""
+        shard, all-gather of the finished shards into ``dw`` -- all on the handle's stream, ordered after the current stream.
+        ``sums`` must have room for world * shard floats behind its first element (the library checks the capacity we declare:
+        what the tensor's storage really holds)."""
         from .matmul import _dtype_code
         st = torch.cuda.current_stream(dw.device).cuda_stream
-        self._check(self._lib.bsmm_dist_dw_begin(self._h, sums.data_ptr(), dw.data_ptr(), staging.data_ptr(),
+        self._check(self._lib.bsmm_dist_dw_begin(self._h, sums.data_ptr(), sums_capacity(sums), dw.data_ptr(), staging.data_ptr(),
                                                  gate.data_ptr() if gate is not None else None, blocks, bsize, _dtype_code(dw.dtype),
                                                  alpha, beta, st), "bsmm_dist_dw_begin")
 
@@ -221,10 +229,17 @@ class DwReduce(object):
         if not self._active():
             b.updat_finalize(sums, alpha=alpha, beta=beta, dw=dw, gate=gate)
             return dw
-        if not sums.is_cuda:          # gloo: same arithmetic through torch.distributed
-            tot = sums.clone()
-            work = dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._cpu = (work, tot, dw, alpha, beta, gate)
+        if not sums.is_cuda:          # gloo: the SAME three steps and shard arithmetic (bsmm_dist_dw_layout) through torch.distributed
+            from . import _lib
+            rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+            total = b.blocks * b.bsize * b.bsize
+            shard, lo, hi, cap = _lib.dw_layout(world, rank, b.blocks, b.bsize)
+            padded = torch.zeros(cap, dtype=torch.float32)
+            padded[:total] = sums.reshape(-1)
+            # 1. reduce-scatter of `world` shard-sized pieces (gloo has no reduce_scatter: one reduce per owner)
+            works = [dist.reduce(padded[r * shard:(r + 1) * shard], dst=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                 op=dist.ReduceOp.SUM, group=self.group, async_op=True) for r in range(world)]
+            self._cpu = (works, padded, dw, alpha, beta, gate, (rank, world, total, shard, lo, hi))
             return dw
         if self.comm is None:
             self.comm = RcclComm(sums.device, self.group)      # raises on every rank alike if rank 0 could not make an id
@@ -232,18 +247,34 @@ class DwReduce(object):
         need = self.comm.world * shard
         if self._staging is None or self._staging.numel() < need or self._staging.dtype != dw.dtype:
             self._staging = torch.empty(need, dtype=dw.dtype, device=dw.device)
+        if sums_capacity(sums) < need:
+            # an exactly-sized tensor (a clone, accumulated sums): the reduce-scatter works on world * shard floats -- give it the room
+            # (the library refuses a short buffer with BSMM_ERR_WORKSPACE instead of reading past its end)
+            padded = torch.zeros(need, dtype=torch.float32, device=sums.device)
+            padded[:sums.numel()] = sums.reshape(-1)
+            sums = padded
         self._hold = (sums, dw, gate)                           # alive until wait(): the work runs on the handle's stream
         self.comm.dw_begin(sums, dw, self._staging, gate, b.blocks, b.bsize, alpha, beta)
         return dw
 
     def wait(self):
         if self._cpu is not None:
-            work, tot, dw, alpha, beta, gate = self._cpu
-            work.wait()
-            v = tot * alpha if gate is None else tot * (alpha * gate.reshape(-1, 1, 1))
-            if beta != 0.0:
-                v = v + beta * dw.float()
-            dw.copy_(v.to(dw.dtype))
+            works, padded, dw, alpha, beta, gate, (rank, world, total, shard, lo, hi) = self._cpu
+            for wk in works:
+                wk.wait()
+            # 2. alpha / beta / gate and the ONE rounding on this rank's elements [lo, hi) only
+            staging = torch.zeros(world * shard, dtype=dw.dtype)
+            if hi > lo:
+                v = padded[lo:hi] * alpha
+                if gate is not None:
+                    v = v * gate.reshape(-1)[torch.arange(lo, hi) // (self.bsmm.bsize * self.bsmm.bsize)]
+                if beta != 0.0:
+                    v = v + beta * dw.reshape(-1)[lo:hi].float()
+                staging[lo:hi] = v.to(dw.dtype)
+            # 3. all-gather of the shard-sized pieces in the storage type, then the copy into dw
+            pieces = [torch.empty(shard, dtype=dw.dtype) for _ in range(world)]
+            dist.all_gather(pieces, staging[rank * shard:(rank + 1) * shard].clone(), group=self.group)
+            dw.copy_(torch.cat(pieces)[:total].reshape(dw.shape))
             self._cpu = None
             return
         if self._hold is not None:

@@ -25,6 +25,7 @@ Differences from the reference that a user can observe:
     updat kernel: the gate is applied in its summing pass), the per-segment / per-block kernels otherwise.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -169,7 +170,8 @@ class BlocksparseMatMul(object):
         self.layout = ref["layout"]
         self._device_cache = {}
         self._workspaces = {}
-        self._prepared_w = {}             # op -> ((op, w.data_ptr, w._version, stream), buffer): bsmm_prepare_weights results
+        self._prepared_w = {}             # op -> (weakref(w), (op, w.data_ptr, w._version, stream), buffer): bsmm_prepare_weights results
+        self.cache_prepared = True        # False: prepare on every call (no per-weights cache at all)
         self._inner = None
         self._split64_hit = None
         self.native64 = True          # bsize 64: call the library with bsize = 64 (False: always the host-side quadrant view)
@@ -193,16 +195,30 @@ class BlocksparseMatMul(object):
         perm, _ = self._idx64(w.device)
         return w.contiguous().view(self.blocks, 2, 32, 2, 32).permute(0, 1, 3, 2, 4).reshape(4 * self.blocks, 32, 32).index_select(0, perm)
 
+    @staticmethod
+    def _same_weights(entry, w, key):
+        """A cached per-weights image is valid only for the SAME tensor object (weak reference still alive and identical -- a new
+        tensor that the allocator put at the old address is a different object), at the same version, with the same key."""
+        return entry is not None and entry[0]() is w and entry[1] == key
+
+    def invalidate_weights(self):
+        """Forget every per-weights image (prepared pieces, quadrant views).  Needed only after a mutation PyTorch's version counter
+        cannot see (``w.data.add_()``, a raw-pointer write, another library writing into the storage)."""
+        self._prepared_w.clear()
+        self._split64_hit = None
+        if self._inner is not None:
+            self._inner.invalidate_weights()
+
     def _split64_cached(self, w):
-        """The quadrant view of a weight tensor for fprop / bprop, made once per (storage, version): W is constant across the calls
-        of a pass; an in-place update (``w._version``) or another tensor invalidates it.  Not used under autograd (the gather is
-        part of the graph there)."""
+        """The quadrant view of a weight tensor for fprop / bprop, made once per (tensor object, version): W is constant across the
+        calls of a pass; an in-place update (``w._version``) or ANOTHER tensor (even at the same address: the entry holds a weak
+        reference and compares identity) invalidates it.  Not used under autograd (the gather is part of the graph there)."""
         if w.requires_grad and torch.is_grad_enabled():
             return self._split64(w)
         key = (w.data_ptr(), w._version, w.dtype, w.device)
-        if self._split64_hit is None or self._split64_hit[0] != key:
-            self._split64_hit = (key, self._split64(w))
-        return self._split64_hit[1]
+        if not self._same_weights(self._split64_hit, w, key):
+            self._split64_hit = (weakref.ref(w), key, self._split64(w))
+        return self._split64_hit[2]
 
     def _merge64(self, w32):
         _, inv = self._idx64(w32.device)
@@ -283,20 +299,23 @@ class BlocksparseMatMul(object):
 
     def _prepared(self, a, op, w):
         """The per-weights preparation of the library (bsmm_prepare_weights: fp32 / bsize 32 with a plan = the bf16 pieces of W), made
-        once per (op, parameter tensor, version) and handed to the call in ``a.prepared_w`` -- W is constant across the calls of a
-        pass, only an in-place update (optimizer step: ``w._version`` changes) invalidates it."""
+        once per (op, tensor OBJECT, version) and handed to the call in ``a.prepared_w`` -- W is constant across the calls of a
+        pass; an in-place update (optimizer step: ``w._version`` changes) or any other tensor invalidates it.  The entry keeps a weak
+        reference to ``w`` and compares identity: a temporary (``w_master.to(bf16)``, ``W * mask``, an ``l2_normalize`` output) that the
+        allocator places at a freed tensor's address with the same version is a different object and is prepared again.
+        A mutation the version counter cannot see (``w.data.add_()``) needs ``invalidate_weights()``; ``cache_prepared = False``
+        prepares on every call."""
         lib = _lib.load()
         need = lib.bsmm_prepared_bytes(op, ctypes.byref(a))
         if not need:
             return
         key = (op, w.data_ptr(), w._version, a.stream)
         hit = self._prepared_w.get(op)
-        if hit is None or hit[0] != key:
-            buf = hit[1] if (hit is not None and hit[1].numel() >= need) else torch.empty(need, dtype=torch.uint8, device=w.device)
+        if not (self.cache_prepared and self._same_weights(hit, w, key)):
+            buf = hit[2] if (hit is not None and hit[2].numel() >= need) else torch.empty(need, dtype=torch.uint8, device=w.device)
             _lib.check(lib.bsmm_prepare_weights(op, w.data_ptr(), buf.data_ptr(), ctypes.byref(a)), "bsmm_prepare_weights")
-            self._prepared_w[op] = (key, buf)
-            hit = self._prepared_w[op]
-        a.prepared_w = hit[1].data_ptr()
+            hit = self._prepared_w[op] = (weakref.ref(w), key, buf)
+        a.prepared_w = hit[2].data_ptr()
 
     def _out_shape(self, x, feat_out):
         shp = list(x.shape)
@@ -366,8 +385,8 @@ class BlocksparseMatMul(object):
         ``gate``: gated dw (op attr gated_dw): the sum of block w is scaled by gate[w].
         ``sums_only``: return the raw fp32 sums [blocks, bs, bs] (a view of the call's workspace, valid until the next updat on
         this stream with the same ``slot``) instead of DW -- the data-parallel path reduces them over the ranks in fp32
-        (``dist.DwReduce``) or calls ``updat_finalize``; only the streaming kernel (bsize 32, feature axis 1, 16-bit types) can,
-        other configurations raise BsmmError(-2).  ``gate`` is NOT applied to the sums: pass it to the finalize step.
+        (``dist.DwReduce``) or calls ``updat_finalize``; only the streaming kernel (bsize 32, either feature axis, 16-bit types)
+        can, other configurations raise BsmmError(-2).  ``gate`` is NOT applied to the sums: pass it to the finalize step.
         ``slot``: which of the op's workspaces to use -- alternate 0 / 1 when the sums of one step are still being reduced while
         the next step's updat runs."""
         if isinstance(xs, torch.Tensor):
@@ -386,7 +405,15 @@ class BlocksparseMatMul(object):
                 raise ValueError("all pairs must share the minibatch size")
         # bsize 64: the library takes it for 16-bit types (bsmm_args.bsize = 64 with a 'BS64' plan: quadrant sums + one finalize pass);
         # fp32 and the raw-sums form go through the host-side quadrant view
-        if self._inner is not None and not (self.native64 and xs[0].dtype != torch.float32 and not sums_only):
+        native64 = self._inner is not None and self.native64 and xs[0].dtype != torch.float32 and not sums_only
+        if native64:
+            # what the library's composite bsize-64 updat cannot take runs on the host-side quadrant view instead of raising
+            # (ADVICE r3): operands beyond the streaming kernel's 32-bit offsets, unaligned operands, plans forced to another
+            # kernel family, the NO_PLAN / FORCE_VALU test variants
+            native64 = ((N * max(self.C, self.K) < (1 << 30)) and all(t.data_ptr() % 16 == 0 for t in xs + dys)
+                        and not (_lib.call_flags() & (_lib.FLAG_NO_PLAN | _lib.FLAG_FORCE_VALU))
+                        and (self.plan_options & 0xf0) in (0, _lib.PLAN_STREAM_16, _lib.PLAN_STREAM_8, _lib.PLAN_STREAM_32))
+        if self._inner is not None and not native64:
             if sums_only:                # the fp32 sums of the quadrants (a view of the inner call's workspace), put together as a copy
                 if gate is not None:
                     raise ValueError("updat(sums_only=True) returns the ungated sums: pass the gate to updat_finalize / DwReduce.start")
@@ -426,7 +453,12 @@ class BlocksparseMatMul(object):
         arr = ctypes.c_void_p * len(xs)
         xp = arr(*[t.data_ptr() for t in xs])
         ep = arr(*[t.data_ptr() for t in dys])
-        _lib.check(lib.bsmm_updat(xp, ep, dw.data_ptr() if dw is not None else None, ctypes.byref(a)), "bsmm_updat")
+        rc = lib.bsmm_updat(xp, ep, dw.data_ptr() if dw is not None else None, ctypes.byref(a))
+        if rc == -2 and self._inner is not None and not sums_only:      # BSMM_ERR_UNSUPPORTED from the composite path: quadrant view
+            dw32 = self._inner.updat(xs, dys, alpha=alpha, beta=beta, dw=self._split64(dw) if beta != 0.0 else None, gate=self._gate64(gate))
+            dw.copy_(self._merge64(dw32))
+            return dw
+        _lib.check(rc, "bsmm_updat")
         if sums_only:
             n = self.blocks * self.bsize * self.bsize
             return ws[:4 * n].view(torch.float32).view(self.w_shape)

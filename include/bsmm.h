@@ -43,7 +43,11 @@
 extern "C" {
 #endif
 
-#define BSMM_VERSION 100 /* 0.1.0 */
+/* ABI version: bumped whenever struct bsmm_args, a plan format or an option bit range changes.  Bindings compare it with the
+ * header they were written against (blocksparse_amd/_lib.py does at load time).
+ *   100 rounds 1-2;  110 round 3 (bsmm_args.prepared_w, BSMM_PLAN_UPDAT_SETS_SHIFT moved to bits 12..15, 'BSX7' plans v2, composite
+ *   'BSS8' / 'BS64' descriptors);  120 round 4 (see DESIGN.md "Round 4") */
+#define BSMM_VERSION 120
 
 enum { BSMM_F32 = 0, BSMM_F16 = 1, BSMM_BF16 = 2 };
 enum {
@@ -78,7 +82,7 @@ enum {
     BSMM_PLAN_STREAM_16 = 0x40,     /*                 streaming kernel (bsmm_updat_v2.h, axis 1), 16x16-block windows      */
     BSMM_PLAN_STREAM_8 = 0x50,      /*                 streaming kernel, 8x8-block windows (dense layouts)                  */
     BSMM_PLAN_STREAM_32 = 0x60,     /*                 streaming kernel, 32x32-block windows (sparse layouts, feature axis 1)    */
-    BSMM_PLAN_WINDOW_MASK = 0xf0,   /* (0: axis 1 -> streaming kernel, window side by density; axis 0 -> 8x8 windows)       */
+    BSMM_PLAN_WINDOW_MASK = 0xf0,   /* (0: bsize 32, either feature axis -> streaming kernel, window side by density; bsize 16 -> 16x16 windows) */
     /* experiment knobs of the builders (0 = the builder's own choice); disjoint bit ranges, one meaning each: */
     BSMM_PLAN_XPROP_PH_SHIFT = 8,   /* bits  8..10  xprop staged plans ('BSX2'): steps per phase (2, 3, 4)                      */
     BSMM_PLAN_UPDAT_SETS_SHIFT = 12 /* bits 12..15  updat streaming plan ('BSU2'): item sets (1, 2, 4, 8)                       */

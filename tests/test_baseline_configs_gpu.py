@@ -389,14 +389,27 @@ def test_bsize64_axis1_helper_ops(env):
     yv.backward(torch.ones_like(yv))
     assert xg.grad is not None and wg.grad is not None and gg.grad is not None and torch.isfinite(gg.grad).all()
     # the quadrant copy of a constant W is made once per (op, storage, version): by the library call path (bsmm_prepare_weights) ...
-    b.fprop(x, W); key = b._prepared_w[lib.OP_FPROP][0]
-    b.fprop(x, W); assert b._prepared_w[lib.OP_FPROP][0] == key
-    W.add_(0.0); b.fprop(x, W); assert b._prepared_w[lib.OP_FPROP][0] != key
+    b.fprop(x, W); key = b._prepared_w[lib.OP_FPROP][1]
+    b.fprop(x, W); assert b._prepared_w[lib.OP_FPROP][1] == key
+    W.add_(0.0); b.fprop(x, W); assert b._prepared_w[lib.OP_FPROP][1] != key
     # ... and by the host-side quadrant view
     b.native64 = False
-    b.fprop(x, W); first = b._split64_hit[1]
-    b.bprop(dy, W); assert b._split64_hit[1] is first
-    W.add_(0.0); b.fprop(x, W); assert b._split64_hit[1] is not first
+    b.fprop(x, W); first = b._split64_hit[2]
+    b.bprop(dy, W); assert b._split64_hit[2] is first
+    W.add_(0.0); b.fprop(x, W); assert b._split64_hit[2] is not first
+    # a NEW tensor at a recycled address (same data_ptr, same version) must not hit either cache
+    for native in (True, False):
+        b.native64 = native
+        b.invalidate_weights()
+        W1 = torch.randn_like(W) * 0.05
+        y_1 = b.fprop(x, W1)
+        del W1
+        W2 = torch.empty_like(W)                          # the caching allocator hands the freed block back
+        W2.copy_(torch.randn_like(W) * 0.05)
+        y_2 = b.fprop(x, W2)
+        assert torch.equal(y_2, b.fprop(x, W2.clone())), native
+        assert not torch.equal(y_1, y_2)
+    b.native64 = True
 
 
 # ---- (e) the reference's own test matrix ------------------------------------------------------------------------------

@@ -101,11 +101,66 @@ def test_fused_dw_reduce_world_size_one(env):
             red.wait()
             torch.cuda.synchronize()
             assert torch.equal(got, want), (alpha, beta)
+            # an exactly-sized copy of the sums (no workspace tail behind it): DwReduce gives the reduce-scatter its room
+            got2 = dw0.clone()
+            red.start(sums.clone(), got2, alpha=alpha, beta=beta, gate=gt)
+            red.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(got2, want), ("exactly sized sums", alpha, beta)
         with pytest.raises(ValueError):
             b.updat(x, dy, sums_only=True, gate=gate)              # the sums are ungated: the gate belongs to the finalize step
     finally:
         lib.set_kernel_variant(0)
         comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_fused_dw_reduce_emulated_ranks_on_one_gpu(env, world):
+    """bsmm_dist_dw_emulate: the fused reduction for `world` VIRTUAL ranks on one device -- the library's own shard arithmetic
+    (bsmm_dist_dw_layout), its shard-finalize kernel with every rank's bounds, collectives replaced by sums / copies over the same
+    regions RCCL would touch.  Every rank's dw must equal the single-rank finalize of the summed sums BIT FOR BIT, for block counts
+    whose totals do not divide into shards, every dtype and block size, alpha / beta / gate; the padding of the sums buffers holds
+    NaNs (it must never reach dw)."""
+    import ctypes
+    torch, BSMM, lib = env
+    L = lib.load()
+    g = torch.Generator(device="cuda").manual_seed(world)
+    st = torch.cuda.current_stream().cuda_stream
+    for bs, blocks in ((8, 7), (16, 61), (32, 127), (32, 3)):
+        for td, code in ((torch.bfloat16, lib.BF16), (torch.float16, lib.F16), (torch.float32, lib.F32)):
+            total = blocks * bs * bs
+            shard, _, _, cap = lib.dw_layout(world, 0, blocks, bs)
+            sums = [torch.full((cap,), float("nan"), device="cuda") for _ in range(world)]
+            for s in sums:
+                s[:total] = torch.randn(total, device="cuda", generator=g)
+            gate = torch.rand(blocks, device="cuda", generator=g)
+            dw0 = (torch.randn(blocks, bs, bs, device="cuda", generator=g) * 0.1).to(td)
+            for alpha, beta, gt in ((1.0, 0.0, None), (0.5, 2.0, gate)):
+                tot = sums[0][:total].clone()
+                for s in sums[1:]:
+                    tot += s[:total]                                            # the emulation sums the ranks in rank order too
+                want = dw0.clone()
+                lib.check(L.bsmm_updat_finalize(tot.data_ptr(), want.data_ptr(), gt.data_ptr() if gt is not None else None, blocks, bs, code,
+                                                alpha, beta, st), "bsmm_updat_finalize")
+                work = [s.clone() for s in sums]
+                dws = [dw0.clone() for _ in range(world)]
+                stg = [torch.empty(cap, dtype=td, device="cuda") for _ in range(world)]
+                arr = ctypes.c_void_p * world
+                rc = L.bsmm_dist_dw_emulate(world, arr(*[t.data_ptr() for t in work]), cap, arr(*[t.data_ptr() for t in dws]),
+                                            arr(*[t.data_ptr() for t in stg]), gt.data_ptr() if gt is not None else None, blocks, bs, code,
+                                            alpha, beta, st)
+                assert rc == 0, rc
+                torch.cuda.synchronize()
+                for r in range(world):
+                    assert torch.equal(dws[r], want), (world, bs, blocks, td, alpha, beta, r)
+    # an exactly-sized sums buffer is refused (and DwReduce pads such a tensor itself: see test_fused_dw_reduce_world_size_one)
+    blocks, bs = 7, 8
+    exact = [torch.zeros(blocks * bs * bs, device="cuda") for _ in range(world)]
+    arr = ctypes.c_void_p * world
+    if lib.dw_layout(world, 0, blocks, bs)[3] > blocks * bs * bs:
+        rc = L.bsmm_dist_dw_emulate(world, arr(*[t.data_ptr() for t in exact]), exact[0].numel(), arr(*[t.data_ptr() for t in exact]),
+                                    arr(*[t.data_ptr() for t in exact]), None, blocks, bs, lib.F32, 1.0, 0.0, st)
+        assert rc == -3
 
 
 _WORKER = r"""

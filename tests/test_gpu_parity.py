@@ -540,9 +540,9 @@ def test_prepared_weights_cache_fp32(env):
     try:
         y1, dx1 = b.fprop(x, w), b.bprop(dy, w)
         assert lib.last_kernel() == lib.K_XCOL32_F32SPLIT and set(b._prepared_w) == {lib.OP_FPROP, lib.OP_BPROP}
-        keys = {k: v[0] for k, v in b._prepared_w.items()}
+        keys = {k: v[1] for k, v in b._prepared_w.items()}
         y2 = b.fprop(x, w)
-        assert torch.equal(y1, y2) and b._prepared_w[lib.OP_FPROP][0] == keys[lib.OP_FPROP]            # cache hit
+        assert torch.equal(y1, y2) and b._prepared_w[lib.OP_FPROP][1] == keys[lib.OP_FPROP]            # cache hit
         # the uncached call (prepared_w = NULL: the library splits W into the workspace) gives the same bits
         L = lib.load()
         tabs = b._tables_on(x.device)
@@ -554,9 +554,26 @@ def test_prepared_weights_cache_fp32(env):
         assert torch.equal(y1, y3)
         w.mul_(2.0)                                                                                   # optimizer step: version changes
         y4 = b.fprop(x, w)
-        assert b._prepared_w[lib.OP_FPROP][0] != keys[lib.OP_FPROP]
+        assert b._prepared_w[lib.OP_FPROP][1] != keys[lib.OP_FPROP]
         assert torch.allclose(y4, 2.0 * y1, rtol=1e-6, atol=1e-6)
         dx2 = b.bprop(dy, w)
         assert torch.allclose(dx2, 2.0 * dx1, rtol=1e-6, atol=1e-6)
+        # a temporary at a recycled address with the same version is ANOTHER tensor, not a cache hit
+        wa = (w * 0.5).contiguous()
+        ya = b.fprop(x, wa)
+        ptr, ver = wa.data_ptr(), wa._version
+        del wa
+        wb = (w * 0.25).contiguous()                                                                  # same size: usually the same block
+        recycled = wb.data_ptr() == ptr and wb._version == ver
+        yb = b.fprop(x, wb)
+        assert torch.allclose(yb, 0.5 * ya, rtol=1e-6, atol=1e-6), ("stale prepared weights", recycled)
+        # a mutation the version counter cannot see needs invalidate_weights(); cache_prepared = False never caches
+        wb.data.mul_(2.0)
+        b.invalidate_weights()
+        assert torch.allclose(b.fprop(x, wb), ya, rtol=1e-6, atol=1e-6)
+        b.cache_prepared = False
+        wb.data.mul_(2.0)
+        assert torch.allclose(b.fprop(x, wb), 2.0 * ya, rtol=1e-6, atol=1e-6)
+        b.cache_prepared = True
     finally:
         lib.set_kernel_variant(0)
