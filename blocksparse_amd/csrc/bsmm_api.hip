@@ -406,7 +406,8 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
             // bsize 8 on the matrix cores: expand W into the 32x32 super-blocks of the 'BSS8' plan and run the bsize-32 kernel
             const bool shape_ok = a->C % 32 == 0 && a->K % 32 == 0 && !(AXIS == 0 && (a->N % 8 != 0));
             const bool fill = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= device_cus() * 7 / 8;
-            if (plan_ok && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && shape_ok && (fill || force)) return XP_SUPER8;
+            // (locked reference-policy tables stay on the exact kernel: the repair pass of the super-block path writes Y directly)
+            if (plan_ok && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && shape_ok && a->locks == 0 && (fill || force)) return XP_SUPER8;
         }
         return XP_VALU;
     }
@@ -477,13 +478,29 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     const XPath path = xprop_path<DT, BS, AXIS>(X, W, Y, a);
     if (path == XP_SUPER8) {
         if constexpr (BS == 8 && DT::is16) {
+            // Exactness with non-finite activations: a super-block multiplies its zero-filled (absent) 8x8 parts with live
+            // activations, and 0 * Inf = NaN would reach outputs the reference leaves finite (it walks only the lookup-table entries,
+            // blocksparse/matmul.py:353-392).  One scan of X leaves a flag behind the expanded weights; when it is set -- never, for a
+            // healthy network -- the per-entry V_FMA kernel recomputes Y after the matrix-core pass (same stream, Y fully rewritten).
             const int ns = a->plan_width;
-            const size_t need = (size_t)ns * 1024 * elem_size(a->dtype);
+            const size_t wbytes = round16((size_t)ns * 1024 * elem_size(a->dtype)), need = wbytes + 16;
             if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
-            if (fprop) expand8_kernel<DT, true><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
-            else       expand8_kernel<DT, false><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace));
+            int32_t* flag = reinterpret_cast<int32_t*>(static_cast<char*>(a->workspace) + wbytes);
+            if (fprop) expand8_kernel<DT, true><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace), flag);
+            else       expand8_kernel<DT, false><<<ns, 256, 0, st>>>(static_cast<const T*>(W), a->plan, static_cast<T*>(a->workspace), flag);
+            const size_t n8 = (size_t)a->N * a->C / 8;                 // (C % 32 == 0 and X 16-byte aligned on this path)
+            const int sgrid = (int)std::min<size_t>((n8 + 255) / 256, (size_t)device_cus() * 8);
+            if (a->dtype == BSMM_BF16) nonfinite16_kernel<0x7f80u><<<sgrid, 256, 0, st>>>(static_cast<const uint4*>(X), n8, flag);
+            else                       nonfinite16_kernel<0x7c00u><<<sgrid, 256, 0, st>>>(static_cast<const uint4*>(X), n8, flag);
             bsmm_args b = s8_inner(a, false);
-            const int rc = launch_xgroup32<DT, AXIS>(X, a->workspace, Y, &b, st, false);
+            int rc = launch_xgroup32<DT, AXIS>(X, a->workspace, Y, &b, st, false);
+            if (rc) return rc;
+            dim3 grid(a->segments, (a->N + 255) / 256);
+            if (fprop) xprop_valu_kernel<DT, BS, AXIS, true><<<grid, 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut,
+                                                                                  a->N, a->C, a->K, nullptr, nullptr, flag);
+            else       xprop_valu_kernel<DT, BS, AXIS, false><<<grid, 256, 0, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut,
+                                                                                   a->N, a->C, a->K, nullptr, nullptr, flag);
+            rc = (int)hipGetLastError();
             trace(a, BSMM_K_XPROP_SUPER8);
             return rc;
         }
@@ -1351,7 +1368,7 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
             b.flags = BSMM_FLAG_DW_SUMS; b.split = 0;
             return bsmm_workspace_bytes(op, &b);
         }
-        return op == BSMM_OP_UPDAT ? blk * sizeof(float) : std::max(blk * elem_size(a->dtype), lock);
+        return op == BSMM_OP_UPDAT ? blk * sizeof(float) : std::max(round16(blk * elem_size(a->dtype)) + 16, lock);   // (+ the non-finite flag of the call)
     }
     if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32) {
         if (a->plan_magic == U2PLAN_MAGIC) {   // streaming kernel: the fp32 sums + one region of partial sums per (round, workgroup)

@@ -3,6 +3,10 @@
 //   expand8:  W (8x8 blocks)  ->  Wsel (32x32 super-blocks in the [out feature][in feature] order the xcol kernels multiply),
 //             absent sub-blocks zero-filled.  ~2 KiB written per super-block, a few microseconds per pass.
 //   gather8:  fp32 sums of the 32x32 super-blocks ([c][k]) -> DW (the present 8x8 blocks): alpha, beta, ONE rounding.
+//   nonfinite16: does the activation tensor hold an Inf / NaN?  A super-block multiplies its zero-filled (absent) 8x8 parts with
+//             live activations: 0 * x = 0 for every finite x, but 0 * Inf = NaN would reach outputs the reference leaves finite
+//             (it walks only the lookup-table entries, blocksparse/matmul.py:353-392).  The flag this scan leaves makes the call
+//             exact: when it is set, the per-entry V_FMA kernel recomputes the output after the matrix-core pass.
 // Both: one workgroup of 256 threads per super-block, a thread moves 4 consecutive elements (8 bytes).
 #pragma once
 #include "bsmm_common.h"
@@ -14,9 +18,11 @@ namespace bsmm {
 // otherwise they are stored [out][in] (bprop: out = c) and copied.
 template <class DT, bool FROM_IN_OUT>
 __global__ void __launch_bounds__(256)
-expand8_kernel(const typename DT::T* __restrict__ W8, const int32_t* __restrict__ plan, typename DT::T* __restrict__ W32) {
+expand8_kernel(const typename DT::T* __restrict__ W8, const int32_t* __restrict__ plan, typename DT::T* __restrict__ W32,
+               int32_t* __restrict__ clear_flag = nullptr) {
     static_assert(DT::is16, "super8 path: 16-bit storage types");
     const int s = blockIdx.x;
+    if (clear_flag && s == 0 && threadIdx.x == 0) clear_flag[0] = 0;      // the non-finite flag of this call (nonfinite16_kernel runs next)
     if (plan[0] != S8PLAN_MAGIC || plan[1] != S8PLAN_VERSION || s >= plan[2]) return;
     const int32_t* sub = plan + plan[3] + 16 * s;
     const int o32 = threadIdx.x >> 3, i0 = (threadIdx.x & 7) * 4;            // 4 consecutive in-features of one sub-block
@@ -33,6 +39,25 @@ expand8_kernel(const typename DT::T* __restrict__ W8, const int32_t* __restrict_
         }
     }
     *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(W32) + (size_t)s * 1024 + o32 * 32 + i0) = v;
+}
+
+// flag[0] = 1 if any of the n8 * 8 16-bit elements at X has all exponent bits set (Inf / NaN).  EXPMASK: 0x7f80 (bf16) / 0x7c00 (f16).
+// flag[0] must be 0 before (expand8_kernel of the same call clears it: `clear_flag`).
+template <uint32_t EXPMASK>
+__global__ void __launch_bounds__(256)
+nonfinite16_kernel(const uint4* __restrict__ X, size_t n8, int32_t* __restrict__ flag) {
+    constexpr uint32_t M = EXPMASK | (EXPMASK << 16);
+    uint32_t hit = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 v = X[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t z = (w[e] & M) ^ M;                        // a 16-bit half of z is 0 <=> that element is Inf / NaN
+            hit |= (z - 0x00010001u) & ~z & 0x80008000u;              // "has a zero half" (exact as an any-test)
+        }
+    }
+    if (hit) flag[0] = 1;
 }
 
 template <class DT>

@@ -129,6 +129,54 @@ def test_bench_shape_skewed_layout(env):
     _check_sampled(torch, lib, b, layout, 4096, "bf16", seed=13, expect={"xprop": lib.K_XCOL32_STAGED, "updat": lib.K_UPDAT_STREAM}, ctx="bench BA")
 
 
+@pytest.mark.parametrize("bs,axis,density", [(32, 1, 0.2), (32, 0, 0.2), (16, 0, 0.1), (16, 1, 0.1), (8, 0, 0.1), (8, 1, 0.1)])
+def test_full_output_at_4096_against_float64_oracle(env, bs, axis, density):
+    """EVERY element of Y, DX and DW at 4096^2 / N = 1024 under FORCE_PLAN against the float64 oracle (`*_fast` evaluated in
+    float64 on the rounded inputs, rounded once to bf16): a plan that mis-schedules one output column, one window or one block
+    anywhere fails here -- the sampled checks at N = 8192 above cannot see that.  Per-column / per-block
+    L2 errors, so a single bad column is not averaged away."""
+    torch, BSMM, lib = env
+    CB = 4096 // bs
+    layout = P.random_layout(CB, CB, density, seed=1234)
+    b = BSMM(layout, block_size=bs, feature_axis=axis)
+    N = 1024
+    w, x, e = _inputs(torch, b, N, "bf16", seed=21)
+    W, X, E = P.to_host(w), P.to_host(x), P.to_host(e)
+    t = orc.build_layout_luts(layout, bs)
+    bar = P.L2_BAR["bf16"]
+    want = {8: (lib.K_XPROP_SUPER8, lib.K_UPDAT_SUPER8), 16: (lib.K_XCOL16_STAGED, lib.K_UPDAT16_WIN), 32: (lib.K_XCOL32_STAGED, lib.K_UPDAT_STREAM)}[bs]
+    lib.set_kernel_variant(3)
+    try:
+        y = P.to_host(b.fprop(x, w)); kf = lib.last_kernel()
+        dx = P.to_host(b.bprop(e, w)); kb = lib.last_kernel()
+        dw = P.to_host(b.updat(x, e)); ku = lib.last_kernel()
+    finally:
+        lib.set_kernel_variant(0)
+    assert (kf, kb, ku) == (want[0], want[0], want[1]), (kf, kb, ku)
+
+    def per_block_l2(got, ref, feat_blocks):
+        # L2 error of every 32 / 16 / 8-wide feature block of an activation-shaped result
+        g = got.reshape(N, feat_blocks, bs) if axis else got.reshape(feat_blocks, bs, N).transpose(2, 0, 1)
+        r = ref.reshape(N, feat_blocks, bs) if axis else ref.reshape(feat_blocks, bs, N).transpose(2, 0, 1)
+        num = np.sqrt(((g.astype(np.float64) - r) ** 2).sum(axis=(0, 2)))
+        den = np.sqrt((r ** 2).sum(axis=(0, 2)))
+        return num / np.maximum(den, 1e-30), den
+    for name, got, ref, nb in (("Y", y, orc.round_to(orc.fprop_fast(t, X, W, axis, dtype=np.float64), "bf16"), b.KB),
+                               ("DX", dx, orc.round_to(orc.bprop_fast(t, E, W, axis, dtype=np.float64), "bf16"), b.CB)):
+        assert np.isfinite(got).all(), name
+        err, den = per_block_l2(got, ref, nb)
+        assert (err[den > 0] <= 2 * bar).all(), "%s bs %d axis %d: worst block column %d L2 %.3e" % (name, bs, axis, int(err.argmax()), err.max())
+        assert (np.abs(got.reshape(N, nb, bs) if axis else got.reshape(nb, bs, N).transpose(2, 0, 1)).sum(axis=(0, 2))[den == 0] == 0).all(), name
+        l2, _ = P.errors(got, ref)
+        assert l2 <= bar, (name, l2)
+    ref = orc.round_to(orc.updat_fast(t, X, E, axis, dtype=np.float64), "bf16")
+    num = np.sqrt(((dw.astype(np.float64) - ref) ** 2).reshape(b.blocks, -1).sum(axis=1))
+    den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
+    assert np.isfinite(dw).all() and (num / np.maximum(den, 1e-30) <= 4 * bar).all(), "DW bs %d axis %d: worst block %d" % (bs, axis, int((num / np.maximum(den, 1e-30)).argmax()))
+    l2, _ = P.errors(dw, ref)
+    assert l2 <= bar, ("DW", l2)
+
+
 # ---- (b) BASELINE configs[3] -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("axis,N,force", [(1, 512, False), (1, 512, True), (1, 4096, False), (0, 512, True), (0, 4096, False)])
 def test_cfg3_8192_5pct(env, axis, N, force):

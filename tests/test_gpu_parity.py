@@ -489,8 +489,10 @@ def test_inf_in_an_unconnected_feature_does_not_reach_the_output(env, bs, axis):
     (blocksparse/matmul.py:353-392 walks only the lut entries): an Inf / NaN there leaves that output finite.  The plan kernels
     that K-concatenate blocks (bsize 16: two input blocks per v_mfma_f32_16x16x32) mask the ACTIVATIONS of an absent partner,
     not only its weights, so the same holds for them -- forced here with BSMM_FLAG_FORCE_PLAN.  bsize 8 with a plan multiplies
-    zero-filled 32x32 super-blocks (a documented deviation: 0 * Inf inside a super-block that holds another block of that
-    feature); BSMM_FLAG_NO_PLAN is the exact path and is what is checked for it."""
+    zero-filled 32x32 super-blocks, where 0 * Inf WOULD appear: the call scans the activations for non-finite values and, when
+    there is one, recomputes the output with the per-entry kernel after the matrix-core pass (round 4; bsmm_super8.h) -- checked
+    here on the super-block path itself (FORCE_PLAN, BSMM_K_XPROP_SUPER8 asserted), with an Inf, with a NaN, and with clean inputs
+    (whose result must be the matrix-core one: identical to a second clean call)."""
     torch, BSMM, lib = env
     rng = np.random.default_rng(3 + bs + axis)
     CB = KB = 48 if bs != 8 else 64
@@ -508,12 +510,24 @@ def test_inf_in_an_unconnected_feature_does_not_reach_the_output(env, bs, axis):
     (xs[:, c_bad * bs:(c_bad + 1) * bs] if axis else xs[c_bad * bs:(c_bad + 1) * bs, :]).fill_(float("inf"))
     es = dy.clone()
     (es[:, k_bad * bs:(k_bad + 1) * bs] if axis else es[k_bad * bs:(k_bad + 1) * bs, :]).fill_(float("nan"))
-    lib.set_kernel_variant(2 if bs == 8 else 3)
+    lib.set_kernel_variant(3)
     try:
         y = b.fprop(xs, w).float()
+        k_f = lib.last_kernel()
         dx = b.bprop(es, w).float()
-        if bs != 8:
-            assert lib.last_kernel() in (lib.K_XCOL32_STAGED, lib.K_XCOL16_STAGED)
+        assert lib.last_kernel() == k_f and k_f in ((lib.K_XPROP_SUPER8,) if bs == 8 else (lib.K_XCOL32_STAGED, lib.K_XCOL16_STAGED))
+        if bs == 8:
+            # where the output is finite it must also be RIGHT (the repair pass rewrote all of it): against the exact kernels
+            lib.set_kernel_variant(2)
+            y_e, dx_e = b.fprop(xs, w).float(), b.bprop(es, w).float()
+            lib.set_kernel_variant(3)
+            fin = torch.isfinite(y_e)
+            assert torch.equal(torch.isfinite(y), fin) and torch.allclose(y[fin], y_e[fin], rtol=2e-2, atol=1e-3)
+            fin = torch.isfinite(dx_e)
+            assert torch.equal(torch.isfinite(dx), fin) and torch.allclose(dx[fin], dx_e[fin], rtol=2e-2, atol=1e-3)
+            # clean inputs: the flag stays clear, the matrix-core result stands (and a dirty call in between does not stick)
+            y_c1 = b.fprop(x, w); b.fprop(xs, w); y_c2 = b.fprop(x, w)
+            assert lib.last_kernel() == lib.K_XPROP_SUPER8 and torch.equal(y_c1, y_c2) and bool(torch.isfinite(y_c1.float()).all())
     finally:
         lib.set_kernel_variant(0)
     for k in range(KB):
