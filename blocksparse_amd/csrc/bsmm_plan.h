@@ -306,6 +306,181 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
 }  // namespace bsmm
 
 // =================================================================================================
+// flow xcol plan ('BSX4', round 4): schedule of the barrier-free persistent xprop kernel (bsmm_xflow.h).  Groups of X4_G = 16
+// consecutive output blocks, wave v owns output block first + v; a group walks the union of its input-block PAIRS in ascending
+// order, one pair = one STEP = one 16 KiB activation slab in a ring of X4_D slabs.  The plan is a list of EVENTS per (group, wave),
+// in the order the wave executes them; a wave never looks at a step it has nothing to do in:
+//   BLOCK(step, half)   multiply my weight block of that step (the block sits in my private slot: fetched two BLOCK events earlier)
+//   REQ(step, part)     request part `part` (of X4_PARTS) of the slab of `step` by LDS-DMA.  Placed X4_DX steps ahead of the step
+//                       in the wave's order and dealt by the builder to waves WITHOUT blocks around that point (at 20 % density
+//                       10 of the 16 waves have none in a given step)
+//   ANN(step, part)     one step later in the wave's order: wait for those requests, announce the part
+//   NOP                 list head: carries the first two weight fetches
+// Every event names the weight block to FETCH once it is over (none: all ones) and, for the wave's progress word, the step of the
+// wave's next BLOCK.  The order of a wave's vector-memory operations is therefore fixed by the plan, and BLOCK / ANN events carry the
+// exact `vmcnt` they wait with: the number of operations the wave issues between the fetch / request they need and themselves.
+// Layout (int32): [0] magic 'BSX4' [1] version [2] X4_G [3] ngroups [4] nsteps_total [5] off_groups [6] off_pairs
+//                 [7] off_lists [8] n_out_blocks [9] max list length [10] max steps of a group [11] X4_D | X4_DX << 8 | X4_PARTS << 16
+//   groups[ngroups][8] = (step_off, nsteps, first_out_block, n_out_blocks_in_group, list_off, lcap, blocks_in_group, 0)
+//   pairs [nsteps_total]            pair index p of each step (input blocks 2p, 2p + 1)
+//   lists at off_lists + list_off:  counts[16], then per wave lcap entries of 2 words:
+//        word 0: type (2 bits: 0 NOP, 1 BLOCK, 2 REQ, 3 ANN) | half or part << 2 | step << 4 (12 bits) | step of my next BLOCK << 16
+//                (12 bits, nsteps if none) | step % X4_D << 28
+//        word 1: weight block to fetch after the event (27 bits, all ones = none) | vmcnt to wait with << 27 (capped at 15)
+// Groups are sorted longest first (as in the 'BSX2' plan).
+// =================================================================================================
+namespace bsmm {
+
+constexpr int32_t X4PLAN_MAGIC = 0x42535834;
+constexpr int32_t X4PLAN_VERSION = 3;
+constexpr uint32_t X4_NOFETCH = 0x7ffffffu;
+constexpr int X4_G = 16;
+constexpr int X4_HDR = 12;
+constexpr int X4_GROUP = 8;
+#ifndef X4_D_SLABS
+#define X4_D_SLABS 5
+#endif
+#ifndef X4_DX_AHEAD
+#define X4_DX_AHEAD 4
+#endif
+#ifndef X4_DUTY_PARTS
+#define X4_DUTY_PARTS 2
+#endif
+constexpr int X4_D = X4_D_SLABS;          // slabs in the ring
+constexpr int X4_DX = X4_DX_AHEAD;        // a slab is requested this many steps ahead
+constexpr int X4_PARTS = X4_DUTY_PARTS;   // a slab is requested in this many parts (by different waves): 1, 2 or 4
+static_assert(X4_DX >= 1 && X4_DX < X4_D && X4_D <= 7 && (X4_PARTS == 1 || X4_PARTS == 2 || X4_PARTS == 4), "flow plan constants");
+
+inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
+    const int G = X4_G, ngroups = (n_out_blocks + G - 1) / G;
+    struct E { int p, wave, half, w; };
+    std::vector<std::vector<E>> per_group(ngroups);
+    for (int s = 0; s < segments; ++s) {
+        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
+        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
+        for (int e = 0; e < cnt; ++e) {
+            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
+            if (w < 0 || w >= blocks || c < 0) return -1;
+            if (c >= (1 << 24)) return 0;
+            per_group[ob / G].push_back({c >> 1, ob % G, c & 1, w});
+        }
+    }
+    std::vector<int32_t> groups, pairs, lists;
+    int max_l = 0, max_s = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        auto& v = per_group[g];
+        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : (a.wave != b.wave ? a.wave < b.wave : a.half < b.half); });
+        const int step_off = (int)pairs.size();
+        struct B { int step, half, w; };
+        std::vector<std::vector<B>> wb(G);
+        int t = -1, cur = -1;
+        for (auto& e : v) {
+            if (e.p != cur) { cur = e.p; ++t; pairs.push_back(e.p); }
+            wb[e.wave].push_back({t, e.half, e.w});
+        }
+        const int nsteps = t + 1;
+        if (nsteps >= 4096) return 0;                               // 12-bit step fields
+        // blocks per (wave, step), for the dealing of the duties
+        std::vector<std::vector<int>> busy(G, std::vector<int>(nsteps + 1, 0));
+        for (int wv = 0; wv < G; ++wv) for (auto& b : wb[wv]) busy[wv][b.step]++;
+        // events: (trigger, kind order, payload).  REQ(step s) has trigger s - X4_DX, its ANN one step later; at equal trigger a wave
+        // announces first, then requests, then multiplies
+        struct Ev { int trig, kind, a, b; };                        // kind 0 ANN / 1 REQ (a = step, b = part), 2 BLOCK (a = index into wb[wave])
+        std::vector<std::vector<Ev>> evs(G);
+        for (int wv = 0; wv < G; ++wv) for (size_t i = 0; i < wb[wv].size(); ++i) evs[wv].push_back({wb[wv][i].step, 2, (int)i, 0});
+        std::vector<int> nduty(G, 0), last_trig(G, -1000);
+        int rot = g * 5;
+        for (int s = 0; s < nsteps; ++s)
+            for (int q = 0; q < X4_PARTS; ++q) {
+                const int trig = s - X4_DX;
+                int best = -1; long best_cost = 0;
+                for (int k = 0; k < G; ++k) {
+                    const int wv = (rot + k) % G;
+                    long cost = 0;
+                    for (int d = -1; d <= 2; ++d) { const int st = trig + d; if (st >= 0 && st < nsteps) cost += busy[wv][st] * (d == 0 || d == 1 ? 100 : 40); }
+                    if (trig - last_trig[wv] < 2) cost += 60;        // it is still waiting for its previous requests
+                    cost += nduty[wv];
+                    if (best < 0 || cost < best_cost) { best = wv; best_cost = cost; }
+                }
+                rot = (best + 1) % G;
+                evs[best].push_back({trig, 1, s, q});
+                evs[best].push_back({trig + 1, 0, s, q});
+                nduty[best]++; last_trig[best] = trig;
+            }
+        int lcap = 1;
+        std::vector<std::vector<int32_t>> wl(G);
+        for (int wv = 0; wv < G; ++wv) {
+            auto& ev = evs[wv];
+            std::stable_sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.trig != b.trig ? a.trig < b.trig : a.kind < b.kind; });
+            const auto& bl = wb[wv];
+            if (bl.size() >= (size_t)X4_NOFETCH) return 0;
+            auto next_block_step = [&](size_t from_block) { return from_block < bl.size() ? bl[from_block].step : nsteps; };
+            auto word0 = [&](int type, int hp, int step, int nxt) {
+                return (int32_t)((uint32_t)type | ((uint32_t)hp << 2) | ((uint32_t)step << 4) | ((uint32_t)nxt << 16) | ((uint32_t)(step % X4_D) << 28));
+            };
+            auto word1 = [&](long fetch, long wait) {
+                return (int32_t)((fetch < 0 ? X4_NOFETCH : (uint32_t)fetch) | ((uint32_t)std::min<long>(std::max<long>(wait, 0), 15) << 27));
+            };
+            // the wave's vector-memory operations in program order: `ops` = issued so far; a fetch is 2, a request 16 / X4_PARTS
+            long ops = 0;
+            std::vector<long> fetch_seq(bl.size() + 2, 0);          // ops right after the fetch of block j
+            std::vector<long> req_seq((size_t)nsteps * X4_PARTS, 0);
+            size_t nfetch = 0;
+            auto fetch_next = [&]() -> long { if (nfetch < bl.size()) { ops += 2; fetch_seq[nfetch] = ops; return bl[nfetch++].w; } return -1; };
+            // two NOPs carry the first two fetches
+            for (int k = 0; k < 2; ++k) { wl[wv].push_back(word0(0, 0, 0, next_block_step(0))); const long f = fetch_next(); wl[wv].push_back(word1(f, 0)); }
+            size_t nb = 0;                                          // blocks seen so far in event order
+            for (auto& e : ev) {
+                if (e.kind == 1) {
+                    wl[wv].push_back(word0(2, e.b, e.a, next_block_step(nb))); wl[wv].push_back(word1(-1, 0));
+                    ops += 16 / X4_PARTS; req_seq[(size_t)e.a * X4_PARTS + e.b] = ops;
+                } else if (e.kind == 0) {
+                    wl[wv].push_back(word0(3, e.b, e.a, next_block_step(nb))); wl[wv].push_back(word1(-1, ops - req_seq[(size_t)e.a * X4_PARTS + e.b]));
+                } else {
+                    const B& b = bl[e.a];
+                    const long wait = ops - fetch_seq[nb];          // operations issued after this block's fetch
+                    wl[wv].push_back(word0(1, b.half, b.step, next_block_step(nb + 1)));
+                    const long f = fetch_next();                    // block nb + 2 goes into the slot this one frees
+                    wl[wv].push_back(word1(f, wait));
+                    ++nb;
+                }
+            }
+            lcap = std::max(lcap, (int)wl[wv].size() / 2);
+        }
+        max_l = std::max(max_l, lcap); max_s = std::max(max_s, nsteps);
+        const int list_off = (int)lists.size();
+        for (int wv = 0; wv < G; ++wv) lists.push_back((int32_t)wl[wv].size() / 2);
+        for (int wv = 0; wv < G; ++wv) {
+            lists.insert(lists.end(), wl[wv].begin(), wl[wv].end());
+            lists.insert(lists.end(), (size_t)2 * lcap - wl[wv].size(), 0);
+        }
+        groups.insert(groups.end(), {step_off, nsteps, g * G, std::min(G, n_out_blocks - g * G), list_off, lcap, (int32_t)v.size(), 0});
+    }
+    {
+        std::vector<int> order(ngroups);
+        for (int g = 0; g < ngroups; ++g) order[g] = g;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[X4_GROUP * a + 6] > groups[X4_GROUP * b + 6]; });
+        std::vector<int32_t> sorted;
+        for (int g : order) sorted.insert(sorted.end(), groups.begin() + X4_GROUP * g, groups.begin() + X4_GROUP * (g + 1));
+        groups.swap(sorted);
+    }
+    const int off_groups = X4_HDR, off_pairs = off_groups + (int)groups.size(), off_lists = off_pairs + (int)pairs.size();
+    const long total = off_lists + (long)lists.size();
+    if (out) {
+        const int32_t hdr[X4_HDR] = {X4PLAN_MAGIC, X4PLAN_VERSION, G, ngroups, (int32_t)pairs.size(), off_groups, off_pairs, off_lists,
+                                     n_out_blocks, max_l, max_s, X4_D | (X4_DX << 8) | (X4_PARTS << 16)};
+        std::copy(hdr, hdr + X4_HDR, out);
+        std::copy(groups.begin(), groups.end(), out + off_groups);
+        std::copy(pairs.begin(), pairs.end(), out + off_pairs);
+        std::copy(lists.begin(), lists.end(), out + off_lists);
+    }
+    return total;
+}
+
+}  // namespace bsmm
+
+// =================================================================================================
 // staged xcol16 plan ('BSX7', bsize 16): the staged scheme of the 'BSX2' plan for 16x16 blocks (bsmm_xcol16_v2.h).  Groups of
 // X7_G = 32 consecutive output blocks, wave v of 16 owns blocks 2v and 2v+1; a step is a QUAD of input blocks (64 features);
 // a phase = up to two steps and up to X7_WCAP weight blocks = one half of the LDS ring (2 activation slabs of 16 KiB + X7_WCAP

@@ -1,0 +1,289 @@
+// bsmm_xflow.h -- xprop kernel "wave owns an output column", barrier-free and persistent ('BSX4' plans, round 4): feature_axis = 1,
+// bsize 32, 16-bit storage types.
+//
+// What bounded bsmm_xcol_v2.h (profiles/r02_xcol_v2_ablation.md, r03_xcol_ab.md): its request stream alone and its matrix work alone
+// each take ~65 us of a ~85 us pass -- the stream because every phase ends in a full drain (vmcnt(0) + barrier: ~0.5 us with nothing
+// in flight), the matrix work because a phase lasts as long as its busiest SIMD (1.5x the mean at 20 % density) and every wave pays
+// every barrier.  Here there is NO workgroup barrier in the main loop and a wave executes only the EVENTS the plan lists for it:
+//   * one STEP = one pair of input blocks = one 16 KiB activation slab [128 rows][128 B] in a ring of X4_D slabs;
+//   * BLOCK event: the wave's weight block of a step (private to it: it owns the output column) sits in one of its own two 2 KiB
+//     slots, fetched by the wave itself two BLOCK events earlier and awaited with its own vmcnt; the wave then waits until the
+//     slab's parts have been announced (full[slot][part] = global step number + 1), multiplies, and publishes its PROGRESS word =
+//     the step of its next block ("I need no slab before that one");
+//   * REQ event: request one part of a slab X4_DX steps ahead, once every wave's progress word has passed the slab that occupied
+//     the ring slot; ANN event, one step later in the wave's order: wait for those requests, announce the part.  The plan deals
+//     these duties to waves that have no blocks around that point (10 of 16 at 20 % density);
+//   * the plan fixes the order of a wave's vector-memory operations, so every wait is a counted vmcnt the plan supplies;
+//   * a wave never visits a step it has nothing to do in (first version: every wave walked every step with two polls and two
+//     counter updates: 136 us of pure bookkeeping per pass at the bench shape -- the scalar unit is shared by the CU's 16 waves);
+//   * the kernel is PERSISTENT: one workgroup per CU walks its (row tile, group) units back to back; ring slots and step numbers
+//     run through the unit boundaries, the waves that are done with a unit start the next one's duties while the others finish;
+//     the epilogue of a wave goes through its own (then idle) weight slots, so it needs no barrier either.
+// Fragment layouts, swizzles, MFMA order per column: those of bsmm_xcol_v2.h (a column sums its blocks in the same order with the
+// same instructions: bit-identical outputs).
+#pragma once
+#include "bsmm_common.h"
+#include "bsmm_plan.h"
+#include "bsmm_updat_v2.h"   // glds16_saddr, uniform_ptr
+#include "bsmm_updat_tr.h"   // ds_tr16
+#include "bsmm_xprop.h"      // XMap
+
+namespace bsmm {
+
+#ifndef X4_NO_XDMA
+#define X4_NO_XDMA 0          // ablation switches: wrong results by construction
+#endif
+#ifndef X4_NO_WDMA
+#define X4_NO_WDMA 0
+#endif
+#ifndef X4_NO_MATH
+#define X4_NO_MATH 0
+#endif
+constexpr int X4_R = 128;                              // minibatch rows per unit
+constexpr int X4_SLAB = X4_R * 128;                    // 16 KiB
+constexpr int X4_S = 2;                                // private weight slots per wave
+constexpr int X4_WBASE = X4_D * X4_SLAB;
+constexpr int X4_WWAVE = X4_S * 2048;                  // bytes of weight slots per wave
+constexpr int X4_FLAGS = X4_WBASE + X4_G * X4_WWAVE;   // prog[16] (uint32), then full[8]
+constexpr int X4_LDS = X4_FLAGS + 64 + 32;
+constexpr int X4_DI = 16 / X4_PARTS;                   // DMA instructions of 1 KiB per slab part
+static_assert(X4_LDS <= 163840, "flow kernel: ring must fit the LDS");
+static_assert(X4_WWAVE >= 64 * 64, "the epilogue stages 64 rows x 64 B per pass in a wave's weight slots");
+static_assert((X4_WWAVE & (X4_WWAVE - 1)) == 0 && X4_WBASE % X4_WWAVE == 0, "weight slot toggling by XOR needs aligned slots");
+
+// The CU's 16 waves share ONE scalar unit: a scalar instruction per event and wave costs 16 cycles per event round.  The per-event
+// fields therefore live in lane-indexed vector registers (lane j = event j of the chunk), are derived once per unit with vector
+// instructions, and are used in place under EXEC = that lane: the helpers below take the lane mask `em` (1 << event).
+// counter / word update by the event's own lane: [addr] (+)= value, both lane-resident
+__device__ __forceinline__ void x4_lane_write(uint64_t em, uint32_t v_addr, uint32_t v_value) {
+    asm volatile("s_mov_b64 exec, %0\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, -1" ::"s"(em), "v"(v_addr), "v"(v_value) : "memory");
+}
+__device__ __forceinline__ void x4_lane_add(uint64_t em, uint32_t v_addr, uint32_t v_value) {
+    asm volatile("s_mov_b64 exec, %0\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, -1" ::"s"(em), "v"(v_addr), "v"(v_value) : "memory");
+}
+// spin until [addr] >= target, compared in the event's own lane
+__device__ __forceinline__ void x4_lane_poll_ge(uint64_t em, uint32_t v_addr, uint32_t v_target) {
+    uint32_t t;
+    asm volatile("s_mov_b64 exec, %1\n"
+                 "1:\n\tds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_cmp_ge_u32 vcc, %0, %3\n\ts_cbranch_vccnz 2f\n\ts_sleep 1\n\ts_branch 1b\n"
+                 "2:\n\ts_mov_b64 exec, -1"
+                 : "=&v"(t) : "s"(em), "v"(v_addr), "v"(v_target) : "memory", "vcc");
+}
+// spin until every lane's word [addr] >= need (all lanes active; lane l reads the progress word of wave l & 15)
+__device__ __forceinline__ void x4_poll_all_ge(uint32_t v_addr, uint32_t s_need) {
+    uint32_t t;
+    asm volatile("1:\n\tds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tv_cmp_gt_u32 vcc, %2, %0\n\ts_cbranch_vccz 2f\n\ts_sleep 1\n\ts_branch 1b\n2:"
+                 : "=&v"(t) : "v"(v_addr), "s"(s_need) : "memory", "vcc");
+}
+
+template <class DT, bool TRANSW>
+__global__ void __launch_bounds__(64 * X4_G, 4)
+xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel, typename DT::T* __restrict__ Y,
+               const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "flow kernel: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t base_addr = lds_addr_of(smem);
+    const uint32_t prog_addr = base_addr + X4_FLAGS, full_addr = base_addr + X4_FLAGS + 64;
+    if (threadIdx.x < 24) reinterpret_cast<uint32_t*>(smem + X4_FLAGS)[threadIdx.x] = 0u;
+    __syncthreads();                                   // the only workgroup barrier of the kernel
+
+    const int npairs_full = Cin / 64;
+    const unsigned char* xt = reinterpret_cast<const unsigned char*>(X);
+    const unsigned char* wsel = static_cast<const unsigned char*>(uniform_ptr(Wsel));
+    // weight DMA (bsmm_xcol_v2.h): lane i of an instruction writes piece i of a 1 KiB half block; it fetches the piece that the read
+    // swizzle expects there (none for the transposing reads of fprop)
+    const uint32_t wvoff = TRANSW ? (uint32_t)lane * 16u : (uint32_t)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    const uint32_t wslot0 = X4_WBASE + wave * X4_WWAVE;                  // my weight slots (byte offset inside smem)
+    // fragment read offsets: activations (slab 0, half 0; the event's word XORs in slot << 14 | half << 6), weights (my slot 0; XOR 2048)
+    const int xsw = (r >> 1) & 7;
+    uint32_t xrd[2], wrd[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        xrd[kk] = r * 128 + (((2 * kk + h) ^ xsw) << 4);
+        if constexpr (TRANSW) {
+            const int g16 = lane >> 4, t16 = lane & 15;
+            wrd[kk] = wslot0 + (16 * kk + 8 * h + (t16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (t16 & 3)) * 2;
+        } else {
+            wrd[kk] = wslot0 + r * 64 + (((2 * kk + h) ^ ((r >> 2) & 3)) << 4);
+        }
+    }
+    const uint32_t prog_rd = prog_addr + 4 * (lane & 15);               // a lane's word of the progress table
+    const uint32_t my_prog = prog_addr + 4 * wave;
+    const uint32_t v_one = 1u;
+    // slab request offsets of a full tile: DMA instruction ii covers rows 8 ii + (lane >> 3); the 16-byte piece a lane fetches is
+    // (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ (lane >> 4) ^ (4 (ii & 1)): one pattern for even, one for odd instructions
+    const uint32_t stride16 = (uint32_t)Cin * 16u;                       // bytes between the first rows of consecutive instructions
+    const uint32_t pc_e = (uint32_t)((lane & 7) ^ (lane >> 4));
+    const uint32_t vo_e = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u + pc_e * 16u, vo_o = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u + (pc_e ^ 4u) * 16u;
+
+    uint32_t gs = 0;                 // global step number of the current unit's step 0 (ring slot = global step % X4_D)
+    const int nunits = map.grid();
+    for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+        int tile, grp;
+        if (!xmap_decode(map, unit, tile, grp)) continue;
+        const int32_t* gh = plan + plan[5] + X4_GROUP * grp;
+        const int step_off = __builtin_amdgcn_readfirstlane(gh[0]), nsteps = __builtin_amdgcn_readfirstlane(gh[1]);
+        const int ob0 = __builtin_amdgcn_readfirstlane(gh[2]), nob = __builtin_amdgcn_readfirstlane(gh[3]);
+        const int list_off = __builtin_amdgcn_readfirstlane(gh[4]), lcap = __builtin_amdgcn_readfirstlane(gh[5]);
+        const int32_t* pairs = plan + plan[6] + step_off;
+        const int32_t* lists = plan + plan[7] + list_off;
+        const int nev = __builtin_amdgcn_readfirstlane(lists[wave]);
+        const int32_t* mine = lists + X4_G + (size_t)2 * lcap * wave;
+        const int n_tile = tile * X4_R;
+        if (nsteps <= 0) continue;
+        const unsigned char* xtile = static_cast<const unsigned char*>(uniform_ptr(xt + (size_t)n_tile * Cin * 2));
+        const bool fast_tile = n_tile + X4_R <= N;                       // no row of the tile lies past N: the request offsets are regular
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+        uint32_t s_w = 0, s_wf = 0;  // XOR offset of the weight slot to multiply from / to fetch into (0 or 2048)
+        for (int eb = 0; eb < nev; eb += 64) {
+            // ---- my events [eb, eb + 64), lane-indexed; the per-event fields are derived here, once, with vector instructions ----
+            const int ei = min(eb + lane, nev - 1);
+            const uint32_t w0 = (uint32_t)mine[2 * ei], w1 = (uint32_t)mine[2 * ei + 1];
+            const uint32_t ty = w0 & 3, hp = (w0 >> 2) & 3, step = (w0 >> 4) & 0xfff, nxt = (w0 >> 16) & 0xfff;
+            const uint32_t gstep = gs + step, sm = gstep % (uint32_t)X4_D, guse = gstep / (uint32_t)X4_D + 1u;   // ring slot, its uses so far
+            uint32_t p128 = 0;
+            if (ty == 2) p128 = (uint32_t)pairs[step];                   // REQ lanes: the pair of their step
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (drains the wave's memory queue: once per unit and 64 events)
+            const uint32_t wn = w1 >> 27;                                // vmcnt the plan computed for this event's wait
+            // control word: type | wait class << 2 (0: vmcnt(0), 1: vmcnt(2), 2: vmcnt(X4_DI)) | has-fetch << 4 | request-needs-the-slow-path << 5
+            const uint32_t f27 = w1 & X4_NOFETCH;
+            uint32_t v_ctl = ty | ((wn >= (uint32_t)X4_DI ? 2u : (wn >= 2u ? 1u : 0u)) << 2) | ((f27 != X4_NOFETCH ? 1u : 0u) << 4) |
+                             ((ty == 2 && (!fast_tile || (int)p128 >= npairs_full)) ? 32u : 0u);
+            // BLOCK: XOR word of the activation fragment addresses; REQ: byte offset of the part inside the ring
+            uint32_t v_x = ty == 1 ? ((sm << 14) | (hp << 6)) : (sm * (uint32_t)X4_SLAB + hp * (uint32_t)(X4_DI * 1024));
+            // BLOCK / ANN: address of the slab's counter; REQ: byte offset of the pair inside an activation row
+            uint32_t v_fa = ty == 2 ? p128 * 128u : full_addr + 4 * sm;
+            // BLOCK: the counter value that says "every part of this step's slab is in" (the slot's uses so far, this one included, times
+            // the parts); REQ: global number of the step + 1 (the progress every wave must have passed, plus X4_D)
+            uint32_t v_g = ty == 2 ? gstep + 1u : guse * (uint32_t)X4_PARTS;
+            uint32_t v_pv = gs + nxt;                                    // my progress after the event: the step of my next block
+            uint32_t v_fw = f27 << 11;                                   // byte offset of the weight block to fetch after the event
+            asm volatile("" : "+v"(v_ctl), "+v"(v_x), "+v"(v_fa), "+v"(v_g), "+v"(v_pv), "+v"(v_fw));
+            const int nchunk = min(64, nev - eb);
+            for (int idx = 0; idx < nchunk; ++idx) {
+                const uint64_t em = 1ull << idx;
+                const uint32_t ctl = (uint32_t)__builtin_amdgcn_readlane(v_ctl, idx);
+                const uint32_t ty_s = ctl & 3;
+                if (ty_s & 1) {                                          // BLOCK (1) or ANN (3): wait for my fetch / my requests
+                    const uint32_t wc = (ctl >> 2) & 3;
+                    if (wc == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if (wc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X4_DI) : "memory");
+                }
+                if (ty_s == 1) {
+                    // ---- BLOCK: my weight block (fetched two BLOCK events ago) x the slab of its step ----
+                    x4_lane_poll_ge(em, v_fa, v_g);                      // every part of the slab has been announced
+                    if (!X4_NO_MATH) {
+                        const uint32_t sx = (uint32_t)__builtin_amdgcn_readlane(v_x, idx);
+                        uint4 wq[2];
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            if constexpr (TRANSW) {
+                                const uint2 lo = ds_tr16(smem + (wrd[kk] ^ s_w)), hi = ds_tr16(smem + (wrd[kk] ^ s_w) + 4 * 64);
+                                wq[kk] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                            } else {
+                                wq[kk] = *reinterpret_cast<const uint4*>(smem + (wrd[kk] ^ s_w));
+                            }
+                        }
+                        uint4 xf[4][2];
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) xf[t][kk] = *reinterpret_cast<const uint4*>(smem + (xrd[kk] ^ sx) + t * 4096);
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc[t] = DT::mfma32(wq[kk], xf[t][kk], acc[t]);
+                    }
+                    s_w ^= 2048u;
+                } else if (ty_s == 2) {
+                    // ---- REQ: request one part of a slab, once every wave's next block lies beyond the slab that occupied the slot ----
+                    const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane(v_g, idx);
+                    if (g1 > (uint32_t)X4_D) x4_poll_all_ge(prog_rd, g1 - (uint32_t)X4_D);
+                    if (!X4_NO_XDMA) {
+                        const uint32_t dst = base_addr + (uint32_t)__builtin_amdgcn_readlane(v_x, idx);
+                        const uint32_t poff = (uint32_t)__builtin_amdgcn_readlane(v_fa, idx);
+                        const uint32_t part_i = (uint32_t)__builtin_amdgcn_readlane(v_x, idx) % (uint32_t)X4_SLAB / 1024u;   // first instruction of the part
+                        if (!(ctl & 32u)) {
+                            // instruction ii covers rows 8 ii ..: lane offset = ii * 16 Cin + the even / odd pattern (+ the pair's offset)
+                            const uint32_t k0 = part_i * stride16 + poff;
+#pragma unroll
+                            for (int k = 0; k < X4_DI; k += 4)
+                                glds16_saddr_x4(xtile, vo_e + (k0 + (k + 0) * stride16), vo_o + (k0 + (k + 1) * stride16), vo_e + (k0 + (k + 2) * stride16),
+                                                vo_o + (k0 + (k + 3) * stride16), dst + k * 1024);
+                        } else {
+                            const bool tail = (int)(poff >> 7) >= npairs_full;
+#pragma unroll
+                            for (int k = 0; k < X4_DI; ++k) {
+                                const int row = 8 * ((int)part_i + k) + (lane >> 3);
+                                const int xr = min(n_tile + row, N - 1) - n_tile;    // rows past N are clamped (never stored)
+                                const int piece = (lane & 7) ^ ((row >> 1) & 7);
+                                uint32_t voff = (uint32_t)xr * (uint32_t)Cin * 2u + piece * 16 + poff;
+                                if (tail && (piece & 4)) voff -= 64;                 // last pair of an odd block count: re-read its even half
+                                glds16_saddr(xtile, voff, dst + k * 1024);
+                            }
+                        }
+                    }
+                } else if (ty_s == 3) {
+                    // ---- ANN: my requests for that part have landed -> count it in ----
+                    x4_lane_add(em, v_fa, v_one);
+                }
+                if (ty_s < 2) {
+                    // ---- after a BLOCK / NOP: my next weight fetch (into the slot the block just freed), my progress ----
+                    if (ctl & 16u) {
+                        if (!X4_NO_WDMA) {
+                            const uint32_t fo = (uint32_t)__builtin_amdgcn_readlane(v_fw, idx);
+                            glds16_saddr_x2(wsel, wvoff + fo, wvoff + fo + 1024u, base_addr + (wslot0 ^ s_wf));
+                        }
+                        s_wf ^= 2048u;
+                    }
+                    x4_lane_write(em, my_prog, v_pv);
+                }
+            }
+        }
+        gs += (uint32_t)nsteps;
+
+        // Epilogue, per wave, through its own weight slots (idle now): D[o][n] with col n = r, rows o = (reg & 3) + 8 (reg >> 2) + 4h.
+        // Two passes of two row tiles: [64 rows][64 B], the four 16-byte pieces of row n XOR-swizzled with (n >> 2) & 3; read back as
+        // full 64-byte rows and stored (16 rows per instruction).
+        if (wave < nob) {
+            unsigned char* stage = smem + wslot0;
+            unsigned char* ybase = reinterpret_cast<unsigned char*>(Y + (size_t)(ob0 + wave) * 32);
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = 2 * pass + tt;
+                    const int n = tt * 32 + r;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t lo = (uint32_t)DT::from_f32(acc[t][4 * q + 0]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 1]) << 16);
+                        const uint32_t hi = (uint32_t)DT::from_f32(acc[t][4 * q + 2]) | ((uint32_t)DT::from_f32(acc[t][4 * q + 3]) << 16);
+                        *reinterpret_cast<uint2*>(stage + n * 64 + ((q ^ ((n >> 2) & 3)) << 4) + 8 * h) = make_uint2(lo, hi);
+                    }
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = 16 * i + (lane >> 2), pc = lane & 3;
+                    const uint4 v = *reinterpret_cast<const uint4*>(stage + n * 64 + ((pc ^ ((n >> 2) & 3)) << 4));
+                    const int gn = n_tile + 64 * pass + n;
+                    if (gn < N) *reinterpret_cast<uint4*>(ybase + (size_t)gn * Kout * 2 + pc * 16) = v;
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+}
+
+}  // namespace bsmm

@@ -65,7 +65,7 @@ enum {
 enum {
     BSMM_K_NONE = 0,
     BSMM_K_XPROP_VALU = 1, BSMM_K_XPROP_SEGMENT = 2, BSMM_K_XCOL32 = 3, BSMM_K_XCOL16 = 4, BSMM_K_XCOL32_F32SPLIT = 5,
-    BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7, BSMM_K_XCOL32_STAGED = 8, BSMM_K_XCOL16_STAGED = 9,
+    BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7, BSMM_K_XCOL32_STAGED = 8, BSMM_K_XCOL16_STAGED = 9, BSMM_K_XCOL32_FLOW = 10,
     BSMM_K_UPDAT_VALU = 16, BSMM_K_UPDAT_BLOCK = 17, BSMM_K_UPDAT_BLOCK_TR = 18, BSMM_K_UPDAT_WIN = 19, BSMM_K_UPDAT16_WIN = 20,
     BSMM_K_UPDAT_SUPER8 = 21, BSMM_K_UPDAT_STREAM = 22
 };
@@ -76,6 +76,7 @@ enum {
     BSMM_PLAN_F32_MFMA = 2,         /* xprop fp32 bsize 32: schedule for the fp32 matrix-core kernel instead of the bf16 split */
     BSMM_PLAN_XCOL_UNSTAGED = 4,    /* xprop bsize 32 / 16, 16-bit: the round-1 kernel (weights by register loads, bsmm_xcol.h)
                                        instead of the staged one (weights through LDS as well, bsmm_xcol_v2.h)                */
+    BSMM_PLAN_XCOL_FLOW = 8,        /* xprop bsize 32, 16-bit, feature axis 1: the barrier-free persistent kernel (bsmm_xflow.h, 'BSX4' plans) */
     BSMM_PLAN_WINDOW_8 = 0x10,      /* updat bsize 32: round-1 windowed kernel, 8x8-block windows, 8 waves                  */
     BSMM_PLAN_WINDOW_16 = 0x20,     /*                 round-1 windowed kernel, 16x16-block windows, 8 waves                */
     BSMM_PLAN_WINDOW_16W = 0x30,    /*                 round-1 windowed kernel, 16x16-block windows, 16 waves               */
