@@ -1183,6 +1183,12 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
     return (int)hipGetLastError();
 }
 
+#ifdef X4_TIMELINE
+extern "C" int bsmm_debug_x4_timeline_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_tl), sizeof(bsmm::g_x4_tl)); }
+#endif
+#ifdef X4_STAMPS
+extern "C" int bsmm_debug_x4_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_trace), sizeof(bsmm::g_x4_trace)); }
+#endif
 #ifdef BSMM_XC_TRACE
 int bsmm_debug_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_xc_trace), sizeof(bsmm::g_xc_trace)); }
 #endif

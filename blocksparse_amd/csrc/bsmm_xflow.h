@@ -39,6 +39,34 @@ namespace bsmm {
 #ifndef X4_NO_MATH
 #define X4_NO_MATH 0
 #endif
+#ifndef X4_READS_FIRST
+#define X4_READS_FIRST 1
+#endif
+#ifndef X4_PUBLISH_FIRST
+#define X4_PUBLISH_FIRST 1
+#endif
+#ifndef X4_PRIO
+#define X4_PRIO 0             // 1: a wave multiplying a block runs at raised issue priority (the pollers at 0)
+#endif
+#ifdef X4_TIMELINE
+// time line of workgroup 0 (debug builds): per global step [0..255]: [0..3] REQ start (after its progress poll) of part 0 / 1, then REQ
+// issued of part 0 / 1; [4..5] ANN of part 0 / 1; [6 + 2 w] BLOCK of wave w has its slab, [7 + 2 w] BLOCK done; bsmm_debug_x4_timeline_copy()
+__device__ unsigned long long g_x4_tl[256 * 40];
+#define X4_TL(step, k) do { if (blockIdx.x == 0 && (step) < 256) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) g_x4_tl[(step) * 40 + (k)] = t_; } } while (0)
+#else
+#define X4_TL(step, k) do { } while (0)
+#endif
+#ifdef X4_STAMPS
+// cycle accounting of the first 64 workgroups (debug builds; s_memtime): per wave [0] waits for my fetch / requests, [1] slab polls,
+// [2] multiplies, [3] progress polls of REQ, [4] request issue, [5] fetch issue + progress write, [6] whole kernel, [7] events;
+// read back with bsmm_debug_x4_trace_copy()
+__device__ unsigned long long g_x4_trace[64 * 16 * 8];
+#define X4_T0() const unsigned long long t0_ = __builtin_readcyclecounter()
+#define X4_T1(k) tacc[k] += __builtin_readcyclecounter() - t0_
+#else
+#define X4_T0() do { } while (0)
+#define X4_T1(k) do { } while (0)
+#endif
 constexpr int X4_R = 128;                              // minibatch rows per unit
 constexpr int X4_SLAB = X4_R * 128;                    // 16 KiB
 constexpr int X4_S = 2;                                // private weight slots per wave
@@ -76,6 +104,13 @@ __device__ __forceinline__ void x4_poll_all_ge(uint32_t v_addr, uint32_t s_need)
                  : "=&v"(t) : "v"(v_addr), "s"(s_need) : "memory", "vcc");
 }
 
+// the wait of a BLOCK / ANN event, chosen by the event's control word: bit 3 vmcnt(2), bit 4 vmcnt(0), else vmcnt(X4_DI)
+__device__ __forceinline__ void x4_wait_ctl(uint32_t ctl) {
+    asm volatile("s_bitcmp1_b32 %0, 3\n\ts_cbranch_scc0 1f\n\ts_waitcnt vmcnt(2)\n\ts_branch 3f\n"
+                 "1:\n\ts_bitcmp1_b32 %0, 4\n\ts_cbranch_scc0 2f\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n"
+                 "2:\n\ts_waitcnt vmcnt(%1)\n3:" ::"s"(ctl), "n"(X4_DI) : "memory", "scc");
+}
+
 template <class DT, bool TRANSW>
 __global__ void __launch_bounds__(64 * X4_G, 4)
 xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel, typename DT::T* __restrict__ Y,
@@ -111,15 +146,17 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
             wrd[kk] = wslot0 + r * 64 + (((2 * kk + h) ^ ((r >> 2) & 3)) << 4);
         }
     }
-    const uint32_t prog_rd = prog_addr + 4 * (lane & 15);               // a lane's word of the progress table
-    const uint32_t my_prog = prog_addr + 4 * wave;
-    const uint32_t v_one = 1u;
+    const uint32_t my_prog_s = prog_addr + 4 * wave;                     // (uniform: materialised in a vector register only where it is used)
     // slab request offsets of a full tile: DMA instruction ii covers rows 8 ii + (lane >> 3); the 16-byte piece a lane fetches is
     // (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ (lane >> 4) ^ (4 (ii & 1)): one pattern for even, one for odd instructions
     const uint32_t stride16 = (uint32_t)Cin * 16u;                       // bytes between the first rows of consecutive instructions
     const uint32_t pc_e = (uint32_t)((lane & 7) ^ (lane >> 4));
-    const uint32_t vo_e = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u + pc_e * 16u, vo_o = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u + (pc_e ^ 4u) * 16u;
+    const uint32_t vo_e = (uint32_t)(lane >> 3) * (uint32_t)Cin * 2u + pc_e * 16u;     // (odd instructions: the piece index XOR 4 = +- 64 bytes)
 
+#ifdef X4_STAMPS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tstart = __builtin_readcyclecounter();
+#endif
     uint32_t gs = 0;                 // global step number of the current unit's step 0 (ring slot = global step % X4_D)
     const int nunits = map.grid();
     for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
@@ -155,10 +192,10 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
             if (ty == 2) p128 = (uint32_t)pairs[step];                   // REQ lanes: the pair of their step
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (drains the wave's memory queue: once per unit and 64 events)
             const uint32_t wn = w1 >> 27;                                // vmcnt the plan computed for this event's wait
-            // control word: type | wait class << 2 (0: vmcnt(0), 1: vmcnt(2), 2: vmcnt(X4_DI)) | has-fetch << 4 | request-needs-the-slow-path << 5
+            // control word: type (bits 0..1) | wait: bit 3 vmcnt(2), bit 4 vmcnt(0), neither vmcnt(X4_DI) | bit 6 has a fetch | bit 7 request needs the slow path
             const uint32_t f27 = w1 & X4_NOFETCH;
-            uint32_t v_ctl = ty | ((wn >= (uint32_t)X4_DI ? 2u : (wn >= 2u ? 1u : 0u)) << 2) | ((f27 != X4_NOFETCH ? 1u : 0u) << 4) |
-                             ((ty == 2 && (!fast_tile || (int)p128 >= npairs_full)) ? 32u : 0u);
+            uint32_t v_ctl = ty | (wn >= (uint32_t)X4_DI ? 0u : (wn >= 2u ? 8u : 16u)) | (f27 != X4_NOFETCH ? 64u : 0u) |
+                             ((ty == 2 && (!fast_tile || (int)p128 >= npairs_full)) ? 128u : 0u);
             // BLOCK: XOR word of the activation fragment addresses; REQ: byte offset of the part inside the ring
             uint32_t v_x = ty == 1 ? ((sm << 14) | (hp << 6)) : (sm * (uint32_t)X4_SLAB + hp * (uint32_t)(X4_DI * 1024));
             // BLOCK / ANN: address of the slab's counter; REQ: byte offset of the pair inside an activation row
@@ -169,20 +206,27 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
             uint32_t v_pv = gs + nxt;                                    // my progress after the event: the step of my next block
             uint32_t v_fw = f27 << 11;                                   // byte offset of the weight block to fetch after the event
             asm volatile("" : "+v"(v_ctl), "+v"(v_x), "+v"(v_fa), "+v"(v_g), "+v"(v_pv), "+v"(v_fw));
+#ifdef X4_TIMELINE
+            const uint32_t v_dbg = gstep | (hp << 16);
+#endif
             const int nchunk = min(64, nev - eb);
             for (int idx = 0; idx < nchunk; ++idx) {
                 const uint64_t em = 1ull << idx;
                 const uint32_t ctl = (uint32_t)__builtin_amdgcn_readlane(v_ctl, idx);
                 const uint32_t ty_s = ctl & 3;
-                if (ty_s & 1) {                                          // BLOCK (1) or ANN (3): wait for my fetch / my requests
-                    const uint32_t wc = (ctl >> 2) & 3;
-                    if (wc == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else if (wc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X4_DI) : "memory");
-                }
+#ifdef X4_STAMPS
+                tacc[7] += 1;
+#endif
+                if (ty_s & 1) { X4_T0(); x4_wait_ctl(ctl); X4_T1(0); }     // BLOCK (1) or ANN (3): wait for my fetch / my requests
                 if (ty_s == 1) {
                     // ---- BLOCK: my weight block (fetched two BLOCK events ago) x the slab of its step ----
-                    x4_lane_poll_ge(em, v_fa, v_g);                      // every part of the slab has been announced
+                    { X4_T0(); x4_lane_poll_ge(em, v_fa, v_g); X4_T1(1); }  // every part of the slab has been announced
+#ifdef X4_TIMELINE
+                    const uint32_t dbg_s = (uint32_t)__builtin_amdgcn_readlane(v_dbg, idx) & 0xffff;
+                    X4_TL(dbg_s, 6 + 2 * wave);
+#endif
+                    X4_T0();
+                    if (X4_PRIO) __builtin_amdgcn_s_setprio(3);
                     if (!X4_NO_MATH) {
                         const uint32_t sx = (uint32_t)__builtin_amdgcn_readlane(v_x, idx);
                         uint4 wq[2];
@@ -195,6 +239,23 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                                 wq[kk] = *reinterpret_cast<const uint4*>(smem + (wrd[kk] ^ s_w));
                             }
                         }
+#if X4_READS_FIRST
+                        // a block is on its wave's critical path: its LATENCY counts.  Both weight fragments and the four K-half-0
+                        // activation fragments are in flight before the first MFMA; each K-half-1 fragment is requested right behind
+                        // the MFMA that consumed its K-half-0 sibling (into the same registers) and lands under the other three
+                        uint4 xf[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const uint4*>(smem + (xrd[0] ^ sx) + t * 4096);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc[t] = DT::mfma32(wq[0], xf[t], acc[t]);
+                            xf[t] = *reinterpret_cast<const uint4*>(smem + (xrd[1] ^ sx) + t * 4096);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[t] = DT::mfma32(wq[1], xf[t], acc[t]);
+#else
                         uint4 xf[4][2];
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
@@ -204,19 +265,34 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                             for (int t = 0; t < 4; ++t) acc[t] = DT::mfma32(wq[kk], xf[t][kk], acc[t]);
+#endif
                     }
                     s_w ^= 2048u;
+#ifdef X4_STAMPS
+                    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+#endif
+                    X4_T1(2);
+#ifdef X4_TIMELINE
+                    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+                    X4_TL(dbg_s, 7 + 2 * wave);
+#endif
                 } else if (ty_s == 2) {
                     // ---- REQ: request one part of a slab, once every wave's next block lies beyond the slab that occupied the slot ----
                     const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane(v_g, idx);
-                    if (g1 > (uint32_t)X4_D) x4_poll_all_ge(prog_rd, g1 - (uint32_t)X4_D);
+                    { X4_T0(); if (g1 > (uint32_t)X4_D) x4_poll_all_ge(prog_addr + 4 * (lane & 15), g1 - (uint32_t)X4_D); X4_T1(3); }
+                    X4_T0();
+#ifdef X4_TIMELINE
+                    const uint32_t dbg_r = (uint32_t)__builtin_amdgcn_readlane(v_dbg, idx);
+                    X4_TL(dbg_r & 0xffff, dbg_r >> 16);
+#endif
                     if (!X4_NO_XDMA) {
                         const uint32_t dst = base_addr + (uint32_t)__builtin_amdgcn_readlane(v_x, idx);
                         const uint32_t poff = (uint32_t)__builtin_amdgcn_readlane(v_fa, idx);
                         const uint32_t part_i = (uint32_t)__builtin_amdgcn_readlane(v_x, idx) % (uint32_t)X4_SLAB / 1024u;   // first instruction of the part
-                        if (!(ctl & 32u)) {
+                        if (!(ctl & 128u)) {
                             // instruction ii covers rows 8 ii ..: lane offset = ii * 16 Cin + the even / odd pattern (+ the pair's offset)
                             const uint32_t k0 = part_i * stride16 + poff;
+                            const uint32_t vo_o = (pc_e & 4u) ? vo_e - 64u : vo_e + 64u;
 #pragma unroll
                             for (int k = 0; k < X4_DI; k += 4)
                                 glds16_saddr_x4(xtile, vo_e + (k0 + (k + 0) * stride16), vo_o + (k0 + (k + 1) * stride16), vo_e + (k0 + (k + 2) * stride16),
@@ -234,20 +310,31 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                             }
                         }
                     }
+                    X4_T1(4);
+#ifdef X4_TIMELINE
+                    X4_TL(dbg_r & 0xffff, 2 + (dbg_r >> 16));
+#endif
                 } else if (ty_s == 3) {
                     // ---- ANN: my requests for that part have landed -> count it in ----
-                    x4_lane_add(em, v_fa, v_one);
+                    x4_lane_add(em, v_fa, 1u);
+#ifdef X4_TIMELINE
+                    { const uint32_t dbg_a = (uint32_t)__builtin_amdgcn_readlane(v_dbg, idx); X4_TL(dbg_a & 0xffff, 4 + (dbg_a >> 16)); }
+#endif
                 }
                 if (ty_s < 2) {
                     // ---- after a BLOCK / NOP: my next weight fetch (into the slot the block just freed), my progress ----
-                    if (ctl & 16u) {
+                    X4_T0();
+                    if (X4_PUBLISH_FIRST) x4_lane_write(em, my_prog_s, v_pv);   // (first: the requesters of the slot I just left are waiting for this)
+                    if (ctl & 64u) {
                         if (!X4_NO_WDMA) {
                             const uint32_t fo = (uint32_t)__builtin_amdgcn_readlane(v_fw, idx);
                             glds16_saddr_x2(wsel, wvoff + fo, wvoff + fo + 1024u, base_addr + (wslot0 ^ s_wf));
                         }
                         s_wf ^= 2048u;
                     }
-                    x4_lane_write(em, my_prog, v_pv);
+                    if (!X4_PUBLISH_FIRST) x4_lane_write(em, my_prog_s, v_pv);
+                    if (X4_PRIO) __builtin_amdgcn_s_setprio(0);
+                    X4_T1(5);
                 }
             }
         }
@@ -284,6 +371,11 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
             }
         }
     }
+#ifdef X4_STAMPS
+    tacc[6] = __builtin_readcyclecounter() - tstart;
+    if (blockIdx.x < 64 && lane == 0)
+        for (int k = 0; k < 8; ++k) g_x4_trace[(blockIdx.x * 16 + wave) * 8 + k] = tacc[k];
+#endif
 }
 
 }  // namespace bsmm

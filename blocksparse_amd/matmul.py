@@ -112,6 +112,13 @@ class _DeviceTables(object):
         # plans exist only for 16-bit types (they do not depend on which of the two) ...
         self.fprop_plan = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.BF16, axis, plan_options))
         self.bprop_plan = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.BF16, axis, plan_options))
+        # bsize 32 on feature axis 1: the barrier-free persistent kernel ('BSX4' plans, csrc/bsmm_xflow.h) for ungated calls; the staged
+        # kernel's plans above stay for gated calls and as the comparison path (BlocksparseMatMul.flow = False).  A caller who names
+        # another kernel family in plan_options gets exactly that.
+        self.fprop_flow = self.bprop_flow = None
+        if bsize == 32 and axis == 1 and not (plan_options & (_lib.PLAN_XCOL_UNSTAGED | _lib.PLAN_XCOL_NARROW | _lib.PLAN_XCOL_FLOW | (7 << _lib.PLAN_XPROP_PH_SHIFT))):
+            self.fprop_flow = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_XCOL_FLOW))
+            self.bprop_flow = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_XCOL_FLOW))
         # ... and fp32 has its own (xprop-only) plan kernels for bsize 32; the schedule format is the library's business
         self.fprop_plan_f32 = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.F32, axis, plan_options))
         self.bprop_plan_f32 = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.F32, axis, plan_options))
@@ -175,6 +182,7 @@ class BlocksparseMatMul(object):
         self._inner = None
         self._split64_hit = None
         self.native64 = True          # bsize 64: call the library with bsize = 64 (False: always the host-side quadrant view)
+        self.flow = True              # bsize 32, feature axis 1, 16-bit, no gate: the barrier-free xprop kernel (False: the staged one)
         if block_size == 64:
             # same weights, cut into 32x32 blocks: inner block n is quadrant (i, j) of outer block b
             self._inner = BlocksparseMatMul(np.kron(self.layout, np.ones((2, 2), dtype=self.layout.dtype)), block_size=32, feature_axis=feature_axis,
@@ -350,7 +358,8 @@ class BlocksparseMatMul(object):
         tabs = self._tables_on(x.device)
         y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
         a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype,
-                       plan=tabs.fprop_plan_f32 if x.dtype == torch.float32 else tabs.fprop_plan)
+                       plan=tabs.fprop_plan_f32 if x.dtype == torch.float32 else
+                       (tabs.fprop_flow if (self.flow and gate is None and tabs.fprop_flow is not None) else tabs.fprop_plan))
         a.gate = gate.data_ptr() if gate is not None else None
         self._prepared(a, _lib.OP_FPROP, w)
         self._workspace(a, _lib.OP_FPROP, x.device)
@@ -371,7 +380,8 @@ class BlocksparseMatMul(object):
         tabs = self._tables_on(dy.device)
         dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)
         a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype,
-                       plan=tabs.bprop_plan_f32 if dy.dtype == torch.float32 else tabs.bprop_plan)
+                       plan=tabs.bprop_plan_f32 if dy.dtype == torch.float32 else
+                       (tabs.bprop_flow if (self.flow and gate is None and tabs.bprop_flow is not None) else tabs.bprop_plan))
         a.gate = gate.data_ptr() if gate is not None else None
         self._prepared(a, _lib.OP_BPROP, w)
         self._workspace(a, _lib.OP_BPROP, dy.device)

@@ -18,7 +18,9 @@ def timeit(fn, reps=100):
     return e0.elapsed_time(e1) / reps * 1e3
 
 def pair(layout):
-    return (BlocksparseMatMul(layout, block_size=32, feature_axis=1), BlocksparseMatMul(layout, block_size=32, feature_axis=1, plan_options=lib.PLAN_XCOL_FLOW))
+    b2 = BlocksparseMatMul(layout, block_size=32, feature_axis=1)
+    b2.flow = False
+    return (b2, BlocksparseMatMul(layout, block_size=32, feature_axis=1))
 
 cases = [("tiny 4x4 N=128", P.random_layout(4, 4, 0.6, seed=1), 128, torch.bfloat16),
          ("40x24 N=1000 (ragged rows, partial group)", P.random_layout(40, 24, 0.3, seed=2), 1000, torch.bfloat16),

@@ -20,7 +20,7 @@ lib.set_kernel_variant(3)
 out = []
 for d in [float(v) for v in os.environ.get("DENS", "0.1,0.2,0.5").split(",")]:
     lay = P.random_layout(128, 128, d, seed=1234)
-    b4 = BlocksparseMatMul(lay, block_size=32, feature_axis=1, plan_options=lib.PLAN_XCOL_FLOW)
+    b4 = BlocksparseMatMul(lay, block_size=32, feature_axis=1)
     N = 8192
     w = (torch.randn(b4.w_shape, device="cuda") * 0.01).bfloat16()
     x = (torch.randn(b4.i_shape(N), device="cuda") * 0.1).bfloat16()
@@ -28,7 +28,7 @@ for d in [float(v) for v in os.environ.get("DENS", "0.1,0.2,0.5").split(",")]:
     s = "d%.2f flow f %.1f b %.1f" % (d, timeit(lambda: b4.fprop(x, w)), timeit(lambda: b4.bprop(dy, w)))
     assert lib.last_kernel() == lib.K_XCOL32_FLOW
     if os.environ.get("REF"):
-        b2 = BlocksparseMatMul(lay, block_size=32, feature_axis=1)
+        b2 = BlocksparseMatMul(lay, block_size=32, feature_axis=1); b2.flow = False
         s += " | staged f %.1f b %.1f" % (timeit(lambda: b2.fprop(x, w)), timeit(lambda: b2.bprop(dy, w)))
     out.append(s)
 print("%-14s %s" % (os.environ.get("TAG", os.path.basename(os.environ.get("BSMM_LIB", "default"))), "  ||  ".join(out)), flush=True)

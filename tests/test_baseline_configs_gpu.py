@@ -36,8 +36,11 @@ def _updat_kernel(lib, axis, opt=0):
 
 
 def _xprop_kernel(lib, axis, opt=0):
-    """which bsize-32 16-bit xprop plan kernel runs: the staged kernel (bsmm_xcol_v2.h) unless the plan options say otherwise"""
-    return lib.K_XCOL32_STAGED if not (opt & (lib.PLAN_XCOL_UNSTAGED | lib.PLAN_XCOL_NARROW)) else lib.K_XCOL32
+    """which bsize-32 16-bit xprop plan kernel an UNGATED call runs: feature axis 1 -> the barrier-free persistent kernel
+    (bsmm_xflow.h), feature axis 0 -> the staged kernel (bsmm_xcol_v2.h), unless the plan options name the round-1 kernel"""
+    if opt & (lib.PLAN_XCOL_UNSTAGED | lib.PLAN_XCOL_NARROW):
+        return lib.K_XCOL32
+    return lib.K_XCOL32_FLOW if axis == 1 else lib.K_XCOL32_STAGED
 
 
 def _inputs(torch, b, N, dtype, seed):
@@ -117,7 +120,7 @@ def test_bench_shape_fp16_and_ragged_minibatch(env):
     torch, BSMM, lib = env
     layout = P.random_layout(128, 128, 0.2, seed=1234)
     b = BSMM(layout, block_size=32, feature_axis=1)
-    _check_sampled(torch, lib, b, layout, 8192 - 24, "f16", seed=12, expect={"xprop": lib.K_XCOL32_STAGED, "updat": lib.K_UPDAT_STREAM}, ctx="bench f16 ragged")
+    _check_sampled(torch, lib, b, layout, 8192 - 24, "f16", seed=12, expect={"xprop": lib.K_XCOL32_FLOW, "updat": lib.K_UPDAT_STREAM}, ctx="bench f16 ragged")
 
 
 def test_bench_shape_skewed_layout(env):
@@ -126,7 +129,7 @@ def test_bench_shape_skewed_layout(env):
     torch, BSMM, lib = env
     layout = P.ba_layout(128, 14, seed=1)
     b = BSMM(layout, block_size=32, feature_axis=1)
-    _check_sampled(torch, lib, b, layout, 4096, "bf16", seed=13, expect={"xprop": lib.K_XCOL32_STAGED, "updat": lib.K_UPDAT_STREAM}, ctx="bench BA")
+    _check_sampled(torch, lib, b, layout, 4096, "bf16", seed=13, expect={"xprop": lib.K_XCOL32_FLOW, "updat": lib.K_UPDAT_STREAM}, ctx="bench BA")
 
 
 @pytest.mark.parametrize("bs,axis,density", [(32, 1, 0.2), (32, 0, 0.2), (16, 0, 0.1), (16, 1, 0.1), (8, 0, 0.1), (8, 1, 0.1)])
@@ -144,7 +147,7 @@ def test_full_output_at_4096_against_float64_oracle(env, bs, axis, density):
     W, X, E = P.to_host(w), P.to_host(x), P.to_host(e)
     t = orc.build_layout_luts(layout, bs)
     bar = P.L2_BAR["bf16"]
-    want = {8: (lib.K_XPROP_SUPER8, lib.K_UPDAT_SUPER8), 16: (lib.K_XCOL16_STAGED, lib.K_UPDAT16_WIN), 32: (lib.K_XCOL32_STAGED, lib.K_UPDAT_STREAM)}[bs]
+    want = {8: (lib.K_XPROP_SUPER8, lib.K_UPDAT_SUPER8), 16: (lib.K_XCOL16_STAGED, lib.K_UPDAT16_WIN), 32: (lib.K_XCOL32_FLOW if axis == 1 else lib.K_XCOL32_STAGED, lib.K_UPDAT_STREAM)}[bs]
     lib.set_kernel_variant(3)
     try:
         y = P.to_host(b.fprop(x, w)); kf = lib.last_kernel()
@@ -306,14 +309,17 @@ def test_staged_and_round1_xprop_kernels_agree_bitwise(env, axis):
     torch, BSMM, lib = env
     layout = P.random_layout(128, 128, 0.2, seed=1234)
     outs = []
-    for o in (0, lib.PLAN_XCOL_UNSTAGED):
+    for o, flow in ((0, True), (0, False), (lib.PLAN_XCOL_UNSTAGED, False)):      # flow (axis 1) | staged | round-1 kernel
         b = BSMM(layout, block_size=32, feature_axis=axis, plan_options=o)
+        b.flow = flow
         w, x, e = _inputs(torch, b, 8192, "bf16", seed=5)
         y = b.fprop(x, w); k1 = lib.last_kernel()
         dx = b.bprop(e, w)
-        assert k1 == lib.last_kernel() == _xprop_kernel(lib, axis, o)
+        want = _xprop_kernel(lib, axis, o) if flow or o else lib.K_XCOL32_STAGED
+        assert k1 == lib.last_kernel() == want, (k1, want)
         outs.append((y, dx))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for y, dx in outs[1:]:
+        assert torch.equal(outs[0][0], y) and torch.equal(outs[0][1], dx)
 
 
 @pytest.mark.parametrize("axis", [1, 0])
@@ -512,10 +518,10 @@ def test_bench_shape_bsize8(env, axis):
 
 
 # ---- (h) the kernel-choice cost models at measured points (profiles/r02_sweeps.md: the faster kernel wins by > 15 % there) ----
-@pytest.mark.parametrize("CB,dens,N,xk,uk", [(128, 0.2, 256, "K_XPROP_SEGMENT", "K_UPDAT_BLOCK_TR"), (128, 0.2, 2048, "K_XCOL32_STAGED", "K_UPDAT_STREAM"),
+@pytest.mark.parametrize("CB,dens,N,xk,uk", [(128, 0.2, 256, "K_XPROP_SEGMENT", "K_UPDAT_BLOCK_TR"), (128, 0.2, 2048, "K_XCOL32_FLOW", "K_UPDAT_STREAM"),
                                              (128, 0.05, 2048, None, "K_UPDAT_STREAM"), (128, 0.05, 512, "K_XPROP_SEGMENT", "K_UPDAT_BLOCK_TR"),
-                                             (256, 0.05, 512, "K_XPROP_SEGMENT", "K_UPDAT_STREAM"), (256, 0.05, 2048, "K_XCOL32_STAGED", "K_UPDAT_STREAM"),
-                                             (64, 0.2, 512, "K_XPROP_SEGMENT", "K_UPDAT_BLOCK_TR"), (64, 0.2, 8192, "K_XCOL32_STAGED", None)])
+                                             (256, 0.05, 512, "K_XPROP_SEGMENT", "K_UPDAT_STREAM"), (256, 0.05, 2048, "K_XCOL32_FLOW", "K_UPDAT_STREAM"),
+                                             (64, 0.2, 512, "K_XPROP_SEGMENT", "K_UPDAT_BLOCK_TR"), (64, 0.2, 8192, "K_XCOL32_FLOW", None)])
 def test_cost_models_pick_the_measured_winner(env, CB, dens, N, xk, uk):
     """Production dispatch (no flags) on a 256-CU part: at these (layout, minibatch) points of the sweeps one kernel family is clearly
     faster; (128, 5 %, N = 2048) is the updat point the model once got wrong (auto 33.6 us on the per-block kernel, plan 25.2)."""
