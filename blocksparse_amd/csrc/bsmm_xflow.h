@@ -171,7 +171,7 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
         const int nev = __builtin_amdgcn_readfirstlane(lists[wave]);
         const int32_t* mine = lists + X4_G + (size_t)2 * lcap * wave;
         const int n_tile = tile * X4_R;
-        if (nsteps <= 0) continue;
+        // (a group without any block has no steps: its waves run their two NOPs and the epilogue writes the zeros the output must hold)
         const unsigned char* xtile = static_cast<const unsigned char*>(uniform_ptr(xt + (size_t)n_tile * Cin * 2));
         const bool fast_tile = n_tile + X4_R <= N;                       // no row of the tile lies past N: the request offsets are regular
 

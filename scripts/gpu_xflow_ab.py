@@ -28,7 +28,8 @@ cases = [("tiny 4x4 N=128", P.random_layout(4, 4, 0.6, seed=1), 128, torch.bfloa
          ("128x128 20% N=2048", P.random_layout(128, 128, 0.2, seed=1234), 2048, torch.bfloat16),
          ("128x128 50% N=1024 (lists > 64 blocks)", P.random_layout(128, 128, 0.55, seed=5), 1024, torch.bfloat16),
          ("300x16 5% N=640 (> 64 steps)", P.random_layout(300, 16, 0.05, seed=6), 640, torch.bfloat16),
-         ("BA 128 N=4096", P.ba_layout(128, 14, seed=1), 4096, torch.bfloat16)]
+         ("BA 128 N=4096", P.ba_layout(128, 14, seed=1), 4096, torch.bfloat16),
+         ("15x33 with an output group without blocks, N=520", np.eye(15, 33, dtype=np.int32), 520, torch.float16)]
 lib.set_kernel_variant(3)
 ok = True
 for name, lay, N, td in cases:

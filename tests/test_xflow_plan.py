@@ -40,7 +40,7 @@ def _columns(side):
 
 @pytest.mark.parametrize("name,layout", [("random 40x24", P.random_layout(40, 24, 0.3, seed=2)), ("dense 12x20", np.ones((12, 20), dtype=np.int32)),
                                          ("BA 64", P.ba_layout(64, 5, seed=1)), ("sparse 300x16", P.random_layout(300, 16, 0.05, seed=6)),
-                                         ("single", np.ones((1, 1), dtype=np.int32)), ("bench 20 %", P.random_layout(128, 128, 0.2, seed=1234))])
+                                         ("single", np.ones((1, 1), dtype=np.int32)), ("groups without blocks", np.eye(15, 40, dtype=np.int32)), ("bench 20 %", P.random_layout(128, 128, 0.2, seed=1234))])
 @pytest.mark.parametrize("which", ["fprop", "bprop"])
 def test_flow_plan_event_lists(name, layout, which):
     t, side, n_out, p = _plan(layout, which)
