@@ -37,7 +37,50 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                                            # GB/s (spec)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
+CLOCK_GHZ = 2.4                                              # nominal shader clock the per-clock figures are quoted at
+L2_TO_LDS_CEILING = 52.0                                     # B/clk/CU: the L2-resident LDS-DMA streaming micro-benchmark (scripts/micro/l2_bw.hip)
+
+
+def ba_layout(n, m, seed):
+    """Barabasi-Albert adjacency + I (the reference's own bench layout, test/blocksparse_matmul_bench.py:66-68; same generator as
+    tests/_parity.py, without networkx)"""
+    rng = np.random.RandomState(seed)
+    lay = np.eye(n, dtype=np.int32)
+    targets = list(range(m))
+    repeated = []
+    for src in range(m, n):
+        for t in set(targets):
+            lay[src, t] = lay[t, src] = 1
+        repeated.extend(targets)
+        repeated.extend([src] * m)
+        targets = []
+        while len(targets) < m:
+            x = repeated[rng.randint(len(repeated))]
+            if x not in targets:
+                targets.append(x)
+    lay[:m, :m] = 1
+    return lay
+
+
+def delivery_roof(layout, bsize, N, kernel_ms, cus):
+    """The roof DESIGN.md argues is binding for the bsize-32 xprop kernels: bytes one pass moves through the L2 -> LDS path (every
+    (row tile of 128, group of 16 output blocks) unit stages the 16 KiB slab of each input-block pair its group touches and the 2 KiB of
+    each of its weight blocks), per clock and CU, against the L2-resident LDS-DMA streaming rate measured on this part."""
+    if bsize != 32:
+        return None
+    lay = np.asarray(layout) != 0
+    CB, KB = lay.shape
+    tiles = (N + 127) // 128
+    per_tile = 0
+    for g0 in range(0, KB, 16):
+        sub = lay[:, g0:g0 + 16]
+        rows = np.nonzero(sub.any(axis=1))[0]
+        per_tile += len(set((rows // 2).tolist())) * 16384 + int(sub.sum()) * 2048
+    byts = tiles * per_tile
+    rate = byts / (kernel_ms * 1e-3 * CLOCK_GHZ * 1e9 * cus)
+    return {"bytes_l2_to_lds": int(byts), "b_per_clk_per_cu": round(rate, 2), "ceiling_b_per_clk": L2_TO_LDS_CEILING, "frac": round(rate / L2_TO_LDS_CEILING, 4),
+            "clock_ghz": CLOCK_GHZ, "kernel": "bsmm_xprop(fprop)", "note": "analytic bytes of the plan (slabs + weight blocks per unit) / HIP-event time of the pass"}
 
 
 def random_layout(CB, KB, density, seed):
@@ -304,12 +347,36 @@ CONFIGS = {
 }
 
 
-def measured_counters():
-    """per-density MFMA busy / measured HBM GB/s / HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)"""
+def git_head():
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_counters.json")))
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
     except Exception:
-        return {}
+        return None
+
+
+def kernel_sources_digest():
+    """sha256 over the kernel sources the profiled numbers depend on (the GPU box has no .git: this is what ties a counters file to a tree)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "blocksparse_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_counters():
+    """per-workload MFMA busy / measured HBM GB/s / HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), USED ONLY when
+    the file was taken on this tree's kernels: scripts/make_counters_json.py stamps the digest of blocksparse_amd/csrc and the profiled
+    kernel names; a mismatch drops the block and says why."""
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_counters.json")))
+    except Exception:
+        return {}, "no profiles/%s_counters.json" % PROFILE_ROUND
+    stamp = c.get("_stamp", {})
+    if stamp.get("csrc_digest") != kernel_sources_digest():
+        return {}, "profiles/%s_counters.json was taken on other kernel sources (digest %s, tree %s): not quoted" % (PROFILE_ROUND, stamp.get("csrc_digest"), kernel_sources_digest())
+    return c, None
 
 
 def main():
@@ -435,7 +502,9 @@ def main():
         via = red.via if use_dist else None
         return el, per, via
 
-    def summarize(b, n_local, dtype, el, per, steps):
+    cus = torch.cuda.get_device_properties(local).multi_processor_count
+
+    def summarize(b, n_local, dtype, el, per, steps, layout=None):
         """metrics of one workload: whole-job TFLOP/s, per-pass times, roofline of the dominant kernel"""
         s = 4 if dtype == "f32" else 2
         flops_pass = 2.0 * b.blocks * b.bsize ** 2 * n_local
@@ -446,6 +515,10 @@ def main():
         cand = {"bsmm_xprop(bprop)": (b_ms, flops_pass, alg_bytes_xprop(b, n_local, s)), "bsmm_updat": (u_ms, flops_pass, alg_bytes_updat(b, n_local, s))}
         dom = max(cand, key=lambda k: cand[k][0])
         roof = roofline_of(dom, *cand[dom], dtype)
+        if layout is not None and b.axis == 1 and dtype != "f32":
+            dl = delivery_roof(layout, b.bsize, n_local, f_ms, cus)
+            if dl:
+                roof["delivery"] = dl
         return {"blocks": int(b.blocks), "value": round(3 * flops_pass * world * steps / el / 1e12, 3), "ms_per_step": round(el / steps * 1e3, 4),
                 "pass_ms": {"fprop": round(f_ms, 4), "bprop": round(b_ms, 4), "updat": round(u_ms, 4)},
                 "pass_tflops": {"fprop": round(flops_pass / f_ms / 1e9, 2), "bprop": round(flops_pass / b_ms / 1e9, 2),
@@ -457,17 +530,24 @@ def main():
         return ("bsmm fprop+bprop+updat %dx%d block_size=%d density=%.0f%% feature_axis=%d, minibatch %d per GPU, "
                 "layout default_rng(1234)" % (hidden, hidden, bsize, dens * 100, axis, n_local))
 
-    counters = measured_counters()
+    counters, counters_why = measured_counters()
 
     def attach_counters(rec, workload):
-        """measured HBM bytes / GB/s and MFMA busy of the dominant kernel, when the committed PMC passes are of exactly this workload"""
+        """measured HBM bytes / GB/s and MFMA busy of the dominant kernel, when the committed PMC passes are of exactly this workload AND
+        of this tree's kernels"""
+        if world != 1:
+            return
+        if counters_why:
+            rec["measured"] = {"dropped": counters_why}
+            return
         c = counters.get(workload)
-        if not c or world != 1:
+        if not c:
             return
         k = c.get(rec["roofline"]["kernel"])
         if k:
             rec["roofline"]["traffic"] = k.get("hbm_bytes")
-            rec["measured"] = {"source": "profiles/%s_counters.json (rocprofv3 --pmc, separate passes)" % PROFILE_ROUND,
+            rec["measured"] = {"source": "profiles/%s_counters.json (rocprofv3 --pmc, separate passes; csrc digest %s)" % (PROFILE_ROUND, counters.get("_stamp", {}).get("csrc_digest")),
+                               "kernels_profiled": k.get("kernel_names"),
                                "hbm_gbps_measured": k.get("hbm_gbps"), "mfma_busy": k.get("mfma_busy"), "kernel_us_profiled": k.get("time_us")}
 
     # ---- the main workload of this run ----
@@ -481,7 +561,7 @@ def main():
     n_global = n_local * world
     layout, b, w, x, dy = setup(hidden0, bsize0, axis0, dens0, dtype0, n_local)
     el, per, via = run(b, w, x, dy, a.steps, a.warmup, a.prewarm_seconds)
-    head = summarize(b, n_local, dtype0, el, per, a.steps)
+    head = summarize(b, n_local, dtype0, el, per, a.steps, layout)
     dname = "d%d" % round(dens0 * 100)
     workload_name = workload_string(hidden0, bsize0, axis0, dens0, n_local)
     attach_counters(head, workload_name)
@@ -551,10 +631,10 @@ def main():
         for d in (0.1, 0.5):
             if abs(d - dens0) < 1e-9:
                 continue
-            _, b2, w2, x2, dy2 = setup(hidden0, bsize0, axis0, d, dtype0, n_local)
+            lay2, b2, w2, x2, dy2 = setup(hidden0, bsize0, axis0, d, dtype0, n_local)
             st2 = max(10, a.steps // 2)
             el2, per2, _ = run(b2, w2, x2, dy2, st2, max(3, a.warmup // 2), min(a.prewarm_seconds, 0.2))
-            r = summarize(b2, n_local, dtype0, el2, per2, st2)
+            r = summarize(b2, n_local, dtype0, el2, per2, st2, lay2)
             attach_counters(r, workload_string(hidden0, bsize0, axis0, d, n_local))
             key = "d%d" % round(d * 100)
             dens[key] = {k: r[k] for k in ("blocks", "value", "ms_per_step", "pass_ms", "pass_tflops", "roofline") }
@@ -570,13 +650,38 @@ def main():
             lay2, b2, w2, x2, dy2 = setup(hid, bsz, ax, dn, dt, nl)
             st2 = max(10, a.steps // 4)
             el2, per2, _ = run(b2, w2, x2, dy2, st2, 5, 0.2)
-            r = summarize(b2, nl, dt, el2, per2, st2)
+            r = summarize(b2, nl, dt, el2, per2, st2, lay2)
             wl = workload_string(hid, bsz, ax, dn, nl)
             attach_counters(r, wl)
             r["workload"] = "BASELINE configs[%s]: %s%s" % (name[3], wl, " (the whole global minibatch on one GPU)" if name == "cfg3" else "")
             r.update(parity_check(torch, b2, lay2, w2, x2, dy2, dt))
             out[name] = r
             del b2, w2, x2, dy2
+    # the reference's own bench layout (Barabasi-Albert + I, test/blocksparse_matmul_bench.py:66-68) at the headline size, the small
+    # minibatches of its bench (:78: N = 64; BASELINE configs[3]'s per-GPU shard: 512), and bsize 8 (north_star) -- each with its roofline
+    if extras:
+        def side_row(name, layout_x, bsz, ax, nl, what, steps_x=30):
+            td = td_of["bf16"]
+            bx = BlocksparseMatMul(layout_x, block_size=bsz, feature_axis=ax)
+            gx = torch.Generator(device="cuda").manual_seed(11)
+            wx = (torch.randn(bx.w_shape, device="cuda", generator=gx) * 0.01).to(td)
+            xx = (torch.randn(bx.i_shape(nl), device="cuda", generator=gx) * 0.1).to(td)
+            dyx = (torch.randn(bx.o_shape(nl), device="cuda", generator=gx) * 0.1).to(td)
+            elx, perx, _ = run(bx, wx, xx, dyx, steps_x, 5, 0.1)
+            r = summarize(bx, nl, "bf16", elx, perx, steps_x, layout_x)
+            r["workload"] = what
+            r.update(parity_check(torch, bx, layout_x, wx, xx, dyx, "bf16"))
+            out[name] = r
+        lay_ba = ba_layout(hidden0 // 32, 14, seed=1)
+        side_row("ba", lay_ba, 32, 1, n_local, "Barabasi-Albert(%d, 14) + I layout (the reference's bench layout), block_size=32 feature_axis=1 bf16, minibatch %d, "
+                 "fprop+bprop+updat" % (hidden0 // 32, n_local))
+        small = {}
+        for nn in (64, 512):
+            side_row("_small", layout, 32, 1, nn, "headline layout (4096^2 bs 32 20 %%), minibatch %d" % nn, steps_x=50)
+            small["n%d" % nn] = out.pop("_small")
+        out["small_n"] = small
+        side_row("bs8", random_layout(hidden0 // 8, hidden0 // 8, 0.10, seed=1234), 8, 0, n_local,
+                 "4096x4096 block_size=8 density=10%% feature_axis=0 bf16, minibatch %d, fprop+bprop+updat (super-block path)" % n_local, steps_x=20)
     # BASELINE.json configs[1]: same layout, fp32, feature_axis=1, fprop only.  Priced against the fp32 matrix-core peak
     # (157.3 TF; AI 195 > ridge 20) although the kernel computes the fp32 result exactly from bf16 pieces on the 16-bit
     # matrix cores (six MFMAs per product, bsmm_xcols.h), whose ceiling for this formulation is 2500 / 6 = 417 TF.
@@ -586,21 +691,28 @@ def main():
         g32 = torch.Generator(device="cuda").manual_seed(7)
         w32 = torch.randn(b32.w_shape, device="cuda", generator=g32) * 0.01
         x32 = torch.randn(b32.i_shape(N), device="cuda", generator=g32) * 0.1
-        for _ in range(20):
-            b32.fprop(x32, w32)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            b32.fprop(x32, w32)
-        e1.record()
-        torch.cuda.synchronize()
-        ms32 = e0.elapsed_time(e1) / 50
+        def time32(bump):
+            for _ in range(20):
+                b32.fprop(x32, w32)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                if bump:
+                    b32.invalidate_weights()           # a training step sees every weights version once per op: no cache hit
+                b32.fprop(x32, w32)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 50
+        ms32_cached = time32(False)
+        ms32 = time32(True)
         tf32 = 2.0 * b32.blocks * bsize0 ** 2 * N / ms32 / 1e9
         out["fp32_fprop_axis1"] = {"workload": "BASELINE configs[1]: %dx%d bs%d d%.0f%% fp32 feature_axis=1 fprop, minibatch %d" %
                                                (hidden0, hidden0, bsize0, dens0 * 100, N),
-                                   "kernel": "exact three-piece bf16 split on v_mfma_f32_32x32x16_bf16 (incl. the split pre-passes)",
-                                   "ms": round(ms32, 4), "tflops": round(tf32, 2), "peak": PEAK_MFMA["f32"],
+                                   "kernel": "exact three-piece bf16 split on v_mfma_f32_32x32x16_bf16; `ms` includes BOTH split pre-passes (activations "
+                                             "and weights: what a training step pays), `ms_weights_cached` only the activation split (inference: "
+                                             "bsmm_prepare_weights once per weights version)",
+                                   "ms": round(ms32, 4), "ms_weights_cached": round(ms32_cached, 4), "tflops": round(tf32, 2), "peak": PEAK_MFMA["f32"],
                                    "frac": round(tf32 / PEAK_MFMA["f32"], 4),
                                    "peak_bf16_six_products": round(PEAK_MFMA["bf16"] / 6, 1),
                                    "frac_bf16_six_products": round(tf32 / (PEAK_MFMA["bf16"] / 6), 4)}

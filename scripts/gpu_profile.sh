@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence for profiles/ (round 3): per WORKLOAD (headline at 10 / 20 / 50 %, BASELINE configs[2], configs[3]) one kernel trace
+# rocprofv3 evidence for profiles/: per WORKLOAD (headline at 10 / 20 / 50 %, BASELINE configs[2], configs[3]) one kernel trace
 # and the PMC passes (separate runs: TCC has 4 slots, FETCH_SIZE costs 3, WRITE_SIZE 2), plus the unprofiled default bench line.
 # Runs on the GPU box (gpurun); every profiler invocation sits under its own `timeout`.  Output: gpurun_out/prof/*.
 set -u
