@@ -19,6 +19,7 @@ K_XPROP_VALU, K_XPROP_SEGMENT, K_XCOL32, K_XCOL16, K_XCOL32_F32SPLIT, K_XCOL32_F
 K_XCOL32_STAGED = 8
 K_XCOL16_STAGED = 9
 K_XCOL32_FLOW = 10
+K_XPROP_SMALL = 11
 K_UPDAT_VALU, K_UPDAT_BLOCK, K_UPDAT_BLOCK_TR, K_UPDAT_WIN, K_UPDAT16_WIN, K_UPDAT_SUPER8, K_UPDAT_STREAM = 16, 17, 18, 19, 20, 21, 22
 # plan-builder options (BSMM_PLAN_*)
 PLAN_XCOL_UNSTAGED = 4

@@ -19,6 +19,7 @@
 #include "bsmm_xcol.h"
 #include "bsmm_xcol_v2.h"
 #include "bsmm_xflow.h"
+#include "bsmm_xsmall.h"
 #include "bsmm_xcol16.h"
 #include "bsmm_xcol16_v2.h"
 #include "bsmm_b64.h"
@@ -414,7 +415,10 @@ inline size_t lock_acc_bytes(const bsmm_args* a) {
     return (a->locks > 0 && a->dtype != BSMM_F32) ? (size_t)a->N * a->K * sizeof(float) : 0;
 }
 
-enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_F32MFMA, XP_SUPER8 };
+enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_F32MFMA, XP_SUPER8, XP_SMALL };
+#ifndef BSMM_SMALL_N_MAX
+#define BSMM_SMALL_N_MAX 4096     // the small-minibatch kernel (bsmm_xsmall.h) is considered up to this many minibatch rows (the cost model decides)
+#endif
 
 // ONE decision, used for the workspace layout, the zero-fill of locked outputs and the launch (the three used to be
 // derived separately and could disagree).
@@ -438,7 +442,18 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         return XP_VALU;
     }
     if (variant == 1 || !vec_ok) return XP_VALU;
-    if (!plan_ok) return XP_SEGMENT;
+    // small minibatches on feature axis 1: every output block's entry list cut over the 8 waves of a workgroup (bsmm_xsmall.h); needs no plan.
+    // Measured as hipGraph replays (scripts/gpu_smalln_sweep.py, profiles/r04_smalln.txt): 3 + 1.35e-5 us per (block, minibatch row)
+    bool small_ok = false;
+    double t_small = 0.0;
+    if constexpr (BS == 32 && DT::is16 && AXIS == 1) {
+        small_ok = variant == 0 && !a->gate && a->locks == 0 && a->N <= BSMM_SMALL_N_MAX && a->C % 32 == 0 && a->K % 32 == 0;
+        t_small = 3.0 + 1.35e-5 * (double)a->blocks * a->N;
+    }
+    if (!plan_ok) {
+        if (small_ok && t_small < 6.0 + 1.2e-5 * (double)a->blocks * a->N + 8.0) return XP_SMALL;     // (the per-segment fprop also pays a transpose pre-pass)
+        return XP_SEGMENT;
+    }
     // grouped kernels need enough (row tile x group) workgroups to fill 256 CUs; below that the per-segment kernel,
     // which has segments x tiles workgroups, is faster
     if constexpr (BS == 16) {
@@ -479,8 +494,9 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
             // costs 0.28 us per pair step + 0.040 us per block of the group, up to 20 % more when the round fills all CUs
             const double fill = std::min(1.0, ntiles * ngroups / rounds / cus);
             t_group = rounds * (0.28 * steps + 0.040 * a->blocks / ngroups) * (1.0 + 0.2 * fill) + 4.0;
-            t_segment = std::max(14.4, 10.0 + 1.04e-5 * (double)a->blocks * a->N);
+            t_segment = 6.0 + 1.2e-5 * (double)a->blocks * a->N;        // (round 4: refit on graph replays -- the 14.4 us floor of round 2 was the host's)
         }
+        if (small_ok && t_small <= t_group && t_small <= t_segment) return XP_SMALL;
         return t_group < t_segment ? XP_XCOL32 : XP_SEGMENT;
     }
     return XP_SEGMENT;
@@ -530,6 +546,17 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
             rc = (int)hipGetLastError();
             trace(a, BSMM_K_XPROP_SUPER8);
             return rc;
+        }
+    }
+    if (path == XP_SMALL) {
+        if constexpr (BS == 32 && DT::is16 && AXIS == 1) {
+            if (fprop) { if (int rc = ensure_lds<&xsmall32_kernel<DT, true>>(XSM_LDS)) return rc; }
+            else       { if (int rc = ensure_lds<&xsmall32_kernel<DT, false>>(XSM_LDS)) return rc; }
+            trace(a, BSMM_K_XPROP_SMALL);
+            dim3 grid(a->segments, (a->N + XSM_R - 1) / XSM_R);
+            if (fprop) xsmall32_kernel<DT, true><<<grid, 64 * XSM_NW, XSM_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N, a->C, a->K);
+            else       xsmall32_kernel<DT, false><<<grid, 64 * XSM_NW, XSM_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N, a->C, a->K);
+            return (int)hipGetLastError();
         }
     }
     if (path == XP_F32SPLIT) {

@@ -65,7 +65,7 @@ enum {
 enum {
     BSMM_K_NONE = 0,
     BSMM_K_XPROP_VALU = 1, BSMM_K_XPROP_SEGMENT = 2, BSMM_K_XCOL32 = 3, BSMM_K_XCOL16 = 4, BSMM_K_XCOL32_F32SPLIT = 5,
-    BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7, BSMM_K_XCOL32_STAGED = 8, BSMM_K_XCOL16_STAGED = 9, BSMM_K_XCOL32_FLOW = 10,
+    BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7, BSMM_K_XCOL32_STAGED = 8, BSMM_K_XCOL16_STAGED = 9, BSMM_K_XCOL32_FLOW = 10, BSMM_K_XPROP_SMALL = 11,
     BSMM_K_UPDAT_VALU = 16, BSMM_K_UPDAT_BLOCK = 17, BSMM_K_UPDAT_BLOCK_TR = 18, BSMM_K_UPDAT_WIN = 19, BSMM_K_UPDAT16_WIN = 20,
     BSMM_K_UPDAT_SUPER8 = 21, BSMM_K_UPDAT_STREAM = 22
 };
