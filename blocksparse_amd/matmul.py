@@ -177,6 +177,7 @@ class BlocksparseMatMul(object):
         self.layout = ref["layout"]
         self._device_cache = {}
         self._workspaces = {}
+        self._args_cache = {}
         self._prepared_w = {}             # op -> (weakref(w), (op, w.data_ptr, w._version, stream), buffer): bsmm_prepare_weights results
         self.cache_prepared = True        # False: prepare on every call (no per-weights cache at all)
         self._inner = None
@@ -291,6 +292,37 @@ class BlocksparseMatMul(object):
         a.stream = torch.cuda.current_stream(lut_t.device).cuda_stream
         return a
 
+    def _call_args(self, op, tabs, lut_t, side, N, Cin, Kout, dtype, plan, slot=0, pcount=1, flags=0):
+        """The argument block of a call and its workspace, made once per (op, minibatch, dtype, stream, plan, ...) and reused: filling the
+        ctypes struct, attaching the plan and asking the library for the workspace size cost more host time than a small-minibatch
+        kernel takes on the device (profiles/r04_smalln.txt: 14-15 us per eager call before this cache).  Fields that change from call to
+        call (gate, alpha / beta, prepared_w) are set by the caller."""
+        stream = torch.cuda.current_stream(lut_t.device).cuda_stream
+        key = (op, N, dtype, lut_t.device.index, stream, id(plan), slot, pcount, _lib.call_flags() | flags, self.updat_split)
+        hit = self._args_cache.get(key)
+        if hit is None:
+            a = self._args(lut_t, side, N, Cin, Kout, dtype, pcount=pcount, plan=plan)
+            a.flags |= flags
+            need_prep = bool(op != _lib.OP_UPDAT and _lib.load().bsmm_prepared_bytes(op, ctypes.byref(a)))
+            need_ws = 0 if need_prep else int(_lib.load().bsmm_workspace_bytes(op, ctypes.byref(a)))   # (prepared calls size theirs after prepared_w is set)
+            hit = (a, need_ws, need_prep)
+            if len(self._args_cache) > 256:
+                self._args_cache.clear()
+            self._args_cache[key] = hit
+        a, need_ws, need_prep = hit
+        a.gate = None
+        a.alpha, a.beta = 1.0, 0.0
+        ws = None
+        if need_ws:
+            # the scratch is shared by every call of this op on this stream (grown on demand): point the cached block at the current one
+            wkey = (lut_t.device.index, stream, op, slot)
+            ws = self._workspaces.get(wkey)
+            if ws is None or ws.numel() < need_ws:
+                ws = torch.empty(max(need_ws, 16), dtype=torch.uint8, device=lut_t.device)
+                self._workspaces[wkey] = ws
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        return a, ws, need_prep
+
     def _workspace(self, a, op, device, slot=0):
         """Device scratch for one call, kept per (device, stream, op) and grown on demand: the entry points never allocate, and
         consecutive calls on a stream reuse the same bytes in stream order (nothing inside the timed region of a step)."""
@@ -357,12 +389,14 @@ class BlocksparseMatMul(object):
         lib = _lib.load()
         tabs = self._tables_on(x.device)
         y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
-        a = self._args(tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype,
-                       plan=tabs.fprop_plan_f32 if x.dtype == torch.float32 else
-                       (tabs.fprop_flow if (self.flow and gate is None and tabs.fprop_flow is not None) else tabs.fprop_plan))
+        plan = (tabs.fprop_plan_f32 if x.dtype == torch.float32 else
+                (tabs.fprop_flow if (self.flow and gate is None and tabs.fprop_flow is not None) else tabs.fprop_plan))
+        a, _, need_prep = self._call_args(_lib.OP_FPROP, tabs, tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype, plan)
         a.gate = gate.data_ptr() if gate is not None else None
-        self._prepared(a, _lib.OP_FPROP, w)
-        self._workspace(a, _lib.OP_FPROP, x.device)
+        if need_prep:
+            a.prepared_w = None
+            self._prepared(a, _lib.OP_FPROP, w)
+            self._workspace(a, _lib.OP_FPROP, x.device)
         _lib.check(lib.bsmm_fprop(x.data_ptr(), w.data_ptr(), y.data_ptr(), ctypes.byref(a)), "bsmm_fprop")
         return y
 
@@ -379,12 +413,14 @@ class BlocksparseMatMul(object):
         lib = _lib.load()
         tabs = self._tables_on(dy.device)
         dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)
-        a = self._args(tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype,
-                       plan=tabs.bprop_plan_f32 if dy.dtype == torch.float32 else
-                       (tabs.bprop_flow if (self.flow and gate is None and tabs.bprop_flow is not None) else tabs.bprop_plan))
+        plan = (tabs.bprop_plan_f32 if dy.dtype == torch.float32 else
+                (tabs.bprop_flow if (self.flow and gate is None and tabs.bprop_flow is not None) else tabs.bprop_plan))
+        a, _, need_prep = self._call_args(_lib.OP_BPROP, tabs, tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype, plan)
         a.gate = gate.data_ptr() if gate is not None else None
-        self._prepared(a, _lib.OP_BPROP, w)
-        self._workspace(a, _lib.OP_BPROP, dy.device)
+        if need_prep:
+            a.prepared_w = None
+            self._prepared(a, _lib.OP_BPROP, w)
+            self._workspace(a, _lib.OP_BPROP, dy.device)
         _lib.check(lib.bsmm_bprop(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ctypes.byref(a)), "bsmm_bprop")
         return dx
 
@@ -450,16 +486,15 @@ class BlocksparseMatMul(object):
             self._check_tensor(dw, "dw")
             if tuple(dw.shape) != self.w_shape or dw.dtype != xs[0].dtype or not dw.is_contiguous():
                 raise ValueError("dw must be a contiguous %s tensor of dtype %s" % (self.w_shape, xs[0].dtype))
-        a = self._args(tabs.updat, None, N, self.C, self.K, xs[0].dtype, pcount=len(xs), alpha=alpha, beta=beta,
-                       plan=tabs.updat_plan if xs[0].dtype != torch.float32 else None)
         gate = self._check_gate(gate, dev)
-        if gate is not None and not sums_only:
-            a.gate, a.flags = gate.data_ptr(), a.flags | _lib.FLAG_GATED_DW
-        if sums_only:
-            a.flags |= _lib.FLAG_DW_SUMS
         if sums_only and gate is not None:
             raise ValueError("updat(sums_only=True) returns the ungated sums: pass the gate to updat_finalize / DwReduce.start")
-        ws = self._workspace(a, _lib.OP_UPDAT, dev, slot)
+        flags = (_lib.FLAG_GATED_DW if (gate is not None and not sums_only) else 0) | (_lib.FLAG_DW_SUMS if sums_only else 0)
+        a, ws, _ = self._call_args(_lib.OP_UPDAT, tabs, tabs.updat, None, N, self.C, self.K, xs[0].dtype,
+                                   tabs.updat_plan if xs[0].dtype != torch.float32 else None, slot=slot, pcount=len(xs), flags=flags)
+        a.alpha, a.beta = alpha, beta
+        if gate is not None and not sums_only:
+            a.gate = gate.data_ptr()
         arr = ctypes.c_void_p * len(xs)
         xp = arr(*[t.data_ptr() for t in xs])
         ep = arr(*[t.data_ptr() for t in dys])
