@@ -675,10 +675,60 @@ def main():
         lay_ba = ba_layout(hidden0 // 32, 14, seed=1)
         side_row("ba", lay_ba, 32, 1, n_local, "Barabasi-Albert(%d, 14) + I layout (the reference's bench layout), block_size=32 feature_axis=1 bf16, minibatch %d, "
                  "fprop+bprop+updat" % (hidden0 // 32, n_local))
+        def graph_us(fn, K=20):
+            """us per call of fn as a hipGraph replay of K back-to-back calls: at small minibatches the eager Python call path (~10 us per call)
+            is longer than the kernels"""
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(K):
+                    fn()
+            for _ in range(5):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                g.replay()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / 20 / K * 1e6
+
         small = {}
-        for nn in (64, 512):
-            side_row("_small", layout, 32, 1, nn, "headline layout (4096^2 bs 32 20 %%), minibatch %d" % nn, steps_x=50)
-            small["n%d" % nn] = out.pop("_small")
+        for hid_s, dens_s, nn in ((hidden0, dens0, 64), (hidden0, dens0, 512), (8192, 0.05, 512)):
+            lay_s = layout if hid_s == hidden0 else random_layout(hid_s // 32, hid_s // 32, dens_s, seed=1234)
+            bs_ = BlocksparseMatMul(lay_s, block_size=32, feature_axis=1)
+            gs_ = torch.Generator(device="cuda").manual_seed(13)
+            ws_ = (torch.randn(bs_.w_shape, device="cuda", generator=gs_) * 0.01).bfloat16()
+            xs_ = (torch.randn(bs_.i_shape(nn), device="cuda", generator=gs_) * 0.1).bfloat16()
+            dys_ = (torch.randn(bs_.o_shape(nn), device="cuda", generator=gs_) * 0.1).bfloat16()
+            dws_ = torch.empty(bs_.w_shape, dtype=torch.bfloat16, device="cuda")
+            f_us, b_us, u_us = graph_us(lambda: bs_.fprop(xs_, ws_)), graph_us(lambda: bs_.bprop(dys_, ws_)), graph_us(lambda: bs_.updat(xs_, dys_, dw=dws_))
+            step_us = graph_us(lambda: (bs_.fprop(xs_, ws_), bs_.updat(xs_, dys_, dw=dws_), bs_.bprop(dys_, ws_)), K=10)
+            eager_us = 0.0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                bs_.fprop(xs_, ws_); bs_.updat(xs_, dys_, dw=dws_); bs_.bprop(dys_, ws_)
+            torch.cuda.synchronize()
+            eager_us = (time.perf_counter() - t0) / 50 * 1e6
+            fl = 2.0 * bs_.blocks * 1024 * nn
+            cand = {"bsmm_xprop(bprop)": (b_us * 1e-3, fl, alg_bytes_xprop(bs_, nn, 2)), "bsmm_updat": (u_us * 1e-3, fl, alg_bytes_updat(bs_, nn, 2))}
+            dom = max(cand, key=lambda k: cand[k][0])
+            r = {"workload": "%dx%d bs 32 %.0f%% feature_axis=1 bf16, minibatch %d%s" % (hid_s, hid_s, dens_s * 100, nn, " (BASELINE configs[3]'s per-GPU shard)" if hid_s == 8192 else ""),
+                 "timing": "hipGraph replay (20 calls per graph); eager_us_per_step = the same step through the Python call path",
+                 "blocks": int(bs_.blocks), "pass_us": {"fprop": round(f_us, 2), "bprop": round(b_us, 2), "updat": round(u_us, 2)},
+                 "us_per_step": round(step_us, 2), "eager_us_per_step": round(eager_us, 1), "value": round(3 * fl / step_us / 1e6, 2), "unit": "TFLOP/s",
+                 "roofline": roofline_of(dom, *cand[dom], "bf16")}
+            r.update(parity_check(torch, bs_, lay_s, ws_, xs_, dys_, "bf16"))
+            small["%d_n%d" % (hid_s, nn)] = r
+            del bs_, ws_, xs_, dys_, dws_
         out["small_n"] = small
         side_row("bs8", random_layout(hidden0 // 8, hidden0 // 8, 0.10, seed=1234), 8, 0, n_local,
                  "4096x4096 block_size=8 density=10%% feature_axis=0 bf16, minibatch %d, fprop+bprop+updat (super-block path)" % n_local, steps_x=20)
