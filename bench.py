@@ -701,7 +701,7 @@ def main():
             return (time.perf_counter() - t0) / 20 / K * 1e6
 
         small = {}
-        for hid_s, dens_s, nn in ((hidden0, dens0, 64), (hidden0, dens0, 512), (8192, 0.05, 512)):
+        for hid_s, dens_s, nn in ((hidden0, dens0, 64), (hidden0, dens0, 512), (hidden0, dens0, 2048), (8192, 0.05, 512)):
             lay_s = layout if hid_s == hidden0 else random_layout(hid_s // 32, hid_s // 32, dens_s, seed=1234)
             bs_ = BlocksparseMatMul(lay_s, block_size=32, feature_axis=1)
             gs_ = torch.Generator(device="cuda").manual_seed(13)

@@ -361,23 +361,35 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
 }
 
 // barrier-free persistent kernel ('BSX4' plans, bsmm_xflow.h): one workgroup per CU walks its (row tile, group) units
-template <class DT, bool TRANSW>
-int launch_xflow(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+template <class DT, bool TRANSW, int RT>
+int launch_xflow_rt(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
     const int n_out = a->K / 32;
+    constexpr int R = 32 * RT;
     XMap m;
-    m.ntiles = (a->N + X4_R - 1) / X4_R;
+    m.ntiles = (a->N + R - 1) / R;
     m.segments = (n_out + X4_G - 1) / X4_G;
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds<&xflow32_kernel<DT, TRANSW>>(X4_LDS)) return rc;
+    if (int rc = ensure_lds<&xflow32_kernel<DT, TRANSW, RT>>(X4_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_FLOW);
     const int cus = device_cus();
     const int grid = std::min(m.grid(), std::max(8, cus / 8 * 8));
-    xflow32_kernel<DT, TRANSW><<<grid, 64 * X4_G, X4_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                                a->N, a->C, a->K);
+    xflow32_kernel<DT, TRANSW, RT><<<grid, 64 * X4_G, X4_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan,
+                                                                    m, a->N, a->C, a->K);
     return (int)hipGetLastError();
+}
+
+// Units of 128 rows unless they leave CUs idle: 64-row units (twice as many, each with half the multiplies per weight block) from there down.
+#ifndef BSMM_FLOW_RT
+#define BSMM_FLOW_RT 0            // 0: by the unit count; 2 / 4: forced (measurement builds)
+#endif
+template <class DT, bool TRANSW>
+int launch_xflow(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
+    const long units128 = (long)((a->N + X4_R - 1) / X4_R) * ((a->K / 32 + X4_G - 1) / X4_G);
+    const bool half = BSMM_FLOW_RT == 2 || (BSMM_FLOW_RT == 0 && units128 < device_cus());
+    return half ? launch_xflow_rt<DT, TRANSW, 2>(X, Wsel, Y, a, st) : launch_xflow_rt<DT, TRANSW, 4>(X, Wsel, Y, a, st);
 }
 
 template <class DT, int AXIS>

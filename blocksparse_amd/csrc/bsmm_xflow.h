@@ -73,8 +73,8 @@ constexpr int X4_S = 2;                                // private weight slots p
 constexpr int X4_WBASE = X4_D * X4_SLAB;
 constexpr int X4_WWAVE = X4_S * 2048;                  // bytes of weight slots per wave
 constexpr int X4_FLAGS = X4_WBASE + X4_G * X4_WWAVE;   // prog[16] (uint32), then full[8]
-constexpr int X4_LDS = X4_FLAGS + 64 + 32;
-constexpr int X4_DI = 16 / X4_PARTS;                   // DMA instructions of 1 KiB per slab part
+constexpr int X4_LDS = X4_FLAGS + 64 + 64;             // (full[]: up to 16 slab counters)
+constexpr int X4_DI = 16 / X4_PARTS;                   // DMA instructions of 1 KiB per slab part of a 128-row slab (what the PLAN counts per REQ)
 static_assert(X4_LDS <= 163840, "flow kernel: ring must fit the LDS");
 static_assert(X4_WWAVE >= 64 * 64, "the epilogue stages 64 rows x 64 B per pass in a wave's weight slots");
 static_assert((X4_WWAVE & (X4_WWAVE - 1)) == 0 && X4_WBASE % X4_WWAVE == 0, "weight slot toggling by XOR needs aligned slots");
@@ -104,26 +104,33 @@ __device__ __forceinline__ void x4_poll_all_ge(uint32_t v_addr, uint32_t s_need)
                  : "=&v"(t) : "v"(v_addr), "s"(s_need) : "memory", "vcc");
 }
 
-// the wait of a BLOCK / ANN event, chosen by the event's control word: bit 3 vmcnt(2), bit 4 vmcnt(0), else vmcnt(X4_DI)
+// the wait of a BLOCK / ANN event, chosen by the event's control word: bit 3 vmcnt(2), bit 4 vmcnt(0), else vmcnt(DI) with DI = the requests a REQ
+// of THIS kernel issues (the plan counts X4_DI per REQ; a kernel with smaller slabs issues fewer, and the wait must not assume more)
+template <int DI>
 __device__ __forceinline__ void x4_wait_ctl(uint32_t ctl) {
     asm volatile("s_bitcmp1_b32 %0, 3\n\ts_cbranch_scc0 1f\n\ts_waitcnt vmcnt(2)\n\ts_branch 3f\n"
                  "1:\n\ts_bitcmp1_b32 %0, 4\n\ts_cbranch_scc0 2f\n\ts_waitcnt vmcnt(0)\n\ts_branch 3f\n"
-                 "2:\n\ts_waitcnt vmcnt(%1)\n3:" ::"s"(ctl), "n"(X4_DI) : "memory", "scc");
+                 "2:\n\ts_waitcnt vmcnt(%1)\n3:" ::"s"(ctl), "n"(DI) : "memory", "scc");
 }
 
-template <class DT, bool TRANSW>
+// RT = 32-row tiles per unit: 4 (128 rows, slabs of 16 KiB, ring of X4_D) or 2 (64 rows, slabs of 8 KiB, ring of 2 X4_D: twice the units for
+// minibatches that do not fill the chip with 128-row units; same plans, same LDS layout).
+template <class DT, bool TRANSW, int RT = 4>
 __global__ void __launch_bounds__(64 * X4_G, 4)
 xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel, typename DT::T* __restrict__ Y,
                const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
     typedef typename DT::T T;
     static_assert(DT::is16, "flow kernel: 16-bit storage types");
+    static_assert(RT == 4 || RT == 2, "flow kernel: units of 128 or 64 rows");
+    constexpr int R = 32 * RT, SLAB = R * 128, D = X4_D * 4 / RT, DI = X4_DI * RT / 4;     // rows, slab bytes, ring depth, requests per REQ
+    static_assert(D * SLAB == X4_WBASE && DI % 4 == 0 && D <= 16, "flow kernel: ring geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     const uint32_t base_addr = lds_addr_of(smem);
     const uint32_t prog_addr = base_addr + X4_FLAGS, full_addr = base_addr + X4_FLAGS + 64;
-    if (threadIdx.x < 24) reinterpret_cast<uint32_t*>(smem + X4_FLAGS)[threadIdx.x] = 0u;
+    if (threadIdx.x < 32) reinterpret_cast<uint32_t*>(smem + X4_FLAGS)[threadIdx.x] = 0u;
     __syncthreads();                                   // the only workgroup barrier of the kernel
 
     const int npairs_full = Cin / 64;
@@ -170,14 +177,14 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
         const int32_t* lists = plan + plan[7] + list_off;
         const int nev = __builtin_amdgcn_readfirstlane(lists[wave]);
         const int32_t* mine = lists + X4_G + (size_t)2 * lcap * wave;
-        const int n_tile = tile * X4_R;
+        const int n_tile = tile * R;
         // (a group without any block has no steps: its waves run their two NOPs and the epilogue writes the zeros the output must hold)
         const unsigned char* xtile = static_cast<const unsigned char*>(uniform_ptr(xt + (size_t)n_tile * Cin * 2));
-        const bool fast_tile = n_tile + X4_R <= N;                       // no row of the tile lies past N: the request offsets are regular
+        const bool fast_tile = n_tile + R <= N;                       // no row of the tile lies past N: the request offsets are regular
 
-        f32x16 acc[4];
+        f32x16 acc[RT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -187,7 +194,7 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
             const int ei = min(eb + lane, nev - 1);
             const uint32_t w0 = (uint32_t)mine[2 * ei], w1 = (uint32_t)mine[2 * ei + 1];
             const uint32_t ty = w0 & 3, hp = (w0 >> 2) & 3, step = (w0 >> 4) & 0xfff, nxt = (w0 >> 16) & 0xfff;
-            const uint32_t gstep = gs + step, sm = gstep % (uint32_t)X4_D, guse = gstep / (uint32_t)X4_D + 1u;   // ring slot, its uses so far
+            const uint32_t gstep = gs + step, sm = gstep % (uint32_t)D, guse = gstep / (uint32_t)D + 1u;   // ring slot, its uses so far
             uint32_t p128 = 0;
             if (ty == 2) p128 = (uint32_t)pairs[step];                   // REQ lanes: the pair of their step
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (drains the wave's memory queue: once per unit and 64 events)
@@ -197,7 +204,7 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
             uint32_t v_ctl = ty | (wn >= (uint32_t)X4_DI ? 0u : (wn >= 2u ? 8u : 16u)) | (f27 != X4_NOFETCH ? 64u : 0u) |
                              ((ty == 2 && (!fast_tile || (int)p128 >= npairs_full)) ? 128u : 0u);
             // BLOCK: XOR word of the activation fragment addresses; REQ: byte offset of the part inside the ring
-            uint32_t v_x = ty == 1 ? ((sm << 14) | (hp << 6)) : (sm * (uint32_t)X4_SLAB + hp * (uint32_t)(X4_DI * 1024));
+            uint32_t v_x = ty == 1 ? ((sm * (uint32_t)SLAB) | (hp << 6)) : (sm * (uint32_t)SLAB + hp * (uint32_t)(DI * 1024));
             // BLOCK / ANN: address of the slab's counter; REQ: byte offset of the pair inside an activation row
             uint32_t v_fa = ty == 2 ? p128 * 128u : full_addr + 4 * sm;
             // BLOCK: the counter value that says "every part of this step's slab is in" (the slot's uses so far, this one included, times
@@ -217,7 +224,7 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
 #ifdef X4_STAMPS
                 tacc[7] += 1;
 #endif
-                if (ty_s & 1) { X4_T0(); x4_wait_ctl(ctl); X4_T1(0); }     // BLOCK (1) or ANN (3): wait for my fetch / my requests
+                if (ty_s & 1) { X4_T0(); x4_wait_ctl<DI>(ctl); X4_T1(0); }     // BLOCK (1) or ANN (3): wait for my fetch / my requests
                 if (ty_s == 1) {
                     // ---- BLOCK: my weight block (fetched two BLOCK events ago) x the slab of its step ----
                     { X4_T0(); x4_lane_poll_ge(em, v_fa, v_g); X4_T1(1); }  // every part of the slab has been announced
@@ -243,43 +250,43 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                         // a block is on its wave's critical path: its LATENCY counts.  Both weight fragments and the four K-half-0
                         // activation fragments are in flight before the first MFMA; each K-half-1 fragment is requested right behind
                         // the MFMA that consumed its K-half-0 sibling (into the same registers) and lands under the other three
-                        uint4 xf[4];
+                        uint4 xf[RT];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const uint4*>(smem + (xrd[0] ^ sx) + t * 4096);
+                        for (int t = 0; t < RT; ++t) xf[t] = *reinterpret_cast<const uint4*>(smem + (xrd[0] ^ sx) + t * 4096);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
+                        for (int t = 0; t < RT; ++t) {
                             acc[t] = DT::mfma32(wq[0], xf[t], acc[t]);
                             xf[t] = *reinterpret_cast<const uint4*>(smem + (xrd[1] ^ sx) + t * 4096);
                             __builtin_amdgcn_sched_barrier(0);
                         }
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = DT::mfma32(wq[1], xf[t], acc[t]);
+                        for (int t = 0; t < RT; ++t) acc[t] = DT::mfma32(wq[1], xf[t], acc[t]);
 #else
-                        uint4 xf[4][2];
+                        uint4 xf[RT][2];
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) xf[t][kk] = *reinterpret_cast<const uint4*>(smem + (xrd[kk] ^ sx) + t * 4096);
+                            for (int t = 0; t < RT; ++t) xf[t][kk] = *reinterpret_cast<const uint4*>(smem + (xrd[kk] ^ sx) + t * 4096);
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) acc[t] = DT::mfma32(wq[kk], xf[t][kk], acc[t]);
+                            for (int t = 0; t < RT; ++t) acc[t] = DT::mfma32(wq[kk], xf[t][kk], acc[t]);
 #endif
                     }
                     s_w ^= 2048u;
 #ifdef X4_STAMPS
-                    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+                    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[RT - 1][0]));
 #endif
                     X4_T1(2);
 #ifdef X4_TIMELINE
-                    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+                    asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[RT - 1][0]));
                     X4_TL(dbg_s, 7 + 2 * wave);
 #endif
                 } else if (ty_s == 2) {
                     // ---- REQ: request one part of a slab, once every wave's next block lies beyond the slab that occupied the slot ----
                     const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane(v_g, idx);
-                    { X4_T0(); if (g1 > (uint32_t)X4_D) x4_poll_all_ge(prog_addr + 4 * (lane & 15), g1 - (uint32_t)X4_D); X4_T1(3); }
+                    { X4_T0(); if (g1 > (uint32_t)D) x4_poll_all_ge(prog_addr + 4 * (lane & 15), g1 - (uint32_t)D); X4_T1(3); }
                     X4_T0();
 #ifdef X4_TIMELINE
                     const uint32_t dbg_r = (uint32_t)__builtin_amdgcn_readlane(v_dbg, idx);
@@ -288,19 +295,19 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                     if (!X4_NO_XDMA) {
                         const uint32_t dst = base_addr + (uint32_t)__builtin_amdgcn_readlane(v_x, idx);
                         const uint32_t poff = (uint32_t)__builtin_amdgcn_readlane(v_fa, idx);
-                        const uint32_t part_i = (uint32_t)__builtin_amdgcn_readlane(v_x, idx) % (uint32_t)X4_SLAB / 1024u;   // first instruction of the part
+                        const uint32_t part_i = (uint32_t)__builtin_amdgcn_readlane(v_x, idx) % (uint32_t)SLAB / 1024u;   // first instruction of the part
                         if (!(ctl & 128u)) {
                             // instruction ii covers rows 8 ii ..: lane offset = ii * 16 Cin + the even / odd pattern (+ the pair's offset)
                             const uint32_t k0 = part_i * stride16 + poff;
                             const uint32_t vo_o = (pc_e & 4u) ? vo_e - 64u : vo_e + 64u;
 #pragma unroll
-                            for (int k = 0; k < X4_DI; k += 4)
+                            for (int k = 0; k < DI; k += 4)
                                 glds16_saddr_x4(xtile, vo_e + (k0 + (k + 0) * stride16), vo_o + (k0 + (k + 1) * stride16), vo_e + (k0 + (k + 2) * stride16),
                                                 vo_o + (k0 + (k + 3) * stride16), dst + k * 1024);
                         } else {
                             const bool tail = (int)(poff >> 7) >= npairs_full;
 #pragma unroll
-                            for (int k = 0; k < X4_DI; ++k) {
+                            for (int k = 0; k < DI; ++k) {
                                 const int row = 8 * ((int)part_i + k) + (lane >> 3);
                                 const int xr = min(n_tile + row, N - 1) - n_tile;    // rows past N are clamped (never stored)
                                 const int piece = (lane & 7) ^ ((row >> 1) & 7);
@@ -347,7 +354,7 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
             unsigned char* stage = smem + wslot0;
             unsigned char* ybase = reinterpret_cast<unsigned char*>(Y + (size_t)(ob0 + wave) * 32);
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
+            for (int pass = 0; pass < RT / 2; ++pass) {
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
                     const int t = 2 * pass + tt;
