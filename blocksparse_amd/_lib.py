@@ -25,6 +25,7 @@ K_UPDAT_VALU, K_UPDAT_BLOCK, K_UPDAT_BLOCK_TR, K_UPDAT_WIN, K_UPDAT16_WIN, K_UPD
 PLAN_XCOL_UNSTAGED = 4
 PLAN_XCOL_FLOW = 8
 PLAN_XPROP_PH_SHIFT, PLAN_UPDAT_SETS_SHIFT = 8, 12
+PLAN_FLOW_SCHEDULED = 0x10000  # BSX4 plans, experiment: list-scheduled step order instead of ascending input blocks
 PLAN_XCOL_NARROW, PLAN_F32_MFMA, PLAN_WINDOW_8, PLAN_WINDOW_16, PLAN_WINDOW_16W, PLAN_STREAM_16, PLAN_STREAM_8, PLAN_STREAM_32 = 1, 2, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60
 
 SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_updat_finalize", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_sparse_op", "bsmm_sparse_mul_grad", "bsmm_workspace_bytes",

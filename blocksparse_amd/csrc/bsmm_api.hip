@@ -1287,7 +1287,7 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
         return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
     }
     if ((options & BSMM_PLAN_XCOL_FLOW) && axis == 1 && !(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // barrier-free persistent kernel
-        const long n = build_xflow_plan(lut, segments, blocks, n_out, out);
+        const long n = build_xflow_plan(lut, segments, blocks, n_out, out, (options & BSMM_PLAN_FLOW_SCHEDULED) != 0);
         if (n != 0) return n;
     }
     if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel (either feature axis)

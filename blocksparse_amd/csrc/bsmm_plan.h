@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <array>
 #include <vector>
 
 
@@ -351,7 +352,7 @@ constexpr int X4_DX = X4_DX_AHEAD;        // a slab is requested this many steps
 constexpr int X4_PARTS = X4_DUTY_PARTS;   // a slab is requested in this many parts (by different waves): 1, 2 or 4
 static_assert(X4_DX >= 1 && X4_DX < X4_D && X4_D <= 7 && (X4_PARTS == 1 || X4_PARTS == 2 || X4_PARTS == 4), "flow plan constants");
 
-inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, bool balance = false) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
     const int G = X4_G, ngroups = (n_out_blocks + G - 1) / G;
     struct E { int p, wave, half, w; };
@@ -366,11 +367,79 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
             per_group[ob / G].push_back({c >> 1, ob % G, c & 1, w});
         }
     }
+    // ORDER of the steps (a sum over input blocks: any order is the same product; fp32 rounding follows the order).  In ascending order a
+    // pass is paced by the wave whose blocks happen to cluster inside the ring's window: pace ~ E[max over the 16 waves of their blocks in
+    // X4_D consecutive steps] x (cycles per block) / X4_D (profiles/r04_headline_ab.md).  List scheduling against a small timing model of
+    // the kernel (a block costs TB cycles on its wave; a slab is usable LAT cycles after every wave has left the slab that held its slot)
+    // picks, among the next KC pairs in ascending order, the one after which the groups' clocks stand lowest.  ONE order for all groups:
+    // the groups of a row tile run side by side on one XCD and share the activation slabs in its L2 only if they walk them in step
+    // (a per-group order measured 6-14 % SLOWER than ascending order for that reason).  MEASURED with one order for all groups: 56.9 / 83.2 /
+    // 154.4 us against 56.9 / 83.7 / 157.2 in ascending order (fprop, 10 / 20 / 50 %): nothing -- the pass is not paced by that window
+    // (the look-ahead distance does not move it either).  Hence OFF unless BSMM_PLAN_FLOW_SCHEDULED asks for it: ascending order keeps
+    // the flow kernel bit-identical to the staged one.
+    std::vector<int> rank;                                           // pair -> position (empty: ascending)
+    if (balance) {
+        constexpr double TB = 1500., LAT = 1900.;
+        constexpr size_t KC = 64;
+        int max_p = -1;
+        for (auto& v : per_group) for (auto& e : v) max_p = std::max(max_p, e.p);
+        const int np = max_p + 1;
+        if (np > 2 && (double)np * ngroups <= 4e6) {
+            // load[g][p][wave]: sparse per group (pairs it touches)
+            std::vector<std::vector<std::pair<int, std::array<uint8_t, X4_G>>>> at(np);   // per pair: (group, loads)
+            for (int g = 0; g < ngroups; ++g) {
+                std::vector<int> idx(np, -1);
+                for (auto& e : per_group[g]) {
+                    if (idx[e.p] < 0) { idx[e.p] = (int)at[e.p].size(); at[e.p].push_back({g, {}}); at[e.p].back().second.fill(0); }
+                    at[e.p][idx[e.p]].second[e.wave]++;
+                }
+            }
+            std::vector<int> left;
+            for (int p = 0; p < np; ++p) if (!at[p].empty()) left.push_back(p);
+            std::vector<std::array<double, X4_G>> wt(ngroups);
+            for (auto& w : wt) w.fill(0.);
+            std::vector<std::vector<double>> done(ngroups);             // per group: its clock after each of ITS steps
+            std::vector<double> gclock(ngroups, 0.);
+            rank.assign(np, 0);
+            int pos = 0;
+            while (!left.empty()) {
+                size_t best = 0; double best_sum = 0., best_sq = 0.;
+                const size_t nc = std::min(left.size(), KC);
+                for (size_t k = 0; k < nc; ++k) {
+                    double sum = 0., sq = 0.;
+                    for (auto& gl : at[left[k]]) {
+                        const int g = gl.first;
+                        const size_t ps = done[g].size();
+                        const double usable = (ps < (size_t)X4_D ? 0. : done[g][ps - X4_D]) + LAT;
+                        double mx = gclock[g];
+                        for (int wv = 0; wv < G; ++wv)
+                            if (gl.second[wv]) { const double v = std::max(wt[g][wv], usable) + gl.second[wv] * TB; mx = std::max(mx, v); sq += v * v - wt[g][wv] * wt[g][wv]; }
+                        sum += mx - gclock[g];
+                    }
+                    if (k == 0 || sum < best_sum || (sum == best_sum && sq < best_sq)) { best = k; best_sum = sum; best_sq = sq; }
+                }
+                const int p = left[best];
+                left.erase(left.begin() + best);
+                for (auto& gl : at[p]) {
+                    const int g = gl.first;
+                    const size_t ps = done[g].size();
+                    const double usable = (ps < (size_t)X4_D ? 0. : done[g][ps - X4_D]) + LAT;
+                    for (int wv = 0; wv < G; ++wv)
+                        if (gl.second[wv]) { wt[g][wv] = std::max(wt[g][wv], usable) + gl.second[wv] * TB; gclock[g] = std::max(gclock[g], wt[g][wv]); }
+                    done[g].push_back(gclock[g]);
+                }
+                rank[p] = pos++;
+            }
+        }
+    }
     std::vector<int32_t> groups, pairs, lists;
     int max_l = 0, max_s = 0;
     for (int g = 0; g < ngroups; ++g) {
         auto& v = per_group[g];
-        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : (a.wave != b.wave ? a.wave < b.wave : a.half < b.half); });
+        std::sort(v.begin(), v.end(), [&](const E& a, const E& b) {
+            const int ra = rank.empty() ? a.p : rank[a.p], rb = rank.empty() ? b.p : rank[b.p];
+            return ra != rb ? ra < rb : (a.wave != b.wave ? a.wave < b.wave : a.half < b.half);
+        });
         const int step_off = (int)pairs.size();
         struct B { int step, half, w; };
         std::vector<std::vector<B>> wb(G);

@@ -86,7 +86,9 @@ enum {
     BSMM_PLAN_WINDOW_MASK = 0xf0,   /* (0: bsize 32, either feature axis -> streaming kernel, window side by density; bsize 16 -> 16x16 windows) */
     /* experiment knobs of the builders (0 = the builder's own choice); disjoint bit ranges, one meaning each: */
     BSMM_PLAN_XPROP_PH_SHIFT = 8,   /* bits  8..10  xprop staged plans ('BSX2'): steps per phase (2, 3, 4)                      */
-    BSMM_PLAN_UPDAT_SETS_SHIFT = 12 /* bits 12..15  updat streaming plan ('BSU2'): item sets (1, 2, 4, 8)                       */
+    BSMM_PLAN_UPDAT_SETS_SHIFT = 12,/* bits 12..15  updat streaming plan ('BSU2'): item sets (1, 2, 4, 8)                       */
+    BSMM_PLAN_FLOW_SCHEDULED = 0x10000 /* 'BSX4' plans, experiment: steps in the order the builder's list scheduling picks instead of ascending
+                                       input blocks (the same sums in another fp32 summation order; measured no faster, see bsmm_plan.h) */
 };
 
 enum {

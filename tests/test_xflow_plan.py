@@ -1,6 +1,7 @@
 """Host-side checks of the 'BSX4' plans of the barrier-free xprop kernel (csrc/bsmm_plan.h build_xflow_plan, csrc/bsmm_xflow.h): the
 event lists are the whole synchronisation contract of that kernel, so they are validated here WITHOUT a GPU --
-  * every lut entry of an output column appears exactly once as a BLOCK of its wave, in step order, with the fetch of block j + 2
+  * every lut entry of an output column appears exactly once as a BLOCK of its wave, in step order (default: ascending input
+    blocks; BSMM_PLAN_FLOW_SCHEDULED plans: the order the builder's list scheduling picked -- a permutation of the steps), with the fetch of block j + 2
     riding on block j (and blocks 0 / 1 on the two leading NOPs);
   * every (step, part) has exactly one REQ and one ANN, REQ before ANN in the same wave;
   * the vmcnt each BLOCK / ANN waits with equals the number of vector-memory operations its wave issues in between (capped at 15);
@@ -20,11 +21,12 @@ from blocksparse_amd.matmul import _host_plan
 NOFETCH = 0x7ffffff
 
 
-def _plan(layout, which):
+def _plan(layout, which, order="natural"):
     t = L.build_tables(layout, z_order=True, segmented=False)
     side = t[which]
     n_out = t["KB"] if which == "fprop" else t["CB"]
-    words = _host_plan(side["lut"], side["segments"], t["blocks"], n_out, 32, lib.BF16, 1, lib.PLAN_XCOL_FLOW)
+    words = _host_plan(side["lut"], side["segments"], t["blocks"], n_out, 32, lib.BF16, 1,
+                       lib.PLAN_XCOL_FLOW | (lib.PLAN_FLOW_SCHEDULED if order == "scheduled" else 0))
     return t, side, n_out, words
 
 
@@ -42,8 +44,9 @@ def _columns(side):
                                          ("BA 64", P.ba_layout(64, 5, seed=1)), ("sparse 300x16", P.random_layout(300, 16, 0.05, seed=6)),
                                          ("single", np.ones((1, 1), dtype=np.int32)), ("groups without blocks", np.eye(15, 40, dtype=np.int32)), ("bench 20 %", P.random_layout(128, 128, 0.2, seed=1234))])
 @pytest.mark.parametrize("which", ["fprop", "bprop"])
-def test_flow_plan_event_lists(name, layout, which):
-    t, side, n_out, p = _plan(layout, which)
+@pytest.mark.parametrize("order", ["natural", "scheduled"])
+def test_flow_plan_event_lists(name, layout, which, order):
+    t, side, n_out, p = _plan(layout, which, order)
     assert p is not None and p[0] == 0x42535834 and p[2] == 16
     D, DX, PARTS = p[11] & 0xff, (p[11] >> 8) & 0xff, (p[11] >> 16) & 0xff
     assert 1 <= DX < D and PARTS in (1, 2, 4)
@@ -56,7 +59,9 @@ def test_flow_plan_event_lists(name, layout, which):
         assert ob0 % 16 == 0 and ob0 not in seen_groups
         seen_groups.add(ob0)
         pairs = p[p[6] + step_off:p[6] + step_off + nsteps]
-        assert list(pairs) == sorted(set(pairs))
+        assert len(set(pairs)) == len(pairs)
+        if order == "natural":              # ascending input blocks: the summation order of the staged kernel
+            assert list(pairs) == sorted(pairs)
         base = p[7] + list_off
         counts = p[base:base + 16]
         reqs, anns = {}, {}
@@ -92,7 +97,11 @@ def test_flow_plan_event_lists(name, layout, which):
                     fetch_seq.append(ops)
                     fetched.append(f)
                 events.append((ty, hp, step, nxt))
-            assert [b[0] for b in blocks] == [c for c, _ in want] and fetched == [w for _, w in want], (name, g, wv)
+            # every lut entry of my column exactly once, with ITS weight block, in the plan's step order (ascending input blocks when natural)
+            assert sorted(zip([b[0] for b in blocks], fetched)) == want, (name, g, wv)
+            assert [b[1] for b in blocks] == sorted(b[1] for b in blocks)
+            if order == "natural":
+                assert [b[0] for b in blocks] == [c for c, _ in want]
             # progress words: after a BLOCK / NOP = the step of the next BLOCK (nsteps if none)
             bsteps = [b[1] for b in blocks]
             k = 0
