@@ -13,13 +13,14 @@ LIB_PATH = os.environ.get("BSMM_LIB") or os.path.join(_HERE, "libbsmm_hip.so")
 ABI_VERSION = 120        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
-FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN, FLAG_DW_SUMS = 1, 2, 4, 8, 16
+FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN, FLAG_DW_SUMS, FLAG_FORCE_MID = 1, 2, 4, 8, 16, 32
 # bsmm_args.trace codes (include/bsmm.h BSMM_K_*)
 K_XPROP_VALU, K_XPROP_SEGMENT, K_XCOL32, K_XCOL16, K_XCOL32_F32SPLIT, K_XCOL32_F32MFMA, K_XPROP_SUPER8 = 1, 2, 3, 4, 5, 6, 7
 K_XCOL32_STAGED = 8
 K_XCOL16_STAGED = 9
 K_XCOL32_FLOW = 10
 K_XPROP_SMALL = 11
+K_XPROP_MID = 12
 K_UPDAT_VALU, K_UPDAT_BLOCK, K_UPDAT_BLOCK_TR, K_UPDAT_WIN, K_UPDAT16_WIN, K_UPDAT_SUPER8, K_UPDAT_STREAM = 16, 17, 18, 19, 20, 21, 22
 # plan-builder options (BSMM_PLAN_*)
 PLAN_XCOL_UNSTAGED = 4
@@ -65,8 +66,8 @@ class BstArgs(ctypes.Structure):
 _lib = None
 
 # Test hook (host side only -- the library itself keeps no switches): flags OR-ed into every call the host classes make.
-#   0 production dispatch, 1 = FLAG_FORCE_VALU, 2 = FLAG_NO_PLAN, 3 = FLAG_FORCE_PLAN
-_VARIANT_FLAGS = {0: 0, 1: FLAG_FORCE_VALU, 2: FLAG_NO_PLAN, 3: FLAG_FORCE_PLAN}
+#   0 production dispatch, 1 = FLAG_FORCE_VALU, 2 = FLAG_NO_PLAN, 3 = FLAG_FORCE_PLAN, 4 = FLAG_FORCE_MID
+_VARIANT_FLAGS = {0: 0, 1: FLAG_FORCE_VALU, 2: FLAG_NO_PLAN, 3: FLAG_FORCE_PLAN, 4: FLAG_FORCE_MID}
 _call_flags = 0
 _last_kernel = ctypes.c_int32(0)
 

@@ -20,6 +20,7 @@
 #include "bsmm_xcol_v2.h"
 #include "bsmm_xflow.h"
 #include "bsmm_xsmall.h"
+#include "bsmm_xmid.h"
 #include "bsmm_xcol16.h"
 #include "bsmm_xcol16_v2.h"
 #include "bsmm_b64.h"
@@ -427,9 +428,18 @@ inline size_t lock_acc_bytes(const bsmm_args* a) {
     return (a->locks > 0 && a->dtype != BSMM_F32) ? (size_t)a->N * a->K * sizeof(float) : 0;
 }
 
-enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_F32MFMA, XP_SUPER8, XP_SMALL };
+enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_F32MFMA, XP_SUPER8, XP_SMALL, XP_MID };
 #ifndef BSMM_SMALL_N_MAX
 #define BSMM_SMALL_N_MAX 4096     // the small-minibatch kernel (bsmm_xsmall.h) is considered up to this many minibatch rows (the cost model decides)
+#endif
+#ifndef BSMM_MID_MODE
+#define BSMM_MID_MODE 0           // medium-minibatch kernel (bsmm_xmid.h): 0 = by the cost model, 1 = whenever it can run, -1 = never (measurement builds)
+#endif
+#ifndef BSMM_MID_MAP
+#define BSMM_MID_MAP 0            // its workgroup shape: 0 = by the size of the activations, 1 = one block x 4 row chunks, 2 = 4 blocks x one row chunk
+#endif
+#ifndef BSMM_MID_RT
+#define BSMM_MID_RT 0             // its rows per wave: 0 = by the wave count, 2 = 64, 4 = 128 (measurement builds)
 #endif
 
 // ONE decision, used for the workspace layout, the zero-fill of locked outputs and the launch (the three used to be
@@ -462,7 +472,20 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         small_ok = variant == 0 && !a->gate && a->locks == 0 && a->N <= BSMM_SMALL_N_MAX && a->C % 32 == 0 && a->K % 32 == 0;
         t_small = 3.0 + 1.35e-5 * (double)a->blocks * a->N;
     }
+    // medium minibatches: one wave per (output block, 64 rows) walks the block's whole entry list from a private LDS ring (bsmm_xmid.h)
+    bool mid_ok = false;
+    double t_mid = 0.0;
+    if constexpr (BS == 32 && DT::is16 && AXIS == 1) {
+        mid_ok = BSMM_MID_MODE >= 0 && (variant == 0 || (a->flags & BSMM_FLAG_FORCE_MID)) && !a->gate && a->locks == 0 && a->C % 32 == 0 && a->K % 32 == 0 && a->segments > 0 &&
+                 (long)a->N * a->C * 2 < (1L << 32) && a->blocks < (1 << 21);
+        // measured as hipGraph replays (profiles/r04_smalln.txt): ~0.9 us per entry of a column and round of 8 waves per CU; a half-empty
+        // machine is not proportionally faster (occupancy o: o >= 1 -> o, below -> 0.25 + 0.5 o)
+        const double o = (double)a->segments * ((a->N + 63) / 64) / (8.0 * device_cus());
+        t_mid = 4.5 + 0.9 * ((double)a->blocks / a->segments) * std::max(1.12 * o, 0.25 + 0.5 * o);   // (full rounds: 12 % more per round, measured)
+        if ((BSMM_MID_MODE > 0 || (a->flags & BSMM_FLAG_FORCE_MID)) && mid_ok) return XP_MID;
+    }
     if (!plan_ok) {
+        if (mid_ok && t_mid < (small_ok ? t_small : 1e30) && t_mid < 6.0 + 1.2e-5 * (double)a->blocks * a->N + 8.0) return XP_MID;
         if (small_ok && t_small < 6.0 + 1.2e-5 * (double)a->blocks * a->N + 8.0) return XP_SMALL;     // (the per-segment fprop also pays a transpose pre-pass)
         return XP_SEGMENT;
     }
@@ -508,6 +531,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
             t_group = rounds * (0.28 * steps + 0.040 * a->blocks / ngroups) * (1.0 + 0.2 * fill) + 4.0;
             t_segment = 6.0 + 1.2e-5 * (double)a->blocks * a->N;        // (round 4: refit on graph replays -- the 14.4 us floor of round 2 was the host's)
         }
+        if (mid_ok && t_mid <= t_group && t_mid <= t_segment && (!small_ok || t_mid < t_small)) return XP_MID;
         if (small_ok && t_small <= t_group && t_small <= t_segment) return XP_SMALL;
         return t_group < t_segment ? XP_XCOL32 : XP_SEGMENT;
     }
@@ -569,6 +593,38 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
             if (fprop) xsmall32_kernel<DT, true><<<grid, 64 * XSM_NW, XSM_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N, a->C, a->K);
             else       xsmall32_kernel<DT, false><<<grid, 64 * XSM_NW, XSM_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N, a->C, a->K);
             return (int)hipGetLastError();
+        }
+    }
+    if (path == XP_MID) {
+        if constexpr (BS == 32 && DT::is16 && AXIS == 1) {
+            trace(a, BSMM_K_XPROP_MID);
+            // (128-row waves -- <4, 6>, half the weight traffic per output -- measured no faster anywhere the flow kernel is not faster
+            //  still: BSMM_MID_RT=4 builds them for measurements)
+            const bool big = BSMM_MID_RT == 4;
+            auto go = [&](auto rt_tag, auto dws_tag) -> int {
+                constexpr int RT = decltype(rt_tag)::value, DWS = decltype(dws_tag)::value;
+                // which four tasks make a workgroup: see the kernel
+                const int by_column = BSMM_MID_MAP == 1 || (BSMM_MID_MAP == 0 && (long)a->N * a->C * 2 <= (5L << 20)) ? 1 : 0;
+                const int nchunks = (a->N + xmd_rows(RT) - 1) / xmd_rows(RT);
+                XMap m;
+                m.ntiles = by_column ? (nchunks + XMD_NW - 1) / XMD_NW : nchunks;
+                m.segments = by_column ? a->segments : (a->segments + XMD_NW - 1) / XMD_NW;
+                m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+                if (m.P > m.segments) m.P = m.segments;
+                m.SP = (m.segments + m.P - 1) / m.P;
+                constexpr int LDS = xmd_lds(RT, DWS);
+                if (fprop) {
+                    if (int rc = ensure_lds<&xmid32_kernel<DT, true, RT, DWS>>(LDS)) return rc;
+                    xmid32_kernel<DT, true, RT, DWS><<<m.grid(), 64 * XMD_NW, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, m,
+                                                                                        a->segments, a->N, a->C, a->K, by_column);
+                } else {
+                    if (int rc = ensure_lds<&xmid32_kernel<DT, false, RT, DWS>>(LDS)) return rc;
+                    xmid32_kernel<DT, false, RT, DWS><<<m.grid(), 64 * XMD_NW, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, m,
+                                                                                         a->segments, a->N, a->C, a->K, by_column);
+                }
+                return (int)hipGetLastError();
+            };
+            return big ? go(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{}) : go(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
         }
     }
     if (path == XP_F32SPLIT) {

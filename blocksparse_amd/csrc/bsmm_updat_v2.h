@@ -93,7 +93,7 @@ __device__ __forceinline__ void glds16_saddr_x2(const void* sbase, uint32_t voff
                  "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff0), "v"(voff1), "s"(sbase), "s"(lds_byte_addr)
-                 : "memory");
+                 : "memory", "scc");      // (s_add_u32 writes SCC: without the clobber a compare hoisted above the block loses its result)
 }
 
 __device__ __forceinline__ void glds16_saddr_x4(const void* sbase, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t lds_byte_addr) {
@@ -104,7 +104,7 @@ __device__ __forceinline__ void glds16_saddr_x4(const void* sbase, uint32_t v0, 
                  "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_byte_addr)
-                 : "memory");
+                 : "memory", "scc");
 }
 
 // entry `idx` (wave-uniform, runtime) of a pointer list that lives in kernel-argument SGPRs: a chain of scalar selects

@@ -55,17 +55,19 @@ enum {
     BSMM_FLAG_FORCE_VALU = 2,   /* per call: plain V_FMA kernels for every bsize (independent second implementation)      */
     BSMM_FLAG_NO_PLAN = 4,      /* per call: ignore bsmm_args.plan (per-segment / per-block matrix-core kernels)          */
     BSMM_FLAG_FORCE_PLAN = 8,   /* per call: take the plan kernels whenever a plan is given, whatever the size heuristic   */
-    BSMM_FLAG_DW_SUMS = 16      /* updat: leave the raw fp32 sums sum_p X_p DY_p^T of every block in the workspace
+    BSMM_FLAG_DW_SUMS = 16,     /* updat: leave the raw fp32 sums sum_p X_p DY_p^T of every block in the workspace
                                    ([blocks][bsize][bsize] floats at its start) and do NOT write DW -- the data-parallel path
                                    all-reduces those sums in fp32 and then calls bsmm_updat_finalize().  Kernels that cannot
                                    (no plan / not the streaming kernel) answer BSMM_ERR_UNSUPPORTED                          */
+    BSMM_FLAG_FORCE_MID = 32    /* per call, xprop: the medium-minibatch kernel (bsmm_xmid.h: bsize 32, 16-bit, feature axis 1, no gate,
+                                   no locks) whenever it can run, whatever the cost model says (tests)                       */
 };
 
 /* bsmm_args.trace: which kernel family a call dispatched to (tests assert that the intended kernel ran) */
 enum {
     BSMM_K_NONE = 0,
     BSMM_K_XPROP_VALU = 1, BSMM_K_XPROP_SEGMENT = 2, BSMM_K_XCOL32 = 3, BSMM_K_XCOL16 = 4, BSMM_K_XCOL32_F32SPLIT = 5,
-    BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7, BSMM_K_XCOL32_STAGED = 8, BSMM_K_XCOL16_STAGED = 9, BSMM_K_XCOL32_FLOW = 10, BSMM_K_XPROP_SMALL = 11,
+    BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7, BSMM_K_XCOL32_STAGED = 8, BSMM_K_XCOL16_STAGED = 9, BSMM_K_XCOL32_FLOW = 10, BSMM_K_XPROP_SMALL = 11, BSMM_K_XPROP_MID = 12,
     BSMM_K_UPDAT_VALU = 16, BSMM_K_UPDAT_BLOCK = 17, BSMM_K_UPDAT_BLOCK_TR = 18, BSMM_K_UPDAT_WIN = 19, BSMM_K_UPDAT16_WIN = 20,
     BSMM_K_UPDAT_SUPER8 = 21, BSMM_K_UPDAT_STREAM = 22
 };

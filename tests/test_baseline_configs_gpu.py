@@ -543,12 +543,48 @@ def test_small_minibatch_kernel(env, dtype):
                 assert np.count_nonzero(y[:, :7 * 32]) == 0 and np.count_nonzero(y[:, 8 * 32:]) == 0
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_medium_minibatch_kernel(env, dtype):
+    """bsmm_xmid.h (round 4): feature axis 1, bsize 32 -- one wave per (output block, 64 rows) walks the block's lut segment from a
+    private LDS ring.  Forced per call (BSMM_FLAG_FORCE_MID): every output element of fprop and bprop against the float64 oracle AND
+    bit for bit against the plan kernels (same summation order: the lut's), both workgroup shapes (one block x 4 row chunks for small
+    activation matrices, 4 blocks x one row chunk above 5 MB); layouts with empty columns, a single block, more than 64 entries per
+    column (two chunks of the lane-resident list), fewer entries than ring stages; ragged minibatches."""
+    torch, BSMM, lib = env
+    lone = np.zeros((9, 11), dtype=np.int32); lone[3, 7] = 1
+    cases = [(P.ba_layout(160, 5, seed=0), (64, 37, 200)), (P.random_layout(40, 24, 0.5, seed=3), (8, 130, 1000)), (lone, (64,)),
+             (np.ones((20, 3), dtype=np.int32), (100,)), (P.random_layout(128, 128, 0.2, seed=1234), (512,)),
+             (P.random_layout(128, 128, 0.55, seed=5), (300,)), (P.random_layout(256, 256, 0.05, seed=1234), (520,)), (np.eye(15, 33, dtype=np.int32), (70,))]
+    for li, (lay, Ns) in enumerate(cases):
+        b = BSMM(lay, block_size=32, feature_axis=1)
+        t = orc.build_layout_luts(lay, 32)
+        for N in Ns:
+            W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=li * 7 + N)
+            w, x, e = P.to_dev(W, dtype, torch), P.to_dev(X, dtype, torch), P.to_dev(E, dtype, torch)
+            lib.set_kernel_variant(4)
+            try:
+                ty = b.fprop(x, w); kf = lib.last_kernel()
+                tdx = b.bprop(e, w); kb = lib.last_kernel()
+                lib.set_kernel_variant(3)
+                py, pdx = b.fprop(x, w), b.bprop(e, w)
+            finally:
+                lib.set_kernel_variant(0)
+            assert kf == kb == lib.K_XPROP_MID, (li, N, kf, kb)
+            assert torch.equal(ty, py) and torch.equal(tdx, pdx), (li, N)
+            y, dx = P.to_host(ty), P.to_host(tdx)
+            l2y, _ = P.errors(y, orc.round_to(orc.fprop(t, X, W, 1), dtype))
+            l2x, _ = P.errors(dx, orc.round_to(orc.bprop(t, E, W, 1), dtype))
+            assert l2y <= P.L2_BAR[dtype] and l2x <= P.L2_BAR[dtype], (li, N, l2y, l2x)
+            if li == 2:        # output blocks without entries are zero, not garbage
+                assert np.count_nonzero(y[:, :7 * 32]) == 0 and np.count_nonzero(y[:, 8 * 32:]) == 0
+
+
 # ---- (h) the kernel-choice cost models at measured points (profiles/r02_sweeps.md: the faster kernel wins by > 15 % there) ----
-@pytest.mark.parametrize("CB,dens,N,xk,uk", [(128, 0.2, 256, "K_XPROP_SMALL", "K_UPDAT_BLOCK_TR"), (128, 0.2, 2048, "K_XCOL32_FLOW", "K_UPDAT_STREAM"),
-                                             (128, 0.05, 2048, None, "K_UPDAT_STREAM"), (128, 0.05, 512, "K_XPROP_SMALL", "K_UPDAT_BLOCK_TR"),
-                                             (256, 0.05, 512, "K_XPROP_SMALL", "K_UPDAT_STREAM"), (256, 0.05, 2048, "K_XCOL32_FLOW", "K_UPDAT_STREAM"),
-                                             (64, 0.2, 512, "K_XPROP_SMALL", "K_UPDAT_BLOCK_TR"), (64, 0.2, 8192, "K_XCOL32_FLOW", None),
-                                             (128, 0.2, 64, "K_XPROP_SMALL", None), (128, 0.2, 1024, "K_XCOL32_FLOW", None)])
+@pytest.mark.parametrize("CB,dens,N,xk,uk", [(128, 0.2, 256, None, "K_UPDAT_BLOCK_TR"), (128, 0.2, 2048, "K_XCOL32_FLOW", "K_UPDAT_STREAM"),
+                                             (128, 0.05, 2048, None, "K_UPDAT_STREAM"), (128, 0.05, 512, None, "K_UPDAT_BLOCK_TR"),
+                                             (256, 0.05, 512, "K_XPROP_MID", "K_UPDAT_STREAM"), (256, 0.05, 2048, "K_XCOL32_FLOW", "K_UPDAT_STREAM"),
+                                             (64, 0.2, 512, None, "K_UPDAT_BLOCK_TR"), (64, 0.2, 8192, "K_XCOL32_FLOW", None),
+                                             (128, 0.2, 64, "K_XPROP_SMALL", None), (128, 0.2, 512, "K_XPROP_MID", None), (128, 0.2, 4096, "K_XCOL32_FLOW", None)])
 def test_cost_models_pick_the_measured_winner(env, CB, dens, N, xk, uk):
     """Production dispatch (no flags) on a 256-CU part: at these (layout, minibatch) points of the sweeps (round 4: timed as hipGraph
     replays, profiles/r04_smalln.txt) one kernel family is clearly faster; (128, 5 %, N = 2048) is the updat point the model once got wrong (auto 33.6 us on the per-block kernel, plan 25.2)."""
