@@ -21,7 +21,6 @@
 #include "bsmm_xflow.h"
 #include "bsmm_xsmall.h"
 #include "bsmm_xmid.h"
-#include "bsmm_xcol16.h"
 #include "bsmm_xcol16_v2.h"
 #include "bsmm_b64.h"
 #include "bsmm_xprop.h"
@@ -95,8 +94,8 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (a->bsize == 64) return (m == B64PLAN_MAGIC && a->plan_inner == (updat ? 1 : 0)) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
-    if (a->bsize == 16) return ((m == XC16PLAN_MAGIC || (m == X7PLAN_MAGIC && a->plan_width == X7_G)) && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
-    if (a->dtype == BSMM_F32) return ((m == XCPLAN_MAGIC && a->plan_width == XS_G) || m == XFPLAN_MAGIC) ? BSMM_OK : BSMM_ERR_ARG;
+    if (a->bsize == 16) return (m == X7PLAN_MAGIC && a->plan_width == X7_G && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
+    if (a->dtype == BSMM_F32) return (m == XCPLAN_MAGIC && a->plan_width == XS_G) ? BSMM_OK : BSMM_ERR_ARG;
     return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G) || (m == X4PLAN_MAGIC && a->plan_width == X4_G && a->axis == 1)) ? BSMM_OK : BSMM_ERR_ARG;
 }
 
@@ -161,24 +160,6 @@ int launch_xprop_mfma(const void* X, const void* Wsel, void* Y, const bsmm_args*
 #endif
 inline bool use_xcol() { return true; }
 
-template <class DT, int AXIS, int NW, int PH>
-int launch_xcol16_g(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    typedef typename DT::T T;
-    const int n_out = a->K / 16;
-    XMap m;
-    m.ntiles = (a->N + XC_R - 1) / XC_R;
-    m.segments = (n_out + 2 * NW - 1) / (2 * NW);
-    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
-    if (m.P > m.segments) m.P = m.segments;
-    m.SP = (m.segments + m.P - 1) / m.P;
-    constexpr int LDS = xc_lds_bytes(NW, PH);
-    if (int rc = ensure_lds<&xcol16_kernel<DT, AXIS, NW, PH>>(LDS)) return rc;
-    trace(a, BSMM_K_XCOL16);
-    xcol16_kernel<DT, AXIS, NW, PH><<<m.grid(), 64 * NW, LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                                   a->N, a->C, a->K);
-    return (int)hipGetLastError();
-}
-
 // bsize 16, 'BSX7' plan: which inner loop.  The list-driven kernel multiplies every block on its own with the K = 16 instruction; where most
 // blocks have their pair partner (dense layouts) the round-2 kernel's K = 32 instruction per PAIR wins on feature axis 1 -- measured at 4096^2,
 // N = 8192 (profiles/r03_x7_density.txt): 20 % 152 / 145 against 166 / 149 us, 30 % 201 / 193 against 210 / 184, 50 % 315 / 319 against 284 / 263;
@@ -226,28 +207,8 @@ int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* 
 
 template <class DT, int AXIS>
 int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
-    if (a->plan_magic == X7PLAN_MAGIC) return a->plan_width == X7_G ? launch_xcol16_v2<DT, AXIS>(X, Wsel, Y, a, st, transw) : BSMM_ERR_ARG;
-    if (a->plan_magic != XC16PLAN_MAGIC) return BSMM_ERR_ARG;
-    if (a->plan_width == 32) return launch_xcol16_g<DT, AXIS, 16, BSMM_XC_WIDE_PH>(X, Wsel, Y, a, st);
-    if (a->plan_width == XC16_G) return launch_xcol16_g<DT, AXIS, 8, XC_PH>(X, Wsel, Y, a, st);
-    return BSMM_ERR_ARG;
-}
-
-template <int AXIS>
-int launch_xcol32f(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    const int n_out = a->K / 32;
-    XMap m;
-    m.ntiles = (a->N + XF_R - 1) / XF_R;
-    m.segments = (n_out + XC_G - 1) / XC_G;
-    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
-    if (m.P > m.segments) m.P = m.segments;
-    m.SP = (m.segments + m.P - 1) / m.P;
-    if (a->plan_magic != XFPLAN_MAGIC || a->plan_width != XC_G) return BSMM_ERR_ARG;
-    if (int rc = ensure_lds<&xcol32f_kernel<AXIS>>(XF_LDS)) return rc;
-    trace(a, BSMM_K_XCOL32_F32MFMA);
-    xcol32f_kernel<AXIS><<<m.grid(), 512, XF_LDS, st>>>(static_cast<const float*>(X), static_cast<const float*>(Wsel), static_cast<float*>(Y),
-                                                        a->plan, m, a->N, a->C, a->K);
-    return (int)hipGetLastError();
+    // ('BSX7' plans only: the round-1 kernel and its 'BSX6' plans were retired in round 4)
+    return (a->plan_magic == X7PLAN_MAGIC && a->plan_width == X7_G) ? launch_xcol16_v2<DT, AXIS>(X, Wsel, Y, a, st, transw) : BSMM_ERR_ARG;
 }
 
 // fp32 on the bf16 matrix cores: split pre-passes into the workspace ([3][N*C] activation pieces, then [3][blocks*1024]
@@ -428,7 +389,7 @@ inline size_t lock_acc_bytes(const bsmm_args* a) {
     return (a->locks > 0 && a->dtype != BSMM_F32) ? (size_t)a->N * a->K * sizeof(float) : 0;
 }
 
-enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_F32MFMA, XP_SUPER8, XP_SMALL, XP_MID };
+enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_SUPER8, XP_SMALL, XP_MID };
 #ifndef BSMM_SMALL_N_MAX
 #define BSMM_SMALL_N_MAX 4096     // the small-minibatch kernel (bsmm_xsmall.h) is considered up to this many minibatch rows (the cost model decides)
 #endif
@@ -495,16 +456,16 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         if constexpr (!DT::is16) return XP_SEGMENT;
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // 16-byte aligned row pieces
         if (a->plan_magic == X7PLAN_MAGIC && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;   // 32-bit lane offsets
-        const bool enough = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 16 + XC16_G - 1) / XC16_G) >= device_cus() * 7 / 8;
+        const bool enough = (long)((a->N + XC_R - 1) / XC_R) * ((a->K / 16 + 15) / 16) >= device_cus() * 7 / 8;
         return (enough || force) ? XP_XCOL16 : XP_SEGMENT;
     }
     if constexpr (BS == 32 && !DT::is16) {
-        const bool split = a->plan_magic == XCPLAN_MAGIC;               // 'BSXC' (G = 16): exact bf16 split; 'BSXF': fp32 MFMA
-        if (AXIS == 0 && (a->N % (split ? 8 : 4) != 0)) return XP_SEGMENT;
-        if (split && a->C % 32 != 0) return XP_SEGMENT;
-        const bool enough = (long)((a->N + XF_R - 1) / XF_R) * ((a->K / 32 + XC_G - 1) / XC_G) >= device_cus() * 7 / 8;
+        if (a->plan_magic != XCPLAN_MAGIC) return XP_SEGMENT;           // 'BSXC' (G = 16): the exact bf16 split
+        if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;
+        if (a->C % 32 != 0) return XP_SEGMENT;
+        const bool enough = (long)((a->N + 127) / 128) * ((a->K / 32 + XC_G - 1) / XC_G) >= device_cus() * 7 / 8;
         if (!(enough || force)) return XP_SEGMENT;
-        return split ? XP_F32SPLIT : XP_F32MFMA;
+        return XP_F32SPLIT;
     }
     if constexpr (BS == 32 && DT::is16) {
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // axis-0 xcol needs 16-byte aligned row pieces
@@ -672,9 +633,6 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         case XP_XCOL16:
             if constexpr (BS == 16 && DT::is16) rc = launch_xcol16<DT, AXIS>(X, Wsel, Y, a, st, staged16 && fprop);
             break;
-        case XP_F32MFMA:
-            if constexpr (BS == 32 && !DT::is16) rc = launch_xcol32f<AXIS>(X, Wsel, Y, a, st);
-            break;
         default: break;
     }
     if (rc == 0 && yacc) {
@@ -697,7 +655,7 @@ int xprop_dt(bool fprop, const void* X, const void* W, void* Y, const bsmm_args*
 // ---- bsize 64 (feature axis 1): the quadrant view on the bsize-32 path ('BS64' plans, bsmm_plan.h / bsmm_b64.h) ----
 // descriptor of a 'BS64' plan in bsmm_args (bsmm_plan_attach): plan_width / plan_items = the nested plan's, plan_waves = the nested plan's
 // waves (5 bits) | code of its format << 5 | its `inner` word << 8, plan_inner = 0 (xprop) / 1 (updat)
-const int32_t kNestedMagic[8] = {0, XCPLAN_MAGIC, X2PLAN_MAGIC, XFPLAN_MAGIC, UPLAN_MAGIC, U2PLAN_MAGIC, X4PLAN_MAGIC, 0};
+const int32_t kNestedMagic[8] = {0, XCPLAN_MAGIC, X2PLAN_MAGIC, 0 /* (3: 'BSXF', retired) */, UPLAN_MAGIC, U2PLAN_MAGIC, X4PLAN_MAGIC, 0};
 inline int nested_code(int32_t magic) { for (int i = 1; i < 8; ++i) if (kNestedMagic[i] == magic) return i; return 0; }
 inline size_t b64_w_bytes(const bsmm_args* a) { return round16((size_t)a->blocks * 4096 * elem_size(a->dtype)); }
 inline size_t b64_gate_bytes(const bsmm_args* a) { return a->gate ? round16((size_t)a->blocks * 4 * sizeof(float)) : 0; }
@@ -767,53 +725,6 @@ inline int updat_split(const bsmm_args* a, int nitems, int nchunks) {
     const int cus = device_cus();
     while (nitems * split < cus && split * 2 <= nchunks / 8 && split < 8) split *= 2;
     return split;
-}
-
-// Windowed bsize-32 kernels (bsmm_updat_win.h).  raw_sums: leave the fp32 sums of every block in a->workspace (zeroed
-// here) and apply no alpha / beta -- the bsize-8 super-block path finishes them itself; DW is not touched then.
-template <class DT, int AXIS>
-int launch_updat32_win(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a, bool raw_sums) {
-    typedef typename DT::T T;
-    hipStream_t st = static_cast<hipStream_t>(a->stream);
-    const int N = a->N, nitems = a->plan_items;
-    if (nitems <= 0 || a->plan_magic != UPLAN_MAGIC) return BSMM_ERR_ARG;
-    // the descriptor names the window side and the waves per workgroup the plan was dealt for: 16x16 windows use 32-row chunks
-    const bool wide_win = a->plan_width == 16, waves16 = a->plan_waves == 16;
-    if (!((a->plan_width == 8 && a->plan_waves == 8) || (AXIS == 1 && wide_win && (a->plan_waves == 8 || waves16)))) return BSMM_ERR_ARG;
-    int rc_attr = 0;
-    if constexpr (AXIS == 0) rc_attr = ensure_lds<&updat32_a0_win_kernel<DT>>(UW0_LDS);
-    else if (waves16)        rc_attr = ensure_lds<&updat32_a1_win_kernel<DT, 16, 16>>(UWN_LDS);
-    else if (wide_win)       rc_attr = ensure_lds<&updat32_a1_win_kernel<DT, 16>>(UWN_LDS);
-    else                     rc_attr = ensure_lds<&updat32_a1_win_kernel<DT, 8>>(UWN_LDS);
-    if (rc_attr) return rc_attr;
-    const int nchunks = wide_win ? (N + 31) / 32 : (N + 63) / 64;
-    const int split = updat_split(a, nitems, nchunks);
-    trace(a, BSMM_K_UPDAT_WIN);
-    float* scratch = nullptr;
-    if (split > 1 || raw_sums) {
-        const size_t need = (size_t)a->blocks * 1024 * sizeof(float);
-        if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
-        scratch = static_cast<float*>(a->workspace);
-        hipError_t e = hipMemsetAsync(scratch, 0, need, st);
-        if (e != hipSuccess) return (int)e;
-    }
-    if constexpr (AXIS == 0)
-        updat32_a0_win_kernel<DT><<<dim3(nitems, split), 512, UW0_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K, a->pcount,
-                                                                            a->alpha, a->beta);
-    else if (waves16)
-        updat32_a1_win_kernel<DT, 16, 16><<<dim3(nitems, split), 1024, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K,
-                                                                                     a->pcount, a->alpha, a->beta);
-    else if (wide_win)
-        updat32_a1_win_kernel<DT, 16><<<dim3(nitems, split), 512, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K,
-                                                                                a->pcount, a->alpha, a->beta);
-    else
-        updat32_a1_win_kernel<DT, 8><<<dim3(nitems, split), 512, UWN_LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, N, a->C, a->K, a->pcount,
-                                                                               a->alpha, a->beta);
-    if (scratch && !raw_sums) {
-        const size_t n = (size_t)a->blocks * 1024;
-        updat_finalize_kernel<DT><<<(unsigned)((n / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), n, a->alpha, a->beta);
-    }
-    return (int)hipGetLastError();
 }
 
 // Streaming kernel (bsmm_updat_v2.h, 'BSU2' plans).  Default grid: 8 x U workgroups (U = CUs / 8) in the XCD-aware schedule of
@@ -918,14 +829,9 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             bsmm_args b = s8_inner(a, true);
             b.flags = 0; b.gate = nullptr; b.trace = nullptr;
             b.lut = a->plan + s8_off_lut32(ns);
-            int rc;
-            if (b.plan_magic == U2PLAN_MAGIC) {      // streaming kernel, raw fp32 sums of the super-blocks at the start of the workspace
-                b.flags = BSMM_FLAG_DW_SUMS; b.split = 0;
-                rc = launch_updat2<DT, AXIS>(xs, es, nullptr, &b, nullptr);
-            } else {
-                rc = launch_updat32_win<DT, AXIS>(xs, es, nullptr, &b, true);
-            }
-            if (rc) return rc;
+            if (b.plan_magic != U2PLAN_MAGIC) return BSMM_ERR_ARG;      // (the nested plan is the streaming kernel's since round 3)
+            b.flags = BSMM_FLAG_DW_SUMS; b.split = 0;      // raw fp32 sums of the super-blocks at the start of the workspace
+            if (int rc = launch_updat2<DT, AXIS>(xs, es, nullptr, &b, nullptr)) return rc;
             trace(a, BSMM_K_UPDAT_SUPER8);
             gather8_kernel<DT><<<ns, 256, 0, st>>>(static_cast<const float*>(a->workspace), a->plan, static_cast<T*>(DW), a->alpha, a->beta);
             return (int)hipGetLastError();
@@ -970,25 +876,6 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             }
         }
         if (sums_only) return BSMM_ERR_UNSUPPORTED;
-        if (!use_valu && !gated && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_magic == UPLAN_MAGIC && a->plan_items > 0) {   // windowed kernels (plan = bsmm_updat_plan_build)
-            // Sparse layouts at small minibatch (BASELINE configs[3]'s per-GPU shard: 8192^2, 5 %, N = 512): a window holds ~3
-            // blocks, so the windowed kernel streams 64 KiB per chunk for almost nothing, while the per-block transposing-read
-            // kernel moves 128 bytes per (block, row).  Fitted to measurements (us): windowed 8 + rounds * chunks * 0.9 (1.8x that
-            // per chunk with 16x16 windows); per block 8 + rounds of 512 blocks * N * 0.0065 .. 0.0105.
-            bool windowed = true;
-            if (AXIS == 1 && variant == 0) {
-                const bool w16 = a->plan_width == 16;
-                const double chunks = std::ceil(N / 64.0) * a->pcount;                 // 64-row units per window
-                const int split = updat_split(a, a->plan_items, w16 ? (N + 31) / 32 : (N + 63) / 64);   // as launch_updat32_win chooses it
-                const double rounds = std::max(1.0, std::ceil(a->plan_items * (double)split / (double)device_cus()));
-                const double t_win = 8.0 + rounds * (chunks / split) * 0.9 * (w16 ? 1.8 : 1.0) + (split > 1 ? 6.0 : 0.0);
-                // per-block kernel: two workgroups per CU, each walks the whole minibatch for ONE block
-                const double rounds_b = std::max(1.0, std::ceil(a->blocks / (2.0 * device_cus())));
-                const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * (N > 1024 ? 0.0105 : 0.0065);
-                windowed = t_win <= t_blk;
-            }
-            if (windowed) return launch_updat32_win<DT, AXIS>(xs, es, DW, a, false);
-        }
     }
     if constexpr (BS == 32 && AXIS == 1 && DT::is16) {
         bool al = aligned16(DW);
@@ -1313,7 +1200,6 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
 
 // widths the plan options select (defaults: the wide shapes)
 static inline int opt_xc_group(int32_t options) { return (options & BSMM_PLAN_XCOL_NARROW) ? XC_G : 16; }
-static inline int opt_xc16_group(int32_t options) { return (options & BSMM_PLAN_XCOL_NARROW) ? XC16_G : 32; }
 
 static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int32_t n_out, int32_t bsize, int32_t dtype, int32_t axis,
                        int32_t options, int32_t* out) {
@@ -1332,16 +1218,10 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
     if (bsize != 32 && bsize != 16) return 0;   // plan kernels: bsize 32 (any dtype) / 16 and 8 (16-bit)
     if (dtype == BSMM_F32) {
         if (bsize != 32) return 0;
-        return (options & BSMM_PLAN_F32_MFMA) ? build_xcolf_plan(lut, segments, blocks, n_out, out)
-                                              : build_xcol_plan(lut, segments, blocks, n_out, out, XS_G);
+        return build_xcol_plan(lut, segments, blocks, n_out, out, XS_G);      // (BSMM_PLAN_F32_MFMA named the retired fp32 matrix-core kernel: ignored)
     }
-    if (bsize == 16) {
-        if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel
-            const long n = build_xcol16s_plan(lut, segments, blocks, n_out, out);
-            if (n != 0) return n;
-        }
-        return build_xcol16_plan(lut, segments, blocks, n_out, out, opt_xc16_group(options));
-    }
+    if (bsize == 16)         // 'BSX7' (staged / list kernels); BSMM_PLAN_XCOL_UNSTAGED / _NARROW named the round-1 kernel, retired in round 4: ignored
+        return build_xcol16s_plan(lut, segments, blocks, n_out, out);      // (0: the layout does not fit the table fields -> no plan, per-segment kernels)
     if ((options & BSMM_PLAN_XCOL_FLOW) && axis == 1 && !(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // barrier-free persistent kernel
         const long n = build_xflow_plan(lut, segments, blocks, n_out, out, (options & BSMM_PLAN_FLOW_SCHEDULED) != 0);
         if (n != 0) return n;
@@ -1365,17 +1245,6 @@ int bsmm_xprop_plan_build(const int32_t* host_lut, int32_t segments, int32_t blo
     return n > 0 ? BSMM_OK : (n == 0 ? BSMM_ERR_UNSUPPORTED : BSMM_ERR_ARG);
 }
 
-// bsize 32, axis 1: 16x16-block windows when they hold <= 16 blocks on average (sparse layouts), else 8x8 (bsmm_updat_win.h);
-// the caller can name the shape (BSMM_PLAN_WINDOW_*)
-static int updat_window(int32_t blocks, int32_t CB, int32_t KB, int32_t axis, int32_t options) {   // 8, 16, or 1616 (16x16 windows, 16 waves)
-    const int force = options & BSMM_PLAN_WINDOW_MASK;
-    if (axis != 1) return UW;
-    if (force == BSMM_PLAN_WINDOW_8) return 8;
-    if (force == BSMM_PLAN_WINDOW_16) return 16;
-    if (force == BSMM_PLAN_WINDOW_16W) return 1616;
-    const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);
-    return blocks <= 16.0 * windows ? 16 : UW;     // <= 2 block slots per wave on average (measured: 13 per window 2.1x faster, 26 per window 20 % slower)
-}
 static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype, int32_t axis, int32_t options,
                        int32_t* out) {
     if (dtype == BSMM_F32 || (axis != 0 && axis != 1)) return 0;   // windowed kernels: 16-bit types
@@ -1396,8 +1265,11 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
     if (bsize == 8) return build_super8_updat_plan(lut, blocks, CB, KB, out);   // 'BSS8'
     if (bsize == 16) return build_updat_plan(lut, blocks, CB, KB, UW16, UP16_MAXB, out);
     if (bsize != 32) return 0;
-    const int force = options & BSMM_PLAN_WINDOW_MASK;
-    if (force == 0 || force == BSMM_PLAN_STREAM_16 || force == BSMM_PLAN_STREAM_8 || force == BSMM_PLAN_STREAM_32) {     // either feature axis
+    int force = options & BSMM_PLAN_WINDOW_MASK;
+    // BSMM_PLAN_WINDOW_8 / _16 / _16W named the windowed bsize-32 kernels of round 1 (retired in round 4): the same window side on the streaming kernel
+    if (force == BSMM_PLAN_WINDOW_8) force = BSMM_PLAN_STREAM_8;
+    if (force == BSMM_PLAN_WINDOW_16 || force == BSMM_PLAN_WINDOW_16W) force = BSMM_PLAN_STREAM_16;
+    {     // either feature axis
         // streaming kernel: 16x16 windows while a window's blocks fit the 64 accumulator slots of a workgroup (with some
         // slack for the rows that do not pack: <= 56 on average), 8x8 windows for denser layouts
         const double windows = (double)((CB + 15) / 16) * ((KB + 15) / 16);
@@ -1408,8 +1280,6 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
         if (force == BSMM_PLAN_STREAM_32 || (force == 0 && axis == 1 && windows32 >= 16 && blocks <= 38.0 * windows32)) ws = 32;
         return build_updat2_plan(lut, blocks, CB, KB, ws, out, (options >> BSMM_PLAN_UPDAT_SETS_SHIFT) & 15);
     }
-    const int w = updat_window(blocks, CB, KB, axis, options);
-    return build_updat_plan(lut, blocks, CB, KB, w == 8 ? 8 : 16, UP_MAXB, out, w == 1616 ? 16 : 8);
 }
 
 long bsmm_updat_plan_words(const int32_t* host_updat_lut, int32_t blocks, int32_t CB, int32_t KB, int32_t bsize, int32_t dtype,
@@ -1433,8 +1303,6 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
         case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR || p[11] < 2 || p[11] > 4) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
         case X4PLAN_MAGIC:   if (p[1] != X4PLAN_VERSION || words < X4_HDR || p[2] != X4_G) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
-        case XFPLAN_MAGIC:   if (p[1] != XFPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
-        case XC16PLAN_MAGIC: if (p[1] != XC16PLAN_VERSION || words < XC_HDR) return false; d[1] = p[2]; d[2] = p[2] / 2; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;
         case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR || p[26] != U2_HDR + p[4] * U2_ITEM || words < (long)p[26] + p[5]) return false;   // (the launcher addresses the block map behind the items)
                                d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8] | (p[25] > 0 ? 16 : 0) | (p[27] << 8); break;   // item sets | all equally long | longest set

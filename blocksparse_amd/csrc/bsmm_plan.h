@@ -705,138 +705,7 @@ inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int
 
 }  // namespace bsmm
 
-// =================================================================================================
-// xcolf plan (bsize 32, fp32): the groups and pair walk of the xcol plan, but the work is dealt differently because the
-// fp32 kernel is MFMA-bound and must keep every wave equally busy: wave (t, c) owns row tile t of the workgroup's 128
-// minibatch rows and output blocks 4c..4c+3 of the group, so all waves of class c do identical work, and the two classes
-// share each SIMD.  Per group and class the plan holds the compacted ENTRY list, ordered by step:
-// Layout (int32): [0] magic 'BSXF' [1] version [2] XC_G [3] ngroups [4] nsteps_total [5] off_groups [6] off_pairs
-//                 [7] off_entries (even) [8] n_out_blocks [9] n_entries
-//   groups[ngroups][8] = (step_off, nsteps, first_out_block, n_out_blocks_in_group, ent_off0, ent_cnt0, ent_off1, ent_cnt1)
-//   pairs [nsteps_total]
-//   entries[n_entries][2] = (weight block, step << 3 | j << 1 | half)   j = out block - first - 4c, half = in block & 1;
-//                           every list is followed by four sentinels (-1, INT_MAX), not counted in ent_cnt
-// =================================================================================================
-namespace bsmm {
 
-constexpr int32_t XFPLAN_MAGIC = 0x42535846;
-constexpr int32_t XFPLAN_VERSION = 1;
-
-inline long build_xcolf_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
-    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
-    const int ngroups = (n_out_blocks + XC_G - 1) / XC_G;
-    struct E { int p, slot, w; };   // slot = 2*member + half
-    std::vector<std::vector<E>> per_group(ngroups);
-    for (int s = 0; s < segments; ++s) {
-        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
-        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
-        for (int e = 0; e < cnt; ++e) {
-            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
-            if (w < 0 || w >= blocks || c < 0) return -1;
-            per_group[ob / XC_G].push_back({c >> 1, 2 * (ob % XC_G) + (c & 1), w});
-        }
-    }
-    std::vector<int32_t> groups, pairs, entries;
-    for (int g = 0; g < ngroups; ++g) {
-        auto& v = per_group[g];
-        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : a.slot < b.slot; });
-        const int step_off = (int)pairs.size();
-        std::vector<int32_t> cls[2];
-        int t = -1, cur = -1;
-        for (auto& e : v) {
-            if (e.p != cur) { cur = e.p; ++t; pairs.push_back(e.p); }
-            const int member = e.slot >> 1, half = e.slot & 1, c = member >> 2, j = member & 3;
-            cls[c].push_back(e.w);
-            cls[c].push_back((t << 3) | (j << 1) | half);
-        }
-        const int32_t cnt0 = (int32_t)cls[0].size() / 2, cnt1 = (int32_t)cls[1].size() / 2;
-        for (int c = 0; c < 2; ++c)                      // four sentinels: the kernel reads four entries ahead unconditionally
-            for (int k = 0; k < 4; ++k) cls[c].insert(cls[c].end(), {-1, 0x7fffffff});
-        const int off0 = (int)entries.size() / 2;
-        entries.insert(entries.end(), cls[0].begin(), cls[0].end());
-        const int off1 = (int)entries.size() / 2;
-        entries.insert(entries.end(), cls[1].begin(), cls[1].end());
-        groups.insert(groups.end(), {step_off, t + 1, g * XC_G, std::min(XC_G, n_out_blocks - g * XC_G), off0, cnt0, off1, cnt1});
-    }
-    const int off_groups = XC_HDR, off_pairs = off_groups + (int)groups.size();
-    const int off_ent = (off_pairs + (int)pairs.size() + 1) & ~1;
-    const long total = off_ent + (long)entries.size();
-    if (out) {
-        const int32_t hdr[XC_HDR] = {XFPLAN_MAGIC, XFPLAN_VERSION, XC_G, ngroups, (int32_t)pairs.size(), off_groups, off_pairs, off_ent,
-                                     n_out_blocks, (int32_t)entries.size() / 2, 0, 0};
-        std::fill(out, out + total, 0);
-        std::copy(hdr, hdr + XC_HDR, out);
-        std::copy(groups.begin(), groups.end(), out + off_groups);
-        std::copy(pairs.begin(), pairs.end(), out + off_pairs);
-        std::copy(entries.begin(), entries.end(), out + off_ent);
-    }
-    return total;
-}
-
-}  // namespace bsmm
-
-// =================================================================================================
-// xcol16 plan (bsize 16): XC16_G = 16 consecutive output blocks per group, wave v owns blocks 2v and 2v+1; a step is a
-// QUAD of input blocks (4q .. 4q+3 = 64 features, one 128-byte line per row on axis 1).
-// Layout (int32): [0] magic 'BSX6' [1] version [2] XC16_G [3] ngroups [4] nsteps_total [5] off_groups [6] off_quads
-//                 [7] off_wtab [8] n_out_blocks
-//   groups[ngroups][4] = (step_off, nsteps, first_out_block, n_out_blocks_in_group)
-//   quads [nsteps_total]
-//   wtab  [group][slot][t]   slot = (member * 4 + sub), member = out block - first, sub = in block & 3; weight id or -1
-//                            group base = off_wtab + 4*XC16_G*step_off, index slot*nsteps + t
-// =================================================================================================
-namespace bsmm {
-
-constexpr int32_t XC16PLAN_MAGIC = 0x42535836;
-constexpr int32_t XC16PLAN_VERSION = 1;
-constexpr int XC16_G = 16;
-
-inline long build_xcol16_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int G = XC16_G) {
-    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
-    const int ngroups = (n_out_blocks + G - 1) / G;
-    struct E { int p, slot, w; };
-    std::vector<std::vector<E>> per_group(ngroups);
-    for (int s = 0; s < segments; ++s) {
-        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
-        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
-        for (int e = 0; e < cnt; ++e) {
-            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
-            if (w < 0 || w >= blocks || c < 0) return -1;
-            per_group[ob / G].push_back({c >> 2, 4 * (ob % G) + (c & 3), w});
-        }
-    }
-    std::vector<int32_t> groups, quads, wtab;
-    for (int g = 0; g < ngroups; ++g) {
-        auto& v = per_group[g];
-        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : a.slot < b.slot; });
-        std::vector<int32_t> gp;
-        for (auto& e : v) if (gp.empty() || gp.back() != e.p) gp.push_back(e.p);
-        const int ns = (int)gp.size();
-        const int step_off = (int)quads.size();
-        std::vector<int32_t> tab((size_t)4 * G * ns, -1);
-        int t = -1, cur = -1;
-        for (auto& e : v) {
-            if (e.p != cur) { cur = e.p; ++t; }
-            tab[(size_t)e.slot * ns + t] = e.w;
-        }
-        quads.insert(quads.end(), gp.begin(), gp.end());
-        wtab.insert(wtab.end(), tab.begin(), tab.end());
-        groups.insert(groups.end(), {step_off, ns, g * G, std::min(G, n_out_blocks - g * G)});
-    }
-    const long total = XC_HDR + (long)groups.size() + (long)quads.size() + (long)wtab.size();
-    if (out) {
-        const int off_groups = XC_HDR, off_quads = off_groups + (int)groups.size(), off_wtab = off_quads + (int)quads.size();
-        const int32_t hdr[XC_HDR] = {XC16PLAN_MAGIC, XC16PLAN_VERSION, G, ngroups, (int32_t)quads.size(), off_groups, off_quads,
-                                     off_wtab, n_out_blocks, 0, 0, 0};
-        std::copy(hdr, hdr + XC_HDR, out);
-        std::copy(groups.begin(), groups.end(), out + off_groups);
-        std::copy(quads.begin(), quads.end(), out + off_quads);
-        std::copy(wtab.begin(), wtab.end(), out + off_wtab);
-    }
-    return total;
-}
-
-}  // namespace bsmm
 
 // =================================================================================================
 // super8 plans (bsize 8, 16-bit types): the 8x8 blocks are grouped into the 32x32 SUPER-blocks of the block grid that
@@ -983,11 +852,7 @@ inline long build_super8_updat_plan(const int32_t* updat_lut, int blocks, int CB
             return s8_emit(supers, nested, 1, out);
         }
     }
-    const long nw = build_updat_plan(lut32.data(), ns, CB / 4, KB / 4, UW, UP_MAXB, nullptr);
-    if (nw <= 0) return -1;
-    std::vector<int32_t> nested((size_t)nw);
-    build_updat_plan(lut32.data(), ns, CB / 4, KB / 4, UW, UP_MAXB, nested.data());
-    return s8_emit(supers, nested, 1, out);
+    return 0;      // (the windowed bsize-32 kernel that once took what the streaming plan cannot hold was retired in round 4: no plan, per-block kernels)
 }
 
 }  // namespace bsmm

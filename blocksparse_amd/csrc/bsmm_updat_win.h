@@ -1,4 +1,7 @@
-// bsmm_updat_win.h -- windowed weight-gradient kernel, feature_axis = 1, bsize 32, 16-bit storage types.
+// bsmm_updat_win.h -- windowed weight-gradient kernel.  Round 4: only the bsize-16 kernel (updat16_win_kernel, BASELINE configs[2]) is
+// left; the bsize-32 kernels this file was written for in round 1 (updat32_a1_win_kernel: 8x8 / 16x16-block windows, 8 or 16 waves;
+// updat32_a0_win_kernel) were superseded on both feature axes by the streaming kernel (bsmm_updat_v2.h, rounds 2 - 3: 122 -> 94 us at the
+// bench shape) and retired.  The text below describes the scheme the bsize-16 kernel still follows (window, slabs, swizzles, ring).
 //
 // Why: with one workgroup per weight block (bsmm_updat_tr.h) every block streams its own X and DY column slabs:
 // 2 * N * 64 B per block = 3.4 GB at 4096^2 / 20% / N = 8192, and the kernel runs at the fabric bandwidth (5.6 TB/s,
@@ -34,322 +37,17 @@ constexpr int UWN_NI = UWN_SLAB / 1024 / UP_WAVES;   // DMA instructions per wav
 constexpr int UWN_SLOT = 2 * UWN_SLAB;
 constexpr int UWN_LDS = UWN_D * UWN_SLOT;
 
-// WU = window side in blocks.  8: 8x8 windows, 64-row chunks.  16: 16x16 windows, 32-row chunks (the slabs are 32 KiB either
-// way) for SPARSE layouts: with <= ~28 blocks per 16x16 window an item still fits the 32 block slots, and every slab byte
-// staged feeds twice as many blocks (at 10 % density an 8x8 window holds 6 blocks, at 5 % three).
-// NW = waves per workgroup, each with up to 4 block slots: <16, 16> (1024 threads, 64 slots) lets a 16x16 window of a DENSER
-// layout (20 %: ~51 blocks) stay one item, so the slab traffic per block halves there too; it runs at <= 128 VGPRs, with the
-// fragments of two slots in registers at a time.
-template <class DT, int WU = UW, int NW = UP_WAVES>
-__global__ void __launch_bounds__(64 * NW, NW == 16 ? 4 : 2)
-updat32_a1_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
-                      const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
-    typedef typename DT::T T;
-    static_assert(DT::is16, "windowed updat: 16-bit storage types");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (plan[0] != UPLAN_MAGIC || plan[1] != UPLAN_VERSION || plan[2] != WU || plan[3] != UP_MAXB || plan[7] != NW) return;
-    constexpr int CH = 512 / WU;                 // minibatch rows per chunk
-    constexpr int ROWB = WU * 64;                // bytes per slab row (WU blocks x 64 B)
-    constexpr int SLAB = CH * ROWB;              // 32 KiB
-    constexpr int NI = SLAB / 1024 / NW;         // DMA instructions per wave per slab
-    constexpr int SLOT = 2 * SLAB;
-    static_assert(SLAB == UWN_SLAB && (WU == 8 || WU == 16), "slab geometry");
-    const int32_t* item = plan + plan[6] + (size_t)blockIdx.x * (4 + NW * UP_MAXB * 2);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c0 = item[0], k0 = item[1];
-    if (item[2] == 0) return;   // padding item
-    // (The plan's row / column use masks, item[2] >> 16 and item[3] >> 16, are NOT applied here: skipping unused 64-byte
-    //  blocks inside the 512-byte rows saves bytes but no 128-byte lines, and measured 2-5 % slower.  The axis-0 kernels,
-    //  where an unused block is 32 whole slab rows, do use them.)
-    int meta[UP_MAXB], wid[UP_MAXB];
-#pragma unroll
-    for (int j = 0; j < UP_MAXB; ++j) {
-        meta[j] = item[4 + (wave * UP_MAXB + j) * 2];
-        wid[j] = item[4 + (wave * UP_MAXB + j) * 2 + 1];
-    }
-
-    // rows handled by this workgroup: chunks [q_beg, q_end) of CH rows
-    const int nchunks = (N + CH - 1) / CH;
-    const int per = (nchunks + gridDim.y - 1) / gridDim.y;
-    const int q_beg = blockIdx.y * per, q_end = min(nchunks, q_beg + per);
-
-    const uint32_t base_addr = lds_addr_of(smem);
-    // DMA: a slab is SLAB/1024 instructions of 1 KiB (RPI = 1024/ROWB rows each); wave v issues instructions
-    // NI*v .. NI*v + NI-1 of both slabs.  lane L -> row RPI*i + L / PPR, stored piece L % PPR,
-    // source piece (L % PPR) ^ (4 * (row & 3))
-    constexpr int PPR = ROWB / 16, RPI = 1024 / ROWB;
-    const int drow_in = lane / PPR, dpiece = lane % PPR;
-    int xcol[NI], ecol[NI];   // source element column of this lane for instruction NI*wave + i (clamped inside the row)
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int row = RPI * (NI * wave + i) + drow_in;
-        const int piece = dpiece ^ (4 * (row & 3));
-        xcol[i] = min(c0 * 32 + piece * 8, Cf - 8);
-        ecol[i] = min(k0 * 32 + piece * 8, Kf - 8);
-    }
-    // fragment reads
-    const int g16 = lane >> 4, t16 = lane & 15;
-    const int h = g16 >> 1;
-    const int trow = t16 >> 2;                                            // row inside the 4-row band (= row & 3)
-    const int tsub = (2 * (g16 & 1) + ((t16 & 3) >> 1)) * 16 + (t16 & 1) * 8;   // byte offset inside the block's 64 B
-
-    f32x16 acc[UP_MAXB];
-#pragma unroll
-    for (int j = 0; j < UP_MAXB; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-
-    // Every wave of the item walks the same number of slots (item[3]); a wave with fewer blocks computes its empty
-    // slots on block (0,0) of the window into accumulators that are never stored.  No per-slot branches: the chunk body
-    // is straight-line code, specialised on the slot count, so all transposing reads of a chunk are issued up-front.
-    const int nslots = item[3] & 0xffff;
-    int aoff[UP_MAXB], boff[UP_MAXB];   // per-slot byte offset of this lane's piece inside a slab row band
-#pragma unroll
-    for (int j = 0; j < UP_MAXB; ++j) {
-        const int cidx = meta[j] & 15, kidx = (meta[j] >> 4) & 15;
-        aoff[j] = trow * ROWB + ((cidx ^ trow) << 6) + tsub;
-        boff[j] = SLAB + trow * ROWB + ((kidx ^ trow) << 6) + tsub;
-    }
-    auto run = [&](auto ns_tag) {
-        constexpr int NS = decltype(ns_tag)::value;
-        for (int p = 0; p < pcount; ++p) {
-            const T* X = static_cast<const T*>(Xs.p[p]);
-            const T* E = static_cast<const T*>(Es.p[p]);
-            auto issue = [&](int q, int pos) {
-                const int n0 = min(q, q_end - 1) * CH;   // chunks past the end re-fetch the last one (never read)
-                const uint32_t slot = base_addr + pos * SLOT;
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int row = min(n0 + RPI * (NI * wave + i) + drow_in, N - 1);   // clamped rows are masked below
-                    const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (NI * wave + i) * 1024);
-                    glds16_asm(X + (size_t)row * Cf + xcol[i], dst);
-                    glds16_asm(E + (size_t)row * Kf + ecol[i], dst + SLAB);
-                }
-            };
-            if (q_beg >= q_end) break;
-#pragma unroll
-            for (int d = 0; d < UWN_D - 1; ++d) issue(q_beg + d, d);
-            int pos = 0, wpos = UWN_D - 1;
-            for (int q = q_beg; q < q_end; ++q) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI * (UWN_D - 2)) : "memory");   // my share of chunk q landed
-                __syncthreads();                                  // everyone's did; everyone finished chunk q-1
-                issue(q + UWN_D - 1, wpos);                       // refills the slot chunk q-1 used
-                const unsigned char* slot = smem + pos * SLOT;
-                pos = (pos + 1) & (UWN_D - 1);
-                wpos = (wpos + 1) & (UWN_D - 1);
-                const int n0 = q * CH;
-                constexpr int NK = CH / 16;     // 16 minibatch rows per MFMA
-                const bool tail = n0 + CH > N;  // ragged tail: rows >= N were clamped re-reads -> zero them (X side suffices)
-#pragma unroll
-                for (int kk = 0; kk < NK; ++kk) {   // fragments of one K sub-step for FB slots at a time, then their MFMAs
-                    constexpr int FB = (NW == 16 && NS > 2) ? 2 : NS;      // 16 waves: stay within 128 VGPRs
-#pragma unroll
-                    for (int j0 = 0; j0 < NS; j0 += FB) {
-                        uint4 a[FB], b[FB];
-#pragma unroll
-                        for (int jj = 0; jj < FB; ++jj) {
-                            const int j = (j0 + jj < NS) ? j0 + jj : NS - 1;
-                            const unsigned char* sa = slot + (16 * kk + 8 * h) * ROWB + aoff[j];
-                            const unsigned char* sb = slot + (16 * kk + 8 * h) * ROWB + boff[j];
-                            const uint2 a0 = ds_tr16(sa), a1 = ds_tr16(sa + 4 * ROWB);
-                            const uint2 b0 = ds_tr16(sb), b1 = ds_tr16(sb + 4 * ROWB);
-                            a[jj] = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                            b[jj] = make_uint4(b0.x, b0.y, b1.x, b1.y);
-                        }
-                        if (tail) {
-                            const int nb = n0 + 16 * kk + 8 * h;
-#pragma unroll
-                            for (int jj = 0; jj < FB; ++jj) {
-                                uint32_t* u = reinterpret_cast<uint32_t*>(&a[jj]);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
-                                    u[e] &= (lo | hi);
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < FB; ++jj)
-                            if (j0 + jj < NS) acc[j0 + jj] = DT::mfma32(a[jj], b[jj], acc[j0 + jj]);
-                    }
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();   // ring is re-primed for the next pair
-        }
-    };
-    switch (nslots) {
-        case 1: run(std::integral_constant<int, 1>{}); break;
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        case 3: run(std::integral_constant<int, 3>{}); break;
-        default: run(std::integral_constant<int, 4>{}); break;
-    }
-
-    // D[ci][ko]: col = ko = lane & 31, row ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int j = 0; j < UP_MAXB; ++j) {
-        if (!(meta[j] & 256)) continue;
-        const size_t base = (size_t)wid[j] * 1024 + (lane & 31);
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            const size_t idx = base + ci * 32;
-            if (scratch == nullptr) {
-                float out = alpha * acc[j][reg];
-                if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
-                DW[idx] = DT::from_f32(out);
-            } else {
-                __hip_atomic_fetch_add(scratch + idx, acc[j][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // feature_axis = 0 variant: activations are (C, N) / (K, N), the contraction index n is CONTIGUOUS for both operands, so
 // the slabs are [UW*32 feature rows][64 n] (128 B per row, 8-piece XOR swizzle as in bsmm_xcol.h) and the fragments are
-// plain ds_read_b128 -- no transposing reads.  One chunk = 64 minibatch columns = 4 MFMAs per block.
-// Requires N % 8 == 0 (16-byte aligned row pieces); the launcher falls back to the per-block kernel otherwise.
+// plain ds_read_b128 -- no transposing reads.  Requires N % 8 == 0 (16-byte aligned row pieces); the launcher falls back to the
+// per-block kernel otherwise.  (Geometry constants of the bsize-16 kernel's axis-0 form.)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int UW0_ROWS = UW * 32;
 constexpr int UW0_SLAB = UW0_ROWS * 128;                 // 32 KiB
 constexpr int UW0_SLOT = 2 * UW0_SLAB;
 constexpr int UW0_LDS = 2 * UW0_SLOT;                    // ring depth 2
 constexpr int UW0_NI = UW0_SLAB / 1024 / UP_WAVES;       // DMA instructions per wave per slab (8 rows each)
-
-template <class DT>
-__global__ void __launch_bounds__(512, 2)
-updat32_a0_win_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
-                      const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta) {
-    typedef typename DT::T T;
-    static_assert(DT::is16, "windowed updat: 16-bit storage types");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (plan[0] != UPLAN_MAGIC || plan[1] != UPLAN_VERSION || plan[2] != UW || plan[3] != UP_MAXB || plan[7] != UP_WAVES) return;
-    const int32_t* item = plan + plan[6] + (size_t)blockIdx.x * UP_ITEM;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c0 = item[0], k0 = item[1];
-    if (item[2] == 0) return;   // padding item
-    const int nslots = item[3] & 0xffff;
-    // wave v stages exactly block v of both slabs (UW0_NI instructions = 32 feature rows): skipped when the item has no block there
-    static_assert(8 * UW0_NI == 32, "a wave's DMA share is one 32-row block");
-    const bool xon = ((uint32_t)item[2] >> (16 + wave)) & 1, eon = ((uint32_t)item[3] >> (16 + wave)) & 1;
-    int meta[UP_MAXB], wid[UP_MAXB];
-#pragma unroll
-    for (int j = 0; j < UP_MAXB; ++j) {
-        meta[j] = item[4 + (wave * UP_MAXB + j) * 2];
-        wid[j] = item[4 + (wave * UP_MAXB + j) * 2 + 1];
-    }
-    const int nchunks = (N + 63) >> 6;
-    const int per = (nchunks + gridDim.y - 1) / gridDim.y;
-    const int q_beg = blockIdx.y * per, q_end = min(nchunks, q_beg + per);
-
-    const uint32_t base_addr = lds_addr_of(smem);
-    // DMA: instruction i of a slab covers rows 8i .. 8i+7; lane -> (row 8i + (lane >> 3), stored piece lane & 7)
-    size_t xrow[UW0_NI], erow[UW0_NI];   // element offset of this lane's source row (rows past the matrix are clamped)
-    int dpiece[UW0_NI];
-#pragma unroll
-    for (int i = 0; i < UW0_NI; ++i) {
-        const int row = 8 * (UW0_NI * wave + i) + (lane >> 3);
-        dpiece[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
-        xrow[i] = (size_t)min(c0 * 32 + row, Cf - 1) * N;
-        erow[i] = (size_t)min(k0 * 32 + row, Kf - 1) * N;
-    }
-    const int r = lane & 31, h = lane >> 5;
-    int aoff[UP_MAXB], boff[UP_MAXB];   // byte offset of this lane's row inside the X / DY slab
-    const int fsw = (r >> 1) & 7;
-#pragma unroll
-    for (int j = 0; j < UP_MAXB; ++j) {
-        aoff[j] = ((meta[j] & 15) * 32 + r) * 128;
-        boff[j] = UW0_SLAB + (((meta[j] >> 4) & 15) * 32 + r) * 128;
-    }
-    f32x16 acc[UP_MAXB];
-#pragma unroll
-    for (int j = 0; j < UP_MAXB; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-
-    auto run = [&](auto ns_tag) {
-        constexpr int NS = decltype(ns_tag)::value;
-        for (int p = 0; p < pcount; ++p) {
-            const T* X = static_cast<const T*>(Xs.p[p]);
-            const T* E = static_cast<const T*>(Es.p[p]);
-            auto issue = [&](int q, int pos) {
-                const int n0 = q * 64;
-                const uint32_t slot = base_addr + pos * UW0_SLOT;
-#pragma unroll
-                for (int i = 0; i < UW0_NI; ++i) {
-                    const int col = min(n0 + dpiece[i], N - 8);   // pieces past N are clamped re-reads (masked below)
-                    const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (UW0_NI * wave + i) * 1024);
-                    if (xon) glds16_asm(X + xrow[i] + col, dst);
-                    if (eon) glds16_asm(E + erow[i] + col, dst + UW0_SLAB);
-                }
-            };
-            if (q_beg >= q_end) break;
-            issue(q_beg, 0);
-            int pos = 0;
-            for (int q = q_beg; q < q_end; ++q) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (q + 1 < q_end) issue(q + 1, pos ^ 1);
-                const unsigned char* slot = smem + pos * UW0_SLOT;
-                pos ^= 1;
-                const int n0 = q * 64;
-                const bool tail = n0 + 64 > N;   // ragged tail (N % 64 != 0): zero the X elements whose n >= N
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {     // K = 16 minibatch columns per sub-step, all slots per sub-step
-                    const int po = ((2 * kk + h) ^ fsw) << 4;
-                    uint4 a[NS], b[NS];
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) {
-                        a[j] = *reinterpret_cast<const uint4*>(slot + aoff[j] + po);
-                        b[j] = *reinterpret_cast<const uint4*>(slot + boff[j] + po);
-                    }
-                    if (tail) {
-                        const int nb = n0 + 16 * kk + 8 * h;
-#pragma unroll
-                        for (int j = 0; j < NS; ++j) {
-                            uint32_t* u = reinterpret_cast<uint32_t*>(&a[j]);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const uint32_t lo = (nb + 2 * e < N) ? 0xffffu : 0u, hi = (nb + 2 * e + 1 < N) ? 0xffff0000u : 0u;
-                                u[e] &= (lo | hi);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) acc[j] = DT::mfma32(a[j], b[j], acc[j]);
-                }
-            }
-            __syncthreads();   // ring is re-primed for the next pair
-        }
-    };
-    switch (nslots) {
-        case 1: run(std::integral_constant<int, 1>{}); break;
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        case 3: run(std::integral_constant<int, 3>{}); break;
-        default: run(std::integral_constant<int, 4>{}); break;
-    }
-
-#pragma unroll
-    for (int j = 0; j < UP_MAXB; ++j) {
-        if (!(meta[j] & 256)) continue;
-        const size_t base = (size_t)wid[j] * 1024 + (lane & 31);
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            const size_t idx = base + ci * 32;
-            if (scratch == nullptr) {
-                float out = alpha * acc[j][reg];
-                if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
-                DW[idx] = DT::from_f32(out);
-            } else {
-                __hip_atomic_fetch_add(scratch + idx, acc[j][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // bsize 16: a 16x16-block window is the same 256x256 features, so slabs, DMA and swizzles are those of the bsize-32

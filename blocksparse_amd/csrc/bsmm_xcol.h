@@ -376,208 +376,7 @@ xcol32_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// fp32 version (BASELINE configs[1]): v_mfma_f32_32x32x2_f32, 16 instructions of 64 cycles per block and row tile.  This
-// kernel is MFMA-bound once the L2 feed bound of the per-segment kernel is gone (there every X fragment is fetched from
-// L2 for one single block), so the ownership is chosen for BALANCE, not for register reuse: wave (t, c) = (wave & 3,
-// wave >> 2) owns row tile t of the workgroup's 128 rows and output blocks 4c..4c+3 of the group; all four waves of a class do
-// identical work and each SIMD hosts one wave of either class (waves v and v+4), so the matrix pipes see the same load
-// whatever the layout.  (First attempt, wave = output block as in the 16-bit kernel: 62 TF against 79 TF of the
-// per-segment kernel, the waves with empty slots idle through every step.)
-// A wave walks its class's compacted entry list (xcolf plan), scalar-loading entries two ahead and the weight
-// fragment one entry ahead; the shared X slab goes through the same phase ring as the 16-bit kernel.
-//   axis 1: slab [128 rows][256 B] (a pair = 64 fp32 features), 16-byte pieces XOR-swizzled with row & 15; a lane's 16
-//           K values (k = 16h .. 16h+15) are 4 consecutive pieces -> 4 ds_read_b128.
-//   axis 0: slab [64 feature rows][512 B] (128 minibatch columns); the B operand wants one feature per MFMA for this
-//           lane's column: 16 ds_read_b32 of 128 contiguous bytes per half wave; rows 16..31 / 48..63 are stored with
-//           address bit 7 flipped so that the two half waves hit different banks.
-// ------------------------------------------------------------------------------------------------------------------
-#ifndef BSMM_XF_PH
-#define BSMM_XF_PH 2
-#endif
-#ifndef BSMM_XF_RT
-#define BSMM_XF_RT 1
-#endif
-constexpr int XF_PH = BSMM_XF_PH;                   // steps per phase
-constexpr int XF_RING = 2 * XF_PH;
-constexpr int XF_RT = BSMM_XF_RT;                   // 32-row tiles per wave (each for 4 output blocks)
-constexpr int XF_R = 128 * XF_RT;                   // minibatch rows per workgroup
-constexpr int XF_SLAB = XF_R * 256;                 // 32 KiB per 128 rows (either axis)
-constexpr int XF_LDS = XF_RING * XF_SLAB;           // 128 KiB = the axis-1 epilogue tile [128 rows][8 blocks x 128 B].  (XF_PH = 1:
-                                                    // 64 KiB, two workgroups per CU at 88 VGPRs, epilogue staged in two
-                                                    // halves -- measured SLOWER, 0.80 vs 0.645 ms: a barrier per step and
-                                                    // twice the groups competing for L2.)
-constexpr int XF_NI = XF_SLAB / 1024 / XC_G;        // DMA instructions per wave per slab
-
-template <int AXIS>
-__global__ void __launch_bounds__(512, 2)
-xcol32f_kernel(const float* __restrict__ X, const float* __restrict__ Wsel, float* __restrict__ Y,
-               const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout) {
-    typedef DTf32 DT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int tile, grp;
-    if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
-    if (plan[0] != XFPLAN_MAGIC || plan[1] != XFPLAN_VERSION || plan[2] != XC_G) return;
-    const int32_t* gh = plan + plan[5] + 8 * grp;
-    const int step_off = gh[0], nsteps = gh[1], ob0 = gh[2], nob = gh[3];
-    const int32_t* pairs = plan + plan[6] + step_off;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tw = wave & 3, cls = wave >> 2;
-    const int2* ent = reinterpret_cast<const int2*>(plan + plan[7]) + gh[4 + 2 * cls];
-    const int r = lane & 31, h = lane >> 5;
-    const int n_tile = tile * XF_R;
-    const uint32_t base_addr = lds_addr_of(smem);
-    const int npairs_full = Cin / 64;
-
-    size_t srow[XF_NI];
-    int scol[XF_NI];
-#pragma unroll
-    for (int i = 0; i < XF_NI; ++i) {
-        if constexpr (AXIS == 1) {     // 4 rows of 256 B per instruction; lane -> (row, stored piece lane & 15)
-            const int row = 4 * (XF_NI * wave + i) + (lane >> 4);
-            srow[i] = (size_t)min(n_tile + row, N - 1) * Cin;
-            scol[i] = ((lane & 15) ^ (row & 15)) * 4;              // element offset of the source piece inside the pair
-        } else {                       // feature rows of XF_R * 4 bytes: 1024 / that many rows per instruction
-            constexpr int LPR = XF_R / 4;                              // lanes (16-byte pieces) per row: 32 or 64
-            const int row = (64 / LPR) * (XF_NI * wave + i) + lane / LPR;
-            srow[i] = row;
-            scol[i] = min(n_tile + (((lane % LPR) ^ (8 * ((row >> 4) & 1))) * 4), N - 4);
-        }
-    }
-    auto issue_x = [&](int p, int pos) {
-#pragma unroll
-        for (int i = 0; i < XF_NI; ++i) {
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(base_addr + pos * XF_SLAB + (XF_NI * wave + i) * 1024);
-            if constexpr (AXIS == 1) {
-                const int col = (p < npairs_full || scol[i] < 32) ? scol[i] : scol[i] - 32;   // missing odd block: re-read the even one
-                glds16_asm(X + srow[i] + p * 64 + col, dst);
-            } else {
-                const size_t frow = (size_t)min(p * 64 + (int)srow[i], Cin - 1);
-                glds16_asm(X + frow * N + scol[i], dst);
-            }
-        }
-    };
-
-    f32x16 acc[4][XF_RT];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int u = 0; u < XF_RT; ++u)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[j][u][i] = 0.f;
-
-    auto load_w = [&](int w, Frag32<DT>& f) { f.load_contig(Wsel + (size_t)w * 1024 + r * 32, h); };
-    auto load_x = [&](const unsigned char* slab, int half, int u, Frag32<DT>& xf) {      // tile XF_RT * tw + u of the workgroup
-        if constexpr (AXIS == 1) {
-            const int row = 32 * (XF_RT * tw + u) + r;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = *reinterpret_cast<const float4*>(slab + row * 256 + (((8 * half + 4 * h + g) ^ (row & 15)) << 4));
-                xf.v[4 * g + 0] = v.x; xf.v[4 * g + 1] = v.y; xf.v[4 * g + 2] = v.z; xf.v[4 * g + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                xf.v[k] = *reinterpret_cast<const float*>(slab + (32 * half + 16 * h + k) * (XF_R * 4) + (((32 * (XF_RT * tw + u) + r) * 4) ^ (128 * h)));
-        }
-    };
-
-    // entries are wave-uniform: keep them in SGPRs (lists end with two sentinels (-1, INT_MAX), so reading ahead is safe)
-    auto fetch = [&](int i) {
-        const int2 v = ent[i];
-        return make_int2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y));
-    };
-    // The weight fragment of the next entry is fetched while the current one is multiplied (1024 MFMA cycles).  A deeper
-    // register FIFO (3 entries ahead, counted waits at the phase top) measured slower: 0.735 vs 0.645 ms.
-    int e = 0;
-    int2 cur = fetch(0), nxt = fetch(1);
-    Frag32<DT> wc, wn;
-    wc.zero(); wn.zero();
-    if (cur.x >= 0) load_w(cur.x, wc);
-#pragma unroll
-    for (int u = 0; u < XF_PH; ++u)
-        if (u < nsteps) issue_x(pairs[u], u);
-    for (int s = 0; s < nsteps; s += XF_PH) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < XF_PH; ++u)
-            if (s + XF_PH + u < nsteps) issue_x(pairs[s + XF_PH + u], (s + XF_PH + u) % XF_RING);
-        while ((cur.y >> 3) < s + XF_PH) {
-            if (nxt.x >= 0) load_w(nxt.x, wn);
-            const int2 nn = fetch(e + 2);
-            const unsigned char* slab = smem + ((cur.y >> 3) % XF_RING) * XF_SLAB;
-#pragma unroll
-            for (int u = 0; u < XF_RT; ++u) {
-                Frag32<DT> xf;
-                load_x(slab, cur.y & 1, u, xf);
-                switch ((cur.y >> 1) & 3) {
-                    case 0: mma32<DT>(wc, xf, acc[0][u]); break;
-                    case 1: mma32<DT>(wc, xf, acc[1][u]); break;
-                    case 2: mma32<DT>(wc, xf, acc[2][u]); break;
-                    default: mma32<DT>(wc, xf, acc[3][u]); break;
-                }
-            }
-            wc = wn; cur = nxt; nxt = nn; ++e;
-        }
-    }
-
-    if constexpr (AXIS == 1) {
-        // D[o][n]: col = n = r, rows o = (reg & 3) + 8 * (reg >> 2) + 4h: 4 consecutive o = one 16-byte piece.
-        // Staged as [128 rows][1024 B] (pieces XOR-swizzled with n & 63) and stored as full rows.
-        constexpr int ROWS = (XF_LDS / 1024 < XF_R) ? XF_LDS / 1024 : XF_R;       // rows staged per pass
-        constexpr int PASSES = XF_R / ROWS;
-        static_assert(ROWS % 32 == 0 && PASSES * ROWS == XF_R, "staging passes must cover whole tiles");
-        const int rowbytes = nob * 128;
-        float* ybase = Y + (size_t)ob0 * 32;
-#pragma unroll
-        for (int hp = 0; hp < PASSES; ++hp) {
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < XF_RT; ++u) {
-                const int n = 32 * (XF_RT * tw + u) + r - hp * ROWS;               // row inside this pass
-                if (n >= 0 && n < ROWS) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (4 * cls + j < nob) {
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const int piece = (4 * cls + j) * 8 + 2 * g + h;
-                                *reinterpret_cast<float4*>(smem + n * 1024 + ((piece ^ (n & 63)) << 4)) =
-                                    make_float4(acc[j][u][4 * g + 0], acc[j][u][4 * g + 1], acc[j][u][4 * g + 2], acc[j][u][4 * g + 3]);
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < ROWS * 64; i += 512) {
-                const int nn = i >> 6, piece = i & 63, row = n_tile + hp * ROWS + nn;
-                if (row < N && piece * 16 < rowbytes) {
-                    const float4 v = *reinterpret_cast<const float4*>(smem + nn * 1024 + ((piece ^ (nn & 63)) << 4));
-                    *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)row * Kout) + piece * 16) = v;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < XF_RT; ++u) {
-            const int n = n_tile + 32 * (XF_RT * tw + u) + r;
-            if (n < N) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (4 * cls + j < nob) {
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int o = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                            Y[(size_t)((ob0 + 4 * cls + j) * 32 + o) * N + n] = acc[j][u][reg];
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
+// (The fp32 matrix-core version of this kernel, xcol32f_kernel on v_mfma_f32_32x32x2_f32 with its 'BSXF' plans -- 0.65 / 0.61 ms at the bench
+// shape against 0.48 / 0.47 for the exact bf16 three-piece split of bsmm_xcols.h -- was kept for A/B through round 3 and retired in round 4.)
 
 }  // namespace bsmm

@@ -21,7 +21,15 @@
 #include "bsmm_plan.h"
 #include "bsmm_updat_v2.h"   // glds16_saddr, uniform_ptr
 #include "bsmm_xcol.h"       // slab geometry
-#include "bsmm_xcol16.h"     // BSMM_XC16_TH_*
+#include "bsmm_xcol.h"
+// row tiles whose X fragments the K = 32 pair loop holds in registers at once (measured on the retired round-1 kernel and kept: 2 on
+// feature axis 1, 1 on axis 0 where the transposing LDS reads take longer; all 8 tiles = 156 VGPRs halved the occupancy)
+#ifndef BSMM_XC16_TH_A1
+#define BSMM_XC16_TH_A1 2
+#endif
+#ifndef BSMM_XC16_TH_A0
+#define BSMM_XC16_TH_A0 1
+#endif
 
 namespace bsmm {
 

@@ -46,8 +46,9 @@ extern "C" {
 /* ABI version: bumped whenever struct bsmm_args, a plan format or an option bit range changes.  Bindings compare it with the
  * header they were written against (blocksparse_amd/_lib.py does at load time).
  *   100 rounds 1-2;  110 round 3 (bsmm_args.prepared_w, BSMM_PLAN_UPDAT_SETS_SHIFT moved to bits 12..15, 'BSX7' plans v2, composite
- *   'BSS8' / 'BS64' descriptors);  120 round 4 (see DESIGN.md "Round 4") */
-#define BSMM_VERSION 120
+ *   'BSS8' / 'BS64' descriptors);  120 round 4 (see DESIGN.md "Round 4");  121 round 4: kernels retired -- 'BSX6' (bsize 16, round 1), 'BSXF' (fp32
+ *   matrix-core instruction) and bsize-32 'BSUP' plans are no longer built or accepted, the options that named them are aliases */
+#define BSMM_VERSION 121
 
 enum { BSMM_F32 = 0, BSMM_F16 = 1, BSMM_BF16 = 2 };
 enum {
@@ -66,6 +67,7 @@ enum {
 /* bsmm_args.trace: which kernel family a call dispatched to (tests assert that the intended kernel ran) */
 enum {
     BSMM_K_NONE = 0,
+    /* (4 BSMM_K_XCOL16, 6 BSMM_K_XCOL32_F32MFMA and 19 BSMM_K_UPDAT_WIN belonged to kernels retired in round 4: never reported any more) */
     BSMM_K_XPROP_VALU = 1, BSMM_K_XPROP_SEGMENT = 2, BSMM_K_XCOL32 = 3, BSMM_K_XCOL16 = 4, BSMM_K_XCOL32_F32SPLIT = 5,
     BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7, BSMM_K_XCOL32_STAGED = 8, BSMM_K_XCOL16_STAGED = 9, BSMM_K_XCOL32_FLOW = 10, BSMM_K_XPROP_SMALL = 11, BSMM_K_XPROP_MID = 12,
     BSMM_K_UPDAT_VALU = 16, BSMM_K_UPDAT_BLOCK = 17, BSMM_K_UPDAT_BLOCK_TR = 18, BSMM_K_UPDAT_WIN = 19, BSMM_K_UPDAT16_WIN = 20,
@@ -75,13 +77,15 @@ enum {
 /* options of the plan builders (0 = the library's default for the layout) */
 enum {
     BSMM_PLAN_XCOL_NARROW = 1,      /* xprop bsize 32 / 16: 8 (16) output blocks per workgroup instead of 16 (32)            */
-    BSMM_PLAN_F32_MFMA = 2,         /* xprop fp32 bsize 32: schedule for the fp32 matrix-core kernel instead of the bf16 split */
-    BSMM_PLAN_XCOL_UNSTAGED = 4,    /* xprop bsize 32 / 16, 16-bit: the round-1 kernel (weights by register loads, bsmm_xcol.h)
-                                       instead of the staged one (weights through LDS as well, bsmm_xcol_v2.h)                */
+    BSMM_PLAN_F32_MFMA = 2,         /* (retired in round 4: the fp32 matrix-core kernel xcol32f, 0.65 ms against 0.48 for the exact bf16 split
+                                       at the bench shape; accepted and ignored)                                                 */
+    BSMM_PLAN_XCOL_UNSTAGED = 4,    /* xprop bsize 32, 16-bit: the round-1 kernel (weights by register loads, bsmm_xcol.h) instead of the
+                                       staged one (weights through LDS as well, bsmm_xcol_v2.h).  bsize 16: its round-1 kernel was
+                                       retired in round 4 -- ignored there, as is _NARROW                                        */
     BSMM_PLAN_XCOL_FLOW = 8,        /* xprop bsize 32, 16-bit, feature axis 1: the barrier-free persistent kernel (bsmm_xflow.h, 'BSX4' plans) */
-    BSMM_PLAN_WINDOW_8 = 0x10,      /* updat bsize 32: round-1 windowed kernel, 8x8-block windows, 8 waves                  */
-    BSMM_PLAN_WINDOW_16 = 0x20,     /*                 round-1 windowed kernel, 16x16-block windows, 8 waves                */
-    BSMM_PLAN_WINDOW_16W = 0x30,    /*                 round-1 windowed kernel, 16x16-block windows, 16 waves               */
+    BSMM_PLAN_WINDOW_8 = 0x10,      /* updat bsize 32: (the windowed kernels of round 1 were retired in round 4: now aliases)  = BSMM_PLAN_STREAM_8  */
+    BSMM_PLAN_WINDOW_16 = 0x20,     /*                                                                                  = BSMM_PLAN_STREAM_16 */
+    BSMM_PLAN_WINDOW_16W = 0x30,    /*                                                                                  = BSMM_PLAN_STREAM_16 */
     BSMM_PLAN_STREAM_16 = 0x40,     /*                 streaming kernel (bsmm_updat_v2.h, axis 1), 16x16-block windows      */
     BSMM_PLAN_STREAM_8 = 0x50,      /*                 streaming kernel, 8x8-block windows (dense layouts)                  */
     BSMM_PLAN_STREAM_32 = 0x60,     /*                 streaming kernel, 32x32-block windows (sparse layouts, feature axis 1)    */

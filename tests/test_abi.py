@@ -233,30 +233,16 @@ def test_plan_builder_covers_every_block_once(lib):
                         want.add((ob, c, w))
                 assert got == want
                 # fp32 (bsize 32): the split kernel (bsmm_xcols.h) walks the 16-wide 'BSXC' format of the 16-bit kernels, both axes
-                # (the 'BSXF' format of the fp32-MFMA kernel xcol32f is only built with BSMM_PLAN_F32_MFMA)
+                # (the fp32-MFMA kernel xcol32f and its 'BSXF' plans were retired in round 4: BSMM_PLAN_F32_MFMA is ignored)
+                assert (_host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.F32, axis, lib.PLAN_F32_MFMA) == _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.F32, axis)).all()
                 pf = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.F32, axis)
                 assert pf[0] == 0x42535843 and int(pf[2]) == 16
                 assert _check_xcol_plan(pf, f, t, n_out) == want
-                # bsize 16: quads of input blocks, 16 output blocks per group, slot = 4*member + (c & 3)
-                p16 = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis, lib.PLAN_XCOL_UNSTAGED)   # round-1 'BSX6'
-                assert p16[0] == 0x42535836 and p16[8] == n_out
-                G16 = int(p16[2])
-                groups = p16[p16[5]:p16[6]].reshape(-1, 4)
-                quads = p16[p16[6]:p16[7]]
-                got16 = set()
-                for g, (so, ns, ob0, nob) in enumerate(groups):
-                    assert ob0 == g * G16 and nob == min(G16, n_out - ob0)
-                    gq = quads[so:so + ns]
-                    assert len(set(gq.tolist())) == ns and list(gq) == sorted(gq)
-                    base = int(p16[7]) + 4 * G16 * so
-                    tab = p16[base:base + 4 * G16 * ns].reshape(4 * G16, ns)
-                    for slot in range(4 * G16):
-                        for tt in range(ns):
-                            w = int(tab[slot, tt])
-                            if w >= 0:
-                                assert (slot >> 2) < nob
-                                got16.add((ob0 + (slot >> 2), 4 * int(gq[tt]) + (slot & 3), w))
-                assert got16 == want
+                # bsize 16: the round-1 kernel ('BSX6' plans) was retired in round 4 -- the option that named it is ignored: the 'BSX7' plan
+                # of the staged / list kernels either way (its contents: test_staged16_* below)
+                p16 = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis, lib.PLAN_XCOL_UNSTAGED)
+                d16 = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis)
+                assert p16 is not None and p16[0] == 0x42535837 and (p16 == d16).all()
     # no plan kernels for fp32 at bsize 16, nor for bsize-8 grids that are not whole 32-feature blocks (tests/test_super8_plan.py)
     t = L.build_tables(np.ones((2, 2)))
     assert _host_plan(t["fprop"]["lut"], 2, 4, 2, 16, lib.F32, 1) is None
@@ -408,7 +394,7 @@ def test_staged_xcol16_plan(lib):
 
 
 def test_updat_plan_covers_every_block_once(lib):
-    """bsmm_updat_plan_build, round-1 windowed formats ('BSUP': bsize 16, or BSMM_PLAN_WINDOW_* at bsize 32): every weight
+    """bsmm_updat_plan_build, the windowed format ('BSUP': bsize 16): every weight
     block appears in exactly one (item, wave, slot), inside its window, items are padded to a multiple of 8 (one list per XCD),
     every wave of an item has at most `nslots` blocks."""
     import numpy as np
@@ -419,11 +405,15 @@ def test_updat_plan_covers_every_block_once(lib):
         lay = rng.random((CB, KB)) < dens
         lay[0, 0] = True
         t = L.build_tables(lay)
-        for bsize, axis, opt in ((32, 0, lib.PLAN_WINDOW_8), (32, 1, lib.PLAN_WINDOW_8), (32, 1, lib.PLAN_WINDOW_16), (32, 1, lib.PLAN_WINDOW_16W), (16, 1, 0), (16, 0, 0)):
+        # bsize 32: BSMM_PLAN_WINDOW_* named the windowed kernels of round 1 (retired in round 4) -- the streaming plan with that window side
+        for opt, same in ((lib.PLAN_WINDOW_8, lib.PLAN_STREAM_8), (lib.PLAN_WINDOW_16, lib.PLAN_STREAM_16), (lib.PLAN_WINDOW_16W, lib.PLAN_STREAM_16)):
+            for axis in (0, 1):
+                pw = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, axis, opt)
+                assert pw[0] == 0x42535532 and (pw == _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, axis, same)).all()
+        for bsize, axis, opt in ((16, 1, 0), (16, 0, 0)):
             plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, bsize, lib.BF16, axis, opt)
             assert plan[0] == 0x42535550 and plan[5] == t["blocks"]
-            want_w = {0: 8 if bsize == 32 else 16, lib.PLAN_WINDOW_8: 8, lib.PLAN_WINDOW_16: 16, lib.PLAN_WINDOW_16W: 16}[opt]
-            assert plan[2] == want_w and plan[7] == (16 if opt == lib.PLAN_WINDOW_16W else 8)
+            assert plan[2] == 16 and plan[7] == 8
             UW, MAXB, nitems, waves = int(plan[2]), int(plan[3]), int(plan[4]), int(plan[7])
             assert nitems % 8 == 0
             isz = 4 + waves * MAXB * 2
@@ -606,12 +596,13 @@ def test_plan_attach_descriptor_and_host_side_rejection(lib):
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.BF16, 1, lib.PLAN_XCOL_NARROW))
     assert (a.plan_width, a.plan_waves) == (8, 8)
     a = attach(_host_plan(f["lut"], f["segments"], t["blocks"], 24, 32, lib.F32, 1, lib.PLAN_F32_MFMA))
-    assert a.plan_magic == 0x42535846
-    up = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 32, lib.BF16, 1, lib.PLAN_WINDOW_16W)
+    assert (a.plan_magic, a.plan_width) == (0x42535843, 16)      # fp32: the split kernel's 'BSXC' plan (the fp32-MFMA kernel was retired)
+    up = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 16, lib.BF16, 1)
     a = attach(up)
-    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items) == (0x42535550, 16, 16, int(up[4]))
-    a = attach(_host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 32, lib.BF16, 1, lib.PLAN_WINDOW_8))
-    assert (a.plan_width, a.plan_waves) == (8, 8)
+    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items) == (0x42535550, 16, 8, int(up[4]))      # bsize 16: the windowed 'BSUP' plan
+    up = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 32, lib.BF16, 1, lib.PLAN_WINDOW_8)
+    a = attach(up)
+    assert (a.plan_magic, a.plan_width, a.plan_waves, a.plan_items) == (0x42535532, 8, 16, int(up[4]))       # bsize 32: streaming, 8x8 windows
     s8 = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 8, lib.BF16, 0)
     a = attach(s8)
     # bsize 8: the nested plan's width | its format (2 = the streaming 'BSU2' plan, round 3) << 8 | its descriptor word << 11

@@ -4,7 +4,7 @@ through bsmm_args.trace WHICH kernel family ran, so a silent fall-back to a gene
 
   (a) the bench shape: 4096^2, bsize 32, bf16, minibatch 8192, density 10 / 20 / 50 % (feature axis 1; 20 % on axis 0 too)
   (b) BASELINE configs[3]: 8192^2, 5 %, bf16, the per-GPU shard N = 512 and the whole minibatch N = 4096, all three passes
-  (c) the 16-wave 16x16-window updat variant (BSMM_PLAN_WINDOW_16W) and forced 16x16 / 8x8 windows
+  (c) forced window sides of the streaming updat plan (BSMM_PLAN_STREAM_* and the legacy BSMM_PLAN_WINDOW_* names)
   (d) small forced-plan layouts whose 16x16 windows hold several blocks (multi-block windows, shared fragments, split items)
   (e) the reference's own test matrix at its own size: Barabasi-Albert(160, 5) + I, N in {256,128,64,32,16,8},
       bsize 32/16/8 (test/blocksparse_matmul_test.py:276-328), here on both feature axes
@@ -29,10 +29,9 @@ def env():
 
 
 def _updat_kernel(lib, axis, opt=0):
-    """which bsize-32 updat kernel a plan built with `opt` runs: both axes default to the streaming kernel (bsmm_updat_v2.h)"""
-    if opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8, lib.PLAN_STREAM_32):
-        return lib.K_UPDAT_STREAM
-    return lib.K_UPDAT_WIN
+    """which bsize-32 updat kernel a plan built with `opt` runs: the streaming kernel (bsmm_updat_v2.h) on both axes -- the windowed
+    kernels of round 1 were retired in round 4, BSMM_PLAN_WINDOW_* now name the window side of the streaming plan"""
+    return lib.K_UPDAT_STREAM
 
 
 def _xprop_kernel(lib, axis, opt=0):
@@ -325,13 +324,12 @@ def test_staged_and_round1_xprop_kernels_agree_bitwise(env, axis):
 @pytest.mark.parametrize("axis", [1, 0])
 @pytest.mark.parametrize("opt", [0, "PLAN_XCOL_UNSTAGED"])
 def test_small_layouts_bsize16_xprop_plan_kernels(env, opt, axis):
-    """bsize 16: the staged kernel ('BSX7' plans: weight blocks by LDS-DMA, two per instruction, zero slot for absent partners of a
-    K-concatenated pair) and the round-1 kernel against the full oracle -- dense layouts (steps of 128 blocks are split), block counts
-    that are not multiples of 4 (trailing quad with missing blocks), partial last group, ragged minibatch -- and against each other
-    bit for bit at BASELINE configs[2]."""
+    """bsize 16: the staged / list kernels ('BSX7' plans: weight blocks by LDS-DMA, two per instruction) against the full oracle -- dense
+    layouts (steps of 128 blocks are split), block counts that are not multiples of 4 (trailing quad with missing blocks), partial last
+    group, ragged minibatch.  BSMM_PLAN_XCOL_UNSTAGED named the round-1 kernel (retired in round 4) and is ignored: the same kernels."""
     torch, BSMM, lib = env
     o = getattr(lib, opt) if opt else 0
-    want_k = lib.K_XCOL16 if o else lib.K_XCOL16_STAGED
+    want_k = lib.K_XCOL16_STAGED
     cases = [(np.ones((9, 70), dtype=bool), (72, 200)), (P.random_layout(33, 17, 0.3, seed=3), (104, 8)), (np.ones((1, 1), dtype=bool), (40,)),
              (P.random_layout(80, 80, 0.15, seed=2), (392, 128)), (P.ba_layout(80, 3, seed=1), (264,))]
     try:
@@ -352,14 +350,6 @@ def test_small_layouts_bsize16_xprop_plan_kernels(env, opt, axis):
                     assert l2y <= P.L2_BAR[dtype] and l2x <= P.L2_BAR[dtype], (opt, axis, li, N, dtype, l2y, l2x)
     finally:
         lib.set_kernel_variant(0)
-    if o == 0:
-        layout = P.random_layout(256, 256, 0.1, seed=1234)
-        outs = []
-        for oo in (0, lib.PLAN_XCOL_UNSTAGED):
-            b = BSMM(layout, block_size=16, feature_axis=axis, plan_options=oo)
-            w, x, e = _inputs(torch, b, 4096, "bf16", seed=6)
-            outs.append((b.fprop(x, w), b.bprop(e, w)))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def test_bsize64_axis1(env):
