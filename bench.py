@@ -759,9 +759,10 @@ def main():
         tf32 = 2.0 * b32.blocks * bsize0 ** 2 * N / ms32 / 1e9
         out["fp32_fprop_axis1"] = {"workload": "BASELINE configs[1]: %dx%d bs%d d%.0f%% fp32 feature_axis=1 fprop, minibatch %d" %
                                                (hidden0, hidden0, bsize0, dens0 * 100, N),
-                                   "kernel": "exact three-piece bf16 split on v_mfma_f32_32x32x16_bf16; `ms` includes BOTH split pre-passes (activations "
-                                             "and weights: what a training step pays), `ms_weights_cached` only the activation split (inference: "
-                                             "bsmm_prepare_weights once per weights version)",
+                                   "kernel": "exact three-piece bf16 split on v_mfma_f32_32x32x16_bf16; round 4: the activations are split INSIDE the "
+                                             "kernel (fp32 slabs staged by LDS-DMA, pieces made between LDS and LDS: xcol32sf_kernel), no activation "
+                                             "pre-pass, no pieces in the workspace; `ms` includes the split of the weights (one launch per weights "
+                                             "version: what a training step pays), `ms_weights_cached` does not (bsmm_prepare_weights once)",
                                    "ms": round(ms32, 4), "ms_weights_cached": round(ms32_cached, 4), "tflops": round(tf32, 2), "peak": PEAK_MFMA["f32"],
                                    "frac": round(tf32 / PEAK_MFMA["f32"], 4),
                                    "peak_bf16_six_products": round(PEAK_MFMA["bf16"] / 6, 1),

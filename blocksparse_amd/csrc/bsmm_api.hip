@@ -214,20 +214,28 @@ int launch_xcol16(const void* X, const void* Wsel, void* Y, const bsmm_args* a, 
 // fp32 on the bf16 matrix cores: split pre-passes into the workspace ([3][N*C] activation pieces, then [3][blocks*1024]
 // weight pieces), then the wide xcol kernel with three slabs per step.
 inline size_t xcols_w_bytes(const bsmm_args* a) { return 6 * (size_t)a->blocks * 1024; }
+#ifndef XS_NO_FUSE      // (experiment switch: -DXS_NO_FUSE=1 keeps the activation-split pre-pass on feature axis 1 too, for A/B)
+#define XS_NO_FUSE 0
+#endif
+// feature axis 1 (round 4): the activations are split inside the kernel (xcol32sf_kernel) -- no pieces of X in the workspace
+inline bool xcols_fused(const bsmm_args* a) { return a->axis == 1 && !XS_NO_FUSE; }
 inline size_t xcols_workspace_bytes(const bsmm_args* a) {
-    return 6 * (size_t)a->N * a->C + (a->prepared_w ? 0 : xcols_w_bytes(a));
+    return (xcols_fused(a) ? 0 : 6 * (size_t)a->N * a->C) + (a->prepared_w ? 0 : xcols_w_bytes(a));
 }
 template <int AXIS>
 int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a, hipStream_t st) {
     const size_t nx = (size_t)a->N * a->C;
     if (a->plan_magic != XCPLAN_MAGIC || a->plan_width != XS_G) return BSMM_ERR_ARG;
-    if (!a->workspace || a->workspace_bytes < xcols_workspace_bytes(a) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+    const bool fused = AXIS == 1 && xcols_fused(a);
+    const size_t need = xcols_workspace_bytes(a);
+    if (need && (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace))) return BSMM_ERR_WORKSPACE;
     if (a->prepared_w && !aligned16(a->prepared_w)) return BSMM_ERR_ARG;
+    if (fused && !aligned16(X)) return BSMM_ERR_ARG;                       // (16-byte row pieces of the fp32 activations; C % 32 == 0 is checked by the dispatch)
     uint16_t* xp = static_cast<uint16_t*>(a->workspace);
     const uint16_t* wp = static_cast<const uint16_t*>(a->prepared_w);
-    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X), xp, nx);
+    if (!fused) split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X), xp, nx);
     if (!wp) {      // W's pieces are a constant of the pass: a caller that holds them (bsmm_prepare_weights) skips this launch
-        uint16_t* wq = xp + 3 * nx;
+        uint16_t* wq = fused ? xp : xp + 3 * nx;
         if (fprop) split3_w_kernel<true><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), wq, a->blocks);
         else       split3_w_kernel<false><<<a->blocks, 256, 0, st>>>(static_cast<const float*>(W), wq, a->blocks);
         wp = wq;
@@ -239,8 +247,15 @@ int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds<&xcol32s_kernel<AXIS>>(XS_LDS)) return rc;
     trace(a, BSMM_K_XCOL32_F32SPLIT);
+    if constexpr (AXIS == 1) {
+        if (fused) {
+            if (int rc = ensure_lds<&xcol32sf_kernel>(XSF_LDS)) return rc;
+            xcol32sf_kernel<<<m.grid(), 64 * XS_G, XSF_LDS, st>>>(static_cast<const float*>(X), wp, static_cast<float*>(Y), a->plan, m, a->N, a->C, a->K, a->blocks);
+            return (int)hipGetLastError();
+        }
+    }
+    if (int rc = ensure_lds<&xcol32s_kernel<AXIS>>(XS_LDS)) return rc;
     xcol32s_kernel<AXIS><<<m.grid(), 64 * XS_G, XS_LDS, st>>>(xp, wp, static_cast<float*>(Y), a->plan, m, a->N, a->C, a->K, a->blocks);
     return (int)hipGetLastError();
 }

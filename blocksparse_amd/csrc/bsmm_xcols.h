@@ -55,8 +55,14 @@ split3_w_kernel(const float* __restrict__ W, uint16_t* __restrict__ P, int block
     const float* src = W + (size_t)w * 1024;
     float v[4];
     if constexpr (TRANS) {
+        // through LDS: the block is read as full rows (the strided gather of round 3 made this launch 35 us at the bench shape, against
+        // 8 us for the other orientation), rows padded to 33 words so that the column reads below hit 32 different banks
+        __shared__ float tile[32 * 33];
+        const float4 a = *reinterpret_cast<const float4*>(src + o * 32 + i0);
+        tile[o * 33 + i0 + 0] = a.x; tile[o * 33 + i0 + 1] = a.y; tile[o * 33 + i0 + 2] = a.z; tile[o * 33 + i0 + 3] = a.w;
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = src[(i0 + j) * 32 + o];
+        for (int j = 0; j < 4; ++j) v[j] = tile[(i0 + j) * 33 + o];
     } else {
         const float4 a = *reinterpret_cast<const float4*>(src + o * 32 + i0);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
@@ -272,6 +278,194 @@ xcol32s_kernel(const uint16_t* __restrict__ Xp, const uint16_t* __restrict__ Wp,
             }
         }
     }
+    }
+}
+
+// ---- feature axis 1, round 4: the activation split FUSED into the kernel ---------------------------------------
+// The pre-pass above reads the fp32 activations and writes 6 bytes per element of pieces (335 MB, 52 us at the bench shape) that the main
+// kernel then streams as three 16 KiB slabs per pair step.  Here the fp32 slab itself (128 rows x 64 features = 32 KiB, two thirds of the
+// bytes) is staged by LDS-DMA, and the pieces are made on the way from LDS to LDS: wave v requests rows 8v .. 8v + 7 of a step's slab
+// (two 1 KiB instructions: 4 rows x 256 B) and converts exactly THOSE rows -- so a counted wait on its own requests is all it needs
+// before it reads them -- into the piece slabs of the layout the fragment reads expect (the image the bf16 DMA of xcol32s_kernel
+// produces: row r, 16-byte piece j at position j ^ ((r >> 1) & 7)).  Thread (row R = tid >> 3, piece j = tid & 7) splits 8 values: two
+// 16-byte reads, ~60 vector operations, three 16-byte writes -- per step and wave, next to 48 MFMAs per block.  Ring: two stage slots of
+// 32 KiB (requested TWO steps ahead) + two piece slots of 48 KiB = 160 KiB, one barrier per step as before: at the top of iteration s
+// the barrier says that every wave has converted step s (done in iteration s - 1) and finished the blocks of step s - 1, whose piece
+// slot the conversion of step s + 1 now overwrites.  Same pieces, same MFMA order: bit-identical to the pre-pass form.
+constexpr int XSF_STAGE = XC_R * 256;                 // fp32 slab of a pair step: 32 KiB
+constexpr int XSF_LDS = 2 * XS_SLOT + 2 * XSF_STAGE;  // 160 KiB
+static_assert(XC_R == 128 && XSF_LDS == 163840, "the fused-split kernel fills the LDS of a CU");
+
+__global__ void __launch_bounds__(64 * XS_G, 4)
+xcol32sf_kernel(const float* __restrict__ Xf, const uint16_t* __restrict__ Wp, float* __restrict__ Y,
+                const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout, int blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile, grp;
+    if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
+    if (plan[0] != XCPLAN_MAGIC || plan[1] != XCPLAN_VERSION || plan[2] != XS_G) return;
+    const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
+    const int step_off = gh.x, nsteps = gh.y, ob0 = gh.z, nob = gh.w;
+    const int32_t* pairs = plan + plan[6] + step_off;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t* wt0 = plan + plan[7] + 2 * XS_G * step_off + (2 * wave) * nsteps;   // my column, even half of the pair
+    const int32_t* wt1 = wt0 + nsteps;                                                  // odd half
+    const int r = lane & 31, h = lane >> 5;
+    const int n_tile = tile * XC_R;
+    const uint32_t base_addr = lds_addr_of(smem);
+    unsigned char* stage = smem + 2 * XS_SLOT;
+    const int npairs_full = Cin / 64;
+    const size_t wstride = (size_t)blocks * 1024;
+
+    // stage DMA: instruction i of a slab = rows 4 i .. 4 i + 3 (256 B each), this lane's 16 bytes = floats 4 (lane & 15) .. of row
+    // 4 i + (lane >> 4); wave v issues instructions 2 v and 2 v + 1.  Rows past N re-read row N - 1 (never stored); a trailing pair
+    // without its odd block re-reads the even one (never multiplied: the plan has no entry there).
+    const int d_row0 = 8 * wave + (lane >> 4), d_q = lane & 15;
+    const float* xsrc0 = Xf + (size_t)min(n_tile + d_row0, N - 1) * Cin + 4 * d_q;
+    const float* xsrc1 = Xf + (size_t)min(n_tile + d_row0 + 4, N - 1) * Cin + 4 * d_q;
+    const int oddsub = d_q >= 8 ? 32 : 0;
+    auto issue_x = [&](int p, int pos) {
+        const int off = p * 64 - (p < npairs_full ? 0 : oddsub);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(base_addr + 2 * XS_SLOT + pos * XSF_STAGE + wave * 2048);
+        glds16_asm(xsrc0 + off, dst);
+        glds16_asm(xsrc1 + off, dst + 1024);
+    };
+    // conversion of my rows of a stage slot into a piece slot
+    const int cR = 8 * wave + (lane >> 3), cj = lane & 7;
+    const int c_rd = cR * 256 + cj * 32, c_wr = cR * 128 + ((cj ^ ((cR >> 1) & 7)) << 4);
+    auto convert = [&](int pos) {
+        const unsigned char* src = stage + pos * XSF_STAGE + c_rd;
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 16);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t pc[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(v[j], pc[0][j], pc[1][j], pc[2][j]);
+        unsigned char* dst = smem + pos * XS_SLOT + c_wr;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            *reinterpret_cast<uint4*>(dst + q * XC_SLAB) = make_uint4(pc[q][0] | (pc[q][1] << 16), pc[q][2] | (pc[q][3] << 16),
+                                                                      pc[q][4] | (pc[q][5] << 16), pc[q][6] | (pc[q][7] << 16));
+    };
+    const int xsw = (r >> 1) & 7;
+    int xrd[2][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) xrd[half][kk] = r * 128 + (((4 * half + 2 * kk + h) ^ xsw) << 4);
+
+    f32x16 acc[XC_RT];
+#pragma unroll
+    for (int t = 0; t < XC_RT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    u32x4 wq[3][2];      // weight pieces of the entry this wave handles next: [piece][K half]
+#pragma unroll
+    for (int q = 0; q < 3; ++q) wq[q][0] = wq[q][1] = u32x4{0u, 0u, 0u, 0u};
+    auto request_w = [&](int w) {
+        const uint16_t* row = Wp + (size_t)w * 1024 + r * 32 + 8 * h;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            gload16_asm(wq[q][0], row + q * wstride);
+            gload16_asm(wq[q][1], row + q * wstride + 16);
+        }
+    };
+    auto wait_all = [&]() {      // everything this wave requested has landed; ties the weight registers to the wait
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(wq[0][0]), "+v"(wq[0][1]), "+v"(wq[1][0]), "+v"(wq[1][1]), "+v"(wq[2][0]), "+v"(wq[2][1])
+                     :
+                     : "memory");
+    };
+    auto block = [&](const unsigned char* slot, int half) {
+#pragma unroll
+        for (int t = 0; t < XC_RT; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned char* p = slot + t * 4096 + xrd[half][kk];
+                const uint4 x0 = *reinterpret_cast<const uint4*>(p);
+                const uint4 x1 = *reinterpret_cast<const uint4*>(p + XC_SLAB);
+                const uint4 x2 = *reinterpret_cast<const uint4*>(p + 2 * XC_SLAB);
+                // smallest terms first (the order of xcol32s_kernel)
+                acc[t] = mfma32_bf16(wq[2][kk], x0, acc[t]);
+                acc[t] = mfma32_bf16(wq[1][kk], x1, acc[t]);
+                acc[t] = mfma32_bf16(wq[0][kk], x2, acc[t]);
+                acc[t] = mfma32_bf16(wq[1][kk], x0, acc[t]);
+                acc[t] = mfma32_bf16(wq[0][kk], x1, acc[t]);
+                acc[t] = mfma32_bf16(wq[0][kk], x0, acc[t]);
+            }
+    };
+
+    const bool owner = wave < nob;
+    if (nsteps > 0) {
+        for (int tb = 0; tb < nsteps; tb += 64) {     // lane-indexed tables for steps [tb, tb+64)
+            const int idx = min(tb + lane, nsteps - 1);
+            const int pv = pairs[idx];
+            const int tend = min(64, nsteps - tb);
+            const int w0v = (owner && lane < tend) ? wt0[idx] : -1, w1v = (owner && lane < tend) ? wt1[idx] : -1;
+            const uint64_t m0 = __ballot(w0v >= 0), m1 = __ballot(w1v >= 0);     // bit s: this wave has a block in half 0 / 1 of step s
+            auto next_entry = [&](int e) -> int {      // first entry >= e (e = 2 * step + half), or 128
+                const int s = e >> 1;
+                if (s >= 64) return 128;
+                uint64_t a = m0 >> s;
+                const uint64_t b = m1 >> s;
+                if (e & 1) a &= ~1ull;
+                const int ea = a ? 2 * (s + __builtin_ctzll(a)) : 128;
+                const int eb = b ? 2 * (s + __builtin_ctzll(b)) + 1 : 128;
+                return min(ea, eb);
+            };
+            auto entry_block = [&](int e) -> int {
+                const int s = e >> 1;
+                return (e & 1) ? __builtin_amdgcn_readlane(w1v, s) : __builtin_amdgcn_readlane(w0v, s);
+            };
+            int ne = __builtin_amdgcn_readfirstlane(next_entry(0));
+            // prologue: stages 0 and 1 requested, step 0 converted (my rows; the barrier of iteration 0 makes it everyone's)
+            issue_x(__builtin_amdgcn_readlane(pv, 0), 0);
+            if (tend > 1) issue_x(__builtin_amdgcn_readlane(pv, 1), 1);
+            if (tend > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            convert(0);
+            if (ne < 128) request_w(entry_block(ne));
+            for (int s = 0; s < tend; ++s) {
+                wait_all();            // my rows of stage s + 1 and my next weight pieces have landed
+                __syncthreads();       // everyone converted step s and has left step s - 1
+                if (s + 2 < tend) issue_x(__builtin_amdgcn_readlane(pv, s + 2), s & 1);      // (stage s: converted by me an iteration ago, reads returned)
+                if (s + 1 < tend) convert((s + 1) & 1);
+                const unsigned char* slot = smem + (s & 1) * XS_SLOT;
+                while ((ne >> 1) == s) {
+                    block(slot, ne & 1);
+                    ne = __builtin_amdgcn_readfirstlane(next_entry(ne + 1));
+                    if (ne < 128) request_w(entry_block(ne));      // into the registers just used (the MFMAs have read them)
+                    if ((ne >> 1) == s) wait_all();                // second block of the same step: needed right away
+                }
+            }
+            wait_all();
+            __syncthreads();   // the next batch re-primes the ring
+        }
+    }
+
+    // Epilogue (as xcol32s_kernel, axis 1): 32 rows at a time staged as [32][2 KiB] (pieces XOR-swizzled with n), stored as full rows.
+    const int rowbytes = nob * 128;
+    float* ybase = Y + (size_t)ob0 * 32;
+#pragma unroll
+    for (int t = 0; t < XC_RT; ++t) {
+        __syncthreads();
+        if (owner) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int piece = wave * 8 + 2 * g + h;
+                *reinterpret_cast<float4*>(smem + r * XS_ROWB + ((piece ^ r) << 4)) =
+                    make_float4(acc[t][4 * g + 0], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+            }
+        }
+        __syncthreads();
+        constexpr int PPR = XS_ROWB / 16;      // 128 pieces per row
+        for (int i = threadIdx.x; i < 32 * PPR; i += 64 * XS_G) {
+            const int nn = i / PPR, piece = i % PPR, row = n_tile + 32 * t + nn;
+            if (row < N && piece * 16 < rowbytes) {
+                const float4 v = *reinterpret_cast<const float4*>(smem + nn * XS_ROWB + ((piece ^ nn) << 4));
+                *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)row * Kout) + piece * 16) = v;
+            }
+        }
     }
 }
 

@@ -137,9 +137,19 @@ def test_prepared_weights_entry_points_without_gpu(lib):
     assert L.bsmm_prepared_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * t["blocks"] * 1024   # three bf16 pieces of every weight
     assert L.bsmm_prepared_bytes(lib.OP_BPROP, ctypes.byref(a)) == 6 * t["blocks"] * 1024
     assert L.bsmm_prepared_bytes(lib.OP_UPDAT, ctypes.byref(a)) == 0
-    ws_without = L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a))
+    # feature axis 1 (round 4): the activations are split inside the kernel, so the workspace holds only W's pieces -- nothing at all once
+    # they are prepared (bprop; fprop keeps room for the transposed copy of W the kernels without a plan read, should the call go there)
+    wpieces, wt = 6 * t["blocks"] * 1024, 4 * t["blocks"] * 1024
+    assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == wpieces and L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == wpieces
     a.prepared_w = 8192
-    assert ws_without - L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * t["blocks"] * 1024   # the call no longer splits W
+    assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == wt and L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == 0
+    # feature axis 0 keeps the pre-pass: the pieces of the activations (6 bytes per element) + W's unless prepared
+    a.axis, a.prepared_w = 0, None
+    ws_without = L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a))
+    assert ws_without == 6 * a.N * a.C + wpieces
+    a.prepared_w = 8192
+    assert ws_without - L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == wpieces                   # the call no longer splits W
+    a.axis = 1
     one = ctypes.c_void_p(256)
     assert L.bsmm_prepare_weights(lib.OP_UPDAT, one, one, ctypes.byref(a)) == -1
     assert L.bsmm_prepare_weights(lib.OP_FPROP, None, one, ctypes.byref(a)) == -1
@@ -174,10 +184,14 @@ def test_argument_validation_without_gpu(lib):
     assert L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == 0
     a.bsize = 8
     assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 0
-    # fp32, bsize 32, axis 1 with a plan: bf16 pieces of the activations and the weights (6 bytes per element)
+    # fp32, bsize 32 with a plan: bf16 pieces of the weights (6 bytes per element) -- and of the activations on feature axis 0 (axis 1
+    # splits them inside the kernel since round 4)
     a.bsize, a.dtype, a.axis, a.N, a.C, a.plan, a.plan_magic = 32, lib.F32, 1, 100, 64, 256, 0x42535843
+    assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * 10 * 1024
+    a.axis = 0
     assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * (100 * 64 + 10 * 1024)
-    assert L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == 6 * (100 * 64 + 10 * 1024)
+    a.axis = 1
+    assert L.bsmm_workspace_bytes(lib.OP_BPROP, ctypes.byref(a)) == 6 * 10 * 1024
     a.axis = 0
     assert L.bsmm_workspace_bytes(lib.OP_FPROP, ctypes.byref(a)) == 6 * (100 * 64 + 10 * 1024)
     a.plan = None

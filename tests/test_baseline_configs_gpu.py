@@ -238,6 +238,34 @@ def test_small_layouts_multi_block_windows(env, opt, dtype):
         lib.set_kernel_variant(0)
 
 
+# ---- (c2) fp32 on feature axis 1: the activation split fused into the kernel (round 4) ---------------------------------------------
+@pytest.mark.parametrize("case", ["odd_in_ragged", "odd_out", "ba", "many_steps", "single", "bench_layout"])
+def test_fp32_fused_split_against_the_oracle(env, case):
+    """xcol32sf_kernel (bsmm_xcols.h): fp32 slabs staged by LDS-DMA, the three bf16 pieces made between LDS and LDS by the wave that
+    requested the rows.  Full-output comparison with the float64 oracle at the fp32 bar for the shapes that stress its edges: an odd
+    number of input blocks (the trailing pair has no odd half), ragged minibatch rows (re-read, never stored), an odd number of output
+    blocks (partial group), hub columns, a group with more than 64 pair steps (two table batches: the ring is re-primed), one block."""
+    torch, BSMM, lib = env
+    lay, N = {"odd_in_ragged": (P.random_layout(33, 40, 0.3, seed=3), 520), "odd_out": (P.random_layout(40, 33, 0.3, seed=4), 136),
+              "ba": (P.ba_layout(64, 5, seed=1), 256), "many_steps": (P.random_layout(200, 16, 0.1, seed=6), 384),
+              "single": (np.ones((1, 1), dtype=np.int32), 40), "bench_layout": (P.random_layout(128, 128, 0.2, seed=1234), 512)}[case]
+    b = BSMM(lay, block_size=32, feature_axis=1)
+    t = orc.build_layout_luts(np.asarray(lay), 32)
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=17)
+    w, x, e = P.to_dev(W, "f32", torch), P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)
+    try:
+        lib.set_kernel_variant(3)
+        y = P.to_host(b.fprop(x, w))
+        assert lib.last_kernel() == lib.K_XCOL32_F32SPLIT
+        dx = P.to_host(b.bprop(e, w))
+        assert lib.last_kernel() == lib.K_XCOL32_F32SPLIT
+    finally:
+        lib.set_kernel_variant(0)
+    l2y, _ = P.errors(y, orc.fprop(t, X, W, 1))
+    l2x, _ = P.errors(dx, orc.bprop(t, E, W, 1))
+    assert l2y <= P.L2_BAR["f32"] and l2x <= P.L2_BAR["f32"], (case, l2y, l2x)
+
+
 # ---- (d1) streaming updat at the bench layouts with FEW chunks: empty minibatch parts and empty slices ------------------
 @pytest.mark.parametrize("density", [0.1, 0.2])
 @pytest.mark.parametrize("N", [16, 40, 200])
