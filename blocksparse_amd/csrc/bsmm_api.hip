@@ -251,7 +251,12 @@ int launch_xcol32s(bool fprop, const void* X, const void* W, void* Y, const bsmm
     if constexpr (AXIS == 1) {
         if (fused) {
             if (int rc = ensure_lds<&xcol32sf_kernel>(XSF_LDS)) return rc;
-            xcol32sf_kernel<<<m.grid(), 64 * XS_G, XSF_LDS, st>>>(static_cast<const float*>(X), wp, static_cast<float*>(Y), a->plan, m, a->N, a->C, a->K, a->blocks);
+#ifndef XSF_GMAP
+#define XSF_GMAP 1      // (experiment switch: 0 = the row-tile-per-XCD mapping of the other grouped kernels)
+#endif
+            unsigned grid = (unsigned)m.grid();
+            if (XSF_GMAP && m.segments % 8 == 0 && m.ntiles >= 4) { m.P = 0; grid = (unsigned)(m.segments * m.ntiles); }   // one group per XCD at a time
+            xcol32sf_kernel<<<grid, 64 * XS_G, XSF_LDS, st>>>(static_cast<const float*>(X), wp, static_cast<float*>(Y), a->plan, m, a->N, a->C, a->K, a->blocks);
             return (int)hipGetLastError();
         }
     }

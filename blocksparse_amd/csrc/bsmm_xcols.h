@@ -301,7 +301,16 @@ xcol32sf_kernel(const float* __restrict__ Xf, const uint16_t* __restrict__ Wp, f
                 const int32_t* __restrict__ plan, XMap map, int N, int Cin, int Kout, int blocks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile, grp;
-    if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
+    if (map.P == 0) {
+        // group-per-XCD mapping (the launcher sets map.P = 0 when the groups are a multiple of 8): workgroup b runs on XCD b % 8 and takes
+        // group (b % 8) + 8 * ((b / 8) / ntiles), row tile (b / 8) % ntiles.  An XCD then multiplies with the weight pieces of ONE group at a
+        // time (2.5 MB at the bench shape: they stay in its 4 MB L2) and streams all of X -- which is requested two steps ahead and does not
+        // mind coming from the Infinity Cache -- instead of sharing X and taking every weight piece from beyond the L2 right when it is needed.
+        const int j = blockIdx.x >> 3;
+        grp = (blockIdx.x & 7) + 8 * (j / map.ntiles);
+        tile = j - (j / map.ntiles) * map.ntiles;
+        if (grp >= map.segments) return;
+    } else if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
     if (plan[0] != XCPLAN_MAGIC || plan[1] != XCPLAN_VERSION || plan[2] != XS_G) return;
     const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
     const int step_off = gh.x, nsteps = gh.y, ob0 = gh.z, nob = gh.w;
@@ -362,25 +371,28 @@ xcol32sf_kernel(const float* __restrict__ Xf, const uint16_t* __restrict__ Wp, f
     u32x4 wq[3][2];      // weight pieces of the entry this wave handles next: [piece][K half]
 #pragma unroll
     for (int q = 0; q < 3; ++q) wq[q][0] = wq[q][1] = u32x4{0u, 0u, 0u, 0u};
-    auto request_w = [&](int w) {
-        const uint16_t* row = Wp + (size_t)w * 1024 + r * 32 + 8 * h;
+    auto request_w_half = [&](int w, int kk) {      // K half kk of the pieces of block w (w < 0: nothing)
+        if (w < 0) return;
+        const uint16_t* row = Wp + (size_t)w * 1024 + r * 32 + 8 * h + 16 * kk;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            gload16_asm(wq[q][0], row + q * wstride);
-            gload16_asm(wq[q][1], row + q * wstride + 16);
-        }
+        for (int q = 0; q < 3; ++q) gload16_asm(wq[q][kk], row + q * wstride);
     };
+    auto request_w = [&](int w) { request_w_half(w, 0); request_w_half(w, 1); };
     auto wait_all = [&]() {      // everything this wave requested has landed; ties the weight registers to the wait
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(wq[0][0]), "+v"(wq[0][1]), "+v"(wq[1][0]), "+v"(wq[1][1]), "+v"(wq[2][0]), "+v"(wq[2][1])
                      :
                      : "memory");
     };
-    auto block = [&](const unsigned char* slot, int half) {
+    // K half kk of the block for all four row tiles, then the next block's pieces of that half are requested into the registers just
+    // used -- half a block (768 cycles of MFMAs) earlier than after the whole block: the weight pieces come from beyond the L2 (20 MB of
+    // them at the bench shape) and the wave that has blocks in consecutive steps waits for them at every barrier.  Per accumulator the
+    // order of the products is unchanged (K half 0, then 1).
+    auto block = [&](const unsigned char* slot, int half, int wnext) {
 #pragma unroll
-        for (int t = 0; t < XC_RT; ++t)
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int t = 0; t < XC_RT; ++t) {
                 const unsigned char* p = slot + t * 4096 + xrd[half][kk];
                 const uint4 x0 = *reinterpret_cast<const uint4*>(p);
                 const uint4 x1 = *reinterpret_cast<const uint4*>(p + XC_SLAB);
@@ -393,6 +405,8 @@ xcol32sf_kernel(const float* __restrict__ Xf, const uint16_t* __restrict__ Wp, f
                 acc[t] = mfma32_bf16(wq[0][kk], x1, acc[t]);
                 acc[t] = mfma32_bf16(wq[0][kk], x0, acc[t]);
             }
+            request_w_half(wnext, kk);
+        }
     };
 
     const bool owner = wave < nob;
@@ -432,10 +446,10 @@ xcol32sf_kernel(const float* __restrict__ Xf, const uint16_t* __restrict__ Wp, f
                 if (s + 1 < tend) convert((s + 1) & 1);
                 const unsigned char* slot = smem + (s & 1) * XS_SLOT;
                 while ((ne >> 1) == s) {
-                    block(slot, ne & 1);
+                    const int half = ne & 1;
                     ne = __builtin_amdgcn_readfirstlane(next_entry(ne + 1));
-                    if (ne < 128) request_w(entry_block(ne));      // into the registers just used (the MFMAs have read them)
-                    if ((ne >> 1) == s) wait_all();                // second block of the same step: needed right away
+                    block(slot, half, ne < 128 ? entry_block(ne) : -1);      // (requests the next block's pieces as its own are used up)
+                    if ((ne >> 1) == s) wait_all();                          // second block of the same step: needed right away
                 }
             }
             wait_all();
