@@ -756,6 +756,23 @@ def main():
             return e0.elapsed_time(e1) / 50
         ms32_cached = time32(False)
         ms32 = time32(True)
+        # the other two passes in fp32 (not part of configs[1]): bprop on the same fused-split kernel, updat through the bf16 streaming
+        # kernel (six piece products as six pairs of one launch; the per-block fp32 kernel it replaces ran 2.2 ms on this axis)
+        dy32 = torch.randn(b32.o_shape(N), device="cuda", generator=g32) * 0.1
+        def time_pass(fn):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 20
+        ms32_bprop = time_pass(lambda: b32.bprop(dy32, w32))
+        ms32_updat = time_pass(lambda: b32.updat(x32, dy32))
+        del dy32
         tf32 = 2.0 * b32.blocks * bsize0 ** 2 * N / ms32 / 1e9
         out["fp32_fprop_axis1"] = {"workload": "BASELINE configs[1]: %dx%d bs%d d%.0f%% fp32 feature_axis=1 fprop, minibatch %d" %
                                                (hidden0, hidden0, bsize0, dens0 * 100, N),
@@ -763,7 +780,8 @@ def main():
                                              "kernel (fp32 slabs staged by LDS-DMA, pieces made between LDS and LDS: xcol32sf_kernel), no activation "
                                              "pre-pass, no pieces in the workspace; `ms` includes the split of the weights (one launch per weights "
                                              "version: what a training step pays), `ms_weights_cached` does not (bsmm_prepare_weights once)",
-                                   "ms": round(ms32, 4), "ms_weights_cached": round(ms32_cached, 4), "tflops": round(tf32, 2), "peak": PEAK_MFMA["f32"],
+                                   "ms": round(ms32, 4), "ms_weights_cached": round(ms32_cached, 4), "bprop_ms": round(ms32_bprop, 4), "updat_ms": round(ms32_updat, 4),
+                                   "tflops": round(tf32, 2), "peak": PEAK_MFMA["f32"],
                                    "frac": round(tf32 / PEAK_MFMA["f32"], 4),
                                    "peak_bf16_six_products": round(PEAK_MFMA["bf16"] / 6, 1),
                                    "frac_bf16_six_products": round(tf32 / (PEAK_MFMA["bf16"] / 6), 4)}

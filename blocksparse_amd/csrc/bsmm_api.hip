@@ -93,7 +93,9 @@ int check_plan(bool updat, const bsmm_args* a) {
     const int32_t m = a->plan_magic;
     if (a->bsize == 64) return (m == B64PLAN_MAGIC && a->plan_inner == (updat ? 1 : 0)) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
-    if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32)) && a->plan_items > 0 && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
+    if (updat && a->dtype == BSMM_F32)      // fp32: the streaming plan of bsize 32 (the split path of updat32_f32_split; feature axis 1 uses it)
+        return (m == U2PLAN_MAGIC && a->bsize == 32 && a->plan_items > 0) ? BSMM_OK : BSMM_ERR_ARG;
+    if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32)) && a->plan_items > 0) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->bsize == 16) return (m == X7PLAN_MAGIC && a->plan_width == X7_G && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return (m == XCPLAN_MAGIC && a->plan_width == XS_G) ? BSMM_OK : BSMM_ERR_ARG;
     return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G) || (m == X4PLAN_MAGIC && a->plan_width == X4_G && a->axis == 1)) ? BSMM_OK : BSMM_ERR_ARG;
@@ -971,6 +973,51 @@ int updat_dt(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* 
     return BSMM_ERR_UNSUPPORTED;
 }
 
+// fp32 weight gradient on feature axis 1, bsize 32, with a streaming plan (round 4).  The per-block fp32 kernel gathers its fragments at a
+// stride of C elements there (25 TF: 2.2 ms at the bench shape).  Instead: X and DY are split into three bf16 pieces each (exact:
+// bsmm_xcols.h) and the SIX significant piece products  x3 y1, x2 y2, x1 y3, x2 y1, x1 y2, x1 y1  (smallest first; the other three are below
+// 2^-26 of the product) go through the bf16 streaming kernel as six (x, dy) PAIRS of ONE launch -- its pair list is what the reference's
+// Plist<T, 8> is (src/gpu_types.h:167-170) -- with fp32 sums, and the finalize pass writes the fp32 DW with alpha / beta / gate.  bf16 x bf16
+// products are exact in fp32 and the accumulation is fp32: the result has the accuracy of an fp32 matrix-core product.
+// Workspace: [what the bf16 call needs][pieces of X: 3 N C bf16][pieces of DY: 3 N K bf16].
+inline size_t updat_f32_split_inner_bytes(const bsmm_args* a) {
+    bsmm_args b = *a;
+    b.dtype = BSMM_BF16; b.pcount = 6; b.flags = BSMM_FLAG_DW_SUMS; b.split = 0; b.gate = nullptr;
+    return round16(bsmm_workspace_bytes(BSMM_OP_UPDAT, &b));
+}
+inline bool updat_f32_split_applies(const bsmm_args* a) {
+    return a->dtype == BSMM_F32 && a->bsize == 32 && a->axis == 1 && a->plan && a->plan_magic == U2PLAN_MAGIC && a->pcount == 1 && a->split == 0 &&
+           a->C % 32 == 0 && a->K % 32 == 0 && (long)a->N * std::max(a->C, a->K) < (1L << 30) && call_variant(a) != 1 && call_variant(a) != 2;
+}
+int updat32_f32_split(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;
+    const size_t inner = updat_f32_split_inner_bytes(a), nx = (size_t)a->N * a->C, ne = (size_t)a->N * a->K;
+    if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < inner + 6 * (nx + ne)) return BSMM_ERR_WORKSPACE;
+    if (!aligned16(X[0]) || !aligned16(DY[0]) || (DW && !aligned16(DW))) return BSMM_ERR_ARG;
+    uint16_t* xp = reinterpret_cast<uint16_t*>(static_cast<char*>(a->workspace) + inner);
+    uint16_t* ep = xp + 3 * nx;
+    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X[0]), xp, nx);
+    split3_x_kernel<<<(unsigned)((ne / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(DY[0]), ep, ne);
+    bsmm_args b = *a;
+    b.dtype = BSMM_BF16; b.pcount = 6; b.flags = BSMM_FLAG_DW_SUMS; b.split = 0; b.gate = nullptr; b.trace = nullptr;
+    b.workspace_bytes = inner;
+    static const int xi[6] = {2, 1, 0, 1, 0, 0}, ei[6] = {0, 1, 2, 0, 1, 0};      // piece indices of the six products, smallest first
+    PtrList8 xs, es;
+    for (int p = 0; p < 8; ++p) {
+        xs.p[p] = p < 6 ? xp + xi[p] * nx : nullptr;
+        es.p[p] = p < 6 ? ep + ei[p] * ne : nullptr;
+    }
+    if (int rc = launch_updat2<DTbf16, 1>(xs, es, nullptr, &b, nullptr)) return rc;
+    trace(a, BSMM_K_UPDAT_STREAM);
+    if (sums_only) return (int)hipGetLastError();      // the raw fp32 sums stay at the start of the workspace, as for the 16-bit types
+    const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;
+    const size_t nel = (size_t)a->blocks * 1024;
+    updat_finalize_gated_kernel<DTf32><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(a->workspace), static_cast<float*>(DW), nel, 1024,
+                                                                                         a->alpha, a->beta, ug);
+    return (int)hipGetLastError();
+}
+
 int updat64(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
     // the streaming bsize-32 kernel leaves the fp32 sums of the quadrants in the workspace; one pass puts them together with alpha /
     // beta / gate and ONE rounding.  16-bit types with the streaming plan only (what the reference runs bsize 64 in: fp16 tensor cores).
@@ -1033,6 +1080,14 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
     if (a->bsize == 64 && !a->plan) return BSMM_ERR_UNSUPPORTED;
     if ((rc = check_plan(true, a))) return rc;
     if (a->bsize == 64) return DW ? updat64(X, DY, DW, a) : (int)BSMM_ERR_ARG;
+    if (a->dtype == BSMM_F32 && a->plan) {      // fp32 with a (streaming) plan: the bf16-split path where it applies, else the kernels without a plan
+        // (minibatches of a few rows: two split launches + a six-pair stream cost more than the per-block kernel)
+        if (updat_f32_split_applies(a) && (a->N >= 256 || call_variant(a) == 3 || (a->flags & BSMM_FLAG_DW_SUMS))) return updat32_f32_split(X, DY, DW, a);
+        if (a->flags & BSMM_FLAG_DW_SUMS) return BSMM_ERR_UNSUPPORTED;
+        bsmm_args b = *a;
+        b.plan = nullptr; b.plan_magic = b.plan_width = b.plan_waves = b.plan_items = b.plan_inner = 0;
+        return bsmm_updat(X, DY, DW, &b);
+    }
     if ((a->flags & BSMM_FLAG_DW_SUMS) && !(a->bsize == 32 && a->dtype != BSMM_F32 && a->plan && a->plan_magic == U2PLAN_MAGIC))
         return BSMM_ERR_UNSUPPORTED;
     PtrList8 xs, es;
@@ -1391,6 +1446,8 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
         }
         return op == BSMM_OP_UPDAT ? blk * sizeof(float) : std::max(round16(blk * elem_size(a->dtype)) + 16, lock);   // (+ the non-finite flag of the call)
     }
+    if (op == BSMM_OP_UPDAT && updat_f32_split_applies(a))      // fp32 through the bf16 streaming kernel: its workspace + the pieces of X and DY
+        return updat_f32_split_inner_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K);
     if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32) {
         if (a->plan_magic == U2PLAN_MAGIC) {   // streaming kernel: the fp32 sums + one region of partial sums per (round, workgroup)
             const U2Launch L = updat2_shape(a, true);

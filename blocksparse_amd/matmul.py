@@ -431,8 +431,8 @@ class BlocksparseMatMul(object):
         ``gate``: gated dw (op attr gated_dw): the sum of block w is scaled by gate[w].
         ``sums_only``: return the raw fp32 sums [blocks, bs, bs] (a view of the call's workspace, valid until the next updat on
         this stream with the same ``slot``) instead of DW -- the data-parallel path reduces them over the ranks in fp32
-        (``dist.DwReduce``) or calls ``updat_finalize``; only the streaming kernel (bsize 32, either feature axis, 16-bit types)
-        can, other configurations raise BsmmError(-2).  ``gate`` is NOT applied to the sums: pass it to the finalize step.
+        (``dist.DwReduce``) or calls ``updat_finalize``; only the streaming kernel (bsize 32: 16-bit types on either feature axis, fp32 on
+        feature axis 1) can, other configurations raise BsmmError(-2).  ``gate`` is NOT applied to the sums: pass it to the finalize step.
         ``slot``: which of the op's workspaces to use -- alternate 0 / 1 when the sums of one step are still being reduced while
         the next step's updat runs."""
         if isinstance(xs, torch.Tensor):
@@ -490,8 +490,11 @@ class BlocksparseMatMul(object):
         if sums_only and gate is not None:
             raise ValueError("updat(sums_only=True) returns the ungated sums: pass the gate to updat_finalize / DwReduce.start")
         flags = (_lib.FLAG_GATED_DW if (gate is not None and not sums_only) else 0) | (_lib.FLAG_DW_SUMS if sums_only else 0)
+        # fp32: the library has a plan path for bsize 32 on feature axis 1 (the six significant bf16 piece products as six pairs of one
+        # streaming launch, round 4); other fp32 configurations run the kernels without a plan
+        use_plan = xs[0].dtype != torch.float32 or (self.bsize == 32 and self.axis == 1 and len(xs) == 1)
         a, ws, _ = self._call_args(_lib.OP_UPDAT, tabs, tabs.updat, None, N, self.C, self.K, xs[0].dtype,
-                                   tabs.updat_plan if xs[0].dtype != torch.float32 else None, slot=slot, pcount=len(xs), flags=flags)
+                                   tabs.updat_plan if use_plan else None, slot=slot, pcount=len(xs), flags=flags)
         a.alpha, a.beta = alpha, beta
         if gate is not None and not sums_only:
             a.gate = gate.data_ptr()

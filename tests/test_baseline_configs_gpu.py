@@ -238,6 +238,47 @@ def test_small_layouts_multi_block_windows(env, opt, dtype):
         lib.set_kernel_variant(0)
 
 
+# ---- (c3) fp32 weight gradient on feature axis 1: six bf16 piece products as six pairs of one streaming launch (round 4) ------------
+@pytest.mark.parametrize("case", ["bench_layout", "ragged", "ba", "single"])
+def test_fp32_updat_axis1_through_the_streaming_kernel(env, case):
+    """bsmm_updat, fp32, bsize 32, feature axis 1 with the streaming plan (updat32_f32_split): every block of DW against the float64 oracle
+    at the fp32 bar -- plain, alpha / beta accumulate, gated, and the raw sums + finalize form -- with the streaming kernel asserted; two
+    pairs and tiny minibatches take the kernels without a plan (same results)."""
+    torch, BSMM, lib = env
+    lay, N = {"bench_layout": (P.random_layout(128, 128, 0.2, seed=1234), 1024), "ragged": (P.random_layout(33, 40, 0.3, seed=3), 520),
+              "ba": (P.ba_layout(64, 5, seed=1), 384), "single": (np.ones((1, 1), dtype=np.int32), 264)}[case]
+    b = BSMM(lay, block_size=32, feature_axis=1)
+    t = orc.build_layout_luts(np.asarray(lay), 32)
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=23)
+    x, e = P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)
+    dw = P.to_host(b.updat(x, e))
+    assert lib.last_kernel() == lib.K_UPDAT_STREAM
+    l2, _ = P.errors(dw, orc.updat(t, X, E, 1))
+    assert l2 <= P.L2_BAR["f32"], (case, l2)
+    dw0 = np.random.RandomState(5).normal(size=b.w_shape).astype(np.float32) * 0.05
+    got = P.to_host(b.updat(x, e, alpha=0.5, beta=0.25, dw=P.to_dev(dw0, "f32", torch)))
+    l2, _ = P.errors(got, orc.updat(t, X, E, 1, alpha=0.5, beta=0.25, dw_in=dw0))
+    assert l2 <= P.L2_BAR["f32"], (case, "alpha/beta", l2)
+    gate = np.random.RandomState(6).uniform(0.0, 2.0, size=b.blocks).astype(np.float32)
+    got = P.to_host(b.updat(x, e, gate=torch.from_numpy(gate).cuda()))
+    l2, _ = P.errors(got, orc.updat(t, X, E, 1) * gate[:, None, None])
+    assert l2 <= P.L2_BAR["f32"], (case, "gated", l2)
+    sums = b.updat(x, e, sums_only=True)
+    assert sums.dtype == torch.float32 and lib.last_kernel() == lib.K_UPDAT_STREAM
+    got = P.to_host(b.updat_finalize(sums, alpha=2.0, dtype=torch.float32))
+    l2, _ = P.errors(got, 2.0 * orc.updat(t, X, E, 1))
+    assert l2 <= P.L2_BAR["f32"], (case, "sums + finalize", l2)
+    # two pairs / a tiny minibatch: the kernels without a plan
+    got = P.to_host(b.updat([x, x], [e, e], alpha=0.5))
+    assert lib.last_kernel() != lib.K_UPDAT_STREAM
+    l2, _ = P.errors(got, orc.updat(t, X, E, 1))
+    assert l2 <= P.L2_BAR["f32"], (case, "two pairs", l2)
+    got = P.to_host(b.updat(x[:64].contiguous(), e[:64].contiguous()))
+    assert lib.last_kernel() != lib.K_UPDAT_STREAM
+    l2, _ = P.errors(got, orc.updat(t, X[:64], E[:64], 1))
+    assert l2 <= P.L2_BAR["f32"], (case, "N = 64", l2)
+
+
 # ---- (c2) fp32 on feature axis 1: the activation split fused into the kernel (round 4) ---------------------------------------------
 @pytest.mark.parametrize("case", ["odd_in_ragged", "odd_out", "ba", "many_steps", "single", "bench_layout"])
 def test_fp32_fused_split_against_the_oracle(env, case):
