@@ -468,6 +468,46 @@ def test_updat_plan_covers_every_block_once(lib):
     assert _host_updat_plan(t["updat_lut"], t["blocks"], 16, 16, 8, lib.BF16, 0)[0] == 0x42535338   # 'BSS8' (tests/test_super8_plan.py)
 
 
+def test_fp32_updat_takes_the_streaming_plan_on_axis1_without_gpu(lib):
+    """fp32 / bsize 32 / feature axis 1 / one pair: bsmm_updat accepts the streaming 'BSU2' plan (the six bf16 piece products run as six
+    pairs of one launch) and asks for the bf16 call's workspace plus the pieces of X and DY (6 bytes per element); on feature axis 0,
+    with two pairs, or without a plan the fp32 call needs no workspace; a windowed ('BSUP') plan is refused for fp32."""
+    import numpy as np
+    from blocksparse_amd import lut as LT
+    from blocksparse_amd.matmul import _host_updat_plan
+    L = lib.load()
+    ip = ctypes.POINTER(ctypes.c_int32)
+    lay = np.random.default_rng(2).random((24, 40)) < 0.3
+    lay[0, :] = True
+    t = LT.build_tables(lay)
+    words = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 32, lib.BF16, 1)
+    a = lib.BsmmArgs()
+    a.blocks, a.bsize, a.dtype, a.N, a.C, a.K, a.axis, a.pcount = t["blocks"], 32, lib.F32, 512, 24 * 32, 40 * 32, 1, 1
+    assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(a)) == 0                                   # no plan
+    assert L.bsmm_plan_attach(ctypes.byref(a), words.ctypes.data_as(ip), words.size, ctypes.c_void_p(4096)) == 0
+    b = lib.BsmmArgs()
+    ctypes.memmove(ctypes.byref(b), ctypes.byref(a), ctypes.sizeof(a))
+    b.dtype, b.pcount, b.flags = lib.BF16, 6, lib.FLAG_DW_SUMS
+    inner = L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(b))
+    need = L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(a))
+    assert inner > 0 and need == (inner + 15) // 16 * 16 + 6 * 512 * (24 * 32 + 40 * 32)
+    a.pcount = 2
+    assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(a)) == 0                                   # two pairs: the kernels without a plan
+    a.pcount, a.axis = 1, 0
+    assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(a)) == 0                                   # feature axis 0 likewise
+    # a call with a NULL operand list is refused before anything is launched; so is a windowed plan for fp32
+    a.axis = 1
+    assert L.bsmm_updat(None, None, ctypes.c_void_p(256), ctypes.byref(a)) == -1
+    w16 = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 16, lib.BF16, 1)                          # 'BSUP' (bsize 16)
+    c = lib.BsmmArgs()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(a), ctypes.sizeof(a))
+    c.bsize = 16
+    assert L.bsmm_plan_attach(ctypes.byref(c), w16.ctypes.data_as(ip), w16.size, ctypes.c_void_p(4096)) == 0
+    arr = (ctypes.c_void_p * 1)(256)
+    c.lut = 4096
+    assert L.bsmm_updat(arr, arr, ctypes.c_void_p(256), ctypes.byref(c)) == -1
+
+
 def test_streaming_updat_plan(lib):
     """'BSU2' plans (bsize 32, either feature axis: the default): every block in exactly one (item, wave, slot); a wave holds <= 4 blocks from
     <= 2 rows of the window, group 0 first; a window side of 16 for layouts up to ~22 % density, 8 above; hub rows split over waves;
