@@ -21,6 +21,7 @@ K_XCOL16_STAGED = 9
 K_XCOL32_FLOW = 10
 K_XPROP_SMALL = 11
 K_XPROP_MID = 12
+KV_ONE_WAVE = 1          # trace variant of K_UPDAT_BLOCK_TR: the small-minibatch form, one wave per block
 K_UPDAT_VALU, K_UPDAT_BLOCK, K_UPDAT_BLOCK_TR, K_UPDAT_WIN, K_UPDAT16_WIN, K_UPDAT_SUPER8, K_UPDAT_STREAM = 16, 17, 18, 19, 20, 21, 22
 # plan-builder options (BSMM_PLAN_*)
 PLAN_XCOL_UNSTAGED = 4
@@ -83,7 +84,12 @@ def call_flags():
 
 def last_kernel():
     """BSMM_K_* code of the kernel family the most recent fprop / bprop / updat call of the host classes dispatched to."""
-    return int(_last_kernel.value)
+    return int(_last_kernel.value) & 0xff
+
+
+def last_kernel_variant():
+    """BSMM_KV_* variant inside that family (bits 8..15 of the trace word; 0 = the plain one)."""
+    return (int(_last_kernel.value) >> 8) & 0xff
 
 
 class BsmmError(RuntimeError):

@@ -38,6 +38,9 @@ inline int call_variant(const bsmm_args* a) {
     return 0;
 }
 inline void trace(const bsmm_args* a, int k) { if (a->trace) *a->trace = k; }
+#ifndef UTS_NMAX
+#define UTS_NMAX 768      // minibatch rows (x pairs) up to which the one-wave-per-block updat kernel takes the per-block calls (experiment switch: 0 = never)
+#endif
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); the result is checked.  The kernel is a template
 // ARGUMENT, so every kernel instantiation has its own latch (a latch per function TYPE would be shared by all kernels of one
@@ -891,7 +894,14 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                     const double rounds_b = std::max(1.0, std::ceil(a->blocks / (2.0 * device_cus())));
                     const double foot = (double)N * a->pcount * (a->C + a->K) * 2.0 / 1048576.0;                 // MiB of X and DY
                     const double rate = std::min(0.0105, std::max(0.004, 0.004 + 0.0065 * (foot - 16.0) / 112.0));
-                    const double t_blk = 8.0 + rounds_b * (double)N * a->pcount * rate;
+                    double t_blk = 8.0 + rounds_b * (double)N * a->pcount * rate;
+                    // small minibatches: the one-wave-per-block kernel (updat32_a1_small_kernel; hipGraph replays at 4096^2 20 %: 5.3 / 6.6 / 9.3 /
+                    // 12.1 / 18.1 / 26.8 us at N = 64 / 128 / 256 / 384 / 512 / 768 against 15.9 / 17.1 / 18.2 / 19.7 / 22.9 / 28.5 for the kernel above)
+                    const long rows = (long)N * a->pcount;
+                    if (rows <= UTS_NMAX) {
+                        const double rounds_s = std::max(1.0, std::ceil(a->blocks / (20.0 * device_cus())));
+                        t_blk = std::min(t_blk, 4.0 + rounds_s * (double)rows * (rows <= 384 ? 0.021 : 0.033));
+                    }
                     stream = t_stream <= t_blk || sums_only;
                 }
                 if (stream) return launch_updat2<DT, AXIS>(xs, es, DW, a, ug);
@@ -902,6 +912,14 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     if constexpr (BS == 32 && AXIS == 1 && DT::is16) {
         bool al = aligned16(DW);
         for (int p = 0; p < a->pcount; ++p) al = al && aligned16(xs.p[p]) && aligned16(es.p[p]);
+        if (!use_valu && al && variant != 1 && (long)N * a->pcount <= UTS_NMAX) {   // small minibatches: one wave per block, no reduction (gate in its epilogue)
+            if (int rc = ensure_lds<&updat32_a1_small_kernel<DT>>(UTS_LDS)) return rc;
+            trace(a, BSMM_K_UPDAT_BLOCK_TR | (BSMM_KV_ONE_WAVE << 8));
+            const int grid = 8 * (((a->blocks + 3) / 4 + 7) / 8);
+            updat32_a1_small_kernel<DT><<<grid, 256, UTS_LDS, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K, a->pcount,
+                                                                   a->alpha, a->beta, ug);
+            return (int)hipGetLastError();
+        }
         if (!use_valu && !gated && al && variant != 1) {   // LDS-DMA + transposing-read kernel
             if (int rc = ensure_lds<&updat32_a1_tr_kernel<DT>>(UT_LDS)) return rc;
             trace(a, BSMM_K_UPDAT_BLOCK_TR);

@@ -124,6 +124,101 @@ updat32_a1_tr_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     }
 }
 
+// Small minibatches (round 4): ONE WAVE per weight block.  With a few dozen to a few hundred rows the kernel above spends its time on
+// everything but the products: four waves cut two chunks between them, meet in LDS behind two barriers, and at 64 KiB of LDS per block
+// only 512 blocks are resident at once (6.4 rounds of ~2 us at the bench layout: 16 us at N = 64).  Here a workgroup is four independent
+// waves = four consecutive blocks of the z-ordered lookup table (neighbours share X rows / DY rows in the L2), each streaming its
+// operands through a private ring of UTS_D slots (32 rows x (64 B + 64 B) per slot: 8 KiB per wave, five workgroups per CU, every block
+// of the bench layout resident in one round), counted `vmcnt`, no barrier, no reduction; the wave writes its block itself.
+constexpr int UTS_D = 2;
+constexpr int UTS_LDS = 4 * UTS_D * UT_SLOT;      // 32 KiB
+
+template <class DT>
+__global__ void __launch_bounds__(256, 4)
+updat32_a1_small_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
+                        int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta, const float* __restrict__ gate) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "transposing-read kernel: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int groups = (blocks + 3) >> 2;                                  // workgroups with work; XCD x walks a contiguous range of them
+    const int g = updat_block(blockIdx.x, groups);
+    if (g < 0) return;
+    const int w = 4 * g + wave;
+    if (w >= blocks) return;                                               // (no barrier below: a wave may leave alone)
+    const int c = lut[2 * w], k = lut[2 * w + 1];
+    unsigned char* ring = smem + wave * (UTS_D * UT_SLOT);
+    const uint32_t ring_addr = lds_addr_of(ring);
+    const int drow = lane >> 2, dpiece = lane & 3;
+    const int g16 = lane >> 4, t16 = lane & 15;
+    const int h = g16 >> 1;
+    const int rd_base = (t16 >> 2) * 64 + (16 * (g16 & 1) + 4 * (t16 & 3)) * 2;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nchunks = (N + 31) >> 5;
+    for (int p = 0; p < pcount; ++p) {
+        const T* X = static_cast<const T*>(Xs.p[p]) + c * 32 + dpiece * 8;
+        const T* E = static_cast<const T*>(Es.p[p]) + k * 32 + dpiece * 8;
+        auto issue = [&](int q, int pos) {                                 // chunk q = rows 32 q ..; rows past N are clamped re-reads (masked below)
+            const int n0 = q * 32;
+            const uint32_t slot = __builtin_amdgcn_readfirstlane(ring_addr + pos * UT_SLOT);
+            const int r0 = min(n0 + drow, N - 1), r1 = min(n0 + 16 + drow, N - 1);
+            glds16_asm(X + (size_t)r0 * Cf, slot);
+            glds16_asm(X + (size_t)r1 * Cf, slot + 1024);
+            glds16_asm(E + (size_t)r0 * Kf, slot + 2048);
+            glds16_asm(E + (size_t)r1 * Kf, slot + 3072);
+        };
+#pragma unroll
+        for (int d = 0; d < UTS_D - 1; ++d) issue(d, d);
+        int rd_pos = 0, wr_pos = UTS_D - 1;
+        for (int q = 0; q < nchunks; ++q) {
+            issue(q + UTS_D - 1, wr_pos);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (UTS_D - 1)) : "memory");   // chunk q has landed
+            const unsigned char* slot = ring + rd_pos * UT_SLOT;
+            rd_pos = (rd_pos + 1 == UTS_D) ? 0 : rd_pos + 1;
+            wr_pos = (wr_pos + 1 == UTS_D) ? 0 : wr_pos + 1;
+            const int n0 = q * 32;
+            uint4 a[2], b[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned char* sp = slot + (16 * kk + 8 * h) * 64 + rd_base;
+                const uint2 a0 = ds_tr16(sp), a1 = ds_tr16(sp + 4 * 64);
+                const uint2 b0 = ds_tr16(sp + 2048), b1 = ds_tr16(sp + 2048 + 4 * 64);
+                a[kk] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                b[kk] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+            }
+            if (n0 + 32 > N) {   // ragged tail: rows >= N were clamped re-reads -> zero their contribution (A side suffices)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int nb = n0 + 16 * kk + 8 * h;
+                    uint32_t* u = reinterpret_cast<uint32_t*>(&a[kk]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t lo = (nb + 2 * j < N) ? 0xffffu : 0u, hi = (nb + 2 * j + 1 < N) ? 0xffff0000u : 0u;
+                        u[j] &= (lo | hi);
+                    }
+                }
+            }
+            acc = DT::mfma32(a[0], b[0], acc);
+            acc = DT::mfma32(a[1], b[1], acc);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetch, before the next pair re-primes the ring
+    }
+    // D[ci][ko]: col = ko = lane & 31, row ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const float a_eff = gate ? alpha * gate[w] : alpha;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const size_t idx = (size_t)w * 1024 + ci * 32 + (lane & 31);
+        float out = a_eff * acc[reg];
+        if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+        DW[idx] = DT::from_f32(out);
+    }
+}
+
 // bsize 16 version: 16x16 blocks, v_mfma_f32_16x16x32 (K = 32 minibatch rows per instruction).  Slabs are 32 rows x
 // 32 B (one 1 KiB DMA instruction each); lane (ci = lane & 15, q = lane >> 4) needs rows 8q .. 8q+7 of feature ci: two
 // transposing reads (rows 8q+{0..3}, 8q+{4..7}); 16-lane group q covers exactly the 16 features.

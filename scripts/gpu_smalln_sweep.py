@@ -39,6 +39,6 @@ for hidden, dens in ((4096, 0.2), (8192, 0.05)):
         dw = torch.empty(b.w_shape, dtype=torch.bfloat16, device="cuda")
         tf = graph_time(lambda: b.fprop(x, w)); kf = lib.last_kernel()
         tb = graph_time(lambda: b.bprop(dy, w)); kb = lib.last_kernel()
-        tu = graph_time(lambda: b.updat(x, dy, dw=dw)); ku = lib.last_kernel()
+        tu = graph_time(lambda: b.updat(x, dy, dw=dw)); ku = lib.last_kernel() + 100 * lib.last_kernel_variant()
         te = eager_time(lambda: b.bprop(dy, w))
         print("%-16s %d d%.2f N%-5d fprop %6.1f us (k%d) | bprop %6.1f us (k%d) | updat %6.1f us (k%d) | eager bprop %5.1f" % (tag, hidden, dens, N, tf, kf, tb, kb, tu, ku, te), flush=True)

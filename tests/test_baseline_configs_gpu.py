@@ -238,6 +238,38 @@ def test_small_layouts_multi_block_windows(env, opt, dtype):
         lib.set_kernel_variant(0)
 
 
+# ---- (c4) small-minibatch weight gradient: one wave per block (round 4) -------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("N", [8, 40, 64, 200, 320, 744])
+def test_small_minibatch_updat_one_wave_per_block(env, N, dtype):
+    """updat32_a1_small_kernel (bsmm_updat_tr.h): production dispatch for N * pairs <= 768 on feature axis 1 where the cost model
+    does not prefer the streaming kernel, bsize 32, 16-bit.  Every block
+    against the float64 oracle: plain, alpha / beta accumulate, gated, two pairs while they fit; ragged last chunk (N not a multiple of
+    32); a block count that is not a multiple of 4 (the last workgroup has idle waves)."""
+    torch, BSMM, lib = env
+    for lay in (P.random_layout(40, 24, 0.3, seed=2), P.ba_layout(33, 3, seed=1)):
+        b = BSMM(lay, block_size=32, feature_axis=1)
+        t = orc.build_layout_luts(np.asarray(lay), 32)
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=N)
+        x, e = P.to_dev(X, dtype, torch), P.to_dev(E, dtype, torch)
+        got = P.to_host(b.updat(x, e))
+        one_wave = (lib.last_kernel(), lib.last_kernel_variant()) == (lib.K_UPDAT_BLOCK_TR, lib.KV_ONE_WAVE)
+        assert one_wave or N > 320          # (above a few hundred rows the cost model may prefer the streaming kernel for these small layouts)
+        l2, _ = P.errors(got, orc.round_to(orc.updat(t, X, E, 1), dtype))
+        assert l2 <= P.L2_BAR[dtype], (N, dtype, l2)
+        dw0 = orc.round_to(np.random.RandomState(2).normal(size=b.w_shape).astype(np.float32) * 0.05, dtype)
+        gate = np.random.RandomState(3).uniform(0.0, 2.0, size=b.blocks).astype(np.float32)
+        got = P.to_host(b.updat(x, e, alpha=0.5, beta=0.25, dw=P.to_dev(dw0, dtype, torch), gate=torch.from_numpy(gate).cuda()))
+        assert lib.last_kernel_variant() == lib.KV_ONE_WAVE or N > 320
+        l2, _ = P.errors(got, orc.round_to(orc.updat(t, X, E, 1, alpha=0.5, beta=0.25, dw_in=dw0, gate=gate), dtype))
+        assert l2 <= P.L2_BAR[dtype], (N, dtype, "alpha/beta/gate", l2)
+        if 2 * N <= 768:
+            got = P.to_host(b.updat([x, x], [e, e], alpha=0.5))
+            assert lib.last_kernel_variant() == lib.KV_ONE_WAVE or 2 * N > 320
+            l2, _ = P.errors(got, orc.round_to(orc.updat(t, X, E, 1), dtype))
+            assert l2 <= P.L2_BAR[dtype], (N, dtype, "two pairs", l2)
+
+
 # ---- (c3) fp32 weight gradient on feature axis 1: six bf16 piece products as six pairs of one streaming launch (round 4) ------------
 @pytest.mark.parametrize("case", ["bench_layout", "ragged", "ba", "single"])
 def test_fp32_updat_axis1_through_the_streaming_kernel(env, case):
