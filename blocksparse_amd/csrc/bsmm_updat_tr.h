@@ -130,6 +130,8 @@ updat32_a1_tr_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
 // waves = four consecutive blocks of the z-ordered lookup table (neighbours share X rows / DY rows in the L2), each streaming its
 // operands through a private ring of UTS_D slots (32 rows x (64 B + 64 B) per slot: 8 KiB per wave, five workgroups per CU, every block
 // of the bench layout resident in one round), counted `vmcnt`, no barrier, no reduction; the wave writes its block itself.
+// (Tried: one-wave workgroups with three ring slots, two chunks in flight per wave -- not faster, 6.1 / 11.0 / 18.5 against 5.4 / 9.4 / 18.2 us at
+// N = 64 / 256 / 512: from ~400 rows on the kernel moves its 128 B per (block, row) at the ~12 TB/s the L2 -> LDS path delivers chip-wide.)
 constexpr int UTS_D = 2;
 constexpr int UTS_LDS = 4 * UTS_D * UT_SLOT;      // 32 KiB
 
