@@ -116,7 +116,8 @@ class _DeviceTables(object):
         # kernel's plans above stay for gated calls and as the comparison path (BlocksparseMatMul.flow = False).  A caller who names
         # another kernel family in plan_options gets exactly that.
         self.fprop_flow = self.bprop_flow = None
-        if bsize == 32 and axis == 1 and not (plan_options & (_lib.PLAN_XCOL_UNSTAGED | _lib.PLAN_XCOL_NARROW | _lib.PLAN_XCOL_FLOW | (7 << _lib.PLAN_XPROP_PH_SHIFT))):
+        # (bsize 64 runs on the bsize-32 kernels: its composite plan nests whichever bsize-32 plan the options name)
+        if bsize in (32, 64) and axis == 1 and not (plan_options & (_lib.PLAN_XCOL_UNSTAGED | _lib.PLAN_XCOL_NARROW | _lib.PLAN_XCOL_FLOW | (7 << _lib.PLAN_XPROP_PH_SHIFT))):
             self.fprop_flow = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_XCOL_FLOW))
             self.bprop_flow = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_XCOL_FLOW))
         # ... and fp32 has its own (xprop-only) plan kernels for bsize 32; the schedule format is the library's business
