@@ -95,7 +95,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (reinterpret_cast<uintptr_t>(a->plan) & 15) return BSMM_ERR_ARG;
     const int32_t m = a->plan_magic;
     if (a->bsize == 64) return (m == B64PLAN_MAGIC && a->plan_inner == (updat ? 1 : 0)) ? BSMM_OK : BSMM_ERR_ARG;
-    if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
+    if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && (a->dtype != BSMM_F32 || updat)) ? BSMM_OK : BSMM_ERR_ARG;   // (fp32: updat only, updat8_f32_split)
     if (updat && a->dtype == BSMM_F32)      // fp32: the streaming plan of bsize 32 (the split path of updat32_f32_split; feature axis 1 uses it)
         return (m == U2PLAN_MAGIC && a->bsize == 32 && a->plan_items > 0) ? BSMM_OK : BSMM_ERR_ARG;
     if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32)) && a->plan_items > 0) ? BSMM_OK : BSMM_ERR_ARG;
@@ -1036,6 +1036,49 @@ int updat32_f32_split(const void* const* X, const void* const* DY, void* DW, con
     return (int)hipGetLastError();
 }
 
+// The same for bsize 8 (either feature axis): the six piece products run as six pairs of the streaming launch over the 32x32 SUPER-blocks of
+// the 'BSS8' plan (bsmm_super8.h), gather8_f32_kernel writes the present 8x8 parts in fp32.  (The V_FMA kernel it replaces: 5.9 / 2.0 ms on
+// feature axis 1 / 0 at 4096^2, 10 %, N = 8192.)
+inline bsmm_args updat8_f32_inner(const bsmm_args* a) {
+    bsmm_args b = s8_inner(a, true);
+    b.dtype = BSMM_BF16; b.pcount = 6; b.flags = BSMM_FLAG_DW_SUMS; b.split = 0; b.gate = nullptr; b.trace = nullptr;
+    b.lut = a->plan ? a->plan + s8_off_lut32(a->plan_width) : nullptr;
+    return b;
+}
+inline bool updat8_f32_split_applies(const bsmm_args* a) {
+    if (!(a->dtype == BSMM_F32 && a->bsize == 8 && a->plan && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && a->plan_items > 0)) return false;
+    if (((a->plan_inner >> 8) & 7) != 2) return false;                                  // the nested plan must be the streaming kernel's
+    return a->pcount == 1 && a->split == 0 && !(a->flags & (BSMM_FLAG_GATED_DW | BSMM_FLAG_DW_SUMS)) && a->C % 32 == 0 && a->K % 32 == 0 &&
+           !(a->axis == 0 && a->N % 8 != 0) && (long)a->N * std::max(a->C, a->K) < (1L << 30) && call_variant(a) != 1 && call_variant(a) != 2;
+}
+inline size_t updat8_f32_inner_bytes(const bsmm_args* a) {
+    bsmm_args b = updat8_f32_inner(a);
+    return round16(bsmm_workspace_bytes(BSMM_OP_UPDAT, &b));
+}
+int updat8_f32_split(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const size_t inner = updat8_f32_inner_bytes(a), nx = (size_t)a->N * a->C, ne = (size_t)a->N * a->K;
+    if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < inner + 6 * (nx + ne)) return BSMM_ERR_WORKSPACE;
+    if (!aligned16(X[0]) || !aligned16(DY[0]) || !aligned16(DW)) return BSMM_ERR_ARG;
+    uint16_t* xp = reinterpret_cast<uint16_t*>(static_cast<char*>(a->workspace) + inner);
+    uint16_t* ep = xp + 3 * nx;
+    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X[0]), xp, nx);
+    split3_x_kernel<<<(unsigned)((ne / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(DY[0]), ep, ne);
+    bsmm_args b = updat8_f32_inner(a);
+    b.workspace_bytes = inner;
+    static const int xi[6] = {2, 1, 0, 1, 0, 0}, ei[6] = {0, 1, 2, 0, 1, 0};      // the six products, smallest first (see updat32_f32_split)
+    PtrList8 xs, es;
+    for (int p = 0; p < 8; ++p) {
+        xs.p[p] = p < 6 ? xp + xi[p] * nx : nullptr;
+        es.p[p] = p < 6 ? ep + ei[p] * ne : nullptr;
+    }
+    const int rc = a->axis == 1 ? launch_updat2<DTbf16, 1>(xs, es, nullptr, &b, nullptr) : launch_updat2<DTbf16, 0>(xs, es, nullptr, &b, nullptr);
+    if (rc) return rc;
+    trace(a, BSMM_K_UPDAT_SUPER8);
+    gather8_f32_kernel<<<a->plan_width, 256, 0, st>>>(static_cast<const float*>(a->workspace), a->plan, static_cast<float*>(DW), a->alpha, a->beta);
+    return (int)hipGetLastError();
+}
+
 int updat64(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
     // the streaming bsize-32 kernel leaves the fp32 sums of the quadrants in the workspace; one pass puts them together with alpha /
     // beta / gate and ONE rounding.  16-bit types with the streaming plan only (what the reference runs bsize 64 in: fp16 tensor cores).
@@ -1101,6 +1144,7 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
     if (a->dtype == BSMM_F32 && a->plan) {      // fp32 with a (streaming) plan: the bf16-split path where it applies, else the kernels without a plan
         // (minibatches of a few rows: two split launches + a six-pair stream cost more than the per-block kernel)
         if (updat_f32_split_applies(a) && (a->N >= 256 || call_variant(a) == 3 || (a->flags & BSMM_FLAG_DW_SUMS))) return updat32_f32_split(X, DY, DW, a);
+        if (updat8_f32_split_applies(a) && (a->N >= 256 || call_variant(a) == 3)) return updat8_f32_split(X, DY, DW, a);
         if (a->flags & BSMM_FLAG_DW_SUMS) return BSMM_ERR_UNSUPPORTED;
         bsmm_args b = *a;
         b.plan = nullptr; b.plan_magic = b.plan_width = b.plan_waves = b.plan_items = b.plan_inner = 0;
@@ -1454,6 +1498,8 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
         return (a->prepared_w ? 0 : b64_w_bytes(a)) + b64_gate_bytes(a) + bsmm_workspace_bytes(op, &b);
     }
     const size_t lock = xprop_op ? lock_acc_bytes(a) : 0;
+    if (op == BSMM_OP_UPDAT && updat8_f32_split_applies(a))     // fp32 / bsize 8 through the bf16 streaming kernel: its workspace + the pieces of X and DY
+        return updat8_f32_inner_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K);
     if (a->bsize == 8) {   // 'BSS8' plans: the expanded W (xprop) / the fp32 sums of the super-blocks (updat)
         if (!a->plan || a->plan_magic != S8PLAN_MAGIC || a->plan_width <= 0 || a->dtype == BSMM_F32) return lock;
         const size_t blk = (size_t)a->plan_width * 1024;

@@ -86,4 +86,24 @@ gather8_kernel(const float* __restrict__ S32, const int32_t* __restrict__ plan, 
     *reinterpret_cast<uint2*>(dst) = r;
 }
 
+// fp32 form (round 4: the fp32 weight gradient of bsize 8 through the bf16 streaming kernel, bsmm_api.hip::updat8_f32_split): the same gather,
+// DW8 in fp32 (no rounding)
+__global__ void __launch_bounds__(256)
+gather8_f32_kernel(const float* __restrict__ S32, const int32_t* __restrict__ plan, float* __restrict__ DW8, float alpha, float beta) {
+    const int s = blockIdx.x;
+    if (plan[0] != S8PLAN_MAGIC || plan[1] != S8PLAN_VERSION || s >= plan[2]) return;
+    const int32_t* sub = plan + plan[3] + 16 * s;
+    const int c32 = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * 4;
+    const int w = sub[4 * (c32 >> 3) + (k0 >> 3)];
+    if (w < 0) return;
+    const float4 v = *reinterpret_cast<const float4*>(S32 + (size_t)s * 1024 + c32 * 32 + k0);
+    float4* dst = reinterpret_cast<float4*>(DW8 + (size_t)w * 64 + (c32 & 7) * 8 + (k0 & 7));
+    float4 o = make_float4(alpha * v.x, alpha * v.y, alpha * v.z, alpha * v.w);
+    if (beta != 0.f) {
+        const float4 old = *dst;
+        o.x += beta * old.x; o.y += beta * old.y; o.z += beta * old.z; o.w += beta * old.w;
+    }
+    *dst = o;
+}
+
 }  // namespace bsmm

@@ -270,6 +270,38 @@ def test_small_minibatch_updat_one_wave_per_block(env, N, dtype):
             assert l2 <= P.L2_BAR[dtype], (N, dtype, "two pairs", l2)
 
 
+# ---- (c5) fp32 weight gradient at bsize 8 through the bf16 streaming kernel (round 4) -------------------------------------------------
+@pytest.mark.parametrize("axis", [1, 0])
+def test_fp32_updat_bsize8_through_the_super_block_sums(env, axis):
+    """bsmm_updat, fp32, bsize 8 with the 'BSS8' plan (updat8_f32_split: six bf16 piece products as six pairs of one streaming launch over
+    the super-blocks, gather8_f32_kernel): every block against the float64 oracle at the fp32 bar, plain and alpha / beta accumulate; two
+    pairs, a gate or a tiny minibatch take the V_FMA kernel (same results)."""
+    torch, BSMM, lib = env
+    for lay, N in ((P.random_layout(64, 64, 0.1, seed=5), 512), (P.ba_layout(32, 3, seed=2), 264)):
+        b = BSMM(lay, block_size=8, feature_axis=axis)
+        t = orc.build_layout_luts(np.asarray(lay), 8)
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=29)
+        x, e = P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)
+        got = P.to_host(b.updat(x, e))
+        assert lib.last_kernel() == lib.K_UPDAT_SUPER8, lib.last_kernel()
+        l2, _ = P.errors(got, orc.updat(t, X, E, axis))
+        assert l2 <= P.L2_BAR["f32"], (axis, l2)
+        dw0 = np.random.RandomState(5).normal(size=b.w_shape).astype(np.float32) * 0.05
+        got = P.to_host(b.updat(x, e, alpha=0.5, beta=0.25, dw=P.to_dev(dw0, "f32", torch)))
+        assert lib.last_kernel() == lib.K_UPDAT_SUPER8
+        l2, _ = P.errors(got, orc.updat(t, X, E, axis, alpha=0.5, beta=0.25, dw_in=dw0))
+        assert l2 <= P.L2_BAR["f32"], (axis, "alpha/beta", l2)
+        got = P.to_host(b.updat([x, x], [e, e], alpha=0.5))
+        assert lib.last_kernel() == lib.K_UPDAT_VALU
+        l2, _ = P.errors(got, orc.updat(t, X, E, axis))
+        assert l2 <= P.L2_BAR["f32"], (axis, "two pairs", l2)
+        sl = (slice(None), slice(0, 64)) if axis == 0 else (slice(0, 64),)
+        got = P.to_host(b.updat(x[sl].contiguous(), e[sl].contiguous()))
+        assert lib.last_kernel() == lib.K_UPDAT_VALU
+        l2, _ = P.errors(got, orc.updat(t, X[sl], E[sl], axis))
+        assert l2 <= P.L2_BAR["f32"], (axis, "N = 64", l2)
+
+
 # ---- (c3) fp32 weight gradient on feature axis 1: six bf16 piece products as six pairs of one streaming launch (round 4) ------------
 @pytest.mark.parametrize("case", ["bench_layout", "ragged", "ba", "single"])
 def test_fp32_updat_axis1_through_the_streaming_kernel(env, case):
