@@ -169,8 +169,8 @@ int bsmm_bprop(const void* DY, const void* W, void* DX, const bsmm_args* args);
  * X and DY are HOST arrays of pcount device pointers.
  * fp32 with a streaming plan ('BSU2', bsize 32): on feature axis 1 with one pair the call splits X and DY into bf16 pieces (workspace) and
  * runs the six significant piece products as six pairs of one launch of the bf16 streaming kernel (fp32 accuracy; ask
- * bsmm_workspace_bytes); bsize 8 with its 'BSS8' plan likewise on either feature axis (super-block sums, fp32 gather); every other fp32 call
- * ignores the plan. */
+ * bsmm_workspace_bytes); bsize 8 with its 'BSS8' plan likewise on either feature axis (super-block sums, fp32 gather) and bsize 16 with its
+ * 'BSUP' plan on feature axis 1 (windowed kernel, fp32 sums + finalize); every other fp32 call ignores the plan. */
 int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm_args* args);
 
 /* Per-weights preparation that the xprop kernels would otherwise repeat on every call (fp32, bsize 32, with a plan: the exact

@@ -471,7 +471,7 @@ def test_updat_plan_covers_every_block_once(lib):
 def test_fp32_updat_takes_the_streaming_plan_on_axis1_without_gpu(lib):
     """fp32 / bsize 32 / feature axis 1 / one pair: bsmm_updat accepts the streaming 'BSU2' plan (the six bf16 piece products run as six
     pairs of one launch) and asks for the bf16 call's workspace plus the pieces of X and DY (6 bytes per element); on feature axis 0,
-    with two pairs, or without a plan the fp32 call needs no workspace; a windowed ('BSUP') plan is refused for fp32."""
+    with two pairs, or without a plan the fp32 call needs no workspace; bsize 16 ('BSUP' plan) and bsize 8 ('BSS8') have the same route."""
     import numpy as np
     from blocksparse_amd import lut as LT
     from blocksparse_amd.matmul import _host_updat_plan
@@ -495,17 +495,28 @@ def test_fp32_updat_takes_the_streaming_plan_on_axis1_without_gpu(lib):
     assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(a)) == 0                                   # two pairs: the kernels without a plan
     a.pcount, a.axis = 1, 0
     assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(a)) == 0                                   # feature axis 0 likewise
-    # a call with a NULL operand list is refused before anything is launched; so is a windowed plan for fp32
+    # a call with a NULL operand list is refused before anything is launched
     a.axis = 1
     assert L.bsmm_updat(None, None, ctypes.c_void_p(256), ctypes.byref(a)) == -1
-    w16 = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 16, lib.BF16, 1)                          # 'BSUP' (bsize 16)
+    # bsize 16 with its windowed 'BSUP' plan (feature axis 1) and bsize 8 with its 'BSS8' plan take the same route: the fp32 sums + the pieces
+    w16 = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 16, lib.BF16, 1)
     c = lib.BsmmArgs()
     ctypes.memmove(ctypes.byref(c), ctypes.byref(a), ctypes.sizeof(a))
-    c.bsize = 16
+    c.bsize, c.C, c.K = 16, 24 * 16, 40 * 16
     assert L.bsmm_plan_attach(ctypes.byref(c), w16.ctypes.data_as(ip), w16.size, ctypes.c_void_p(4096)) == 0
+    assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(c)) == (t["blocks"] * 256 * 4 + 15) // 16 * 16 + 6 * 512 * (24 * 16 + 40 * 16)
+    c.axis = 0
+    assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(c)) == 0           # (feature axis 0: the per-block fp32 kernel, no workspace)
+    c.axis = 1
     arr = (ctypes.c_void_p * 1)(256)
     c.lut = 4096
-    assert L.bsmm_updat(arr, arr, ctypes.c_void_p(256), ctypes.byref(c)) == -1
+    assert L.bsmm_updat(arr, arr, ctypes.c_void_p(256), ctypes.byref(c)) == -3          # (accepted: it asks for that workspace)
+    w8 = _host_updat_plan(t["updat_lut"], t["blocks"], 24, 40, 8, lib.BF16, 0)
+    d = lib.BsmmArgs()
+    ctypes.memmove(ctypes.byref(d), ctypes.byref(a), ctypes.sizeof(a))
+    d.bsize, d.C, d.K, d.axis = 8, 24 * 8, 40 * 8, 0
+    assert L.bsmm_plan_attach(ctypes.byref(d), w8.ctypes.data_as(ip), w8.size, ctypes.c_void_p(4096)) == 0
+    assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(d)) > 6 * 512 * (24 * 8 + 40 * 8)
 
 
 def test_streaming_updat_plan(lib):

@@ -270,6 +270,39 @@ def test_small_minibatch_updat_one_wave_per_block(env, N, dtype):
             assert l2 <= P.L2_BAR[dtype], (N, dtype, "two pairs", l2)
 
 
+# ---- (c6) fp32 weight gradient at bsize 16 on the windowed kernel (round 4) ------------------------------------------------------------
+@pytest.mark.parametrize("axis", [1, 0])
+def test_fp32_updat_bsize16_through_the_windowed_kernel(env, axis):
+    """bsmm_updat, fp32, bsize 16, feature axis 1 with the windowed 'BSUP' plan (updat16_f32_split: six bf16 piece products as six pairs of one launch, raw
+    fp32 sums by the kernel's scratch path, fp32 finalize with alpha / beta / gate): every block against the float64 oracle at the fp32 bar;
+    two pairs or a tiny minibatch take the kernels without a plan (same results)."""
+    torch, BSMM, lib = env
+    for lay, N in ((P.random_layout(80, 80, 0.15, seed=2), 512), (P.random_layout(33, 17, 0.3, seed=3), 264)):
+        b = BSMM(lay, block_size=16, feature_axis=axis)
+        t = orc.build_layout_luts(np.asarray(lay), 16)
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=31)
+        x, e = P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)
+        got = P.to_host(b.updat(x, e))
+        assert (lib.last_kernel() == lib.K_UPDAT16_WIN) == (axis == 1), lib.last_kernel()      # (feature axis 0: the per-block fp32 kernel is as fast)
+        l2, _ = P.errors(got, orc.updat(t, X, E, axis))
+        assert l2 <= P.L2_BAR["f32"], (axis, l2)
+        dw0 = np.random.RandomState(5).normal(size=b.w_shape).astype(np.float32) * 0.05
+        gate = np.random.RandomState(6).uniform(0.0, 2.0, size=b.blocks).astype(np.float32)
+        got = P.to_host(b.updat(x, e, alpha=0.5, beta=0.25, dw=P.to_dev(dw0, "f32", torch), gate=torch.from_numpy(gate).cuda()))
+        assert (lib.last_kernel() == lib.K_UPDAT16_WIN) == (axis == 1)
+        l2, _ = P.errors(got, orc.updat(t, X, E, axis, alpha=0.5, beta=0.25, dw_in=dw0, gate=gate))
+        assert l2 <= P.L2_BAR["f32"], (axis, "alpha/beta/gate", l2)
+        got = P.to_host(b.updat([x, x], [e, e], alpha=0.5))
+        assert lib.last_kernel() != lib.K_UPDAT16_WIN
+        l2, _ = P.errors(got, orc.updat(t, X, E, axis))
+        assert l2 <= P.L2_BAR["f32"], (axis, "two pairs", l2)
+        sl = (slice(None), slice(0, 64)) if axis == 0 else (slice(0, 64),)
+        got = P.to_host(b.updat(x[sl].contiguous(), e[sl].contiguous()))
+        assert lib.last_kernel() != lib.K_UPDAT16_WIN
+        l2, _ = P.errors(got, orc.updat(t, X[sl], E[sl], axis))
+        assert l2 <= P.L2_BAR["f32"], (axis, "N = 64", l2)
+
+
 # ---- (c5) fp32 weight gradient at bsize 8 through the bf16 streaming kernel (round 4) -------------------------------------------------
 @pytest.mark.parametrize("axis", [1, 0])
 def test_fp32_updat_bsize8_through_the_super_block_sums(env, axis):
