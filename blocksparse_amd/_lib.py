@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BSMM_LIB: load another build of the same library (kernel A/B experiments: scripts/build_variants.py); product = the default
 LIB_PATH = os.environ.get("BSMM_LIB") or os.path.join(_HERE, "libbsmm_hip.so")
 
-ABI_VERSION = 121        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
+ABI_VERSION = 122        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
 FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN, FLAG_DW_SUMS, FLAG_FORCE_MID = 1, 2, 4, 8, 16, 32
@@ -21,12 +21,14 @@ K_XCOL16_STAGED = 9
 K_XCOL32_FLOW = 10
 K_XPROP_SMALL = 11
 K_XPROP_MID = 12
+K_XCOL32_ROWS = 13
 KV_ONE_WAVE = 1          # trace variant of K_UPDAT_BLOCK_TR: the small-minibatch form, one wave per block
 K_UPDAT_VALU, K_UPDAT_BLOCK, K_UPDAT_BLOCK_TR, K_UPDAT_WIN, K_UPDAT16_WIN, K_UPDAT_SUPER8, K_UPDAT_STREAM = 16, 17, 18, 19, 20, 21, 22
 # plan-builder options (BSMM_PLAN_*)
 PLAN_XCOL_UNSTAGED = 4
 PLAN_XCOL_FLOW = 8
 PLAN_XPROP_PH_SHIFT, PLAN_UPDAT_SETS_SHIFT = 8, 12
+PLAN_XCOL_ROWS = 0x20000       # BSX5 plans: the row-split persistent kernel (csrc/bsmm_xrows.h, round 5)
 PLAN_FLOW_SCHEDULED = 0x10000  # BSX4 plans, experiment: list-scheduled step order instead of ascending input blocks
 PLAN_XCOL_NARROW, PLAN_F32_MFMA, PLAN_WINDOW_8, PLAN_WINDOW_16, PLAN_WINDOW_16W, PLAN_STREAM_16, PLAN_STREAM_8, PLAN_STREAM_32 = 1, 2, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60
 

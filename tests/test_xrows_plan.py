@@ -1,0 +1,147 @@
+"""Host-side checks of the 'BSX5' plans of the row-split xprop kernel (csrc/bsmm_plan.h build_xrows_plan, csrc/bsmm_xrows.h).  The records
+are the whole synchronisation contract of that kernel (one barrier per step, counted vmcnt waits, DMA duties), so they are validated here
+WITHOUT a GPU by replaying them against a model of the LDS ring:
+  * every lut entry of an output column appears exactly once in the block masks, in ascending input-block order per column;
+  * a column half's blocks of a step sit in consecutive weight slots, in mask-bit order, and hold the right weight block when the step runs;
+  * the step's slab slot holds the step's pair when the step runs;
+  * a duty never targets a slot the CURRENT step reads (every other reader is covered by the content checks: the model updates a slot's
+    content when the request is issued), the prologue never touches the staging slab (slot X5_D - 1);
+  * the vmcnt of every (step, wave pair) retires the loads that step reads: replaying the pair's issue order (loads complete in order), none
+    of the loads that may still be in flight targets a slot the step reads, and no slot is requested again while an older request for it
+    may be in flight."""
+import numpy as np
+import pytest
+
+import _parity as P
+from blocksparse_amd import _lib as lib
+from blocksparse_amd import lut as L
+from blocksparse_amd.matmul import _host_plan
+
+MAGIC = 0x42535835
+REC = 32
+
+
+def _plan(layout, which):
+    t = L.build_tables(layout, z_order=True, segmented=False)
+    side = t[which]
+    n_out = t["KB"] if which == "fprop" else t["CB"]
+    words = _host_plan(side["lut"], side["segments"], t["blocks"], n_out, 32, lib.BF16, 1, lib.PLAN_XCOL_ROWS)
+    return t, side, n_out, words
+
+
+def _columns(side):
+    lut = np.asarray(side["lut"])
+    cols = {}
+    for s in range(side["segments"]):
+        off, cnt, ob, _ = lut[4 * s:4 * s + 4]
+        ent = lut[2 * off:2 * (off + cnt)].reshape(-1, 2)
+        cols.setdefault(int(ob), []).extend((int(c), int(w)) for c, w in ent)
+    return cols
+
+
+LAYOUTS = [("random 40x24", P.random_layout(40, 24, 0.3, seed=2)), ("dense 12x20", np.ones((12, 20), dtype=np.int32)),
+           ("dense 64x33", np.ones((64, 33), dtype=np.int32)), ("BA 64", P.ba_layout(64, 5, seed=1)),
+           ("sparse 300x16", P.random_layout(300, 16, 0.05, seed=6)), ("single", np.ones((1, 1), dtype=np.int32)),
+           ("groups without blocks", np.eye(15, 40, dtype=np.int32)), ("half 33x47", P.random_layout(33, 47, 0.5, seed=3)),
+           ("bench 20 %", P.random_layout(128, 128, 0.2, seed=1234)), ("bench 50 %", P.random_layout(128, 128, 0.5, seed=5))]
+
+
+@pytest.mark.parametrize("name,layout", LAYOUTS)
+@pytest.mark.parametrize("which", ["fprop", "bprop"])
+def test_rows_plan_replay(name, layout, which):
+    t, side, n_out, p = _plan(layout, which)
+    assert p is not None and p[0] == MAGIC and p[2] == 16
+    D, NW, CAP, PRO = p[7] & 0xff, (p[7] >> 8) & 0xff, (p[7] >> 16) & 0xff, (p[7] >> 24) & 0xff
+    assert PRO == D - 1 and NW >= 2 * CAP
+    cols = _columns(side)
+    ngroups, off_groups, off_recs = p[3], p[5], p[6]
+    assert off_recs % 4 == 0 and len(p) == off_recs + (p[4] + 1) * REC       # (+ the padding record)
+    seen_groups = set()
+    total_blocks = 0
+    for g in range(ngroups):
+        rec_off, nsteps, ob0, nob, nblk = p[off_groups + 8 * g:off_groups + 8 * g + 5]
+        assert ob0 % 16 == 0 and ob0 not in seen_groups and nob == min(16, n_out - ob0)
+        seen_groups.add(ob0)
+        recs = p[off_recs + rec_off * REC:off_recs + (rec_off + PRO + nsteps) * REC].reshape(PRO + nsteps, REC)
+        slab = [None] * D                   # content: pair index
+        wslot = [None] * NW                 # content: weight block id
+        issued = [[] for _ in range(4)]     # per wave pair: the loads in issue order, as ("x", slab slot) / ("w", weight slot)
+        done = [0] * 4                      # ... and how many of them its waits have retired
+        col_seq = {ob0 + c: [] for c in range(16)}
+        last_pair = -1
+        for rr in range(PRO + nsteps):
+            rc = recs[rr]
+            step = rr - PRO
+            reads_x, reads_w = None, set()
+            if step >= 0:
+                pair, xs = int(rc[0]), int(rc[1])
+                assert pair >= last_pair and 0 <= xs < D
+                last_pair = pair
+                # ---- what the step reads ----
+                assert slab[xs] == pair, (g, step, "slab slot holds another pair")
+                reads_x = xs
+                nblocks_step = 0
+                for hc in range(2):
+                    m = (int(rc[2]) >> (16 * hc)) & 0xffff
+                    s = (int(rc[3]) >> (16 * hc)) & 0xffff
+                    for bit in range(16):
+                        if not (m >> bit) & 1:
+                            continue
+                        kl, half = bit >> 1, bit & 1
+                        ob = ob0 + 8 * hc + kl
+                        c = 2 * pair + half
+                        assert ob < ob0 + nob and s < NW
+                        want = dict(cols.get(ob, [])).get(c)
+                        assert want is not None and wslot[s] == want, (g, step, hc, bit, "weight slot holds another block")
+                        col_seq[ob].append((c, want))
+                        reads_w.add(s)
+                        s += 1
+                        nblocks_step += 1
+                assert 0 < nblocks_step <= CAP
+                total_blocks += nblocks_step
+                # ---- the waits: the loads still allowed in flight must not be read by this step ----
+                # (loads complete in order: what an earlier step's wait retired stays retired)
+                for wp in range(4):
+                    n = (int(rc[4]) >> (8 * wp)) & 0xff
+                    assert n <= 31
+                    done[wp] = max(done[wp], len(issued[wp]) - n)
+                    for kind, slot in issued[wp][done[wp]:]:
+                        assert not (kind == "x" and slot == reads_x) and not (kind == "w" and slot in reads_w), (g, step, wp, n, "wait too weak")
+            else:
+                assert all(int(v) == 0 for v in rc[:5])
+            # ---- duties of the record (issued behind the step's barrier) ----
+            xp = int(rc[5])
+            if xp >= 0:
+                xs = int(rc[6])
+                assert 0 <= xs < D and xs != reads_x and (step >= 0 or xs < D - 1), (g, rr, "slab duty hits a slot in use")
+                slab[xs] = xp
+                for wp in range(4):
+                    assert ("x", xs) not in issued[wp][done[wp]:], (g, rr, "slab slot requested again while an older request may be in flight")
+                    issued[wp] += [("x", xs), ("x", xs)]
+            ents = rc[16:32].reshape(4, 4)
+            valid = 0
+            for e in range(16):
+                v = int(ents[e & 3][e >> 2])
+                if v < 0:
+                    assert all(int(ents[k & 3][k >> 2]) < 0 for k in range(e, 16))      # the list is packed
+                    break
+                w, s = v & 0x1fffff, (v >> 21) & 63
+                assert s < NW and s not in reads_w, (g, rr, "weight duty hits a slot in use")
+                wslot[s] = w
+                assert all(("w", s) not in issued[k][done[k]:] for k in range(4)), (g, rr, "weight slot requested again while an older request may be in flight")
+                issued[e & 3].append(("w", s))
+                valid += 1
+        for ob, seq in col_seq.items():
+            assert seq == sorted(cols.get(ob, [])), (g, ob, "column blocks missing / out of order")
+        assert sum(len(s) for s in col_seq.values()) == nblk
+    assert total_blocks == t["blocks"]
+    assert all(int(v) == 0 for v in p[off_recs + p[4] * REC:])
+
+
+def test_rows_plan_is_refused_for_other_axis_and_dtype():
+    t = L.build_tables(P.random_layout(8, 8, 0.5, seed=1), z_order=True, segmented=False)
+    side = t["fprop"]
+    w0 = _host_plan(side["lut"], side["segments"], t["blocks"], t["KB"], 32, lib.BF16, 0, lib.PLAN_XCOL_ROWS)
+    assert w0 is None or w0[0] != MAGIC          # feature axis 0: the option is ignored (the staged plan)
+    w1 = _host_plan(side["lut"], side["segments"], t["blocks"], t["KB"], 32, lib.F32, 1, lib.PLAN_XCOL_ROWS)
+    assert w1 is None or w1[0] != MAGIC
