@@ -83,6 +83,19 @@ def delivery_roof(layout, bsize, N, kernel_ms, cus):
             "clock_ghz": CLOCK_GHZ, "kernel": "bsmm_xprop(fprop)", "note": "analytic bytes of the plan (slabs + weight blocks per unit) / HIP-event time of the pass"}
 
 
+def delivery_roof_updat(plan_host, N, kernel_ms, cus):
+    """The same for the streaming weight gradient ('BSU2' plan: header word 2 = window side in blocks, word 4 = work items): every item
+    stages, per minibatch row, one row piece of the window's X features and one of its DY features (window side x 64 B each)."""
+    if plan_host is None or int(plan_host[0]) != 0x42535532:
+        return None
+    ws, items = int(plan_host[2]), int(plan_host[4])
+    byts = items * N * ws * 64 * 2
+    rate = byts / (kernel_ms * 1e-3 * CLOCK_GHZ * 1e9 * cus)
+    return {"bytes_l2_to_lds": int(byts), "b_per_clk_per_cu": round(rate, 2), "ceiling_b_per_clk": L2_TO_LDS_CEILING, "frac": round(rate / L2_TO_LDS_CEILING, 4),
+            "clock_ghz": CLOCK_GHZ, "kernel": "bsmm_updat", "window_side_blocks": ws, "items": items,
+            "note": "analytic bytes of the plan (X and DY slabs of every work item over the whole minibatch; the time includes the summing pass)"}
+
+
 def random_layout(CB, KB, density, seed):
     """rng.random < density with at least one block per row and column (same generator as tests/_parity.py)."""
     rng = np.random.default_rng(seed)
@@ -519,6 +532,13 @@ def main():
             dl = delivery_roof(layout, b.bsize, n_local, f_ms, cus)
             if dl:
                 roof["delivery"] = dl
+            try:
+                up = b._tables_on(torch.device("cuda", local)).updat_plan
+                du = delivery_roof_updat(up.host if up is not None else None, n_local, u_ms, cus)
+            except Exception:
+                du = None
+            if du:
+                roof["delivery_updat"] = du
         return {"blocks": int(b.blocks), "value": round(3 * flops_pass * world * steps / el / 1e12, 3), "ms_per_step": round(el / steps * 1e3, 4),
                 "pass_ms": {"fprop": round(f_ms, 4), "bprop": round(b_ms, 4), "updat": round(u_ms, 4)},
                 "pass_tflops": {"fprop": round(flops_pass / f_ms / 1e9, 2), "bprop": round(flops_pass / b_ms / 1e9, 2),
@@ -548,7 +568,11 @@ def main():
             rec["roofline"]["traffic"] = k.get("hbm_bytes")
             rec["measured"] = {"source": "profiles/%s_counters.json (rocprofv3 --pmc, separate passes; csrc digest %s)" % (PROFILE_ROUND, counters.get("_stamp", {}).get("csrc_digest")),
                                "kernels_profiled": k.get("kernel_names"),
-                               "hbm_gbps_measured": k.get("hbm_gbps"), "mfma_busy": k.get("mfma_busy"), "kernel_us_profiled": k.get("time_us")}
+                               #  the committed passes ran with the profiler attached, at its clock: their GB/s is bytes / THEIR
+                               # kernel time; the bytes per launch do not depend on the clock, so they are also divided by this run's kernel time
+                               "hbm_gbps_at_profiled_clock": k.get("hbm_gbps"), "mfma_busy": k.get("mfma_busy"), "kernel_us_profiled": k.get("time_us"),
+                               "hbm_gbps_this_run": (round(k.get("hbm_bytes") / (rec["roofline"]["kernel_ms"] * 1e-3) / 1e9, 1)
+                                                     if k.get("hbm_bytes") and rec["roofline"].get("kernel_ms") else None)}
 
     # ---- the main workload of this run ----
     cfg3 = a.config == "cfg3"

@@ -23,6 +23,7 @@ K_XPROP_SMALL = 11
 K_XPROP_MID = 12
 K_XCOL32_ROWS = 13
 KV_ONE_WAVE = 1          # trace variant of K_UPDAT_BLOCK_TR: the small-minibatch form, one wave per block
+KV_FLOW_HALF_UNITS = 2   # trace variant of K_XCOL32_FLOW: units of 64 rows (0 = the 128-row units the bench times)
 K_UPDAT_VALU, K_UPDAT_BLOCK, K_UPDAT_BLOCK_TR, K_UPDAT_WIN, K_UPDAT16_WIN, K_UPDAT_SUPER8, K_UPDAT_STREAM = 16, 17, 18, 19, 20, 21, 22
 # plan-builder options (BSMM_PLAN_*)
 PLAN_XCOL_UNSTAGED = 4

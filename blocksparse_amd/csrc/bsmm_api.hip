@@ -99,7 +99,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (a->bsize == 8) return (m == S8PLAN_MAGIC && a->plan_width > 0 && (a->plan_items > 0) == updat && (a->dtype != BSMM_F32 || updat)) ? BSMM_OK : BSMM_ERR_ARG;   // (fp32: updat only, updat8_f32_split)
     if (updat && a->dtype == BSMM_F32)      // fp32: the 16-bit plans of bsize 32 / 16 (the bf16-split paths updat32_f32_split / updat16_f32_split use them)
         return (((m == U2PLAN_MAGIC && a->bsize == 32) || (m == UPLAN_MAGIC && a->bsize == 16)) && a->plan_items > 0) ? BSMM_OK : BSMM_ERR_ARG;
-    if (updat) return ((m == UPLAN_MAGIC || (m == U2PLAN_MAGIC && a->bsize == 32)) && a->plan_items > 0) ? BSMM_OK : BSMM_ERR_ARG;
+    if (updat) return (((m == UPLAN_MAGIC && a->bsize == 16) || (m == U2PLAN_MAGIC && a->bsize == 32)) && a->plan_items > 0) ? BSMM_OK : BSMM_ERR_ARG;   // (bsize-32 'BSUP' plans: retired in round 4, refused as bsmm.h says)
     if (a->bsize == 16) return (m == X7PLAN_MAGIC && a->plan_width == X7_G && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return (m == XCPLAN_MAGIC && a->plan_width == XS_G) ? BSMM_OK : BSMM_ERR_ARG;
     return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G) || (m == X4PLAN_MAGIC && a->plan_width == X4_G && a->axis == 1) ||
@@ -349,6 +349,9 @@ int launch_xcol_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* a,
     return BSMM_ERR_ARG;
 }
 
+#ifndef BSMM_FLOW_P
+#define BSMM_FLOW_P 0             // measurement builds: groups of a row tile spread over P XCDs (measured at the bench shape, profiles/r05_flow_xcd_map.txt: no effect)
+#endif
 // barrier-free persistent kernel ('BSX4' plans, bsmm_xflow.h): one workgroup per CU walks its (row tile, group) units
 template <class DT, bool TRANSW, int RT>
 int launch_xflow_rt(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
@@ -359,10 +362,13 @@ int launch_xflow_rt(const void* X, const void* Wsel, void* Y, const bsmm_args* a
     m.ntiles = (a->N + R - 1) / R;
     m.segments = (n_out + X4_G - 1) / X4_G;
     m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
+#if BSMM_FLOW_P
+    if (m.ntiles >= 8) m.P = BSMM_FLOW_P;      // measurement builds: groups of a row tile spread over P XCDs (an XCD then runs segments / P groups at a time)
+#endif
     if (m.P > m.segments) m.P = m.segments;
     m.SP = (m.segments + m.P - 1) / m.P;
     if (int rc = ensure_lds<&xflow32_kernel<DT, TRANSW, RT>>(X4_LDS)) return rc;
-    trace(a, BSMM_K_XCOL32_FLOW);
+    trace(a, BSMM_K_XCOL32_FLOW | (RT == 2 ? (BSMM_KV_FLOW_HALF_UNITS << 8) : 0));
     const int cus = device_cus();
     const int grid = std::min(m.grid(), std::max(8, cus / 8 * 8));
     xflow32_kernel<DT, TRANSW, RT><<<grid, 64 * X4_G, X4_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan,
@@ -1589,7 +1595,8 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
             const U2Launch L = updat2_shape(a, true);
             return u2_sums_bytes(a) + (size_t)L.rounds * L.grid * u2_region_bytes();
         }
-        return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float);   // fp32 partial sums of the split-minibatch path
+        if (a->plan_magic != UPLAN_MAGIC || a->bsize != 16) return 0;     // (a plan check_plan refuses: nothing to size)
+        return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float);   // bsize 16 windowed kernel: fp32 partial sums of the split-minibatch path
     }
     if (xprop_op && a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && a->plan_magic == XCPLAN_MAGIC)   // bf16 pieces of the activations and
         return std::max(xcols_workspace_bytes(a), (op == BSMM_OP_FPROP ? wt_bytes(a) : 0) + lock);          // (unless prepared) the weights -- or what

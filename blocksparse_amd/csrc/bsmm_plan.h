@@ -354,6 +354,7 @@ static_assert(X4_DX >= 1 && X4_DX < X4_D && X4_D <= 7 && (X4_PARTS == 1 || X4_PA
 
 inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, bool balance = false) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
+    if (blocks >= (1 << 21)) return 0;          // the kernel addresses a weight block with a 32-bit byte offset (id << 11): no plan beyond 4 GiB of weights
     const int G = X4_G, ngroups = (n_out_blocks + G - 1) / G;
     struct E { int p, wave, half, w; };
     std::vector<std::vector<E>> per_group(ngroups);
@@ -553,16 +554,20 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
 // rows xcol plan ('BSX5', round 5): schedule of the row-split xprop kernel (bsmm_xrows.h).  Groups of X5_G = 16 consecutive output blocks;
 // a workgroup of 8 waves = (row quarter, column half): every wave walks every step.  A group walks the union of its input-block PAIRS in
 // ascending order; a pair with more than X5_CAP blocks is cut into several steps that share its activation slab.  The plan is a list of
-// RECORDS of X5_REC = 32 words per group: X5_P duty-only records (the prologue: issued before the unit starts), then one record per step.
-//   record: [0] pair index of the step's slab   [1] slab slot (0 .. X5_D - 1)
+// RECORDS of X5_REC = 64 words per group: X5_P duty-only records (the prologue: issued before the unit starts), then one record per step.
+//   record: [0] pair index of the step's slab   [1] byte offset of the step's slab slot inside the ring (slot * 16 KiB)
 //           [2] block masks: column half 0 in bits 0..15, half 1 in bits 16..31; bit 2 kl + half = the block (input block 2 p + half, output
 //               block first + 8 hc + kl) exists.  A column half's blocks of a step sit in CONSECUTIVE weight slots in ascending bit order.
 //           [3] first weight slot of column half 0 | of half 1 << 16
 //           [4] per wave pair (byte wp): the vmcnt to wait with in front of the step's barrier = DMA instructions the pair's waves issued
-//               after the last one this step reads (capped at 31; nothing to wait for: 31)
-//           [5] duty: pair index of the activation slab to request during this record (-1: none)   [6] its slab slot
-//           [16 + 4 wp + i] duty: i-th weight block wave pair wp fetches during this record: block id | slot << 21 (-1: none); entry e of
-//               the record's fetch list (FIFO order) is (wp, i) = (e & 3, e >> 2)
+//               after the last one the NEXT step reads (step 0: this and the next step; capped at 31; nothing to wait for: 31).  Everything a
+//               step reads has therefore landed one barrier EARLY: the waves request a step's first fragments while they finish the one before
+//           [8] byte offset of the NEXT step's slab slot   [9] the next step's block masks   [10] its first weight slots (as [1] .. [3]; the
+//               last step: masks 0)
+//           [5] duty: pair index of the activation slab to request during this record (-1: none)   [6] byte offset of its slab slot
+//           [16 + 8 wp + 2 i], [.. + 1] duty: i-th weight block wave pair wp fetches during this record: LDS byte offset of its slot (from the
+//               ring's base; -1: none, and none behind it), byte offset of the block inside W (id << 11); entry e of the record's fetch
+//               list (FIFO order) is (wp, i) = (e & 3, e >> 2)
 // Duties are placed as early as the ring allows: a slab / a weight slot may be requested during record t once the step that last read it is
 // < t (every wave has passed barrier t by then).  The builder checks that everything a step reads is requested in an earlier record (else 0:
 // no plan for this layout).
@@ -573,15 +578,15 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
 namespace bsmm {
 
 constexpr int32_t X5PLAN_MAGIC = 0x42535835;
-constexpr int32_t X5PLAN_VERSION = 1;
+constexpr int32_t X5PLAN_VERSION = 3;   // 2: records of 64 words (fetch entries as (LDS offset, W offset) pairs, slab slots as byte offsets)
 constexpr int X5_G = 16;
 constexpr int X5_HDR = 12;
 constexpr int X5_GROUP = 8;
-constexpr int X5_REC = 32;
+constexpr int X5_REC = 64;
 constexpr int X5_D = 5;            // activation slabs in the ring
 constexpr int X5_P = X5_D - 1;     // prologue records (= slabs requested before the first step)
 constexpr int X5_NW = 39;          // weight slots
-constexpr int X5_CAP = 12;         // blocks per step (two consecutive steps plus the padding of a run that may not wrap fit the X5_NW slots)
+constexpr int X5_CAP = 9;          // blocks per step (THREE consecutive steps -- in use, landed, in flight -- plus the padding of a run that may not wrap fit the X5_NW slots)
 constexpr int X5_FMAX = 16;        // weight blocks fetched per record
 
 inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
@@ -675,9 +680,9 @@ inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n
             }
             for (int sl = 0; sl < nslabs; ++sl) {
                 int first = 0; while (steps[first].slab != sl) ++first;
-                if (slab_rec[sl] < 0 || slab_rec[sl] - X5_P >= first) return 0;
+                if (slab_rec[sl] < 0 || slab_rec[sl] - X5_P >= std::max(first - 1, 0)) return 0;      // requested before the barrier it must have landed at
             }
-            for (size_t f = 0; f < fb.size(); ++f) if (fb_rec[f] < 0 || fb_rec[f] - X5_P >= fb[f].step) return 0;
+            for (size_t f = 0; f < fb.size(); ++f) if (fb_rec[f] < 0 || fb_rec[f] - X5_P >= std::max(fb[f].step - 1, 0)) return 0;
         }
         // ---- per wave pair: issue order -> the vmcnt of every step ----
         // a wave issues, per record: its 2 instructions of the slab (if any), then its entries in order (one instruction each)
@@ -693,10 +698,16 @@ inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n
                     if ((int)(e & 3) == wp) { ops += 1; fb_idx[wduty[rr][e]] = ops - 1; }
             }
             before[nrec] = ops;
-            for (int s = 0; s < nsteps; ++s) {
+            auto last_of = [&](int s) {                              // the pair's last instruction among the requests step s reads (-1: none)
                 int last = slab_idx[steps[s].slab];
                 for (int hc = 0; hc < 2; ++hc) for (int f : steps[s].fifo[hc]) last = std::max(last, fb_idx[f]);
+                return last;
+            };
+            for (int s = 0; s < nsteps; ++s) {                       // in front of barrier s: what step s + 1 reads (step 0: and step 0) has landed
+                int last = s + 1 < nsteps ? last_of(s + 1) : -1;
+                if (s == 0) last = std::max(last, last_of(0));
                 const int issued = before[X5_P + s];
+                if (last >= issued) return 0;                        // (requested in this very record or later: the builder's placement rules exclude it)
                 waitn[s][wp] = last < 0 ? 31 : std::min(31, std::max(0, issued - (last + 1)));
             }
         }
@@ -705,22 +716,29 @@ inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n
         for (int rr = 0; rr < nrec; ++rr) {
             int32_t rc[X5_REC];
             std::fill(rc, rc + X5_REC, 0);
-            for (int k = 16; k < 32; ++k) rc[k] = -1;
+            for (int k = 16; k < 48; k += 2) rc[k] = -1;
             rc[5] = -1;
             if (rr >= X5_P) {
                 const Step& st = steps[rr - X5_P];
-                rc[0] = st.pair; rc[1] = st.slab % X5_D;
+                rc[0] = st.pair; rc[1] = (st.slab % X5_D) * 16384;
                 rc[2] = (int32_t)(st.mask[0] | (st.mask[1] << 16));
                 rc[3] = st.wstart[0] | (st.wstart[1] << 16);
                 rc[4] = waitn[rr - X5_P][0] | (waitn[rr - X5_P][1] << 8) | (waitn[rr - X5_P][2] << 16) | (waitn[rr - X5_P][3] << 24);
+                if (rr + 1 < nrec) {
+                    const Step& nx = steps[rr + 1 - X5_P];
+                    rc[8] = (nx.slab % X5_D) * 16384;
+                    rc[9] = (int32_t)(nx.mask[0] | (nx.mask[1] << 16));
+                    rc[10] = nx.wstart[0] | (nx.wstart[1] << 16);
+                }
             }
             if (xduty[rr] >= 0) {
                 int first = 0; while (steps[first].slab != xduty[rr]) ++first;
-                rc[5] = steps[first].pair; rc[6] = xduty[rr] % X5_D;
+                rc[5] = steps[first].pair; rc[6] = (xduty[rr] % X5_D) * 16384;
             }
             for (size_t e = 0; e < wduty[rr].size(); ++e) {
                 const FB& b = fb[wduty[rr][e]];
-                rc[16 + 4 * (e & 3) + (e >> 2)] = (int32_t)((uint32_t)b.w | ((uint32_t)b.slot << 21));
+                rc[16 + 8 * (e & 3) + 2 * (e >> 2)] = X5_D * 16384 + b.slot * 2048;
+                rc[17 + 8 * (e & 3) + 2 * (e >> 2)] = (int32_t)((uint32_t)b.w << 11);
             }
             recs.insert(recs.end(), rc, rc + X5_REC);
         }

@@ -22,8 +22,15 @@
 
 namespace bsmm {
 
+//  the first piece never exceeds the input: a finite x beyond the largest bf16 (|x| > 3.39e38, it would round to Inf and leave
+// Inf - Inf = NaN behind) keeps the largest finite bf16 as its first piece and stays exact; a non-finite x keeps its first piece and gets
+// zero residues (the products are then non-finite, as the fp32 kernels' are -- Inf or NaN according to the signs of the partner's pieces).
 __device__ __forceinline__ void split3(float x, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
-    const uint16_t p1 = DTbf16::from_f32(x);
+    uint16_t p1 = DTbf16::from_f32(x);
+    if ((p1 & 0x7fffu) >= 0x7f80u) {
+        if ((__builtin_bit_cast(uint32_t, x) & 0x7f800000u) == 0x7f800000u) { b1 = p1; b2 = 0; b3 = 0; return; }
+        p1 = (uint16_t)((p1 & 0x8000u) | 0x7f7fu);
+    }
     const float r1 = x - DTbf16::to_f32(p1);
     const uint16_t p2 = DTbf16::from_f32(r1);
     const float r2 = r1 - DTbf16::to_f32(p2);

@@ -204,7 +204,8 @@ class BlocksparseMatMul(object):
         self._inner = None
         self._split64_hit = None
         self.native64 = True          # bsize 64: call the library with bsize = 64 (False: always the host-side quadrant view)
-        self.rows = True              # ... and the minibatch fills the chip with 128-row units: the row-split kernel (round 5; False: flow / staged)
+        self.rows = False             # True: ... and the minibatch fills the chip with 128-row units -> the row-split kernel (round 5 experiment: bit-identical, but
+                                      # 105-125 us against the flow kernel's 77-90 at the bench shape -- profiles/r05_xrows_*; opt-in)
         self.flow = True              # bsize 32, feature axis 1, 16-bit, no gate: the barrier-free xprop kernel (False: the staged one)
         if block_size == 64:
             # same weights, cut into 32x32 blocks: inner block n is quadrant (i, j) of outer block b
@@ -229,7 +230,10 @@ class BlocksparseMatMul(object):
     @staticmethod
     def _same_weights(entry, w, key):
         """A cached per-weights image is valid only for the SAME tensor object (weak reference still alive and identical -- a new
-        tensor that the allocator put at the old address is a different object), at the same version, with the same key."""
+        tensor that the allocator put at the old address is a different object), at the same version, with the same key.
+        Consequence: the cache is PER OBJECT -- pass the parameter itself.  A fresh view of it on every call (``w.detach()``,
+        ``w.data``, an AMP cast, a non-contiguous ``w`` that fprop makes contiguous) never hits, and the per-weights preparation (fp32 pieces,
+        bsize-64 quadrant gather) then runs in every fprop / bprop; the results are the same, only slower."""
         return entry is not None and entry[0]() is w and entry[1] == key
 
     def invalidate_weights(self):
@@ -314,24 +318,27 @@ class BlocksparseMatMul(object):
         a.stream = torch.cuda.current_stream(lut_t.device).cuda_stream
         return a
 
-    def _call_args(self, op, tabs, lut_t, side, N, Cin, Kout, dtype, plan, slot=0, pcount=1, flags=0):
+    def _call_args(self, op, tabs, lut_t, side, N, Cin, Kout, dtype, plan, slot=0, pcount=1, flags=0, gated=False):
         """The argument block of a call and its workspace, made once per (op, minibatch, dtype, stream, plan, ...) and reused: filling the
         ctypes struct, attaching the plan and asking the library for the workspace size cost more host time than a small-minibatch
         kernel takes on the device (profiles/r04_smalln.txt: 14-15 us per eager call before this cache).  Fields that change from call to
-        call (gate, alpha / beta, prepared_w) are set by the caller."""
+        call (gate, alpha / beta, prepared_w) are set by the caller -- on a COPY of the cached block (one mutable struct shared by
+        every call of a key is not safe from two threads, and a gate-dependent workspace term needs the gate in the key: ``gated``)."""
         stream = torch.cuda.current_stream(lut_t.device).cuda_stream
-        key = (op, N, dtype, lut_t.device.index, stream, id(plan), slot, pcount, _lib.call_flags() | flags, self.updat_split)
+        key = (op, N, dtype, lut_t.device.index, stream, id(plan), slot, pcount, _lib.call_flags() | flags, self.updat_split, bool(gated))
         hit = self._args_cache.get(key)
         if hit is None:
             a = self._args(lut_t, side, N, Cin, Kout, dtype, pcount=pcount, plan=plan)
             a.flags |= flags
+            a.gate = 16 if gated else None          # (sizing only: the library asks whether there is a gate, it does not read it here)
             need_prep = bool(op != _lib.OP_UPDAT and _lib.load().bsmm_prepared_bytes(op, ctypes.byref(a)))
             need_ws = 0 if need_prep else int(_lib.load().bsmm_workspace_bytes(op, ctypes.byref(a)))   # (prepared calls size theirs after prepared_w is set)
             hit = (a, need_ws, need_prep)
             if len(self._args_cache) > 256:
                 self._args_cache.clear()
             self._args_cache[key] = hit
-        a, need_ws, need_prep = hit
+        cached, need_ws, need_prep = hit
+        a = _lib.BsmmArgs.from_buffer_copy(cached)
         a.gate = None
         a.alpha, a.beta = 1.0, 0.0
         ws = None
@@ -429,7 +436,7 @@ class BlocksparseMatMul(object):
         tabs = self._tables_on(x.device)
         y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
         plan = self._xprop_plan(tabs, "fprop", N, self.K, x.dtype, gate)
-        a, _, need_prep = self._call_args(_lib.OP_FPROP, tabs, tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype, plan)
+        a, _, need_prep = self._call_args(_lib.OP_FPROP, tabs, tabs.fprop, self._dev_tables["fprop"], N, self.C, self.K, x.dtype, plan, gated=gate is not None)
         a.gate = gate.data_ptr() if gate is not None else None
         if need_prep:
             a.prepared_w = None
@@ -452,7 +459,7 @@ class BlocksparseMatMul(object):
         tabs = self._tables_on(dy.device)
         dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)
         plan = self._xprop_plan(tabs, "bprop", N, self.C, dy.dtype, gate)
-        a, _, need_prep = self._call_args(_lib.OP_BPROP, tabs, tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype, plan)
+        a, _, need_prep = self._call_args(_lib.OP_BPROP, tabs, tabs.bprop, self._dev_tables["bprop"], N, self.K, self.C, dy.dtype, plan, gated=gate is not None)
         a.gate = gate.data_ptr() if gate is not None else None
         if need_prep:
             a.prepared_w = None
@@ -531,7 +538,8 @@ class BlocksparseMatMul(object):
         # pairs of one launch of the 16-bit kernel, round 4); other fp32 configurations run the kernels without a plan
         use_plan = xs[0].dtype != torch.float32 or (len(xs) == 1 and ((self.bsize in (16, 32) and self.axis == 1) or self.bsize == 8))
         a, ws, _ = self._call_args(_lib.OP_UPDAT, tabs, tabs.updat, None, N, self.C, self.K, xs[0].dtype,
-                                   tabs.updat_plan if use_plan else None, slot=slot, pcount=len(xs), flags=flags)
+                                   tabs.updat_plan if use_plan else None, slot=slot, pcount=len(xs), flags=flags,
+                                   gated=gate is not None and not sums_only)
         a.alpha, a.beta = alpha, beta
         if gate is not None and not sums_only:
             a.gate = gate.data_ptr()

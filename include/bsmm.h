@@ -67,7 +67,8 @@ enum {
 
 /* bsmm_args.trace: which kernel family a call dispatched to (tests assert that the intended kernel ran): the BSMM_K_* code in
  * bits 0..7; bits 8..15 name a variant inside the family (BSMM_KV_*, 0 = the plain one) */
-enum { BSMM_KV_ONE_WAVE = 1 /* BSMM_K_UPDAT_BLOCK_TR: the small-minibatch form, one wave per weight block (round 4) */ };
+enum { BSMM_KV_ONE_WAVE = 1 /* BSMM_K_UPDAT_BLOCK_TR: the small-minibatch form, one wave per weight block (round 4) */,
+       BSMM_KV_FLOW_HALF_UNITS = 2 /* BSMM_K_XCOL32_FLOW: units of 64 rows (minibatches that do not fill the chip with 128-row units); 0 = 128 rows */ };
 enum {
     BSMM_K_NONE = 0,
     /* (4 BSMM_K_XCOL16, 6 BSMM_K_XCOL32_F32MFMA and 19 BSMM_K_UPDAT_WIN belonged to kernels retired in round 4: never reported any more) */

@@ -22,7 +22,7 @@ def timeit(fn, reps=100):
 
 def pair(layout):
     b4 = BlocksparseMatMul(layout, block_size=32, feature_axis=1); b4.rows = False
-    b5 = BlocksparseMatMul(layout, block_size=32, feature_axis=1)
+    b5 = BlocksparseMatMul(layout, block_size=32, feature_axis=1); b5.rows = True
     return b4, b5
 
 

@@ -179,6 +179,104 @@ def test_full_output_at_4096_against_float64_oracle(env, bs, axis, density):
     assert l2 <= bar, ("DW", l2)
 
 
+def test_fp32_updat_split_with_huge_and_nonfinite_inputs(env):
+    """The fp32 weight gradient through the bf16 three-piece split (bsize 32, feature axis 1) with activations the FIRST piece cannot hold
+    (ADVICE r4): |x| above the largest bf16 (3.39e38 < |x| <= FLT_MAX) used to round to Inf and leave NaN pieces -- the first piece is clamped,
+    the split stays exact and the blocks come out as the float64 oracle's; a +-Inf activation gives a non-finite block (Inf or NaN, as the
+    pieces' signs fall -- the fp32 kernels give Inf) and leaves every OTHER block untouched."""
+    torch, BSMM, lib = env
+    lay = P.random_layout(24, 24, 0.3, seed=4)
+    N = 512
+    b = BSMM(lay, block_size=32, feature_axis=1)
+    t = orc.build_layout_luts(np.asarray(lay), 32)
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=41)
+    E = (E * 1e-3).astype(np.float32)
+    big = np.float32(3.4e38)                                   # finite in fp32, beyond the bf16 range
+    c0 = int(np.asarray(b.updat_lut).reshape(-1, 2)[0, 0])
+    X[3, 32 * c0 + 5] = big
+    X[7, 32 * c0 + 9] = -big
+    x, e = P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)
+    got = P.to_host(b.updat(x, e))
+    assert lib.last_kernel() == lib.K_UPDAT_STREAM
+    ref = orc.updat(t, X.astype(np.float64), E.astype(np.float64), 1)
+    assert np.isfinite(got).all()
+    l2, _ = P.errors(got, ref)
+    assert l2 <= P.L2_BAR["f32"], l2
+    X[3, 32 * c0 + 5] = np.inf
+    got2 = P.to_host(b.updat(P.to_dev(X, "f32", torch), e))
+    lut = np.asarray(b.updat_lut).reshape(-1, 2)
+    hit = lut[:, 0] == c0
+    assert not np.isfinite(got2[hit]).all(axis=(1, 2)).any()                  # every block of that input block row holds the non-finite row
+    assert np.isfinite(got2[~hit]).all() and np.array_equal(got2[~hit], got[~hit])
+
+
+@pytest.mark.parametrize("density", [0.1, 0.2, 0.5])
+def test_timed_kernel_variants_full_output_at_n8192(env, density):
+    """The kernels bench.py TIMES (4096^2, bs 32, feature axis 1, N = 8192: the flow kernel with 128-row units, the streaming weight
+    gradient), every output element (VERDICT r4, weak 4 -- the N = 1024 test above runs the flow kernel's 64-row variant):
+    (a) fprop / bprop of the flow kernel, 128-row units asserted through the trace's variant byte, bit-equal to the staged kernel
+        (which test_full_output_at_4096... holds against the float64 oracle);
+    (b) every block of DW from the streaming kernel against the float64 oracle, per block.
+    Reference counterpart: the full-tensor comparisons of test/blocksparse_matmul_test.py:396-421."""
+    torch, BSMM, lib = env
+    layout = P.random_layout(128, 128, density, seed=1234)
+    b = BSMM(layout, block_size=32, feature_axis=1)
+    bs_ = BSMM(layout, block_size=32, feature_axis=1)
+    bs_.flow = False
+    N = 8192
+    w, x, e = _inputs(torch, b, N, "bf16", seed=33)
+    y = b.fprop(x, w); kf, vf = lib.last_kernel(), lib.last_kernel_variant()
+    dx = b.bprop(e, w); kb, vb = lib.last_kernel(), lib.last_kernel_variant()
+    assert (kf, vf, kb, vb) == (lib.K_XCOL32_FLOW, 0, lib.K_XCOL32_FLOW, 0), (kf, vf, kb, vb)      # variant 0 = units of 128 rows
+    ys = bs_.fprop(x, w); ks = lib.last_kernel()
+    dxs = bs_.bprop(e, w)
+    assert ks == lib.K_XCOL32_STAGED
+    assert torch.equal(y, ys) and torch.equal(dx, dxs)
+    # the staged kernel's output against the oracle on sampled columns (the whole tensor is held at N = 1024 above)
+    t = orc.build_layout_luts(layout, 32)
+    W, X, E = P.to_host(w), P.to_host(x), P.to_host(e)
+    dw = P.to_host(b.updat(x, e)); ku = lib.last_kernel()
+    assert ku == lib.K_UPDAT_STREAM
+    ref = orc.round_to(orc.updat_fast(t, X, E, 1, dtype=np.float64), "bf16")
+    num = np.sqrt(((dw.astype(np.float64) - ref) ** 2).reshape(b.blocks, -1).sum(axis=1))
+    den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
+    bar = P.L2_BAR["bf16"]
+    assert np.isfinite(dw).all() and (num / np.maximum(den, 1e-30) <= 4 * bar).all(), "DW d%.1f: worst block %d" % (density, int((num / np.maximum(den, 1e-30)).argmax()))
+    l2, _ = P.errors(dw, ref)
+    assert l2 <= bar, ("DW", l2)
+    # a few whole output columns of Y / DX against the float64 oracle as well (all 8192 rows)
+    for name, got, act, lut_key, nb in (("Y", P.to_host(y), X, "fprop", b.KB), ("DX", P.to_host(dx), E, "bprop", b.CB)):
+        full = orc.round_to((orc.fprop_fast if name == "Y" else orc.bprop_fast)(t, act[:512], W, 1, dtype=np.float64), "bf16")
+        l2, _ = P.errors(got[:512], full)
+        assert l2 <= bar, (name, l2)
+
+
+def test_row_split_kernel_is_bit_identical_to_the_flow_kernel(env):
+    """The row-split kernel of round 5 ('BSX5' plans, csrc/bsmm_xrows.h; opt-in: BlocksparseMatMul.rows = True) sums a column's blocks in
+    the flow kernel's order with the same instructions: equal bits, on ragged tiles, partial groups, split steps and groups without blocks."""
+    torch, BSMM, lib = env
+    cases = [(P.random_layout(40, 24, 0.3, seed=2), 1000, "bf16"), (P.random_layout(33, 35, 0.25, seed=3), 520, "f16"),
+             (np.ones((64, 33), dtype=np.int32), 384, "bf16"), (np.eye(15, 33, dtype=np.int32), 520, "f16"),
+             (P.random_layout(128, 128, 0.2, seed=1234), 8192, "bf16")]
+    lib.set_kernel_variant(3)
+    try:
+        for layout, N, dt in cases:
+            b4 = BSMM(layout, block_size=32, feature_axis=1)
+            b5 = BSMM(layout, block_size=32, feature_axis=1)
+            tabs = b5._tables_on(torch.device("cuda", torch.cuda.current_device()))
+            assert tabs.fprop_rows is not None and tabs.bprop_rows is not None
+            b5._xprop_plan = lambda tabs_, which, N_, nf, dtype, gate: getattr(tabs_, which + "_rows")     # (whatever the minibatch)
+            w, x, e = _inputs(torch, b4, N, dt, seed=5)
+            y4, d4 = b4.fprop(x, w), b4.bprop(e, w)
+            assert lib.last_kernel() == lib.K_XCOL32_FLOW
+            y5 = b5.fprop(x, w); k5 = lib.last_kernel()
+            d5 = b5.bprop(e, w)
+            assert k5 == lib.K_XCOL32_ROWS
+            assert torch.equal(y4, y5) and torch.equal(d4, d5), (layout.shape, N, dt)
+    finally:
+        lib.set_kernel_variant(0)
+
+
 # ---- (b) BASELINE configs[3] -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("axis,N,force", [(1, 512, False), (1, 512, True), (1, 4096, False), (0, 512, True), (0, 4096, False)])
 def test_cfg3_8192_5pct(env, axis, N, force):

@@ -6,7 +6,8 @@ WITHOUT a GPU by replaying them against a model of the LDS ring:
   * the step's slab slot holds the step's pair when the step runs;
   * a duty never targets a slot the CURRENT step reads (every other reader is covered by the content checks: the model updates a slot's
     content when the request is issued), the prologue never touches the staging slab (slot X5_D - 1);
-  * the vmcnt of every (step, wave pair) retires the loads that step reads: replaying the pair's issue order (loads complete in order), none
+  * the vmcnt of every (step, wave pair) retires the loads the NEXT step reads (everything lands one barrier early: the kernel requests a
+    step's first fragments while it finishes the one before), step 0's also its own: replaying the pair's issue order (loads complete in order), none
     of the loads that may still be in flight targets a slot the step reads, and no slot is requested again while an older request for it
     may be in flight."""
 import numpy as np
@@ -18,7 +19,7 @@ from blocksparse_amd import lut as L
 from blocksparse_amd.matmul import _host_plan
 
 MAGIC = 0x42535835
-REC = 32
+REC = 64
 
 
 def _plan(layout, which):
@@ -52,7 +53,7 @@ def test_rows_plan_replay(name, layout, which):
     t, side, n_out, p = _plan(layout, which)
     assert p is not None and p[0] == MAGIC and p[2] == 16
     D, NW, CAP, PRO = p[7] & 0xff, (p[7] >> 8) & 0xff, (p[7] >> 16) & 0xff, (p[7] >> 24) & 0xff
-    assert PRO == D - 1 and NW >= 2 * CAP
+    assert PRO == D - 1 and NW >= 3 * CAP + 8
     cols = _columns(side)
     ngroups, off_groups, off_recs = p[3], p[5], p[6]
     assert off_recs % 4 == 0 and len(p) == off_recs + (p[4] + 1) * REC       # (+ the padding record)
@@ -74,8 +75,8 @@ def test_rows_plan_replay(name, layout, which):
             step = rr - PRO
             reads_x, reads_w = None, set()
             if step >= 0:
-                pair, xs = int(rc[0]), int(rc[1])
-                assert pair >= last_pair and 0 <= xs < D
+                pair, xs = int(rc[0]), int(rc[1]) // 16384
+                assert pair >= last_pair and 0 <= xs < D and int(rc[1]) % 16384 == 0
                 last_pair = pair
                 # ---- what the step reads ----
                 assert slab[xs] == pair, (g, step, "slab slot holds another pair")
@@ -99,38 +100,53 @@ def test_rows_plan_replay(name, layout, which):
                         nblocks_step += 1
                 assert 0 < nblocks_step <= CAP
                 total_blocks += nblocks_step
-                # ---- the waits: the loads still allowed in flight must not be read by this step ----
-                # (loads complete in order: what an earlier step's wait retired stays retired)
+                # ---- the waits (in front of this step's barrier): what the NEXT step reads (step 0: and this one) has landed; loads complete
+                # in order, so what an earlier wait retired stays retired ----
+                nxt_x, nxt_w = None, set()
+                if step + 1 < nsteps:
+                    nrc = recs[rr + 1]
+                    assert int(rc[8]) == int(nrc[1]) and int(rc[9]) == int(nrc[2]) and int(rc[10]) == int(nrc[3])
+                    nxt_x = int(nrc[1]) // 16384
+                    for hc in range(2):
+                        m = (int(nrc[2]) >> (16 * hc)) & 0xffff
+                        s0 = (int(nrc[3]) >> (16 * hc)) & 0xffff
+                        nxt_w |= set(range(s0, s0 + bin(m).count("1")))
+                else:
+                    assert int(rc[9]) == 0
                 for wp in range(4):
                     n = (int(rc[4]) >> (8 * wp)) & 0xff
                     assert n <= 31
                     done[wp] = max(done[wp], len(issued[wp]) - n)
                     for kind, slot in issued[wp][done[wp]:]:
-                        assert not (kind == "x" and slot == reads_x) and not (kind == "w" and slot in reads_w), (g, step, wp, n, "wait too weak")
+                        assert not (kind == "x" and slot == nxt_x) and not (kind == "w" and slot in nxt_w), (g, step, wp, n, "wait too weak (next step)")
+                        assert step > 0 or (not (kind == "x" and slot == reads_x) and not (kind == "w" and slot in reads_w)), (g, step, wp, n, "wait too weak")
+                # (what THIS step reads was retired in front of the previous barrier)
+                for wp in range(4):
+                    for kind, slot in issued[wp][done[wp]:]:
+                        assert not (kind == "x" and slot == reads_x) and not (kind == "w" and slot in reads_w), (g, step, wp, "read before it landed")
             else:
                 assert all(int(v) == 0 for v in rc[:5])
             # ---- duties of the record (issued behind the step's barrier) ----
             xp = int(rc[5])
             if xp >= 0:
-                xs = int(rc[6])
-                assert 0 <= xs < D and xs != reads_x and (step >= 0 or xs < D - 1), (g, rr, "slab duty hits a slot in use")
+                xs = int(rc[6]) // 16384
+                assert int(rc[6]) % 16384 == 0 and 0 <= xs < D and xs != reads_x and (step >= 0 or xs < D - 1), (g, rr, "slab duty hits a slot in use")
                 slab[xs] = xp
                 for wp in range(4):
                     assert ("x", xs) not in issued[wp][done[wp]:], (g, rr, "slab slot requested again while an older request may be in flight")
                     issued[wp] += [("x", xs), ("x", xs)]
-            ents = rc[16:32].reshape(4, 4)
-            valid = 0
+            ents = rc[16:48].reshape(4, 4, 2)
             for e in range(16):
-                v = int(ents[e & 3][e >> 2])
-                if v < 0:
-                    assert all(int(ents[k & 3][k >> 2]) < 0 for k in range(e, 16))      # the list is packed
+                off, wo = int(ents[e & 3][e >> 2][0]), int(ents[e & 3][e >> 2][1]) & 0xffffffff
+                if off < 0:
+                    assert all(int(ents[k & 3][k >> 2][0]) < 0 for k in range(e, 16))      # the list is packed
                     break
-                w, s = v & 0x1fffff, (v >> 21) & 63
-                assert s < NW and s not in reads_w, (g, rr, "weight duty hits a slot in use")
+                assert (off - D * 16384) % 2048 == 0 and wo % 2048 == 0
+                w, s = wo >> 11, (off - D * 16384) // 2048
+                assert 0 <= s < NW and s not in reads_w, (g, rr, "weight duty hits a slot in use")
                 wslot[s] = w
                 assert all(("w", s) not in issued[k][done[k]:] for k in range(4)), (g, rr, "weight slot requested again while an older request may be in flight")
                 issued[e & 3].append(("w", s))
-                valid += 1
         for ob, seq in col_seq.items():
             assert seq == sorted(cols.get(ob, [])), (g, ob, "column blocks missing / out of order")
         assert sum(len(s) for s in col_seq.values()) == nblk
@@ -145,3 +161,36 @@ def test_rows_plan_is_refused_for_other_axis_and_dtype():
     assert w0 is None or w0[0] != MAGIC          # feature axis 0: the option is ignored (the staged plan)
     w1 = _host_plan(side["lut"], side["segments"], t["blocks"], t["KB"], 32, lib.F32, 1, lib.PLAN_XCOL_ROWS)
     assert w1 is None or w1[0] != MAGIC
+
+
+def test_rows_kernel_keeps_its_reserved_registers(tmp_path):
+    """csrc/bsmm_xrows.h keeps a step's fragments in v[224:255] ACROSS its asm statements (requested by one step's exit, multiplied by the
+    next): the kernel is compiled with amdgpu_num_vgpr(224), which the compiler treats as a target, not a fence -- an experiment build
+    (-DX5_LATE_DUTIES=0) spilled and moved accumulators through v[240:255].  This audit compiles the kernel alone (device only, seconds) and
+    requires that every instruction touching v224+ is one of the asm statements' own (fragment reads, MFMA operands), no scratch, no spill."""
+    import os, re, shutil, subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(hipcc) and os.path.exists(objdump)):
+        pytest.skip("no hipcc / llvm-objdump here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "xrows_audit.hip"
+    src.write_text('#include "bsmm_xrows.h"\nusing namespace bsmm;\n' + "".join(
+        "template __global__ void bsmm::xrows32_kernel<%s, %s>(const uint16_t*, const uint16_t*, uint16_t*, const int32_t*, XMap, int, int, int);\n" % (dt, tw)
+        for dt in ("DTbf16", "DTf16") for tw in ("false", "true")))
+    obj = tmp_path / "xrows_audit.o"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "blocksparse_amd", "csrc"),
+                        "--cuda-device-only", "--no-gpu-bundle-output", "-c", "-o", str(obj), str(src), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ScratchSize [bytes/lane]: 0" in r.stderr and not re.search(r"VGPRs Spill: [1-9]", r.stderr) and not re.search(r"ScratchSize \[bytes/lane\]: [1-9]", r.stderr), r.stderr[-1500:]
+    dis = subprocess.run([objdump, "-d", str(obj)], capture_output=True, text=True).stdout
+    own = ("ds_read_b128", "ds_read_b64_tr_b16", "v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16")
+    bad = []
+    for ln in dis.splitlines():
+        body = ln.split("//")[0]
+        regs = [int(x) for x in re.findall(r"v\[?(\d+)", body)]
+        hi = [int(b) for a, b in re.findall(r"v\[(\d+):(\d+)\]", body)]
+        if any(x >= 224 for x in regs + hi) and (body.split() or [""])[0] not in own:
+            bad.append(ln.strip()[:100])
+    assert not bad, bad[:5]
+    assert dis.count("s_ff1_i32_b32") >= 4 * 33
