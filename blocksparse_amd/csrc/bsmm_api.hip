@@ -387,7 +387,7 @@ int launch_xflow(const void* X, const void* Wsel, void* Y, const bsmm_args* a, h
     return half ? launch_xflow_rt<DT, TRANSW, 2>(X, Wsel, Y, a, st) : launch_xflow_rt<DT, TRANSW, 4>(X, Wsel, Y, a, st);
 }
 
-// row-split persistent kernel ('BSX5' plans, bsmm_xrows.h): one workgroup of 8 waves per CU walks its (row tile of 128, group) units
+// row-split persistent kernel ('BSX5' plans, bsmm_xrows.h): one workgroup of 4 waves (one per SIMD) per CU walks its (row tile of 128, group) units
 template <class DT, bool TRANSW>
 int launch_xrows(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
     typedef typename DT::T T;
@@ -402,7 +402,7 @@ int launch_xrows(const void* X, const void* Wsel, void* Y, const bsmm_args* a, h
     trace(a, BSMM_K_XCOL32_ROWS);
     const int cus = device_cus();
     const int grid = std::min(m.grid(), std::max(8, cus / 8 * 8));
-    xrows32_kernel<DT, TRANSW><<<grid, 512, X5_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan,
+    xrows32_kernel<DT, TRANSW><<<grid, 256, X5_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan,
                                                           m, a->N, a->C, a->K);
     return (int)hipGetLastError();
 }
@@ -1376,6 +1376,9 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
 #ifdef X4_TIMELINE
 extern "C" int bsmm_debug_x4_timeline_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_tl), sizeof(bsmm::g_x4_tl)); }
 #endif
+#ifdef X5_STAMPS
+extern "C" int bsmm_debug_x5_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x5_trace), sizeof(bsmm::g_x5_trace)); }
+#endif
 #ifdef X4_STAMPS
 extern "C" int bsmm_debug_x4_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_trace), sizeof(bsmm::g_x4_trace)); }
 #endif
@@ -1514,7 +1517,7 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR || p[11] < 2 || p[11] > 4) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
         case X4PLAN_MAGIC:   if (p[1] != X4PLAN_VERSION || words < X4_HDR || p[2] != X4_G) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
-        case X5PLAN_MAGIC:   if (p[1] != X5PLAN_VERSION || words < X5_HDR || p[2] != X5_G || p[7] != (X5_D | (X5_NW << 8) | (X5_CAP << 16) | (X5_P << 24))) return false;   d[1] = p[2]; d[2] = 8; d[3] = 0; break;
+        case X5PLAN_MAGIC:   if (p[1] != X5PLAN_VERSION || words < X5_HDR || p[2] != X5_G || p[7] != (X5_D | (X5_NW << 8) | (X5_CAP << 16) | (X5_P << 24))) return false;   d[1] = p[2]; d[2] = 4; d[3] = 0; break;
         case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;
         case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR || p[26] != U2_HDR + p[4] * U2_ITEM || words < (long)p[26] + p[5]) return false;   // (the launcher addresses the block map behind the items)

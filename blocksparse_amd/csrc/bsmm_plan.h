@@ -552,25 +552,26 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
 
 // =================================================================================================
 // rows xcol plan ('BSX5', round 5): schedule of the row-split xprop kernel (bsmm_xrows.h).  Groups of X5_G = 16 consecutive output blocks;
-// a workgroup of 8 waves = (row quarter, column half): every wave walks every step.  A group walks the union of its input-block PAIRS in
-// ascending order; a pair with more than X5_CAP blocks is cut into several steps that share its activation slab.  The plan is a list of
-// RECORDS of X5_REC = 64 words per group: X5_P duty-only records (the prologue: issued before the unit starts), then one record per step.
+// a workgroup of FOUR waves, wave q = row quarter q of the 128-row tile x all 16 output blocks: every wave walks every step and multiplies
+// every block of the group by its own 32 rows.  A group walks the union of its input-block PAIRS in ascending order; a pair with more than
+// X5_CAP blocks is cut into several steps that share its activation slab.  The plan is a list of RECORDS of X5_REC = 64 words per group:
+// X5_P duty-only records (the prologue: issued before the unit starts), then one record per step.
 //   record: [0] pair index of the step's slab   [1] byte offset of the step's slab slot inside the ring (slot * 16 KiB)
-//           [2] block masks: column half 0 in bits 0..15, half 1 in bits 16..31; bit 2 kl + half = the block (input block 2 p + half, output
-//               block first + 8 hc + kl) exists.  A column half's blocks of a step sit in CONSECUTIVE weight slots in ascending bit order.
-//           [3] first weight slot of column half 0 | of half 1 << 16
-//           [4] per wave pair (byte wp): the vmcnt to wait with in front of the step's barrier = DMA instructions the pair's waves issued
-//               after the last one the NEXT step reads (step 0: this and the next step; capped at 31; nothing to wait for: 31).  Everything a
-//               step reads has therefore landed one barrier EARLY: the waves request a step's first fragments while they finish the one before
-//           [8] byte offset of the NEXT step's slab slot   [9] the next step's block masks   [10] its first weight slots (as [1] .. [3]; the
-//               last step: masks 0)
+//           [2] block mask: bit 2 col + half = the block (input block 2 p + half, output block first + col) exists.  The blocks of a step sit
+//               in CONSECUTIVE weight slots in ascending bit order.
+//           [3] first weight slot of the step
+//           [4] per wave (byte q): the vmcnt to wait with in front of the step's barrier = DMA instructions the wave issued after the last
+//               one the NEXT step reads (step 0: this and the next step; capped at 63; nothing to wait for: 63).  Everything a step reads
+//               has therefore landed one barrier EARLY: the waves request a step's first fragments while they finish the one before
 //           [5] duty: pair index of the activation slab to request during this record (-1: none)   [6] byte offset of its slab slot
-//           [16 + 8 wp + 2 i], [.. + 1] duty: i-th weight block wave pair wp fetches during this record: LDS byte offset of its slot (from the
+//           [8] byte offset of the NEXT step's slab slot   [9] the next step's block mask   [10] its first weight slot (the last step: 0, 0, 0)
+//           [16 + 8 q + 2 i], [.. + 1] duty: i-th weight block wave q fetches during this record: LDS byte offset of its slot (from the
 //               ring's base; -1: none, and none behind it), byte offset of the block inside W (id << 11); entry e of the record's fetch
-//               list (FIFO order) is (wp, i) = (e & 3, e >> 2)
+//               list (FIFO order) is (q, i) = (e & 3, e >> 2)
+// A wave issues, per record: its 4 instructions of the slab duty (if any), then 2 per fetch entry, in order.
 // Duties are placed as early as the ring allows: a slab / a weight slot may be requested during record t once the step that last read it is
-// < t (every wave has passed barrier t by then).  The builder checks that everything a step reads is requested in an earlier record (else 0:
-// no plan for this layout).
+// < t (every wave has passed barrier t by then).  The builder checks that everything a step reads is requested at least two records earlier
+// (else 0: no plan for this layout).
 // Layout (int32): [0] magic 'BSX5' [1] version [2] X5_G [3] ngroups [4] nrecords_total [5] off_groups [6] off_records
 //                 [7] X5_D | X5_NW << 8 | X5_CAP << 16 | X5_P << 24  [8] n_out_blocks [9] max steps of a group [10] blocks [11] 0
 //   groups[ngroups][8] = (first record, nsteps, first_out_block, n_out_blocks_in_group, blocks_in_group, 0, 0, 0), longest group first
@@ -578,7 +579,7 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
 namespace bsmm {
 
 constexpr int32_t X5PLAN_MAGIC = 0x42535835;
-constexpr int32_t X5PLAN_VERSION = 3;   // 2: records of 64 words (fetch entries as (LDS offset, W offset) pairs, slab slots as byte offsets)
+constexpr int32_t X5PLAN_VERSION = 4;   // 4: four waves (row quarters) x 16 columns, one run of weight slots per step, waits per wave
 constexpr int X5_G = 16;
 constexpr int X5_HDR = 12;
 constexpr int X5_GROUP = 8;
@@ -587,13 +588,13 @@ constexpr int X5_D = 5;            // activation slabs in the ring
 constexpr int X5_P = X5_D - 1;     // prologue records (= slabs requested before the first step)
 constexpr int X5_NW = 39;          // weight slots
 constexpr int X5_CAP = 9;          // blocks per step (THREE consecutive steps -- in use, landed, in flight -- plus the padding of a run that may not wrap fit the X5_NW slots)
-constexpr int X5_FMAX = 16;        // weight blocks fetched per record
+constexpr int X5_FMAX = 16;        // weight blocks fetched per record (4 per wave)
 
 inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
-    if (blocks >= (1 << 21)) return 0;                               // 32-bit byte offsets of the weight blocks, 21-bit ids in the fetch words
+    if (blocks >= (1 << 21)) return 0;                               // 32-bit byte offsets of the weight blocks
     const int G = X5_G, ngroups = (n_out_blocks + G - 1) / G;
-    struct E { int p, pos, w; };                                     // pos = 32 hc + 2 kl + half: the order inside a step
+    struct E { int p, pos, w; };                                     // pos = 2 col + half: the order inside a step
     std::vector<std::vector<E>> per_group(ngroups);
     for (int s = 0; s < segments; ++s) {
         const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
@@ -602,8 +603,7 @@ inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n
             const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
             if (w < 0 || w >= blocks || c < 0) return -1;
             if (c >= (1 << 24)) return 0;
-            const int col = ob % G;
-            per_group[ob / G].push_back({c >> 1, 32 * (col >> 3) + 2 * (col & 7) + (c & 1), w});
+            per_group[ob / G].push_back({c >> 1, 2 * (ob % G) + (c & 1), w});
         }
     }
     std::vector<int32_t> groups, recs;
@@ -613,7 +613,7 @@ inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n
         std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : a.pos < b.pos; });
         for (size_t i = 1; i < v.size(); ++i) if (v[i].p == v[i - 1].p && v[i].pos == v[i - 1].pos) return 0;   // (a block listed twice: not ours)
         // ---- steps ----
-        struct Step { int pair, slab; uint32_t mask[2]; int wstart[2]; std::vector<int> fifo[2]; };   // fifo: indices into `fb`
+        struct Step { int pair, slab; uint32_t mask; int wstart; std::vector<int> fifo; };   // fifo: indices into `fb`
         struct FB { int w, step, slot; };
         std::vector<Step> steps;
         std::vector<FB> fb;
@@ -621,44 +621,33 @@ inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n
         for (size_t i = 0; i < v.size();) {
             size_t j = i;
             while (j < v.size() && v[j].p == v[i].p) ++j;
-            std::vector<E> half[2];
-            for (size_t k = i; k < j; ++k) half[v[k].pos >> 5].push_back(v[k]);
-            const int n0 = (int)half[0].size(), n1 = (int)half[1].size();
-            int nc = 1;
-            while ((n0 + nc - 1) / nc + (n1 + nc - 1) / nc > X5_CAP) ++nc;
+            const int n = (int)(j - i), nc = (n + X5_CAP - 1) / X5_CAP, per = (n + nc - 1) / nc;
             const int slab = (int)slab_last.size();
             slab_last.push_back(0);
             for (int c = 0; c < nc; ++c) {
-                Step st; st.pair = v[i].p; st.slab = slab; st.mask[0] = st.mask[1] = 0; st.wstart[0] = st.wstart[1] = 0;
-                bool any = false;
-                for (int hc = 0; hc < 2; ++hc) {
-                    const int n = (int)half[hc].size(), per = (n + nc - 1) / nc;
-                    for (int k = c * per; k < std::min(n, (c + 1) * per); ++k) {
-                        st.mask[hc] |= 1u << (half[hc][k].pos & 31);
-                        st.fifo[hc].push_back((int)fb.size());
-                        fb.push_back({half[hc][k].w, (int)steps.size(), 0});
-                        any = true;
-                    }
+                Step st; st.pair = v[i].p; st.slab = slab; st.mask = 0; st.wstart = 0;
+                for (int k = c * per; k < std::min(n, (c + 1) * per); ++k) {
+                    st.mask |= 1u << v[i + k].pos;
+                    st.fifo.push_back((int)fb.size());
+                    fb.push_back({v[i + k].w, (int)steps.size(), 0});
                 }
-                if (!any) continue;
+                if (st.fifo.empty()) continue;
                 slab_last[slab] = (int)steps.size();
                 steps.push_back(st);
             }
             i = j;
         }
         const int nsteps = (int)steps.size(), nslabs = (int)slab_last.size();
-        // ---- weight slots: FIFO positions, a (step, column half) run never wraps ----
+        // ---- weight slots: FIFO positions, a step's run never wraps ----
         {
             int pos = 0;
-            for (auto& st : steps)
-                for (int hc = 0; hc < 2; ++hc) {
-                    const int n = (int)st.fifo[hc].size();
-                    if (!n) continue;
-                    if (pos % X5_NW + n > X5_NW) pos += X5_NW - pos % X5_NW;
-                    st.wstart[hc] = pos % X5_NW;
-                    for (int k = 0; k < n; ++k) fb[st.fifo[hc][k]].slot = (pos + k) % X5_NW;
-                    pos += n;
-                }
+            for (auto& st : steps) {
+                const int n = (int)st.fifo.size();
+                if (pos % X5_NW + n > X5_NW) pos += X5_NW - pos % X5_NW;
+                st.wstart = pos % X5_NW;
+                for (int k = 0; k < n; ++k) fb[st.fifo[k]].slot = (pos + k) % X5_NW;
+                pos += n;
+            }
         }
         // ---- duties, record by record (time t = record - X5_P: the step whose barrier the record follows) ----
         const int nrec = X5_P + nsteps;
@@ -684,23 +673,23 @@ inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n
             }
             for (size_t f = 0; f < fb.size(); ++f) if (fb_rec[f] < 0 || fb_rec[f] - X5_P >= std::max(fb[f].step - 1, 0)) return 0;
         }
-        // ---- per wave pair: issue order -> the vmcnt of every step ----
-        // a wave issues, per record: its 2 instructions of the slab (if any), then its entries in order (one instruction each)
+        // ---- per wave: issue order -> the vmcnt of every step ----
+        // a wave issues, per record: its 4 instructions of the slab (if any), then 2 per entry of its own, in order
         std::vector<std::array<int, 4>> waitn(nsteps);
-        for (int wp = 0; wp < 4; ++wp) {
+        for (int q = 0; q < 4; ++q) {
             std::vector<int> before(nrec + 1, 0);                    // instructions issued in records < rr
-            std::vector<int> slab_idx(nslabs, -1), fb_idx(fb.size(), -1);   // index of the LAST instruction of that request in the pair's order
+            std::vector<int> slab_idx(nslabs, -1), fb_idx(fb.size(), -1);   // index of the LAST instruction of that request in the wave's order
             int ops = 0;
             for (int rr = 0; rr < nrec; ++rr) {
                 before[rr] = ops;
-                if (xduty[rr] >= 0) { ops += 2; slab_idx[xduty[rr]] = ops - 1; }
+                if (xduty[rr] >= 0) { ops += 4; slab_idx[xduty[rr]] = ops - 1; }
                 for (size_t e = 0; e < wduty[rr].size(); ++e)
-                    if ((int)(e & 3) == wp) { ops += 1; fb_idx[wduty[rr][e]] = ops - 1; }
+                    if ((int)(e & 3) == q) { ops += 2; fb_idx[wduty[rr][e]] = ops - 1; }
             }
             before[nrec] = ops;
-            auto last_of = [&](int s) {                              // the pair's last instruction among the requests step s reads (-1: none)
+            auto last_of = [&](int s) {                              // the wave's last instruction among the requests step s reads (-1: none)
                 int last = slab_idx[steps[s].slab];
-                for (int hc = 0; hc < 2; ++hc) for (int f : steps[s].fifo[hc]) last = std::max(last, fb_idx[f]);
+                for (int f : steps[s].fifo) last = std::max(last, fb_idx[f]);
                 return last;
             };
             for (int s = 0; s < nsteps; ++s) {                       // in front of barrier s: what step s + 1 reads (step 0: and step 0) has landed
@@ -708,7 +697,7 @@ inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n
                 if (s == 0) last = std::max(last, last_of(0));
                 const int issued = before[X5_P + s];
                 if (last >= issued) return 0;                        // (requested in this very record or later: the builder's placement rules exclude it)
-                waitn[s][wp] = last < 0 ? 31 : std::min(31, std::max(0, issued - (last + 1)));
+                waitn[s][q] = last < 0 ? 63 : std::min(63, std::max(0, issued - (last + 1)));
             }
         }
         // ---- records ----
@@ -721,14 +710,14 @@ inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n
             if (rr >= X5_P) {
                 const Step& st = steps[rr - X5_P];
                 rc[0] = st.pair; rc[1] = (st.slab % X5_D) * 16384;
-                rc[2] = (int32_t)(st.mask[0] | (st.mask[1] << 16));
-                rc[3] = st.wstart[0] | (st.wstart[1] << 16);
+                rc[2] = (int32_t)st.mask;
+                rc[3] = st.wstart;
                 rc[4] = waitn[rr - X5_P][0] | (waitn[rr - X5_P][1] << 8) | (waitn[rr - X5_P][2] << 16) | (waitn[rr - X5_P][3] << 24);
                 if (rr + 1 < nrec) {
                     const Step& nx = steps[rr + 1 - X5_P];
                     rc[8] = (nx.slab % X5_D) * 16384;
-                    rc[9] = (int32_t)(nx.mask[0] | (nx.mask[1] << 16));
-                    rc[10] = nx.wstart[0] | (nx.wstart[1] << 16);
+                    rc[9] = (int32_t)nx.mask;
+                    rc[10] = nx.wstart;
                 }
             }
             if (xduty[rr] >= 0) {

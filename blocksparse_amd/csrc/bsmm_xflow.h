@@ -45,6 +45,9 @@ namespace bsmm {
 #ifndef X4_PUBLISH_FIRST
 #define X4_PUBLISH_FIRST 1
 #endif
+#ifndef X4_STAGGER
+#define X4_STAGGER 0
+#endif
 #ifndef X4_PRIO
 #define X4_PRIO 0             // 1: a wave multiplying a block runs at raised issue priority (the pollers at 0)
 #endif
@@ -106,6 +109,24 @@ __device__ __forceinline__ void x4_poll_all_ge(uint32_t v_addr, uint32_t s_need)
 
 // the wait of a BLOCK / ANN event, chosen by the event's control word: bit 3 vmcnt(2), bit 4 vmcnt(0), else vmcnt(DI) with DI = the requests a REQ
 // of THIS kernel issues (the plan counts X4_DI per REQ; a kernel with smaller slabs issues fewer, and the wait must not assume more)
+// the activation slabs' requests with a cache policy of their own (X4_XPOL: "" default, " nt" = streaming: measured in profiles/r05_flow_cache_policy.txt)
+#ifndef X4_XPOL
+#define X4_XPOL ""
+#endif
+__device__ __forceinline__ void x4_glds_x(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" X4_XPOL "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void x4_glds_x4(const void* sbase, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5" X4_XPOL "\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5" X4_XPOL "\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5" X4_XPOL "\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5" X4_XPOL "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_byte_addr) : "memory", "scc");
+}
+
 template <int DI>
 __device__ __forceinline__ void x4_wait_ctl(uint32_t ctl) {
     asm volatile("s_bitcmp1_b32 %0, 3\n\ts_cbranch_scc0 1f\n\ts_waitcnt vmcnt(2)\n\ts_branch 3f\n"
@@ -132,6 +153,11 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
     const uint32_t prog_addr = base_addr + X4_FLAGS, full_addr = base_addr + X4_FLAGS + 64;
     if (threadIdx.x < 32) reinterpret_cast<uint32_t*>(smem + X4_FLAGS)[threadIdx.x] = 0u;
     __syncthreads();                                   // the only workgroup barrier of the kernel
+#if X4_STAGGER
+    // experiment: the workgroups of an XCD start X4_STAGGER x 64 cycles apart, so that the tiles that share a weight block (and the groups that
+    // share a slab) do not ask for it in the same few hundred cycles -- the followers should find it in the L2 instead of waiting for the fill
+    for (int i = ((blockIdx.x >> 3) & 31) * X4_STAGGER; i > 0; --i) __builtin_amdgcn_s_sleep(1);
+#endif
 
     const int npairs_full = Cin / 64;
     const unsigned char* xt = reinterpret_cast<const unsigned char*>(X);
@@ -302,7 +328,7 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                             const uint32_t vo_o = (pc_e & 4u) ? vo_e - 64u : vo_e + 64u;
 #pragma unroll
                             for (int k = 0; k < DI; k += 4)
-                                glds16_saddr_x4(xtile, vo_e + (k0 + (k + 0) * stride16), vo_o + (k0 + (k + 1) * stride16), vo_e + (k0 + (k + 2) * stride16),
+                                x4_glds_x4(xtile, vo_e + (k0 + (k + 0) * stride16), vo_o + (k0 + (k + 1) * stride16), vo_e + (k0 + (k + 2) * stride16),
                                                 vo_o + (k0 + (k + 3) * stride16), dst + k * 1024);
                         } else {
                             const bool tail = (int)(poff >> 7) >= npairs_full;
@@ -313,7 +339,7 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                                 const int piece = (lane & 7) ^ ((row >> 1) & 7);
                                 uint32_t voff = (uint32_t)xr * (uint32_t)Cin * 2u + piece * 16 + poff;
                                 if (tail && (piece & 4)) voff -= 64;                 // last pair of an odd block count: re-read its even half
-                                glds16_saddr(xtile, voff, dst + k * 1024);
+                                x4_glds_x(xtile, voff, dst + k * 1024);
                             }
                         }
                     }

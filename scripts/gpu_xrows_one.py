@@ -8,7 +8,7 @@ from blocksparse_amd import BlocksparseMatMul, _lib as lib
 d = float(sys.argv[1]) / 100.0 if len(sys.argv) > 1 else 0.2
 reps = int(os.environ.get("XP_REPS", "10"))
 lay = P.random_layout(128, 128, d, seed=1234)
-b = BlocksparseMatMul(lay, block_size=32, feature_axis=1)
+b = BlocksparseMatMul(lay, block_size=32, feature_axis=1); b.rows = True
 if os.environ.get("FLOW"): b.rows = False
 w = (torch.randn(b.w_shape, device="cuda") * 0.01).bfloat16()
 x = (torch.randn(b.i_shape(8192), device="cuda") * 0.1).bfloat16()

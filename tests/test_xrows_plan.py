@@ -2,11 +2,11 @@
 are the whole synchronisation contract of that kernel (one barrier per step, counted vmcnt waits, DMA duties), so they are validated here
 WITHOUT a GPU by replaying them against a model of the LDS ring:
   * every lut entry of an output column appears exactly once in the block masks, in ascending input-block order per column;
-  * a column half's blocks of a step sit in consecutive weight slots, in mask-bit order, and hold the right weight block when the step runs;
+  * a step's blocks sit in consecutive weight slots, in mask-bit order, and hold the right weight block when the step runs;
   * the step's slab slot holds the step's pair when the step runs;
   * a duty never targets a slot the CURRENT step reads (every other reader is covered by the content checks: the model updates a slot's
     content when the request is issued), the prologue never touches the staging slab (slot X5_D - 1);
-  * the vmcnt of every (step, wave pair) retires the loads the NEXT step reads (everything lands one barrier early: the kernel requests a
+  * the vmcnt of every (step, wave) retires the loads the NEXT step reads (everything lands one barrier early: the kernel requests a
     step's first fragments while it finishes the one before), step 0's also its own: replaying the pair's issue order (loads complete in order), none
     of the loads that may still be in flight targets a slot the step reads, and no slot is requested again while an older request for it
     may be in flight."""
@@ -66,64 +66,55 @@ def test_rows_plan_replay(name, layout, which):
         recs = p[off_recs + rec_off * REC:off_recs + (rec_off + PRO + nsteps) * REC].reshape(PRO + nsteps, REC)
         slab = [None] * D                   # content: pair index
         wslot = [None] * NW                 # content: weight block id
-        issued = [[] for _ in range(4)]     # per wave pair: the loads in issue order, as ("x", slab slot) / ("w", weight slot)
+        issued = [[] for _ in range(4)]     # per wave: the loads in issue order, as ("x", slab slot) / ("w", weight slot)
         done = [0] * 4                      # ... and how many of them its waits have retired
         col_seq = {ob0 + c: [] for c in range(16)}
         last_pair = -1
+
+        def reads_of(rc):
+            xs = int(rc[1]) // 16384
+            m, s0 = int(rc[2]) & 0xffffffff, int(rc[3])
+            return xs, m, s0, set(range(s0, s0 + bin(m).count("1")))
         for rr in range(PRO + nsteps):
             rc = recs[rr]
             step = rr - PRO
             reads_x, reads_w = None, set()
             if step >= 0:
-                pair, xs = int(rc[0]), int(rc[1]) // 16384
+                pair = int(rc[0])
+                xs, m, s, reads_w = reads_of(rc)
                 assert pair >= last_pair and 0 <= xs < D and int(rc[1]) % 16384 == 0
                 last_pair = pair
                 # ---- what the step reads ----
                 assert slab[xs] == pair, (g, step, "slab slot holds another pair")
                 reads_x = xs
-                nblocks_step = 0
-                for hc in range(2):
-                    m = (int(rc[2]) >> (16 * hc)) & 0xffff
-                    s = (int(rc[3]) >> (16 * hc)) & 0xffff
-                    for bit in range(16):
-                        if not (m >> bit) & 1:
-                            continue
-                        kl, half = bit >> 1, bit & 1
-                        ob = ob0 + 8 * hc + kl
-                        c = 2 * pair + half
-                        assert ob < ob0 + nob and s < NW
-                        want = dict(cols.get(ob, [])).get(c)
-                        assert want is not None and wslot[s] == want, (g, step, hc, bit, "weight slot holds another block")
-                        col_seq[ob].append((c, want))
-                        reads_w.add(s)
-                        s += 1
-                        nblocks_step += 1
-                assert 0 < nblocks_step <= CAP
-                total_blocks += nblocks_step
+                assert 0 < len(reads_w) <= CAP and s + len(reads_w) <= NW
+                for bit in range(32):
+                    if not (m >> bit) & 1:
+                        continue
+                    ob, c = ob0 + (bit >> 1), 2 * pair + (bit & 1)
+                    assert ob < ob0 + nob
+                    want = dict(cols.get(ob, [])).get(c)
+                    assert want is not None and wslot[s] == want, (g, step, bit, "weight slot holds another block")
+                    col_seq[ob].append((c, want))
+                    s += 1
+                total_blocks += len(reads_w)
                 # ---- the waits (in front of this step's barrier): what the NEXT step reads (step 0: and this one) has landed; loads complete
                 # in order, so what an earlier wait retired stays retired ----
                 nxt_x, nxt_w = None, set()
                 if step + 1 < nsteps:
                     nrc = recs[rr + 1]
                     assert int(rc[8]) == int(nrc[1]) and int(rc[9]) == int(nrc[2]) and int(rc[10]) == int(nrc[3])
-                    nxt_x = int(nrc[1]) // 16384
-                    for hc in range(2):
-                        m = (int(nrc[2]) >> (16 * hc)) & 0xffff
-                        s0 = (int(nrc[3]) >> (16 * hc)) & 0xffff
-                        nxt_w |= set(range(s0, s0 + bin(m).count("1")))
+                    nxt_x, _, _, nxt_w = reads_of(nrc)
                 else:
                     assert int(rc[9]) == 0
-                for wp in range(4):
-                    n = (int(rc[4]) >> (8 * wp)) & 0xff
-                    assert n <= 31
-                    done[wp] = max(done[wp], len(issued[wp]) - n)
-                    for kind, slot in issued[wp][done[wp]:]:
-                        assert not (kind == "x" and slot == nxt_x) and not (kind == "w" and slot in nxt_w), (g, step, wp, n, "wait too weak (next step)")
-                        assert step > 0 or (not (kind == "x" and slot == reads_x) and not (kind == "w" and slot in reads_w)), (g, step, wp, n, "wait too weak")
-                # (what THIS step reads was retired in front of the previous barrier)
-                for wp in range(4):
-                    for kind, slot in issued[wp][done[wp]:]:
-                        assert not (kind == "x" and slot == reads_x) and not (kind == "w" and slot in reads_w), (g, step, wp, "read before it landed")
+                for q in range(4):
+                    n = (int(rc[4]) >> (8 * q)) & 0xff
+                    assert n <= 63
+                    done[q] = max(done[q], len(issued[q]) - n)
+                    assert len(issued[q]) - done[q] <= 63, "more loads in flight than the counter holds"
+                    for kind, slot in issued[q][done[q]:]:
+                        assert not (kind == "x" and slot == nxt_x) and not (kind == "w" and slot in nxt_w), (g, step, q, n, "wait too weak (next step)")
+                        assert not (kind == "x" and slot == reads_x) and not (kind == "w" and slot in reads_w), (g, step, q, n, "read before it landed")
             else:
                 assert all(int(v) == 0 for v in rc[:5])
             # ---- duties of the record (issued behind the step's barrier) ----
@@ -132,9 +123,9 @@ def test_rows_plan_replay(name, layout, which):
                 xs = int(rc[6]) // 16384
                 assert int(rc[6]) % 16384 == 0 and 0 <= xs < D and xs != reads_x and (step >= 0 or xs < D - 1), (g, rr, "slab duty hits a slot in use")
                 slab[xs] = xp
-                for wp in range(4):
-                    assert ("x", xs) not in issued[wp][done[wp]:], (g, rr, "slab slot requested again while an older request may be in flight")
-                    issued[wp] += [("x", xs), ("x", xs)]
+                for q in range(4):
+                    assert ("x", xs) not in issued[q][done[q]:], (g, rr, "slab slot requested again while an older request may be in flight")
+                    issued[q] += [("x", xs)] * 4
             ents = rc[16:48].reshape(4, 4, 2)
             for e in range(16):
                 off, wo = int(ents[e & 3][e >> 2][0]), int(ents[e & 3][e >> 2][1]) & 0xffffffff
@@ -146,7 +137,7 @@ def test_rows_plan_replay(name, layout, which):
                 assert 0 <= s < NW and s not in reads_w, (g, rr, "weight duty hits a slot in use")
                 wslot[s] = w
                 assert all(("w", s) not in issued[k][done[k]:] for k in range(4)), (g, rr, "weight slot requested again while an older request may be in flight")
-                issued[e & 3].append(("w", s))
+                issued[e & 3] += [("w", s)] * 2
         for ob, seq in col_seq.items():
             assert seq == sorted(cols.get(ob, [])), (g, ob, "column blocks missing / out of order")
         assert sum(len(s) for s in col_seq.values()) == nblk
@@ -164,10 +155,11 @@ def test_rows_plan_is_refused_for_other_axis_and_dtype():
 
 
 def test_rows_kernel_keeps_its_reserved_registers(tmp_path):
-    """csrc/bsmm_xrows.h keeps a step's fragments in v[224:255] ACROSS its asm statements (requested by one step's exit, multiplied by the
-    next): the kernel is compiled with amdgpu_num_vgpr(224), which the compiler treats as a target, not a fence -- an experiment build
-    (-DX5_LATE_DUTIES=0) spilled and moved accumulators through v[240:255].  This audit compiles the kernel alone (device only, seconds) and
-    requires that every instruction touching v224+ is one of the asm statements' own (fragment reads, MFMA operands), no scratch, no spill."""
+    """csrc/bsmm_xrows.h keeps a step's fragments in v[216:255] ACROSS its asm statements (requested by one step's exit, multiplied by the
+    next).  Nothing reserves those registers from the compiler but its own appetite (the accumulators live in AGPRs, its code needs < 100
+    VGPRs): an earlier form of the kernel, with the accumulators in VGPRs, had an experiment build move them through the reserved range.
+    This audit compiles the kernel alone (device only, seconds) and requires that every instruction touching v216+ is one of the asm
+    statements' own (fragment reads, MFMA operands), no scratch, no spill."""
     import os, re, shutil, subprocess
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
@@ -188,9 +180,9 @@ def test_rows_kernel_keeps_its_reserved_registers(tmp_path):
     bad = []
     for ln in dis.splitlines():
         body = ln.split("//")[0]
-        regs = [int(x) for x in re.findall(r"v\[?(\d+)", body)]
-        hi = [int(b) for a, b in re.findall(r"v\[(\d+):(\d+)\]", body)]
-        if any(x >= 224 for x in regs + hi) and (body.split() or [""])[0] not in own:
+        regs = [int(x) for x in re.findall(r"\bv\[?(\d+)", body)]
+        hi = [int(b) for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", body)]
+        if any(x >= 216 for x in regs + hi) and (body.split() or [""])[0] not in own:
             bad.append(ln.strip()[:100])
     assert not bad, bad[:5]
-    assert dis.count("s_ff1_i32_b32") >= 4 * 33
+    assert dis.count("s_ff1_i32_b64") >= 4 * 97
