@@ -45,6 +45,10 @@ namespace bsmm {
 #ifndef X4_PUBLISH_FIRST
 #define X4_PUBLISH_FIRST 1
 #endif
+#ifndef X4_FETCH_EARLY
+#define X4_FETCH_EARLY 0      // 1: a BLOCK event requests its wave's weight block two events ahead right behind its first MFMA instead of behind the
+                              //    block: bit-identical, measured 91.4 / 81.7 against 88.9 / 78.7 us (profiles/r05_flow_fetch_early.txt) -- not taken
+#endif
 #ifndef X4_STAGGER
 #define X4_STAGGER 0
 #endif
@@ -250,6 +254,7 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
 #ifdef X4_STAMPS
                 tacc[7] += 1;
 #endif
+                bool fetched = false;
                 if (ty_s & 1) { X4_T0(); x4_wait_ctl<DI>(ctl); X4_T1(0); }     // BLOCK (1) or ANN (3): wait for my fetch / my requests
                 if (ty_s == 1) {
                     // ---- BLOCK: my weight block (fetched two BLOCK events ago) x the slab of its step ----
@@ -285,6 +290,20 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                             acc[t] = DT::mfma32(wq[0], xf[t], acc[t]);
                             xf[t] = *reinterpret_cast<const uint4*>(smem + (xrd[1] ^ sx) + t * 4096);
                             __builtin_amdgcn_sched_barrier(0);
+#if X4_FETCH_EARLY
+                            // my weight block two BLOCK events ahead goes into the slot THIS block's fragments came from: they are in registers
+                            // once the first MFMA could issue (LDS reads return in order: its activation fragment was requested behind them), so
+                            // the two requests are issued here, under the matrix work, instead of behind the block on the wave's critical path
+                            // (the order of the wave's vector-memory operations, hence every vmcnt of the plan, is unchanged)
+                            if (t == 0 && (ctl & 64u)) {
+                                if (!X4_NO_WDMA) {
+                                    const uint32_t fo = (uint32_t)__builtin_amdgcn_readlane(v_fw, idx);
+                                    glds16_saddr_x2(wsel, wvoff + fo, wvoff + fo + 1024u, base_addr + (wslot0 ^ s_wf));
+                                }
+                                s_wf ^= 2048u;
+                                fetched = true;
+                            }
+#endif
                         }
 #pragma unroll
                         for (int t = 0; t < RT; ++t) acc[t] = DT::mfma32(wq[1], xf[t], acc[t]);
@@ -358,7 +377,7 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                     // ---- after a BLOCK / NOP: my next weight fetch (into the slot the block just freed), my progress ----
                     X4_T0();
                     if (X4_PUBLISH_FIRST) x4_lane_write(em, my_prog_s, v_pv);   // (first: the requesters of the slot I just left are waiting for this)
-                    if (ctl & 64u) {
+                    if ((ctl & 64u) && !fetched) {
                         if (!X4_NO_WDMA) {
                             const uint32_t fo = (uint32_t)__builtin_amdgcn_readlane(v_fw, idx);
                             glds16_saddr_x2(wsel, wvoff + fo, wvoff + fo + 1024u, base_addr + (wslot0 ^ s_wf));

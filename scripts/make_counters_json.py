@@ -5,7 +5,7 @@ per LAUNCH.  hbm_bytes = 2 * FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH
 GRBM_GUI_ACTIVE / 8 XCDs at 2.07 GHz (profiler attached: slower than the bench); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 1024
 SIMDs).  bench.py quotes these next to its own timings when the workload string matches exactly."""
 import json, os, shutil, sys
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
 WL = "bsmm fprop+bprop+updat %dx%d block_size=%d density=%d%% feature_axis=%d, minibatch %d per GPU, layout default_rng(1234)"
 WORKLOADS = {"d10": WL % (4096, 4096, 32, 10, 1, 8192), "d20": WL % (4096, 4096, 32, 20, 1, 8192), "d50": WL % (4096, 4096, 32, 50, 1, 8192),
