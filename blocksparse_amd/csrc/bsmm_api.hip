@@ -1419,10 +1419,11 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
         if (axis != 1 || !lut || segments <= 0 || blocks <= 0 || blocks >= (1 << 28)) return axis != 1 ? 0 : -1;
         std::vector<int32_t> lut32, nested;
         if (!b64_expand_xprop_lut(lut, segments, blocks, lut32)) return -1;
-        const long nw = xprop_plan(lut32.data(), 2 * segments, 4 * blocks, 2 * n_out, 32, dtype, axis, options, nullptr);
+        const int32_t nopt = options & ~BSMM_PLAN_XCOL_ROWS;       // (the composite call runs the flow / staged kernels: no 'BSX5' plans nested)
+        const long nw = xprop_plan(lut32.data(), 2 * segments, 4 * blocks, 2 * n_out, 32, dtype, axis, nopt, nullptr);
         if (nw < 0) return -1;
         nested.resize((size_t)nw);
-        if (nw > 0 && out) xprop_plan(lut32.data(), 2 * segments, 4 * blocks, 2 * n_out, 32, dtype, axis, options, nested.data());
+        if (nw > 0 && out) xprop_plan(lut32.data(), 2 * segments, 4 * blocks, 2 * n_out, 32, dtype, axis, nopt, nested.data());
         return b64_emit(0, blocks, segments, lut32, nested, out);
     }
     if (bsize == 8) return dtype == BSMM_F32 ? 0 : build_super8_xprop_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));   // 'BSS8'

@@ -186,3 +186,21 @@ def test_rows_kernel_keeps_its_reserved_registers(tmp_path):
             bad.append(ln.strip()[:100])
     assert not bad, bad[:5]
     assert dis.count("s_ff1_i32_b64") >= 4 * 97
+
+
+def test_rows_option_with_bsize64_nests_the_usual_plans():
+    """BSMM_PLAN_XCOL_ROWS with bsize 64: the composite 'BS64' plan nests a plan the composite call can run (flow / staged), never 'BSX5',
+    and attaches."""
+    import ctypes
+    lay = P.random_layout(6, 10, 0.4, seed=3)
+    t = L.build_tables(lay, z_order=True, segmented=False)
+    f = t["fprop"]
+    plan = _host_plan(f["lut"], f["segments"], t["blocks"], t["KB"], 64, lib.BF16, 1, lib.PLAN_XCOL_ROWS)
+    assert plan is not None and plan[0] == 0x42533634
+    nested = plan[plan[5]:]
+    assert int(nested[0]) != MAGIC
+    a = lib.BsmmArgs()
+    dev = np.zeros(plan.size + 4, dtype=np.int32)                 # (a host buffer stands in for the device copy: attach only records the pointer)
+    addr = (dev.ctypes.data + 15) & ~15
+    ip = ctypes.POINTER(ctypes.c_int32)
+    assert lib.load().bsmm_plan_attach(ctypes.byref(a), plan.ctypes.data_as(ip), plan.size, ctypes.c_void_p(addr)) == 0
