@@ -1024,13 +1024,36 @@ int updat_dt(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* 
     return BSMM_ERR_UNSUPPORTED;
 }
 
+// Non-finite activations in the fp32 split paths below.  A finite x beyond the bf16 range still splits exactly
+// (bsmm_xcols.h::split3), an Inf or NaN cannot: its products with the partner's three pieces come out as Inf or NaN as their signs fall,
+// where the fp32 kernels -- and the reference's fp32 kernels -- give what IEEE gives for the unsplit product.  So the split kernels raise a
+// flag (4 bytes behind the pieces in the workspace), the finalize pass leaves DW alone when it is set, and the per-block fp32 kernel of
+// the shape -- always launched, the flag is its condition: ~2 us of empty workgroups on finite inputs -- then computes the call the way
+// fp32 ran before round 4.  (A call that asks for the raw sums, BSMM_FLAG_DW_SUMS, gets the split path's sums as they are.)
+constexpr size_t F32_SPLIT_FLAG_BYTES = 16;
+template <int BS, int AXIS>
+int f32_split_repair(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a, const int32_t* flag) {
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    PtrList8 xs, es;
+    for (int p = 0; p < 8; ++p) { xs.p[p] = p == 0 ? X[0] : nullptr; es.p[p] = p == 0 ? DY[0] : nullptr; }
+    const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;
+    const int grid = 8 * ((a->blocks + 7) / 8);
+    if constexpr (BS == 32)
+        updat32_kernel<DTf32, AXIS><<<grid, 256, 0, st>>>(xs, es, static_cast<float*>(DW), a->lut, a->blocks, a->N, a->C, a->K, 1, a->alpha, a->beta, ug, flag);
+    else if constexpr (BS == 16)
+        updat16_kernel<DTf32, AXIS><<<grid, 256, 0, st>>>(xs, es, static_cast<float*>(DW), a->lut, a->blocks, a->N, a->C, a->K, 1, a->alpha, a->beta, ug, flag);
+    else
+        updat_valu_kernel<DTf32, BS, AXIS><<<a->blocks, 256, 0, st>>>(xs, es, static_cast<float*>(DW), a->lut, a->blocks, a->N, a->C, a->K, 1, a->alpha, a->beta, ug, flag);
+    return (int)hipGetLastError();
+}
+
 // fp32 weight gradient on feature axis 1, bsize 32, with a streaming plan (round 4).  The per-block fp32 kernel gathers its fragments at a
 // stride of C elements there (25 TF: 2.2 ms at the bench shape).  Instead: X and DY are split into three bf16 pieces each (exact:
 // bsmm_xcols.h) and the SIX significant piece products  x3 y1, x2 y2, x1 y3, x2 y1, x1 y2, x1 y1  (smallest first; the other three are below
 // 2^-26 of the product) go through the bf16 streaming kernel as six (x, dy) PAIRS of ONE launch -- its pair list is what the reference's
 // Plist<T, 8> is (src/gpu_types.h:167-170) -- with fp32 sums, and the finalize pass writes the fp32 DW with alpha / beta / gate.  bf16 x bf16
 // products are exact in fp32 and the accumulation is fp32: the result has the accuracy of an fp32 matrix-core product.
-// Workspace: [what the bf16 call needs][pieces of X: 3 N C bf16][pieces of DY: 3 N K bf16].
+// Workspace: [what the bf16 call needs][pieces of X: 3 N C bf16][pieces of DY: 3 N K bf16][the non-finite flag, 16 bytes].
 inline size_t updat_f32_split_inner_bytes(const bsmm_args* a) {
     bsmm_args b = *a;
     b.dtype = BSMM_BF16; b.pcount = 6; b.flags = BSMM_FLAG_DW_SUMS; b.split = 0; b.gate = nullptr;
@@ -1044,12 +1067,14 @@ int updat32_f32_split(const void* const* X, const void* const* DY, void* DW, con
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;
     const size_t inner = updat_f32_split_inner_bytes(a), nx = (size_t)a->N * a->C, ne = (size_t)a->N * a->K;
-    if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < inner + 6 * (nx + ne)) return BSMM_ERR_WORKSPACE;
+    if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < inner + 6 * (nx + ne) + F32_SPLIT_FLAG_BYTES) return BSMM_ERR_WORKSPACE;
     if (!aligned16(X[0]) || !aligned16(DY[0]) || (DW && !aligned16(DW))) return BSMM_ERR_ARG;
     uint16_t* xp = reinterpret_cast<uint16_t*>(static_cast<char*>(a->workspace) + inner);
     uint16_t* ep = xp + 3 * nx;
-    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X[0]), xp, nx);
-    split3_x_kernel<<<(unsigned)((ne / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(DY[0]), ep, ne);
+    int32_t* flag = reinterpret_cast<int32_t*>(ep + 3 * ne);
+    if (hipError_t e = hipMemsetAsync(flag, 0, F32_SPLIT_FLAG_BYTES, st); e != hipSuccess) return (int)e;
+    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X[0]), xp, nx, flag);
+    split3_x_kernel<<<(unsigned)((ne / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(DY[0]), ep, ne, flag);
     bsmm_args b = *a;
     b.dtype = BSMM_BF16; b.pcount = 6; b.flags = BSMM_FLAG_DW_SUMS; b.split = 0; b.gate = nullptr; b.trace = nullptr;
     b.workspace_bytes = inner;
@@ -1065,8 +1090,8 @@ int updat32_f32_split(const void* const* X, const void* const* DY, void* DW, con
     const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;
     const size_t nel = (size_t)a->blocks * 1024;
     updat_finalize_gated_kernel<DTf32><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(a->workspace), static_cast<float*>(DW), nel, 1024,
-                                                                                         a->alpha, a->beta, ug);
-    return (int)hipGetLastError();
+                                                                                         a->alpha, a->beta, ug, flag);
+    return f32_split_repair<32, 1>(X, DY, DW, a, flag);
 }
 
 // The same for bsize 8 (either feature axis): the six piece products run as six pairs of the streaming launch over the 32x32 SUPER-blocks of
@@ -1091,12 +1116,14 @@ inline size_t updat8_f32_inner_bytes(const bsmm_args* a) {
 int updat8_f32_split(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     const size_t inner = updat8_f32_inner_bytes(a), nx = (size_t)a->N * a->C, ne = (size_t)a->N * a->K;
-    if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < inner + 6 * (nx + ne)) return BSMM_ERR_WORKSPACE;
+    if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < inner + 6 * (nx + ne) + F32_SPLIT_FLAG_BYTES) return BSMM_ERR_WORKSPACE;
     if (!aligned16(X[0]) || !aligned16(DY[0]) || !aligned16(DW)) return BSMM_ERR_ARG;
     uint16_t* xp = reinterpret_cast<uint16_t*>(static_cast<char*>(a->workspace) + inner);
     uint16_t* ep = xp + 3 * nx;
-    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X[0]), xp, nx);
-    split3_x_kernel<<<(unsigned)((ne / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(DY[0]), ep, ne);
+    int32_t* flag = reinterpret_cast<int32_t*>(ep + 3 * ne);
+    if (hipError_t e = hipMemsetAsync(flag, 0, F32_SPLIT_FLAG_BYTES, st); e != hipSuccess) return (int)e;
+    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X[0]), xp, nx, flag);
+    split3_x_kernel<<<(unsigned)((ne / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(DY[0]), ep, ne, flag);
     bsmm_args b = updat8_f32_inner(a);
     b.workspace_bytes = inner;
     static const int xi[6] = {2, 1, 0, 1, 0, 0}, ei[6] = {0, 1, 2, 0, 1, 0};      // the six products, smallest first (see updat32_f32_split)
@@ -1108,8 +1135,8 @@ int updat8_f32_split(const void* const* X, const void* const* DY, void* DW, cons
     const int rc = a->axis == 1 ? launch_updat2<DTbf16, 1>(xs, es, nullptr, &b, nullptr) : launch_updat2<DTbf16, 0>(xs, es, nullptr, &b, nullptr);
     if (rc) return rc;
     trace(a, BSMM_K_UPDAT_SUPER8);
-    gather8_f32_kernel<<<a->plan_width, 256, 0, st>>>(static_cast<const float*>(a->workspace), a->plan, static_cast<float*>(DW), a->alpha, a->beta);
-    return (int)hipGetLastError();
+    gather8_f32_kernel<<<a->plan_width, 256, 0, st>>>(static_cast<const float*>(a->workspace), a->plan, static_cast<float*>(DW), a->alpha, a->beta, flag);
+    return a->axis == 1 ? f32_split_repair<8, 1>(X, DY, DW, a, flag) : f32_split_repair<8, 0>(X, DY, DW, a, flag);
 }
 
 // ... and for bsize 16 on feature axis 1 on the windowed kernel: six pairs of one launch, raw fp32 sums by its scratch path, fp32 finalize:
@@ -1125,15 +1152,16 @@ template <int AXIS>
 int updat16_f32_split(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     const size_t sums_b = updat16_f32_sums_bytes(a), nx = (size_t)a->N * a->C, ne = (size_t)a->N * a->K, nel = (size_t)a->blocks * 256;
-    if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < sums_b + 6 * (nx + ne)) return BSMM_ERR_WORKSPACE;
+    if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < sums_b + 6 * (nx + ne) + F32_SPLIT_FLAG_BYTES) return BSMM_ERR_WORKSPACE;
     if (!aligned16(X[0]) || !aligned16(DY[0]) || !aligned16(DW)) return BSMM_ERR_ARG;
     float* sums = static_cast<float*>(a->workspace);
     uint16_t* xp = reinterpret_cast<uint16_t*>(static_cast<char*>(a->workspace) + sums_b);
     uint16_t* ep = xp + 3 * nx;
-    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X[0]), xp, nx);
-    split3_x_kernel<<<(unsigned)((ne / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(DY[0]), ep, ne);
-    hipError_t e = hipMemsetAsync(sums, 0, nel * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    int32_t* flag = reinterpret_cast<int32_t*>(ep + 3 * ne);
+    if (hipError_t e = hipMemsetAsync(flag, 0, F32_SPLIT_FLAG_BYTES, st); e != hipSuccess) return (int)e;
+    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X[0]), xp, nx, flag);
+    split3_x_kernel<<<(unsigned)((ne / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(DY[0]), ep, ne, flag);
+    if (hipError_t e = hipMemsetAsync(sums, 0, nel * sizeof(float), st); e != hipSuccess) return (int)e;
     static const int xi[6] = {2, 1, 0, 1, 0, 0}, ei[6] = {0, 1, 2, 0, 1, 0};      // the six products, smallest first (see updat32_f32_split)
     PtrList8 xs, es;
     for (int p = 0; p < 8; ++p) {
@@ -1145,8 +1173,8 @@ int updat16_f32_split(const void* const* X, const void* const* DY, void* DW, con
     const int split = updat_split(a, a->plan_items, (a->N + 63) / 64);
     updat16_win_kernel<DTbf16, AXIS><<<dim3(a->plan_items, split), 512, 2 * UWN_SLOT, st>>>(xs, es, nullptr, sums, a->plan, a->N, a->C, a->K, 6, 1.f, 0.f);
     const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;
-    updat_finalize_gated_kernel<DTf32><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(sums, static_cast<float*>(DW), nel, 256, a->alpha, a->beta, ug);
-    return (int)hipGetLastError();
+    updat_finalize_gated_kernel<DTf32><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(sums, static_cast<float*>(DW), nel, 256, a->alpha, a->beta, ug, flag);
+    return f32_split_repair<16, AXIS>(X, DY, DW, a, flag);
 }
 
 int updat64(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
@@ -1579,7 +1607,7 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     }
     const size_t lock = xprop_op ? lock_acc_bytes(a) : 0;
     if (op == BSMM_OP_UPDAT && updat8_f32_split_applies(a))     // fp32 / bsize 8 through the bf16 streaming kernel: its workspace + the pieces of X and DY
-        return updat8_f32_inner_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K);
+        return updat8_f32_inner_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K) + F32_SPLIT_FLAG_BYTES;
     if (a->bsize == 8) {   // 'BSS8' plans: the expanded W (xprop) / the fp32 sums of the super-blocks (updat)
         if (!a->plan || a->plan_magic != S8PLAN_MAGIC || a->plan_width <= 0 || a->dtype == BSMM_F32) return lock;
         const size_t blk = (size_t)a->plan_width * 1024;
@@ -1591,9 +1619,9 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
         return op == BSMM_OP_UPDAT ? blk * sizeof(float) : std::max(round16(blk * elem_size(a->dtype)) + 16, lock);   // (+ the non-finite flag of the call)
     }
     if (op == BSMM_OP_UPDAT && updat16_f32_split_applies(a))    // fp32 / bsize 16 on the windowed kernel: the fp32 sums + the pieces of X and DY
-        return updat16_f32_sums_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K);
+        return updat16_f32_sums_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K) + F32_SPLIT_FLAG_BYTES;
     if (op == BSMM_OP_UPDAT && updat_f32_split_applies(a))      // fp32 through the bf16 streaming kernel: its workspace + the pieces of X and DY
-        return updat_f32_split_inner_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K);
+        return updat_f32_split_inner_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K) + F32_SPLIT_FLAG_BYTES;
     if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32) {
         if (a->plan_magic == U2PLAN_MAGIC) {   // streaming kernel: the fp32 sums + one region of partial sums per (round, workgroup)
             const U2Launch L = updat2_shape(a, true);

@@ -89,8 +89,10 @@ gather8_kernel(const float* __restrict__ S32, const int32_t* __restrict__ plan, 
 // fp32 form (round 4: the fp32 weight gradient of bsize 8 through the bf16 streaming kernel, bsmm_api.hip::updat8_f32_split): the same gather,
 // DW8 in fp32 (no rounding)
 __global__ void __launch_bounds__(256)
-gather8_f32_kernel(const float* __restrict__ S32, const int32_t* __restrict__ plan, float* __restrict__ DW8, float alpha, float beta) {
+gather8_f32_kernel(const float* __restrict__ S32, const int32_t* __restrict__ plan, float* __restrict__ DW8, float alpha, float beta,
+                   const int32_t* __restrict__ skip_if = nullptr) {
     const int s = blockIdx.x;
+    if (skip_if && skip_if[0] != 0) return;               // non-finite inputs: the repair pass (updat8_f32_split) writes DW8
     if (plan[0] != S8PLAN_MAGIC || plan[1] != S8PLAN_VERSION || s >= plan[2]) return;
     const int32_t* sub = plan + plan[3] + 16 * s;
     const int c32 = threadIdx.x >> 3, k0 = (threadIdx.x & 7) * 4;

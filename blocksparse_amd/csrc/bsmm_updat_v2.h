@@ -636,9 +636,9 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
 template <class DT>
 __global__ void __launch_bounds__(256)
 updat_finalize_gated_kernel(const float* __restrict__ scratch, typename DT::T* __restrict__ DW, size_t n, int bsq, float alpha, float beta,
-                            const float* __restrict__ gate) {
+                            const float* __restrict__ gate, const int32_t* __restrict__ skip_if = nullptr) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
+    if (i >= n || (skip_if && skip_if[0] != 0)) return;      // (skip_if: the fp32 split paths' non-finite flag -- their repair pass writes DW then)
     const float4 s = *reinterpret_cast<const float4*>(scratch + i);
     const float a = gate ? alpha * gate[i / bsq] : alpha;
     float v[4] = {a * s.x, a * s.y, a * s.z, a * s.w};

@@ -24,7 +24,8 @@ namespace bsmm {
 
 //  the first piece never exceeds the input: a finite x beyond the largest bf16 (|x| > 3.39e38, it would round to Inf and leave
 // Inf - Inf = NaN behind) keeps the largest finite bf16 as its first piece and stays exact; a non-finite x keeps its first piece and gets
-// zero residues (the products are then non-finite, as the fp32 kernels' are -- Inf or NaN according to the signs of the partner's pieces).
+// zero residues (the products are then non-finite -- Inf or NaN according to the signs of the partner's pieces; the weight-gradient paths
+// raise a flag for such inputs, split3_x_kernel's last argument, and re-run the call on the fp32 kernels: bsmm_api.hip::f32_split_repair).
 __device__ __forceinline__ void split3(float x, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
     uint16_t p1 = DTbf16::from_f32(x);
     if ((p1 & 0x7fffu) >= 0x7f80u) {
@@ -39,7 +40,7 @@ __device__ __forceinline__ void split3(float x, uint32_t& b1, uint32_t& b2, uint
 
 // P[q][i] = piece q of X[i], i < n (n % 8 == 0); 8 elements per thread
 __global__ void __launch_bounds__(256)
-split3_x_kernel(const float* __restrict__ X, uint16_t* __restrict__ P, size_t n) {
+split3_x_kernel(const float* __restrict__ X, uint16_t* __restrict__ P, size_t n, int32_t* __restrict__ nonfinite = nullptr) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i >= n) return;
     const float4 a = *reinterpret_cast<const float4*>(X + i), b = *reinterpret_cast<const float4*>(X + i + 4);
@@ -47,6 +48,12 @@ split3_x_kernel(const float* __restrict__ X, uint16_t* __restrict__ P, size_t n)
     uint32_t p[3][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) split3(v[j], p[0][j], p[1][j], p[2][j]);
+    if (nonfinite) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad |= (__builtin_bit_cast(uint32_t, v[j]) & 0x7f800000u) == 0x7f800000u;
+        if (bad) nonfinite[0] = 1;
+    }
 #pragma unroll
     for (int q = 0; q < 3; ++q)
         *reinterpret_cast<uint4*>(P + q * n + i) = make_uint4(p[q][0] | (p[q][1] << 16), p[q][2] | (p[q][3] << 16),

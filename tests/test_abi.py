@@ -470,7 +470,7 @@ def test_updat_plan_covers_every_block_once(lib):
 
 def test_fp32_updat_takes_the_streaming_plan_on_axis1_without_gpu(lib):
     """fp32 / bsize 32 / feature axis 1 / one pair: bsmm_updat accepts the streaming 'BSU2' plan (the six bf16 piece products run as six
-    pairs of one launch) and asks for the bf16 call's workspace plus the pieces of X and DY (6 bytes per element); on feature axis 0,
+    pairs of one launch) and asks for the bf16 call's workspace plus the pieces of X and DY (6 bytes per element) and 16 bytes of flag; on feature axis 0,
     with two pairs, or without a plan the fp32 call needs no workspace; bsize 16 ('BSUP' plan) and bsize 8 ('BSS8') have the same route."""
     import numpy as np
     from blocksparse_amd import lut as LT
@@ -490,7 +490,7 @@ def test_fp32_updat_takes_the_streaming_plan_on_axis1_without_gpu(lib):
     b.dtype, b.pcount, b.flags = lib.BF16, 6, lib.FLAG_DW_SUMS
     inner = L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(b))
     need = L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(a))
-    assert inner > 0 and need == (inner + 15) // 16 * 16 + 6 * 512 * (24 * 32 + 40 * 32)
+    assert inner > 0 and need == (inner + 15) // 16 * 16 + 6 * 512 * (24 * 32 + 40 * 32) + 16    # (+ the non-finite flag)
     a.pcount = 2
     assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(a)) == 0                                   # two pairs: the kernels without a plan
     a.pcount, a.axis = 1, 0
@@ -504,7 +504,7 @@ def test_fp32_updat_takes_the_streaming_plan_on_axis1_without_gpu(lib):
     ctypes.memmove(ctypes.byref(c), ctypes.byref(a), ctypes.sizeof(a))
     c.bsize, c.C, c.K = 16, 24 * 16, 40 * 16
     assert L.bsmm_plan_attach(ctypes.byref(c), w16.ctypes.data_as(ip), w16.size, ctypes.c_void_p(4096)) == 0
-    assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(c)) == (t["blocks"] * 256 * 4 + 15) // 16 * 16 + 6 * 512 * (24 * 16 + 40 * 16)
+    assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(c)) == (t["blocks"] * 256 * 4 + 15) // 16 * 16 + 6 * 512 * (24 * 16 + 40 * 16) + 16
     c.axis = 0
     assert L.bsmm_workspace_bytes(lib.OP_UPDAT, ctypes.byref(c)) == 0           # (feature axis 0: the per-block fp32 kernel, no workspace)
     c.axis = 1

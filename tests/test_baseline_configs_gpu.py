@@ -179,35 +179,58 @@ def test_full_output_at_4096_against_float64_oracle(env, bs, axis, density):
     assert l2 <= bar, ("DW", l2)
 
 
-def test_fp32_updat_split_with_huge_and_nonfinite_inputs(env):
-    """The fp32 weight gradient through the bf16 three-piece split (bsize 32, feature axis 1) with activations the FIRST piece cannot hold
-    (ADVICE r4): |x| above the largest bf16 (3.39e38 < |x| <= FLT_MAX) used to round to Inf and leave NaN pieces -- the first piece is clamped,
-    the split stays exact and the blocks come out as the float64 oracle's; a +-Inf activation gives a non-finite block (Inf or NaN, as the
-    pieces' signs fall -- the fp32 kernels give Inf) and leaves every OTHER block untouched."""
+@pytest.mark.parametrize("bsize,axis,kernel", [(32, 1, "K_UPDAT_STREAM"), (16, 1, "K_UPDAT16_WIN"), (8, 1, "K_UPDAT_SUPER8"), (8, 0, "K_UPDAT_SUPER8")])
+def test_fp32_updat_split_with_huge_and_nonfinite_inputs(env, bsize, axis, kernel):
+    """The fp32 weight gradient through the bf16 three-piece split (bsize 32 / 16 on feature axis 1, bsize 8 on either) with activations the
+    FIRST piece cannot hold:
+    (a) |x| above the largest bf16 (3.39e38 < |x| <= FLT_MAX) used to round to Inf and leave NaN pieces -- the first piece is clamped, the
+        split stays exact and the blocks come out as the float64 oracle's;
+    (b) an Inf or NaN activation cannot be split: the call raises its flag and the per-block fp32 kernel computes it (round 5) -- the
+        result then has Inf and NaN exactly where IEEE arithmetic on the unsplit values has them (the float64 oracle's), the finite rest
+        within the fp32 bar, with alpha / beta applied ONCE (the skipped finalize pass must not have touched DW)."""
     torch, BSMM, lib = env
-    lay = P.random_layout(24, 24, 0.3, seed=4)
+    nb = 24 * 32 // bsize
+    lay = P.random_layout(nb, nb, 0.3 if bsize == 32 else 0.2, seed=4)
     N = 512
-    b = BSMM(lay, block_size=32, feature_axis=1)
-    t = orc.build_layout_luts(np.asarray(lay), 32)
+    b = BSMM(lay, block_size=bsize, feature_axis=axis)
+    t = orc.build_layout_luts(np.asarray(lay), bsize)
     W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=41)
     E = (E * 1e-3).astype(np.float32)
     big = np.float32(3.4e38)                                   # finite in fp32, beyond the bf16 range
-    c0 = int(np.asarray(b.updat_lut).reshape(-1, 2)[0, 0])
-    X[3, 32 * c0 + 5] = big
-    X[7, 32 * c0 + 9] = -big
+    lut = np.asarray(b.updat_lut).reshape(-1, 2)
+    c0 = int(lut[0, 0])
+
+    def put(A, n, f, v):                                       # element (minibatch n, feature f) in the layout of the feature axis
+        if axis == 1: A[n, f] = v
+        else:         A[f, n] = v
+    put(X, 3, bsize * c0 + 5, big)
+    put(X, 7, bsize * c0 + 6, -big)
     x, e = P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)
     got = P.to_host(b.updat(x, e))
-    assert lib.last_kernel() == lib.K_UPDAT_STREAM
-    ref = orc.updat(t, X.astype(np.float64), E.astype(np.float64), 1)
+    assert lib.last_kernel() == getattr(lib, kernel)
+    ref = orc.updat(t, X.astype(np.float64), E.astype(np.float64), axis)
     assert np.isfinite(got).all()
     l2, _ = P.errors(got, ref)
     assert l2 <= P.L2_BAR["f32"], l2
-    X[3, 32 * c0 + 5] = np.inf
-    got2 = P.to_host(b.updat(P.to_dev(X, "f32", torch), e))
-    lut = np.asarray(b.updat_lut).reshape(-1, 2)
-    hit = lut[:, 0] == c0
-    assert not np.isfinite(got2[hit]).all(axis=(1, 2)).any()                  # every block of that input block row holds the non-finite row
-    assert np.isfinite(got2[~hit]).all() and np.array_equal(got2[~hit], got[~hit])
+    # (b) an Inf in X, a NaN in DY, accumulated into an existing DW
+    put(X, 3, bsize * c0 + 5, np.inf)
+    k0 = int(lut[-1, 1])
+    put(E, 11, bsize * k0 + 2, np.nan)
+    dw0 = (np.random.default_rng(5).standard_normal(b.w_shape) * 0.1).astype(np.float32)
+    dw = P.to_dev(dw0.copy(), "f32", torch)
+    got2 = P.to_host(b.updat(P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch), alpha=0.5, beta=2.0, dw=dw))
+    assert lib.last_kernel() == getattr(lib, kernel)           # (the trace names the path the call took; the repair pass rides behind it)
+    with np.errstate(invalid="ignore", over="ignore"):
+        ref2 = 0.5 * orc.updat(t, X.astype(np.float64), E.astype(np.float64), axis) + 2.0 * dw0.astype(np.float64)
+    assert np.isnan(ref2).any() and np.isinf(ref2).any()
+    assert np.array_equal(np.isnan(got2), np.isnan(ref2))
+    inf = np.isinf(ref2)
+    assert np.array_equal(np.isinf(got2), inf) and np.array_equal(np.sign(got2[inf]), np.sign(ref2[inf]))
+    fin = np.isfinite(ref2)
+    l2, _ = P.errors(np.where(fin, got2, 0), np.where(fin, ref2, 0))
+    assert l2 <= P.L2_BAR["f32"], l2
+    # ... and the next finite call is back on the split path's result, bit for bit
+    assert np.array_equal(P.to_host(b.updat(x, e)), got)
 
 
 @pytest.mark.parametrize("density", [0.1, 0.2, 0.5])
