@@ -20,6 +20,7 @@
 #include "bsmm_xcol_v2.h"
 #include "bsmm_xflow.h"
 #include "bsmm_xrows.h"
+#include "bsmm_updat16_rows.h"
 #include "bsmm_xsmall.h"
 #include "bsmm_xmid.h"
 #include "bsmm_xcol16_v2.h"
@@ -858,6 +859,52 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     return (int)hipGetLastError();
 }
 
+// Row-owner kernel for bsize 16 on feature axis 0 (bsmm_updat16_rows.h).  grid = items x split, part of the minibatch = linear id % split.
+// split: the caller's (bsmm_args.split, at most U6_MAX_SPLIT), else the smallest power of two that gives every CU a workgroup.  Measured
+// against the windowed kernel (scripts/gpu_updat16_rows_sweep.py, profiles/r05_updat16_rows_sweep.txt): the row-owner kernel wins once
+// three quarters of the CUs get a workgroup and a workgroup keeps 8 chunks of 64 minibatch entries (16 when four or more parts leave
+// their sums for the finalize pass) -- 8 to 31 % at 4096^2 / 8192^2; otherwise BSMM_ERR_UNSUPPORTED: the caller takes the windowed kernel
+// (2048^2 has 16 windows of 512 x 512: never).
+constexpr int U6_MAX_SPLIT = 8;
+template <class DT>
+int launch_updat16_rows(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a) {
+    typedef typename DT::T T;
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const int32_t* sec = a->plan + a->plan_inner;
+    const int nchunks = (a->N + 63) / 64;
+    const int nitems = a->plan_waves >> 8, wk = a->plan_width >> 8;      // (bsmm_plan_attach packs the section's item count / window width there)
+    if (nitems <= 0 || (wk != 32 && wk != 16)) return BSMM_ERR_ARG;
+    int split;
+    if (a->split > 0) {
+        split = std::min(std::min(a->split, nchunks), U6_MAX_SPLIT);
+    } else {
+        const int cus = device_cus();
+        split = 1;
+        while (split < U6_MAX_SPLIT && nitems * split < cus) split *= 2;
+        const bool pays = 4L * nitems * split >= 3L * cus && nchunks / split >= (split >= 4 ? 16 : 8);
+        if (!pays && call_variant(a) != 3) return BSMM_ERR_UNSUPPORTED;
+        split = std::max(1, std::min(split, nchunks));
+    }
+    float* scratch = nullptr;
+    const size_t nel = (size_t)a->blocks * 256;
+    if (split > 1) {      // one fp32 image of the sums per part
+        if (!a->workspace || a->workspace_bytes < (size_t)split * nel * sizeof(float) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
+        scratch = static_cast<float*>(a->workspace);
+    }
+    trace(a, BSMM_K_UPDAT16_ROWS);
+    const unsigned grid = (unsigned)nitems * split;
+    if (wk == 32) {
+        if (int rc = ensure_lds<&updat16_rows_kernel<DT, 32>>(U6Geom<32>::LDS)) return rc;
+        updat16_rows_kernel<DT, 32><<<grid, 64 * U6_WAVES, U6Geom<32>::LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, sec, a->N, a->C, a->K, a->pcount, a->alpha, a->beta, split, nel);
+    } else {
+        if (int rc = ensure_lds<&updat16_rows_kernel<DT, 16>>(U6Geom<16>::LDS)) return rc;
+        updat16_rows_kernel<DT, 16><<<grid, 64 * U6_WAVES, U6Geom<16>::LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, sec, a->N, a->C, a->K, a->pcount, a->alpha, a->beta, split, nel);
+    }
+    if (split > 1)
+        updat16_rows_finalize_kernel<DT><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), nel, split, a->alpha, a->beta);
+    return (int)hipGetLastError();
+}
+
 template <class DT, int BS, int AXIS>
 int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a) {
     typedef typename DT::T T;
@@ -966,7 +1013,15 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
         bool al16 = aligned16(DW) && (AXIS == 1 || N % 8 == 0);
         for (int p = 0; p < a->pcount; ++p) al16 = al16 && aligned16(xs.p[p]) && aligned16(es.p[p]);
         if (!use_valu && !gated && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed, 16x16 blocks
-            if (a->plan_magic != UPLAN_MAGIC || a->plan_width != UW16 || a->plan_waves != UP_WAVES) return BSMM_ERR_ARG;
+            if (a->plan_magic != UPLAN_MAGIC || (a->plan_width & 255) != UW16 || (a->plan_waves & 255) != UP_WAVES) return BSMM_ERR_ARG;   // (bits 8..: the 'BSU6' section's window width / items)
+            if constexpr (AXIS == 0) {
+                // row-owner kernel ('BSU6' section, bsmm_updat16_rows.h): half the bytes per block of the windowed kernel, 64 (or fewer) work items --
+                // taken when every workgroup gets at least U6_MIN_CHUNKS chunks of 64 minibatch entries
+                if (a->plan_inner > 0 && (long)N * std::max(a->C, a->K) < (1L << 31)) {
+                    const int rc = launch_updat16_rows<DT>(xs, es, DW, a);
+                    if (rc != BSMM_ERR_UNSUPPORTED) return rc;
+                }
+            }
             if (int rc = ensure_lds<&updat16_win_kernel<DT, AXIS>>(2 * UWN_SLOT)) return rc;
             trace(a, BSMM_K_UPDAT16_WIN);
             const int nitems = a->plan_items;
@@ -1143,7 +1198,7 @@ int updat8_f32_split(const void* const* X, const void* const* DY, void* DW, cons
 // 1.44 -> 1.12 ms at 4096^2, 10 %, N = 8192.  (Feature axis 0 measured too: 1.05 ms against 1.01 for the per-block fp32 kernel, whose
 // fragments are contiguous there -- not taken.)
 inline bool updat16_f32_split_applies(const bsmm_args* a) {
-    return a->dtype == BSMM_F32 && a->bsize == 16 && a->axis == 1 && a->plan && a->plan_magic == UPLAN_MAGIC && a->plan_width == UW16 && a->plan_waves == UP_WAVES &&
+    return a->dtype == BSMM_F32 && a->bsize == 16 && a->axis == 1 && a->plan && a->plan_magic == UPLAN_MAGIC && (a->plan_width & 255) == UW16 && (a->plan_waves & 255) == UP_WAVES &&
            a->plan_items > 0 && a->pcount == 1 && a->split == 0 && !(a->flags & BSMM_FLAG_DW_SUMS) && a->C % 16 == 0 && a->K % 16 == 0 &&
            !(a->axis == 0 && a->N % 8 != 0) && call_variant(a) != 1 && call_variant(a) != 2;
 }
@@ -1404,6 +1459,9 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
 #ifdef X4_TIMELINE
 extern "C" int bsmm_debug_x4_timeline_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_tl), sizeof(bsmm::g_x4_tl)); }
 #endif
+#ifdef U6_STAMPS
+extern "C" int bsmm_debug_u6_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_u6_trace), sizeof(bsmm::g_u6_trace)); }
+#endif
 #ifdef X5_STAMPS
 extern "C" int bsmm_debug_x5_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x5_trace), sizeof(bsmm::g_x5_trace)); }
 #endif
@@ -1507,7 +1565,17 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
         return b64_emit(1, blocks, 0, lut32, nested, out);
     }
     if (bsize == 8) return build_super8_updat_plan(lut, blocks, CB, KB, out);   // 'BSS8'
-    if (bsize == 16) return build_updat_plan(lut, blocks, CB, KB, UW16, UP16_MAXB, out);
+    if (bsize == 16) {
+        // 'BSUP' items of the windowed kernel; on feature axis 0 the 'BSU6' section of the row-owner kernel behind them (header word [8]):
+        // the call picks per minibatch size (updat_typed)
+        const long base = build_updat_plan(lut, blocks, CB, KB, UW16, UP16_MAXB, out);
+        if (base <= 0 || axis != 0 || (options & BSMM_PLAN_UPDAT16_WINDOWED)) return base;
+        const long off = (base + 3) & ~3L;
+        const long sec = build_updat16_rows_section(lut, blocks, CB, KB, out ? out + off : nullptr);
+        if (sec <= 0) return base;
+        if (out) { std::fill(out + base, out + off, 0); out[8] = (int32_t)off; }
+        return off + sec;
+    }
     if (bsize != 32) return 0;
     int force = options & BSMM_PLAN_WINDOW_MASK;
     // BSMM_PLAN_WINDOW_8 / _16 / _16W named the windowed bsize-32 kernels of round 1 (retired in round 4): the same window side on the streaming kernel
@@ -1548,7 +1616,14 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
         case X4PLAN_MAGIC:   if (p[1] != X4PLAN_VERSION || words < X4_HDR || p[2] != X4_G) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case X5PLAN_MAGIC:   if (p[1] != X5PLAN_VERSION || words < X5_HDR || p[2] != X5_G || p[7] != (X5_D | (X5_NW << 8) | (X5_CAP << 16) | (X5_P << 24))) return false;   d[1] = p[2]; d[2] = 4; d[3] = 0; break;
         case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
-        case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR) return false;    d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; break;
+        case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR || p[8] < 0 || (p[8] > 0 && (p[8] + U6_HDR > words || p[p[8]] != U6PLAN_MAGIC ||
+                                 p[8] + U6_HDR + (long)p[p[8] + 4] * U6_ITEM > words))) return false;
+                             d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8];               // (plan_inner: word offset of the 'BSU6' section, 0 = none;
+                             if (p[8] > 0) {                                                   //  its window width / item count in bits 8.. of width / waves)
+                                 if (p[2] > 255 || p[7] > 255 || p[p[8] + 4] <= 0 || p[p[8] + 4] >= (1 << 23)) return false;
+                                 d[1] |= p[p[8] + 3] << 8; d[2] |= p[p[8] + 4] << 8;
+                             }
+                             break;
         case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR || p[26] != U2_HDR + p[4] * U2_ITEM || words < (long)p[26] + p[5]) return false;   // (the launcher addresses the block map behind the items)
                                d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8] | (p[25] > 0 ? 16 : 0) | (p[27] << 8); break;   // item sets | all equally long | longest set
         default: return false;
@@ -1628,7 +1703,9 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
             return u2_sums_bytes(a) + (size_t)L.rounds * L.grid * u2_region_bytes();
         }
         if (a->plan_magic != UPLAN_MAGIC || a->bsize != 16) return 0;     // (a plan check_plan refuses: nothing to size)
-        return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float);   // bsize 16 windowed kernel: fp32 partial sums of the split-minibatch path
+        // bsize 16 windowed kernel: one fp32 image of the sums (split-minibatch path); with the 'BSU6' section (feature axis 0) one image per part
+        // of the row-owner kernel's minibatch split
+        return (size_t)a->blocks * a->bsize * a->bsize * sizeof(float) * (a->plan_inner > 0 && a->axis == 0 ? U6_MAX_SPLIT : 1);
     }
     if (xprop_op && a->dtype == BSMM_F32 && a->bsize == 32 && a->plan && a->plan_magic == XCPLAN_MAGIC)   // bf16 pieces of the activations and
         return std::max(xcols_workspace_bytes(a), (op == BSMM_OP_FPROP ? wt_bytes(a) : 0) + lock);          // (unless prepared) the weights -- or what

@@ -22,7 +22,8 @@
 // DY slabs (same window column) through that XCD's L2.  Shorter lists are padded with empty items.
 //
 // Layout (int32):  [0] magic 'BSUP'  [1] version  [2] UW  [3] UP_MAXB  [4] nitems (multiple of 8)  [5] nblocks
-//                  [6] off_items  [7] UP_WAVES
+//                  [6] off_items  [7] UP_WAVES  [8] off_rows: word offset of the 'BSU6' section behind the items (bsize 16 on feature axis 0,
+//                  round 5: build_updat16_rows_section below; 0 = none)  [9..11] 0
 //   item: UP_ITEM = 4 + UP_WAVES*UP_MAXB*2 words = (c0_block, k0_block, nblocks_in_item | cmask << 16, nslots | kmask << 16)
 //         then for wave v, slot j:
 //         (nslots = slots every wave of the item walks = max blocks owned by one wave; empty slots have meta = 0;
@@ -32,11 +33,11 @@
 namespace bsmm {
 
 constexpr int32_t UPLAN_MAGIC = 0x42535550;
-constexpr int32_t UPLAN_VERSION = 5;
+constexpr int32_t UPLAN_VERSION = 6;
 constexpr int UW = 8;          // bsize 32: 8x8-block windows, 4 slots per wave
 constexpr int UP_WAVES = 8;
 constexpr int UP_MAXB = 4;
-constexpr int UP_HDR = 8;
+constexpr int UP_HDR = 12;
 constexpr int UP_ITEM = 4 + UP_WAVES * UP_MAXB * 2;
 constexpr int UW16 = 16;       // bsize 16: 16x16-block windows (the same 256x256 features), 8 slots per wave
 constexpr int UP16_MAXB = 8;
@@ -92,7 +93,7 @@ inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int K
     const long nitems = (long)longest * 8;
     const long total = UP_HDR + nitems * UP_ITEM;
     if (out) {
-        const int32_t hdr[UP_HDR] = {UPLAN_MAGIC, UPLAN_VERSION, UW, UP_MAXB, (int32_t)nitems, blocks, UP_HDR, UP_WAVES};
+        const int32_t hdr[UP_HDR] = {UPLAN_MAGIC, UPLAN_VERSION, UW, UP_MAXB, (int32_t)nitems, blocks, UP_HDR, UP_WAVES, 0, 0, 0, 0};
         std::copy(hdr, hdr + UP_HDR, out);
         std::fill(out + UP_HDR, out + total, 0);
         for (int x = 0; x < 8; ++x)
@@ -100,6 +101,105 @@ inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int K
                 std::copy(per_xcd[x].begin() + j * UP_ITEM, per_xcd[x].begin() + (j + 1) * UP_ITEM, out + UP_HDR + (j * 8 + x) * UP_ITEM);
     }
     return total;
+}
+
+// -------------------------------------------------------------------------------------------------
+// 'BSU6' section: work items of the row-owner weight-gradient kernel for bsize 16 on feature axis 0 (bsmm_updat16_rows.h, round 5).
+// A window is U6_WC = 32 block rows (512 features of X) x WK block columns (WK = 32 or 16: 512 / 256 features of DY).  The DY rows of a
+// window go through LDS (one slab per 64-wide minibatch chunk, shared by all waves); the X rows do NOT: wave v OWNS up to U6_ROWS block
+// rows of the window and loads their fragments straight into registers (on feature axis 0 a fragment is 16 contiguous bytes of a row),
+// and every block of those rows is its.  Rows are dealt to the waves longest first onto the least loaded wave (at most U6_ROWS rows and
+// U6_MAXB blocks per wave); a wave's blocks are sorted by (row slot, k).  WK = 32 unless some wave of some window would hold more than
+// U6_MAXB blocks, then 16; no section when that fails too (dense layouts keep the 256 x 256 windows of the items above).
+// Items in window order, row-major: consecutive items share X rows, items WKn apart share DY rows (the launcher keeps runs of consecutive
+// items on one XCD).
+//   section (int32): [0] magic 'BSU6' [1] version [2] U6_WC [3] WK [4] nitems [5] U6_WAVES | U6_ROWS << 8 | U6_MAXB << 16 [6] U6_ITEM [7] 0
+//   item: (c0_block, k0_block, nblocks, 0) then per wave U6_WAVE words:
+//         [0] the wave's block rows inside the window, 8 bits each (0xff = none)
+//         [1] nb: the wave's blocks
+//         [2 + j / 2] 16 bits per block j (low half first): column inside the window | row slot << 8
+//         [2 + U6_MAXB / 2 + j] weight block id of block j
+// -------------------------------------------------------------------------------------------------
+constexpr int32_t U6PLAN_MAGIC = 0x42535536;
+constexpr int32_t U6PLAN_VERSION = 2;
+constexpr int U6_WC = 32, U6_WAVES = 16, U6_ROWS = 2, U6_MAXB = 12, U6_HDR = 8;
+constexpr int U6_WAVE = 2 + U6_MAXB / 2 + U6_MAXB;
+constexpr int U6_ITEM = 4 + U6_WAVES * U6_WAVE;
+
+inline long build_updat16_rows_section(const int32_t* updat_lut, int blocks, int CB, int KB, int32_t* out) {
+    if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0) return -1;
+    struct Ent { int c, k, w; };
+    for (int WK = 32; WK >= 16; WK /= 2) {
+        const int wc = (CB + U6_WC - 1) / U6_WC, wk = (KB + WK - 1) / WK;
+        std::vector<std::vector<Ent>> win((size_t)wc * wk);
+        for (int w = 0; w < blocks; ++w) {
+            const int c = updat_lut[2 * w], k = updat_lut[2 * w + 1];
+            if (c < 0 || c >= CB || k < 0 || k >= KB) return -1;
+            win[(size_t)(c / U6_WC) * wk + (k / WK)].push_back({c, k, w});
+        }
+        std::vector<int32_t> items;
+        bool fits = true;
+        for (int wi = 0; wi < wc && fits; ++wi)
+            for (int wj = 0; wj < wk && fits; ++wj) {
+                auto& v = win[(size_t)wi * wk + wj];
+                if (v.empty()) continue;
+                int cnt[U6_WC] = {0};
+                for (const Ent& e : v) ++cnt[e.c - wi * U6_WC];
+                int order[U6_WC];
+                for (int r = 0; r < U6_WC; ++r) order[r] = r;
+                std::stable_sort(order, order + U6_WC, [&](int a, int b) { return cnt[a] > cnt[b]; });
+                int load[U6_WAVES] = {0}, nrows[U6_WAVES] = {0}, rows[U6_WAVES][U6_ROWS];
+                int owner[U6_WC], slot_of[U6_WC];
+                for (int i = 0; i < U6_WC; ++i) {
+                    const int r = order[i];
+                    owner[r] = -1; slot_of[r] = 0;
+                    if (cnt[r] == 0) continue;
+                    int best = -1;
+                    for (int v2 = 0; v2 < U6_WAVES; ++v2)
+                        if (nrows[v2] < U6_ROWS && (best < 0 || load[v2] < load[best])) best = v2;
+                    if (best < 0 || load[best] + cnt[r] > U6_MAXB) { fits = false; break; }
+                    owner[r] = best; slot_of[r] = nrows[best];
+                    rows[best][nrows[best]++] = r;
+                    load[best] += cnt[r];
+                }
+                if (!fits) break;
+                std::vector<int32_t> it(U6_ITEM, 0);
+                it[0] = wi * U6_WC; it[1] = wj * WK; it[2] = (int32_t)v.size();
+                std::sort(v.begin(), v.end(), [&](const Ent& a, const Ent& b) {
+                    const int ra = a.c - wi * U6_WC, rb = b.c - wi * U6_WC;
+                    if (owner[ra] != owner[rb]) return owner[ra] < owner[rb];
+                    if (slot_of[ra] != slot_of[rb]) return slot_of[ra] < slot_of[rb];
+                    return a.k < b.k;
+                });
+                size_t pos = 0;
+                for (int v2 = 0; v2 < U6_WAVES; ++v2) {
+                    int32_t* wv = &it[4 + v2 * U6_WAVE];
+                    uint32_t rw = 0;
+                    for (int sl = 0; sl < U6_ROWS; ++sl) rw |= (uint32_t)(sl < nrows[v2] ? rows[v2][sl] : 0xff) << (8 * sl);
+                    wv[0] = (int32_t)rw;
+                    int nb = 0;
+                    while (pos < v.size() && owner[v[pos].c - wi * U6_WC] == v2) {
+                        const Ent& e = v[pos++];
+                        const uint32_t m = (uint32_t)(e.k - wj * WK) | ((uint32_t)slot_of[e.c - wi * U6_WC] << 8);
+                        wv[2 + nb / 2] |= (int32_t)(m << (16 * (nb & 1)));
+                        wv[2 + U6_MAXB / 2 + nb] = e.w;
+                        ++nb;
+                    }
+                    wv[1] = nb;
+                }
+                items.insert(items.end(), it.begin(), it.end());
+            }
+        if (!fits) continue;
+        const long nitems = (long)(items.size() / U6_ITEM);
+        const long total = U6_HDR + nitems * U6_ITEM;
+        if (out) {
+            const int32_t hdr[U6_HDR] = {U6PLAN_MAGIC, U6PLAN_VERSION, U6_WC, WK, (int32_t)nitems, U6_WAVES | (U6_ROWS << 8) | (U6_MAXB << 16), U6_ITEM, 0};
+            std::copy(hdr, hdr + U6_HDR, out);
+            std::copy(items.begin(), items.end(), out + U6_HDR);
+        }
+        return total;
+    }
+    return 0;
 }
 
 }  // namespace bsmm

@@ -407,6 +407,56 @@ def test_staged_xcol16_plan(lib):
                 assert got == want
 
 
+def _check_rows_section(plan, off, t, CB, KB):
+    """The 'BSU6' section behind a bsize-16 'BSUP' plan on feature axis 0 (bsmm_plan.h::build_updat16_rows_section; the row-owner
+    weight-gradient kernel, csrc/bsmm_updat16_rows.h): every block in exactly one (item, wave, slot); a wave owns at most 2 block rows
+    of its 32-row window and at most 12 blocks, every one of them in a row it owns and a column inside the window; no block row of a
+    window has two owners."""
+    import numpy as np
+    sec = plan[off:]
+    assert off % 4 == 0 and int(sec[0]) == 0x42535536 and int(sec[1]) == 2 and int(sec[2]) == 32 and int(sec[3]) in (32, 16)
+    WK, nitems = int(sec[3]), int(sec[4])
+    WAVES, ROWS, MAXB = int(sec[5]) & 255, (int(sec[5]) >> 8) & 255, int(sec[5]) >> 16
+    assert (WAVES, ROWS, MAXB) == (16, 2, 12)
+    wave_words = 2 + MAXB // 2 + MAXB
+    isz = 4 + WAVES * wave_words
+    assert int(sec[6]) == isz and sec.size == 8 + nitems * isz
+    items = sec[8:].reshape(nitems, isz)
+    seen, windows = set(), set()
+    for it in items:
+        c0, k0, n = int(it[0]), int(it[1]), int(it[2])
+        assert c0 % 32 == 0 and k0 % WK == 0 and (c0, k0) not in windows
+        windows.add((c0, k0))
+        owned = set()
+        cnt = 0
+        for v in range(WAVES):
+            wv = it[4 + v * wave_words:4 + (v + 1) * wave_words]
+            rows = [(int(np.uint32(wv[0])) >> (8 * r)) & 255 for r in range(ROWS)]
+            live = [r for r in rows if r != 255]
+            assert all(r < 32 for r in live) and len(set(live)) == len(live) and not (set(live) & owned)
+            assert rows[:len(live)] == live                                  # (empty row slots last)
+            owned |= set(live)
+            nb = int(wv[1])
+            assert 0 <= nb <= MAXB
+            used_slots = set()
+            for j in range(MAXB):
+                m = (int(np.uint32(wv[2 + j // 2])) >> (16 * (j & 1))) & 0xffff
+                w = int(wv[2 + MAXB // 2 + j])
+                if j >= nb:
+                    assert m == 0 and w == 0
+                    continue
+                kidx, rs = m & 255, m >> 8
+                assert kidx < WK and rs < len(live)
+                assert tuple(t["updat_lut"][w]) == (c0 + rows[rs], k0 + kidx)
+                assert w not in seen
+                seen.add(w)
+                used_slots.add(rs)
+                cnt += 1
+            assert used_slots == set(range(len(live)))                       # a row slot is only given to a row with blocks
+        assert cnt == n and n > 0
+    assert seen == set(range(t["blocks"]))
+
+
 def test_updat_plan_covers_every_block_once(lib):
     """bsmm_updat_plan_build, the windowed format ('BSUP': bsize 16): every weight
     block appears in exactly one (item, wave, slot), inside its window, items are padded to a multiple of 8 (one list per XCD),
@@ -415,7 +465,7 @@ def test_updat_plan_covers_every_block_once(lib):
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_updat_plan
     rng = np.random.default_rng(5)
-    for CB, KB, dens in ((40, 52, 0.3), (128, 128, 0.2), (5, 3, 1.0), (1, 1, 1.0), (16, 16, 1.0)):
+    for CB, KB, dens in ((40, 52, 0.3), (70, 96, 0.1), (128, 128, 0.2), (5, 3, 1.0), (1, 1, 1.0), (16, 16, 1.0)):
         lay = rng.random((CB, KB)) < dens
         lay[0, 0] = True
         t = L.build_tables(lay)
@@ -431,7 +481,11 @@ def test_updat_plan_covers_every_block_once(lib):
             UW, MAXB, nitems, waves = int(plan[2]), int(plan[3]), int(plan[4]), int(plan[7])
             assert nitems % 8 == 0
             isz = 4 + waves * MAXB * 2
-            items = plan[plan[6]:].reshape(nitems, isz)
+            items = plan[plan[6]:plan[6] + nitems * isz].reshape(nitems, isz)
+            if axis == 0 and int(plan[8]) > 0:
+                _check_rows_section(plan, int(plan[8]), t, CB, KB)
+            else:
+                assert int(plan[8]) == 0 and plan.size == plan[6] + nitems * isz        # (feature axis 1 / dense layouts: no 'BSU6' section)
             seen = set()
             for it in items:
                 c0, k0 = int(it[0]), int(it[1])

@@ -146,7 +146,7 @@ def test_full_output_at_4096_against_float64_oracle(env, bs, axis, density):
     W, X, E = P.to_host(w), P.to_host(x), P.to_host(e)
     t = orc.build_layout_luts(layout, bs)
     bar = P.L2_BAR["bf16"]
-    want = {8: (lib.K_XPROP_SUPER8, lib.K_UPDAT_SUPER8), 16: (lib.K_XCOL16_STAGED, lib.K_UPDAT16_WIN), 32: (lib.K_XCOL32_FLOW if axis == 1 else lib.K_XCOL32_STAGED, lib.K_UPDAT_STREAM)}[bs]
+    want = {8: (lib.K_XPROP_SUPER8, lib.K_UPDAT_SUPER8), 16: (lib.K_XCOL16_STAGED, lib.K_UPDAT16_ROWS if axis == 0 else lib.K_UPDAT16_WIN), 32: (lib.K_XCOL32_FLOW if axis == 1 else lib.K_XCOL32_STAGED, lib.K_UPDAT_STREAM)}[bs]
     lib.set_kernel_variant(3)
     try:
         y = P.to_host(b.fprop(x, w)); kf = lib.last_kernel()
@@ -770,7 +770,7 @@ def test_cfg2_bsize16_10pct(env, axis):
     torch, BSMM, lib = env
     layout = P.random_layout(256, 256, 0.1, seed=1234)
     b = BSMM(layout, block_size=16, feature_axis=axis)
-    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=41, expect={"xprop": lib.K_XCOL16_STAGED, "updat": lib.K_UPDAT16_WIN}, ctx="cfg2 a%d" % axis)
+    _check_sampled(torch, lib, b, layout, 8192, "bf16", seed=41, expect={"xprop": lib.K_XCOL16_STAGED, "updat": lib.K_UPDAT16_ROWS if axis == 0 else lib.K_UPDAT16_WIN}, ctx="cfg2 a%d" % axis)      # (feature axis 0: the row-owner kernel, round 5)
 
 
 def test_cfg1_fp32_axis1(env):

@@ -73,4 +73,4 @@ def test_fuzz_forced_plan_kernels(env, seed, ncase, big):
         lib.set_kernel_variant(0)
     # the cases really ran plan kernels (not a generic fall-back for every one of them)
     assert seen & {lib.K_XCOL32_STAGED, lib.K_XCOL32_FLOW, lib.K_XCOL16_STAGED, lib.K_XPROP_SUPER8}, seen
-    assert seen & {lib.K_UPDAT_STREAM, lib.K_UPDAT16_WIN, lib.K_UPDAT_SUPER8}, seen
+    assert seen & {lib.K_UPDAT_STREAM, lib.K_UPDAT16_WIN, lib.K_UPDAT16_ROWS, lib.K_UPDAT_SUPER8}, seen
