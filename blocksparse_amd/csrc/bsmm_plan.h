@@ -116,14 +116,20 @@ inline long build_updat_plan(const int32_t* updat_lut, int blocks, int CB, int K
 //   section (int32): [0] magic 'BSU6' [1] version [2] U6_WC [3] WK [4] nitems [5] U6_WAVES | U6_ROWS << 8 | U6_MAXB << 16 [6] U6_ITEM [7] 0
 //   item: (c0_block, k0_block, nblocks, 0) then per wave U6_WAVE words:
 //         [0] the wave's block rows inside the window, 8 bits each (0xff = none)
-//         [1] nb: the wave's blocks
+//         [1] nb | ii0 << 8 | ni << 16: the wave's blocks; its DMA duty: instructions ii0 .. ii0 + ni - 1 of the 2 WK (1 KiB = 8 rows each) that stage
+//             a DY slab -- dealt to the waves with the fewest blocks (a block weighs U6_DMA_PER_BLOCK instructions): a wave stalls at issue while
+//             the memory pipeline is full, so the requesting is done by the waves the matrix work leaves idle
 //         [2 + j / 2] 16 bits per block j (low half first): column inside the window | row slot << 8
 //         [2 + U6_MAXB / 2 + j] weight block id of block j
 // -------------------------------------------------------------------------------------------------
 constexpr int32_t U6PLAN_MAGIC = 0x42535536;
-constexpr int32_t U6PLAN_VERSION = 2;
+constexpr int32_t U6PLAN_VERSION = 3;
 constexpr int U6_WC = 32, U6_WAVES = 16, U6_ROWS = 2, U6_MAXB = 12, U6_HDR = 8;
 constexpr int U6_WAVE = 2 + U6_MAXB / 2 + U6_MAXB;
+#ifndef U6_DMA_WEIGHT
+#define U6_DMA_WEIGHT 3
+#endif
+constexpr int U6_DMA_PER_BLOCK = U6_DMA_WEIGHT;
 constexpr int U6_ITEM = 4 + U6_WAVES * U6_WAVE;
 
 inline long build_updat16_rows_section(const int32_t* updat_lut, int blocks, int CB, int KB, int32_t* out) {
@@ -171,6 +177,15 @@ inline long build_updat16_rows_section(const int32_t* updat_lut, int blocks, int
                     if (slot_of[ra] != slot_of[rb]) return slot_of[ra] < slot_of[rb];
                     return a.k < b.k;
                 });
+                // DMA duties: one instruction at a time to the wave whose blocks + duties weigh least
+                int duty[U6_WAVES] = {0}, first[U6_WAVES];
+                for (int i = 0; i < 2 * WK; ++i) {
+                    int best = 0;
+                    for (int v2 = 1; v2 < U6_WAVES; ++v2)
+                        if (U6_DMA_PER_BLOCK * load[v2] + duty[v2] < U6_DMA_PER_BLOCK * load[best] + duty[best]) best = v2;
+                    ++duty[best];
+                }
+                for (int v2 = 0, at = 0; v2 < U6_WAVES; ++v2) { first[v2] = at; at += duty[v2]; }
                 size_t pos = 0;
                 for (int v2 = 0; v2 < U6_WAVES; ++v2) {
                     int32_t* wv = &it[4 + v2 * U6_WAVE];
@@ -185,7 +200,7 @@ inline long build_updat16_rows_section(const int32_t* updat_lut, int blocks, int
                         wv[2 + U6_MAXB / 2 + nb] = e.w;
                         ++nb;
                     }
-                    wv[1] = nb;
+                    wv[1] = nb | (first[v2] << 8) | (duty[v2] << 16);
                 }
                 items.insert(items.end(), it.begin(), it.end());
             }

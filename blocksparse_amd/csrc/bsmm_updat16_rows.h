@@ -11,15 +11,26 @@
 // window is 512 x 512 features: half the bytes per block (1.07 GB at the shape above).
 //
 //   workgroup = 16 waves, one window x one part of the minibatch (grid = items x split, linear id L: part = L % split, item = L / split:
-//               with split = 8 an XCD reads ONE eighth of the minibatch of X and DY -- every re-read of a row by the windows of that
-//               XCD's workgroups stays in its L2, consecutive items = one row of windows = the same X rows);
-//   per chunk:  request the NEXT chunk (the wave's X pieces + 4 x 1 KiB DMA instructions of the slab, rows XOR-swizzled by 16-byte piece as
-//               in the windowed kernel), wait for THIS one (counted vmcnt: the queue never drains), barrier, then per owned block two
-//               v_mfma_f32_16x16x32 (K = the chunk's 64 entries): A = the wave's X fragment of the block's row, B = ds_read_b128 of the DY
-//               rows of the block's column; barrier (the slot is free);
+//               the parts of a window run on neighbouring XCDs, consecutive items = one row of windows = the same X rows);
+//               a wave owns at most 2 block rows and 12 blocks (the plan deals the rows, longest first onto the lightest wave);
+//   per chunk:  wait for everything the wave asked for (its X pieces, its part of this chunk's slab), barrier (so has every other
+//               wave's part), X pieces into operand order (they are loaded 4 rows x 64 contiguous bytes per quarter wave -- a quarter of the
+//               requests of loading in operand order -- and permuted with ds_bpermute), request the NEXT chunk (X pieces into the freed
+//               registers, then the wave's DMA duty of the next slab: 1 KiB instructions, rows XOR-swizzled by 16-byte piece as in the
+//               windowed kernel), then per owned block two v_mfma_f32_16x16x32 (K = the chunk's 64 entries): A = the wave's X fragment of
+//               the block's row, B = ds_read_b128 of the DY rows of the block's column, four blocks' reads in flight; barrier (the slot
+//               is free);
 //   epilogue:   the 16 x 16 sums of a block go to DW (split = 1: alpha / beta here, one rounding) or into the part's own fp32 image in the
-//               workspace, and updat16_rows_finalize_kernel adds the images and rounds once (deterministic: no atomics).
-// N % 8 == 0 and 16-byte aligned operands (row pieces of 16 bytes); a ragged last chunk re-reads the last 8 entries and zeroes both fragments.
+//               workspace, and updat16_rows_finalize_kernel adds the images and rounds once (deterministic: no atomics -- fp32 atomics into
+//               one image cost 6 us per part at BASELINE configs[2]).
+// N % 8 == 0 and 16-byte aligned operands (row pieces of 16 bytes); a ragged last chunk re-reads the last 8 entries and zeroes the X pieces.
+//
+// Measured (profiles/r05_updat16_rows_*.txt): BASELINE configs[2] 97 us against 117-125 for the windowed kernel; 4096^2 20 % 167 against 241;
+// 8192^2 5 % 350 against 476.  Cycle stamps: the data of a chunk (128 KiB per CU) takes 1.8 us = 30 B/clk/CU, what every L2 -> CU stream of
+// this chip gets, and a step takes 2.3 us: a wave STALLS AT ISSUE while the memory pipeline is full (the wait itself is 40-80 cycles), so
+// the part of a step in which the waves request cannot overlap the part in which the same waves multiply; with two slab slots (2 x 64 KiB
+// of the 160) there is no second chunk to work on meanwhile.  Who requests the slab (every wave 4 instructions, or the waves with few
+// blocks all of them: U6_DMA_WEIGHT) makes no difference: 97.5-99.1 us.
 #pragma once
 #include "bsmm_common.h"
 #include "bsmm_plan.h"
@@ -56,7 +67,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int WK> struct U6Geom {
     static constexpr int SLAB = WK * 16 * 128;            // DY rows of the window x 128 bytes (64 minibatch entries)
-    static constexpr int NI = SLAB / 1024 / U6_WAVES;     // DMA instructions per wave and slab
     static constexpr int LDS = 2 * SLAB;
 };
 
@@ -78,7 +88,7 @@ updat16_rows_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, f
     const int c0 = item[0], k0 = item[1];
     const int32_t* wv = item + 4 + wave * U6_WAVE;
     const uint32_t rowsw = (uint32_t)wv[0];
-    const int nb = wv[1];
+    const int nb = wv[1] & 255, ii0 = (wv[1] >> 8) & 255, ni = (wv[1] >> 16) & 255;       // blocks; DMA duty: slab instructions ii0 .. ii0 + ni - 1
     uint32_t mw[U6_MAXB / 2];                     // (column | row slot << 8) of the wave's blocks, 16 bits each: stays in scalar registers
 #pragma unroll
     for (int i = 0; i < U6_MAXB / 2; ++i) mw[i] = (uint32_t)wv[2 + i];
@@ -99,12 +109,9 @@ updat16_rows_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, f
     const uint32_t base_addr = lds_addr_of(smem);
     const int f = lane & 15, q = lane >> 4;
 
-    // DY slab: DMA instruction ii = NI * wave + i covers slab rows 8 ii .. 8 ii + 7 (lane: row 8 ii + lane / 8; position lane % 8 holds piece
-    // pos ^ ((row >> 1) & 7) = pos ^ (lane >> 4) ^ 4 (i & 1): NI is even).  Offsets in elements, 32 bits (the launcher checks N * max(C, K) < 2^31).
-    static_assert(G::NI % 2 == 0, "piece swizzle by the parity of i");
-    uint32_t erow[G::NI];
-#pragma unroll
-    for (int i = 0; i < G::NI; ++i) erow[i] = (uint32_t)min(k0 * 16 + 8 * (G::NI * wave + i) + (lane >> 3), Kf - 1) * (uint32_t)N;
+    // DY slab: DMA instruction ii (of 2 WK) covers slab rows 8 ii .. 8 ii + 7 (lane: row 8 ii + lane / 8; position lane % 8 holds piece
+    // pos ^ ((row >> 1) & 7) = pos ^ (lane >> 4) ^ 4 (ii & 1)).  Offsets in elements, 32 bits (the launcher checks N * max(C, K) < 2^31).
+    const int erow0 = k0 * 16 + (lane >> 3);
     const int ecol0 = ((lane & 7) ^ (lane >> 4)) * 8;
     // X fragments of the wave's own block rows.  The MFMA operand wants lane (f, q) to hold entries 32 ks + 8 q .. + 7 of feature row f --
     // loaded that way a quarter wave touches 16 different rows with 16 bytes each.  Loaded with lane l on row l / 4, piece l % 4 instead (a
@@ -138,15 +145,14 @@ updat16_rows_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, f
             const int n0 = qq * 64;
             const uint32_t slot = base_addr + pos * G::SLAB;
             if (U6_NO_DMA) return;
-#pragma unroll
-            for (int i = 0; i < G::NI; ++i) {
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(slot + (G::NI * wave + i) * 1024);
-                glds16_asm(E + (erow[i] + (uint32_t)min(n0 + (ecol0 ^ (32 * (i & 1))), N - 8)), dst);
+            for (int ii = ii0; ii < ii0 + ni; ++ii) {
+                const uint32_t off = (uint32_t)min(erow0 + 8 * ii, Kf - 1) * (uint32_t)N + (uint32_t)min(n0 + (ecol0 ^ (32 * (ii & 1))), N - 8);
+                glds16_asm(E + off, __builtin_amdgcn_readfirstlane(slot + ii * 1024));
             }
         };
-        // X pieces as loaded, [K-step][row slot], two sets: one being used, one landing
-        u32x4 rawA[2][U6_ROWS], rawB[2][U6_ROWS];
-        auto load_x = [&](int qq, u32x4 (&raw)[2][U6_ROWS]) {
+        // X pieces as loaded, [K-step][row slot]: requested for the NEXT chunk as soon as this chunk's have been put in operand order
+        u32x4 raw[2][U6_ROWS];
+        auto load_x = [&](int qq) {
             const int n0 = qq * 64;
             if (U6_NO_X) return;
 #pragma unroll
@@ -155,33 +161,46 @@ updat16_rows_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, f
                 for (int r = 0; r < U6_ROWS; ++r)
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[ks][r]) : "v"(X + (xrow[r] + (uint32_t)min(n0 + 32 * ks + xpiece, N - 8))) : "memory");
         };
-        // operand order (lane (f, q) pulls from lane 4 f + q); zero past N in a ragged last chunk (N % 8 == 0: whole pieces)
-        auto operand = [&](u32x4 v, bool live) {
-            if (U6_NO_X) v = u32x4(0x3c003c00u);
-            if (U6_NO_BPERM) return live ? make_uint4(v[0], v[1], v[2], v[3]) : zero_u4();
-            uint4 o;
-            o.x = (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v[0]);
-            o.y = (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v[1]);
-            o.z = (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v[2]);
-            o.w = (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v[3]);
-            return live ? o : zero_u4();
+        // operand order (lane (f, q) pulls from lane 4 f + q), all 16 dwords of the chunk in one batch; zero past N in a ragged last chunk
+        // (N % 8 == 0: whole pieces)
+        uint4 x[2][U6_ROWS];
+        auto shuffle = [&](int qq) {
+            const int n0 = qq * 64;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bool live = n0 + 32 * ks + 8 * q < N;
+#pragma unroll
+                for (int r = 0; r < U6_ROWS; ++r) {
+                    u32x4 v = raw[ks][r];
+                    if (U6_NO_X) v = u32x4(0x3c003c00u);
+                    uint4 o;
+                    if (U6_NO_BPERM) o = make_uint4(v[0], v[1], v[2], v[3]);
+                    else {
+                        o.x = (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v[0]);
+                        o.y = (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v[1]);
+                        o.z = (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v[2]);
+                        o.w = (uint32_t)__builtin_amdgcn_ds_bpermute(pull, (int)v[3]);
+                    }
+                    x[ks][r] = live ? o : zero_u4();
+                }
+            }
+            // (the next X loads overwrite raw: they must not pass the permutes that read it)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0][0].x), "+v"(x[0][1].x), "+v"(x[1][0].x), "+v"(x[1][1].x) :: "memory");
         };
         // a chunk: per K-step the blocks in groups of four -- four B fragments requested together, then four MFMAs.  The A fragment is the
         // wave's row slot of the block: blocks are sorted by slot, so `a` changes once per K-step (at e0: a real branch -- the empty asm
         // keeps hipcc from turning it into selects per block).  Slots past nb multiply leftovers into accumulators nobody stores.
-        auto compute = [&](int qq, int pos, u32x4 (&raw)[2][U6_ROWS]) {
+        auto compute = [&](int pos) {
             const unsigned char* slot = smem + pos * G::SLAB;
-            const int n0 = qq * 64;
             if (U6_NO_MATH) {
                 if (U6_NO_MATH == 2) { __builtin_amdgcn_s_sleep(24); __builtin_amdgcn_s_sleep(24); }      // ~3000 cycles asleep instead of the matrix work
-                if (raw[0][0][0] == 0x12345u && raw[1][1][1] == 77u) acc[0][0] += 1.f;
+                if (x[0][0].x == 0x12345u && x[1][1].y == 77u) acc[0][0] += 1.f;
                 return;
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const unsigned char* sl = slot + boff + (((4 * ks + q) ^ fsw) << 4);
-                const bool live = n0 + 32 * ks + 8 * q < N;
-                uint4 a = operand(raw[ks][0], live);
+                uint4 a = x[ks][0];
 #pragma unroll
                 for (int g = 0; g < U6_MAXB / 4; ++g) {
                     if (4 * g < nb) {
@@ -191,45 +210,42 @@ updat16_rows_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, f
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const int jj = 4 * g + t;
-                            if (__builtin_expect(jj == e0, 0)) { a = operand(raw[ks][1], live); asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+                            if (__builtin_expect(jj == e0, 0)) { a = x[ks][1]; asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
                             acc[jj] = DT::mfma16(a, b[t], acc[jj]);
                         }
                     }
                 }
             }
         };
-        // One chunk of the ring.  On entry every wave is past the previous chunk's MFMAs (barrier at the end of step): the other slot is free,
-        // so the NEXT chunk is requested first -- X pieces into the other register set, then the wave's part of the slab -- and only then
-        // does the wave wait for THIS chunk: everything but the 2 U6_ROWS + NI requests just made (the memory queue never drains).  Second
-        // barrier: every wave's part of this chunk's slab is in LDS.
-        auto step = [&](int qq, int pos, u32x4 (&cur)[2][U6_ROWS], u32x4 (&nxt)[2][U6_ROWS]) {
+        // One chunk of the ring.  Everything the wave asked for has landed (its X pieces, its part of this chunk's slab); barrier: so has
+        // every other wave's part.  The X pieces go into operand order (one batch of permutes), the registers they came in are handed to
+        // the next chunk's loads, the wave's DMA duty for the next slab follows (the other slot is free since the barrier that ended the
+        // previous step), then the blocks.  A wave STALLS AT ISSUE while the memory pipeline is full
+        // (profiles/r05_updat16_rows_stamps.txt: a chunk's requests are accepted about as fast as the previous chunk's data arrives),
+        // which is why the plan gives the DMA duty to the waves with few blocks: they stall while the others multiply.
+        auto step = [&](int qq, int pos) {
 #ifdef U6_STAMPS
             tlast = __builtin_readcyclecounter(); tacc[7] += 1;
 #endif
-            if (qq + 1 < q_end) {
-                load_x(qq + 1, nxt);
-                issue(qq + 1, pos ^ 1);
-                U6_STAMP(0)
-                constexpr int INFLIGHT = (U6_NO_X ? 0 : 2 * U6_ROWS) + (U6_NO_DMA ? 0 : G::NI);
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(INFLIGHT) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            // (the registers ride through an asm: nothing that reads them may be scheduled above the wait)
-            asm volatile("" : "+v"(cur[0][0]), "+v"(cur[0][1]), "+v"(cur[1][0]), "+v"(cur[1][1]) :: "memory");
+            // (the registers ride through the asm: nothing that reads them may be scheduled above the wait)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]) :: "memory");
             U6_STAMP(1)
             __syncthreads();
             U6_STAMP(2)
-            compute(qq, pos, cur);
+            shuffle(qq);
+            if (qq + 1 < q_end) { load_x(qq + 1); issue(qq + 1, pos ^ 1); }
+            U6_STAMP(0)
+            compute(pos);
             U6_STAMP(3)
             __syncthreads();
             U6_STAMP(4)
         };
-        load_x(q_beg, rawA);
+        load_x(q_beg);
         issue(q_beg, 0);
-        for (int qq = q_beg; qq < q_end; qq += 2) {
-            step(qq, 0, rawA, rawB);
-            if (qq + 1 < q_end) step(qq + 1, 1, rawB, rawA);
+        int pos = 0;
+        for (int qq = q_beg; qq < q_end; ++qq) {
+            step(qq, pos);
+            pos ^= 1;
         }
     }
 

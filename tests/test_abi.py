@@ -414,7 +414,7 @@ def _check_rows_section(plan, off, t, CB, KB):
     window has two owners."""
     import numpy as np
     sec = plan[off:]
-    assert off % 4 == 0 and int(sec[0]) == 0x42535536 and int(sec[1]) == 2 and int(sec[2]) == 32 and int(sec[3]) in (32, 16)
+    assert off % 4 == 0 and int(sec[0]) == 0x42535536 and int(sec[1]) == 3 and int(sec[2]) == 32 and int(sec[3]) in (32, 16)
     WK, nitems = int(sec[3]), int(sec[4])
     WAVES, ROWS, MAXB = int(sec[5]) & 255, (int(sec[5]) >> 8) & 255, int(sec[5]) >> 16
     assert (WAVES, ROWS, MAXB) == (16, 2, 12)
@@ -428,7 +428,7 @@ def _check_rows_section(plan, off, t, CB, KB):
         assert c0 % 32 == 0 and k0 % WK == 0 and (c0, k0) not in windows
         windows.add((c0, k0))
         owned = set()
-        cnt = 0
+        cnt, duties, weights = 0, 0, []
         for v in range(WAVES):
             wv = it[4 + v * wave_words:4 + (v + 1) * wave_words]
             rows = [(int(np.uint32(wv[0])) >> (8 * r)) & 255 for r in range(ROWS)]
@@ -436,8 +436,10 @@ def _check_rows_section(plan, off, t, CB, KB):
             assert all(r < 32 for r in live) and len(set(live)) == len(live) and not (set(live) & owned)
             assert rows[:len(live)] == live                                  # (empty row slots last)
             owned |= set(live)
-            nb = int(wv[1])
-            assert 0 <= nb <= MAXB
+            nb, ii0, ni = int(wv[1]) & 255, (int(wv[1]) >> 8) & 255, (int(wv[1]) >> 16) & 255
+            assert 0 <= nb <= MAXB and ii0 == duties                                 # the DMA duties tile 0 .. 2 WK - 1 in wave order
+            duties += ni
+            weights.append((3 * nb + ni, ni))
             used_slots = set()
             for j in range(MAXB):
                 m = (int(np.uint32(wv[2 + j // 2])) >> (16 * (j & 1))) & 0xffff
@@ -453,7 +455,9 @@ def _check_rows_section(plan, off, t, CB, KB):
                 used_slots.add(rs)
                 cnt += 1
             assert used_slots == set(range(len(live)))                       # a row slot is only given to a row with blocks
-        assert cnt == n and n > 0
+        assert cnt == n and n > 0 and duties == 2 * WK
+        # greedy deal: a wave that got a duty weighs at most one instruction more than the lightest wave (3 per block + 1 per instruction)
+        assert max(w for w, ni in weights if ni > 0) <= min(w for w, _ in weights) + 1
     assert seen == set(range(t["blocks"]))
 
 
