@@ -83,17 +83,38 @@ def delivery_roof(layout, bsize, N, kernel_ms, cus):
             "clock_ghz": CLOCK_GHZ, "kernel": "bsmm_xprop(fprop)", "note": "analytic bytes of the plan (slabs + weight blocks per unit) / HIP-event time of the pass"}
 
 
-def delivery_roof_updat(plan_host, N, kernel_ms, cus):
-    """The same for the streaming weight gradient ('BSU2' plan: header word 2 = window side in blocks, word 4 = work items): every item
-    stages, per minibatch row, one row piece of the window's X features and one of its DY features (window side x 64 B each)."""
-    if plan_host is None or int(plan_host[0]) != 0x42535532:
+def delivery_roof_updat(plan_host, N, kernel_ms, cus, kernel_code=None):
+    """The same for the weight gradient.  Streaming kernel ('BSU2' plan: header word 2 = window side in blocks, word 4 = work items): every
+    item stages, per minibatch row, one row piece of the window's X features and one of its DY features (window side x 64 B each).
+    bsize 16 ('BSUP' plan): the windowed kernel's items stage 256 + 256 feature rows per minibatch entry; when the call ran the row-owner
+    kernel (kernel_code = K_UPDAT16_ROWS: the 'BSU6' section behind the items, header word 8) a window is 512 X features, read straight into
+    registers, and 16 WK DY features through LDS -- both counted, both come through the same L2 -> CU path."""
+    if plan_host is None:
         return None
-    ws, items = int(plan_host[2]), int(plan_host[4])
-    byts = items * N * ws * 64 * 2
+    magic = int(plan_host[0])
+    if magic == 0x42535532:
+        ws, items = int(plan_host[2]), int(plan_host[4])
+        byts = items * N * ws * 64 * 2
+        what = {"window_side_blocks": ws, "items": items}
+    elif magic == 0x42535550 and int(plan_host[2]) == 16:
+        off = int(plan_host[8])
+        if kernel_code == 23 and off > 0:
+            wk, items = int(plan_host[off + 3]), int(plan_host[off + 4])
+            byts = items * N * (32 * 16 + wk * 16) * 2
+            what = {"window_features": [512, 16 * wk], "items": items, "kernel_family": "row-owner (X rows straight into registers)"}
+        else:
+            isz = 4 + int(plan_host[7]) * int(plan_host[3]) * 2
+            live = int((np.asarray(plan_host[int(plan_host[6]):int(plan_host[6]) + int(plan_host[4]) * isz]).reshape(-1, isz)[:, 2] & 0xffff > 0).sum())
+            byts = live * N * (256 + 256) * 2
+            what = {"window_features": [256, 256], "items": live, "kernel_family": "windowed"}
+    else:
+        return None
     rate = byts / (kernel_ms * 1e-3 * CLOCK_GHZ * 1e9 * cus)
-    return {"bytes_l2_to_lds": int(byts), "b_per_clk_per_cu": round(rate, 2), "ceiling_b_per_clk": L2_TO_LDS_CEILING, "frac": round(rate / L2_TO_LDS_CEILING, 4),
-            "clock_ghz": CLOCK_GHZ, "kernel": "bsmm_updat", "window_side_blocks": ws, "items": items,
-            "note": "analytic bytes of the plan (X and DY slabs of every work item over the whole minibatch; the time includes the summing pass)"}
+    out = {"bytes_l2_to_cu": int(byts), "b_per_clk_per_cu": round(rate, 2), "ceiling_b_per_clk": L2_TO_LDS_CEILING, "frac": round(rate / L2_TO_LDS_CEILING, 4),
+           "clock_ghz": CLOCK_GHZ, "kernel": "bsmm_updat",
+           "note": "analytic bytes of the plan (X and DY rows of every work item over the whole minibatch; the time includes the summing pass)"}
+    out.update(what)
+    return out
 
 
 def random_layout(CB, KB, density, seed):
@@ -473,6 +494,7 @@ def main():
             else:
                 b.updat(x, dy, dw=dws[i & 1])
                 if ev: ev[2].record()
+                if i == 0: b._bench_updat_kernel = _lib.last_kernel()      # (which weight-gradient kernel family the call took: roofline.delivery_updat)
                 if use_dist:
                     red.start(dws[i & 1])                  # generic path: all-reduce through an fp32 copy
             state["pending"] = use_dist
@@ -532,9 +554,10 @@ def main():
             dl = delivery_roof(layout, b.bsize, n_local, f_ms, cus)
             if dl:
                 roof["delivery"] = dl
+        if layout is not None and dtype != "f32" and (b.axis == 1 or b.bsize == 16):
             try:
                 up = b._tables_on(torch.device("cuda", local)).updat_plan
-                du = delivery_roof_updat(up.host if up is not None else None, n_local, u_ms, cus)
+                du = delivery_roof_updat(up.host if up is not None else None, n_local, u_ms, cus, kernel_code=getattr(b, "_bench_updat_kernel", None))
             except Exception:
                 du = None
             if du:
