@@ -892,7 +892,9 @@ int launch_updat16_rows(const PtrList8& xs, const PtrList8& es, void* DW, const 
         scratch = static_cast<float*>(a->workspace);
     }
     trace(a, BSMM_K_UPDAT16_ROWS);
-    const unsigned grid = (unsigned)nitems * split;
+    // (split 1 / 2 / 4 / 8: rounds of 8 workgroups = 8 / split items x split parts, see the kernel's workgroup map)
+    const bool pow2 = split == 1 || split == 2 || split == 4 || split == 8;
+    const unsigned grid = pow2 ? 8u * (unsigned)((nitems + 8 / split - 1) / (8 / split)) : (unsigned)nitems * split;
     if (wk == 32) {
         if (int rc = ensure_lds<&updat16_rows_kernel<DT, 32>>(U6Geom<32>::LDS)) return rc;
         updat16_rows_kernel<DT, 32><<<grid, 64 * U6_WAVES, U6Geom<32>::LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, sec, a->N, a->C, a->K, a->pcount, a->alpha, a->beta, split, nel);

@@ -80,7 +80,18 @@ updat16_rows_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, f
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (sec[0] != U6PLAN_MAGIC || sec[1] != U6PLAN_VERSION || sec[2] != U6_WC || sec[3] != WK ||
         sec[5] != (U6_WAVES | (U6_ROWS << 8) | (U6_MAXB << 16)) || sec[6] != U6_ITEM) return;
-    const int part = blockIdx.x % split, it = blockIdx.x / split;
+    // workgroup -> (part of the minibatch, item).  Workgroup L runs on XCD L % 8 (observed; speed only).  split = 1 / 2 / 4 / 8: XCD x takes
+    // part x / (8 / split) and nothing else, and of that part every (8 / split)-th run of items: an XCD's L2 sees one part of X and DY, and the
+    // 8 / split XCDs of a part divide the windows instead of all reading all of them (the launcher rounds the grid up to whole rounds of 8).
+    // Other splits: parts interleaved.
+    int part, it;
+    if (split == 1 || split == 2 || split == 4 || split == 8) {
+        const int per = 8 / split, x = blockIdx.x & 7;
+        part = x / per;
+        it = (blockIdx.x >> 3) * per + x % per;
+    } else {
+        part = blockIdx.x % split; it = blockIdx.x / split;
+    }
     if (it >= sec[4]) return;
     const int32_t* item = sec + U6_HDR + (size_t)it * U6_ITEM;
     const int lane = threadIdx.x & 63;

@@ -13,7 +13,7 @@ WORKLOADS = {"d10": WL % (4096, 4096, 32, 10, 1, 8192), "d20": WL % (4096, 4096,
 BLOCKS = {"d10": (1667, 32, 8192), "d20": (3279, 32, 8192), "d50": (8210, 32, 8192), "cfg2": (6511, 16, 8192), "cfg3": (3220, 32, 4096)}
 # kernel-name fragment -> label (the labels bench.py's roofline uses, plus the parts of the updat pass)
 NAMES = (("xflow32_kernel<bsmm::DTbf16, false", "bsmm_xprop(bprop)"), ("xflow32_kernel<bsmm::DTbf16, true", "bsmm_xprop(fprop)"),
-         ("updat32_a1_v2", "bsmm_updat_kernel"), ("updat2_reduce", "bsmm_updat_reduce"), ("updat16_win", "bsmm_updat_kernel"), ("updat_finalize", "bsmm_updat_reduce"),
+         ("updat32_a1_v2", "bsmm_updat_kernel"), ("updat2_reduce", "bsmm_updat_reduce"), ("updat16_rows_finalize", "bsmm_updat_reduce"), ("updat16_rows", "bsmm_updat_kernel"), ("updat16_win", "bsmm_updat_kernel"), ("updat_finalize", "bsmm_updat_reduce"),
          ("xcol32_v2_kernel<bsmm::DTbf16, false", "bsmm_xprop(bprop)"), ("xcol32_v2_kernel<bsmm::DTbf16, true", "bsmm_xprop(fprop)"),
          ("xcol16_list_kernel<bsmm::DTbf16, 0, true", "bsmm_xprop(fprop)"), ("xcol16_list_kernel<bsmm::DTbf16, 0, false", "bsmm_xprop(bprop)"),
          ("xcol16_list_kernel<bsmm::DTbf16, 1, true", "bsmm_xprop(fprop)"), ("xcol16_list_kernel<bsmm::DTbf16, 1, false", "bsmm_xprop(bprop)"),
@@ -81,7 +81,7 @@ json.dump(out, open("profiles/%s_counters.json" % rnd, "w"), indent=1)
 md = ["# Counters per workload (from `profiles/%s_pmc.txt`; MI355X, rocprofv3 --pmc, separate passes)" % rnd, "",
       "Per launch.  time = GRBM_GUI_ACTIVE / 8 XCDs at 2.07 GHz (profiler attached, 8 steps per run at cold clocks: 10-15 % slower than the bench line);",
       "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB; gfx950 correction for the read side); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs);",
-      "effective TFLOP/s = 2 x blocks x bs² x N / time.  cfg2's xprop kernel is `xcol16_list_kernel` (TRANSW = true: fprop).", "",
+      "effective TFLOP/s = 2 x blocks x bs² x N / time.  cfg2's xprop kernel is `xcol16_list_kernel` (TRANSW = true: fprop), its weight gradient `updat16_rows_kernel` + `updat16_rows_finalize_kernel` (round 5).", "",
       "| workload | kernel | time µs | HBM MB | HBM GB/s | MFMA busy | eff. TFLOP/s | waves waiting |", "|---|---|---|---|---|---|---|---|"] + rows
 open("profiles/%s_counters.md" % rnd, "w").write("\n".join(md) + "\n")
 print("\n".join(rows))
