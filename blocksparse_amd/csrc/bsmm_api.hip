@@ -863,7 +863,7 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
 // split: the caller's (bsmm_args.split, at most U6_MAX_SPLIT), else the smallest power of two that gives every CU a workgroup.  Measured
 // against the windowed kernel (scripts/gpu_updat16_rows_sweep.py, profiles/r05_updat16_rows_sweep.txt): the row-owner kernel wins once
 // three quarters of the CUs get a workgroup and a workgroup keeps 8 chunks of 64 minibatch entries (16 when four or more parts leave
-// their sums for the finalize pass) -- 8 to 31 % at 4096^2 / 8192^2; otherwise BSMM_ERR_UNSUPPORTED: the caller takes the windowed kernel
+// their sums for the finalize pass) -- 17 to 43 % at 4096^2 / 8192^2, N >= 4096; otherwise BSMM_ERR_UNSUPPORTED: the caller takes the windowed kernel
 // (2048^2 has 16 windows of 512 x 512: never).
 constexpr int U6_MAX_SPLIT = 8;
 template <class DT>

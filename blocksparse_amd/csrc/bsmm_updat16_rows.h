@@ -25,9 +25,9 @@
 //               one image cost 6 us per part at BASELINE configs[2]).
 // N % 8 == 0 and 16-byte aligned operands (row pieces of 16 bytes); a ragged last chunk re-reads the last 8 entries and zeroes the X pieces.
 //
-// Measured (profiles/r05_updat16_rows_*.txt): BASELINE configs[2] 97 us against 117-125 for the windowed kernel; 4096^2 20 % 167 against 241;
-// 8192^2 5 % 350 against 476.  Cycle stamps: the data of a chunk (128 KiB per CU) takes 1.8 us = 30 B/clk/CU, what every L2 -> CU stream of
-// this chip gets, and a step takes 2.3 us: a wave STALLS AT ISSUE while the memory pipeline is full (the wait itself is 40-80 cycles), so
+// Measured (profiles/r05_updat16_rows_*.txt): BASELINE configs[2] 88-92 us against 115-125 for the windowed kernel; 4096^2 20 % 138 against 241;
+// 8192^2 5 % 292 against 481.  Cycle stamps: the data of a chunk (128 KiB per CU) takes 1.8 us = 30 B/clk/CU, what every L2 -> CU stream of
+// this chip gets, and a step takes 2.2 us: a wave STALLS AT ISSUE while the memory pipeline is full (the wait itself is 40-80 cycles), so
 // the part of a step in which the waves request cannot overlap the part in which the same waves multiply; with two slab slots (2 x 64 KiB
 // of the 160) there is no second chunk to work on meanwhile.  Who requests the slab (every wave 4 instructions, or the waves with few
 // blocks all of them: U6_DMA_WEIGHT) makes no difference: 97.5-99.1 us.
