@@ -778,6 +778,11 @@ int xprop(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a)
 // ---------------------------------------------------------------------------------------------
 // workgroups per work item of the windowed kernels (each takes a slice of the minibatch): the caller's choice
 // (bsmm_args.split), else enough to give every CU a workgroup while each keeps >= 8 chunks
+// internal to the library (never set by callers: bsmm_updat clears it on entry of a public call): the blocks of this bsize-32 call are the
+// quadrants of 64 x 64 blocks and DW is the 64-layout (updat64)
+constexpr int32_t FLAG_INTERNAL_Q64 = 1 << 30;
+static thread_local bool tl_inside_updat64 = false;      // (a public call that carries the bit is refused: bsmm_updat)
+
 inline int updat_split(const bsmm_args* a, int nitems, int nchunks) {
     if (a->split > 0) return std::min(a->split, std::max(1, nchunks));
     int split = 1;
@@ -822,7 +827,8 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     if (a->plan_magic != U2PLAN_MAGIC || a->plan_waves != U2_WAVES || a->plan_items <= 0 || (a->plan_width != 16 && a->plan_width != 8 && !(a->plan_width == 32 && AXIS == 1))) return BSMM_ERR_ARG;
     U2Launch L = updat2_shape(a, gate != nullptr);
     const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;
-    if (sums_only) L.scratch = true;
+    const bool q64 = (a->flags & FLAG_INTERNAL_Q64) != 0;       // (updat64: the summing pass writes the quadrants into their 64 x 64 blocks)
+    if (sums_only || q64) L.scratch = true;
     float* scratch = nullptr;      // the partial-sum regions
     float* sums = nullptr;
     if (L.scratch) {
@@ -854,7 +860,7 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
         const int CPI = a->pcount * ((a->N + u2_chunk(a) - 1) / u2_chunk(a));
         const int32_t* bmap = a->plan + U2_HDR + (size_t)a->plan_items * U2_ITEM;     // behind the items (bsmm_plan.h)
         if (sums_only) updat2_reduce_kernel<DT, true><<<a->blocks, 128, 0, st>>>(scratch, nullptr, sums, a->plan, bmap, nullptr, L.grid, L.flat, CPI, 1.f, 0.f);
-        else           updat2_reduce_kernel<DT, false><<<a->blocks, 128, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, bmap, gate, L.grid, L.flat, CPI, a->alpha, a->beta);
+        else           updat2_reduce_kernel<DT, false><<<a->blocks, 128, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, bmap, gate, L.grid, L.flat, CPI, a->alpha, a->beta, q64 ? 1 : 0);
     }
     return (int)hipGetLastError();
 }
@@ -984,12 +990,12 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                         const double rounds_s = std::max(1.0, std::ceil(a->blocks / (20.0 * device_cus())));
                         t_blk = std::min(t_blk, 4.0 + rounds_s * (double)rows * (rows <= 384 ? 0.021 : 0.033));
                     }
-                    stream = t_stream <= t_blk || sums_only;
+                    stream = t_stream <= t_blk || sums_only || (a->flags & FLAG_INTERNAL_Q64);
                 }
                 if (stream) return launch_updat2<DT, AXIS>(xs, es, DW, a, ug);
             }
         }
-        if (sums_only) return BSMM_ERR_UNSUPPORTED;
+        if (sums_only || (a->flags & FLAG_INTERNAL_Q64)) return BSMM_ERR_UNSUPPORTED;      // (only the streaming kernel's summing pass leaves raw sums / knows the quadrant layout)
     }
     if constexpr (BS == 32 && AXIS == 1 && DT::is16) {
         bool al = aligned16(DW);
@@ -1235,25 +1241,23 @@ int updat16_f32_split(const void* const* X, const void* const* DY, void* DW, con
 }
 
 int updat64(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
-    // the streaming bsize-32 kernel leaves the fp32 sums of the quadrants in the workspace; one pass puts them together with alpha /
-    // beta / gate and ONE rounding.  16-bit types with the streaming plan only (what the reference runs bsize 64 in: fp16 tensor cores).
-    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    // the streaming bsize-32 kernel on the quadrants.  16-bit types with the streaming plan only (what the reference runs bsize 64 in: fp16
+    // tensor cores).
     if (!a->plan) return BSMM_ERR_UNSUPPORTED;
     bsmm_args b = b64_inner(a, true);
     if (a->dtype == BSMM_F32 || b.plan_magic != U2PLAN_MAGIC) return BSMM_ERR_UNSUPPORTED;
     const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;
     if (sums_only) return BSMM_ERR_UNSUPPORTED;                  // (the raw sums of a bsize-64 call would be in quadrant order)
-    b.flags = (a->flags & ~BSMM_FLAG_GATED_DW) | BSMM_FLAG_DW_SUMS;
-    b.gate = nullptr; b.alpha = 1.f; b.beta = 0.f;
+    // (round 5: the streaming kernel's summing pass writes every quadrant into its place in the 64 x 64 block with alpha / beta / the block's
+    //  gate and ONE rounding -- the separate pass over the quadrant sums, b64_finalize_kernel: 20 us at the bench shape, is gone)
+    b.flags = a->flags | FLAG_INTERNAL_Q64;
+    b.gate = a->gate; b.alpha = a->alpha; b.beta = a->beta;
     b.workspace = a->workspace; b.workspace_bytes = a->workspace_bytes;
     if (!a->workspace || a->workspace_bytes < bsmm_workspace_bytes(BSMM_OP_UPDAT, &b)) return BSMM_ERR_WORKSPACE;
-    const int rc = bsmm_updat(X, DY, nullptr, &b);
-    if (rc) return rc;
-    const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;
-    const float* sums = static_cast<const float*>(a->workspace);
-    if (a->dtype == BSMM_F16) b64_finalize_kernel<DTf16><<<a->blocks, 256, 0, st>>>(sums, static_cast<uint16_t*>(DW), ug, a->blocks, a->alpha, a->beta);
-    else                      b64_finalize_kernel<DTbf16><<<a->blocks, 256, 0, st>>>(sums, static_cast<uint16_t*>(DW), ug, a->blocks, a->alpha, a->beta);
-    return (int)hipGetLastError();
+    tl_inside_updat64 = true;
+    const int rc = bsmm_updat(X, DY, DW, &b);
+    tl_inside_updat64 = false;
+    return rc;
 }
 
 }  // namespace
@@ -1292,6 +1296,7 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
     int rc = check_common(a);
     if (rc) return rc;
     if (!X || !DY || (!DW && !(a->flags & BSMM_FLAG_DW_SUMS))) return BSMM_ERR_ARG;      // (DW is not written in sums mode)
+    if ((a->flags & FLAG_INTERNAL_Q64) && !tl_inside_updat64) return BSMM_ERR_ARG;       // (the library's own bit)
     if (a->pcount < 1 || a->pcount > 8) return BSMM_ERR_ARG;
     if (a->bsize == 64 && !a->plan) return BSMM_ERR_UNSUPPORTED;
     if ((rc = check_plan(true, a))) return rc;

@@ -33,26 +33,7 @@ b64_gate_kernel(const float* __restrict__ gate, float* __restrict__ gate4, int b
     if (i < 4 * blocks) gate4[i] = gate[i >> 2];
 }
 
-// DW[w] (64 x 64) = alpha * [gate[w] *] (fp32 sums of the four quadrants) + beta * DW[w], rounded once
-template <class DT>
-__global__ void __launch_bounds__(256)
-b64_finalize_kernel(const float* __restrict__ sums, typename DT::T* __restrict__ DW, const float* __restrict__ gate, int blocks, float alpha, float beta) {
-    const int w = blockIdx.x;
-    if (w >= blocks) return;
-    const float a = gate ? alpha * gate[w] : alpha;
-    for (int e = threadIdx.x * 4; e < 4096; e += 1024) {                          // 4 consecutive columns of one row
-        const int row = e >> 6, col = e & 63;
-        const int q = 2 * (row >> 5) + (col >> 5);
-        const float4 s = *reinterpret_cast<const float4*>(sums + ((size_t)(4 * w + q) * 1024 + (row & 31) * 32 + (col & 31)));
-        float v[4] = {a * s.x, a * s.y, a * s.z, a * s.w};
-        typename DT::T* out = DW + (size_t)w * 4096 + e;
-        if (beta != 0.f) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += beta * DT::to_f32(out[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = DT::from_f32(v[k]);
-    }
-}
+// (round 5: the pass that put the quadrant sums of the weight gradient together, b64_finalize_kernel, is gone -- the streaming kernel's summing
+//  pass writes a quadrant straight into its 64 x 64 block: bsmm_updat_v2.h::updat2_reduce_kernel, q64)
 
 }  // namespace bsmm

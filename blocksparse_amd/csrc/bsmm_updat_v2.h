@@ -537,7 +537,7 @@ __device__ __forceinline__ float4 u2_ld(const float4* p) {
 template <class DT, bool SUMS>
 __global__ void __launch_bounds__(128)
 updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict__ DW, float* __restrict__ sums, const int32_t* __restrict__ plan,
-                     const int32_t* __restrict__ bmap, const float* __restrict__ gate, int grid, int flat, int CPI, float alpha, float beta) {
+                     const int32_t* __restrict__ bmap, const float* __restrict__ gate, int grid, int flat, int CPI, float alpha, float beta, int q64 = 0) {
     // 128 threads = (quad pair qq = tid >> 6, lane l): quads qq and qq + 2 -- all workgroups of the bench shape are resident at once,
     // and the block map is addressed from an argument so that its load does not wait for the plan header
     const int w = blockIdx.x;
@@ -616,17 +616,21 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
         const int q = qq + 2 * hq;
         const float4 acc = hq ? acc1 : acc0;
         const float r[4] = {acc.x, acc.y, acc.z, acc.w};
-        const size_t o = (size_t)w * 1024 + (size_t)(8 * q + 4 * (l >> 5)) * 32 + (l & 31);
+        // (q64: the blocks are the quadrants of 64 x 64 blocks, 4 w64 + 2 (row half) + (column half), bsmm_api.hip::updat64 -- the element goes to
+        //  its place in the 64 x 64 block, the gate is the 64-block's: no separate pass puts the quadrants together)
+        const int row = 8 * q + 4 * (l >> 5), col = l & 31;
+        const size_t o = q64 ? (size_t)(w >> 2) * 4096 + (size_t)(32 * ((w >> 1) & 1) + row) * 64 + 32 * (w & 1) + col : (size_t)w * 1024 + (size_t)row * 32 + col;
+        const int ostep = q64 ? 64 : 32;
         if constexpr (SUMS) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sums[o + e * 32] = r[e];
+            for (int e = 0; e < 4; ++e) sums[o + e * ostep] = r[e];
         } else {
-            const float a = gate ? alpha * gate[w] : alpha;
+            const float a = gate ? alpha * gate[q64 ? w >> 2 : w] : alpha;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = a * r[e];
-                if (beta != 0.f) v += beta * DT::to_f32(DW[o + e * 32]);
-                DW[o + e * 32] = DT::from_f32(v);
+                if (beta != 0.f) v += beta * DT::to_f32(DW[o + e * ostep]);
+                DW[o + e * ostep] = DT::from_f32(v);
             }
         }
     }
