@@ -102,3 +102,33 @@ def test_row_owner_updat_at_configs2(env):
     num = np.sqrt(((dw.astype(np.float64) - ref) ** 2).reshape(b.blocks, -1).sum(axis=1))
     den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
     assert (num <= P.L2_BAR["bf16"] * den).all(), float((num / den).max())
+
+
+def test_row_owner_updat_random_shapes(env):
+    """Sixteen random layouts (20 .. 150 blocks a side, 3 .. 25 %), minibatches that are multiples of 8 up to 1500, 1 .. 8 parts, bf16 / fp16,
+    alpha / beta: whatever the section builder makes of them (32- or 16-column windows; none for the densest: those runs must take another
+    kernel), every block against the float64 oracle."""
+    torch, BSMM, lib = env
+    rng = np.random.default_rng(77)
+    ran = 0
+    for it in range(16):
+        CB, KB = int(rng.integers(20, 151)), int(rng.integers(20, 151))
+        dens = float(rng.uniform(0.03, 0.25))
+        N = 8 * int(rng.integers(1, 188))
+        split = int(rng.integers(1, 9))
+        dt = ("bf16", "f16")[it & 1]
+        lay = P.random_layout(CB, KB, dens, seed=100 + it)
+        b = BSMM(lay, block_size=16, feature_axis=0, updat_split=split)
+        has = int(b._tables_on(torch.device("cuda")).updat_plan.host[8]) > 0
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dt, seed=it)
+        x, e = P.to_dev(X, dt, torch), P.to_dev(E, dt, torch)
+        dw0 = P.to_dev(rng.standard_normal(b.w_shape).astype(np.float32) * 0.05, dt, torch)
+        got = P.to_host(b.updat(x, e, alpha=1.5, beta=-0.5, dw=dw0.clone()))
+        assert (lib.last_kernel() == lib.K_UPDAT16_ROWS) == has, (it, CB, KB, dens, N, split, lib.last_kernel())
+        ran += has
+        t = orc.build_layout_luts(np.asarray(lay), 16)
+        ref = orc.round_to(1.5 * orc.updat(t, P.to_host(x).astype(np.float64), P.to_host(e).astype(np.float64), 0) - 0.5 * P.to_host(dw0).astype(np.float64), dt)
+        num = np.sqrt(((got.astype(np.float64) - ref) ** 2).reshape(b.blocks, -1).sum(axis=1))
+        den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
+        assert (num <= P.L2_BAR[dt] * np.maximum(den, 1e-30)).all(), (it, CB, KB, dens, N, split, dt, float((num / np.maximum(den, 1e-30)).max()))
+    assert ran >= 10
