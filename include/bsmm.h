@@ -136,6 +136,8 @@ typedef struct bsmm_args {
     int32_t plan_items;     /*   updat: number of work items (= grid size)                                               */
     int32_t plan_inner;     /*   staged xprop plan: steps per phase; streaming updat plan: item sets | 16 if all equally long | longest set << 8;
                                  bsize 8: width / window side of the nested bsize-32 plan | its format << 8 | its own word of this kind << 11;
+                                 bsize 16 updat plan ('BSUP'): word offset of its 'BSU6' section (row-owner kernel, feature axis 0; 0 = none) --
+                                 the section's window width and item count then ride in bits 8.. of plan_width / plan_waves;
                                  bsize 64: 0 = xprop plan, 1 = updat plan (the nested plan is described in plan_width / plan_items and
                                  plan_waves = its waves | its format << 5 | its own word of this kind << 8)                       */
                             /* The launchers check the descriptor against the kernel they are about to launch and return
