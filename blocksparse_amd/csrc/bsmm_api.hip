@@ -872,10 +872,15 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
 // their sums for the finalize pass) -- 17 to 43 % at 4096^2 / 8192^2, N >= 4096; otherwise BSMM_ERR_UNSUPPORTED: the caller takes the windowed kernel
 // (2048^2 has 16 windows of 512 x 512: never).
 constexpr int U6_MAX_SPLIT = 8;
+// f32: the fp32 call through six bf16 piece pairs (updat16_f32_rows below): `pairs` pairs in xs / es, the images at `images` (always, also for
+// one part), DW in fp32 with alpha / beta / gate by the finalize pass unless *skip_if (the non-finite flag of the split).
 template <class DT>
-int launch_updat16_rows(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a) {
+int launch_updat16_rows(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_args* a, int pairs = 0, float* images = nullptr,
+                        const float* gate = nullptr, const int32_t* skip_if = nullptr) {
     typedef typename DT::T T;
     hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const bool f32 = images != nullptr;
+    const int pcount = f32 ? pairs : a->pcount;
     const int32_t* sec = a->plan + a->plan_inner;
     const int nchunks = (a->N + 63) / 64;
     const int nitems = a->plan_waves >> 8, wk = a->plan_width >> 8;      // (bsmm_plan_attach packs the section's item count / window width there)
@@ -887,13 +892,13 @@ int launch_updat16_rows(const PtrList8& xs, const PtrList8& es, void* DW, const 
         const int cus = device_cus();
         split = 1;
         while (split < U6_MAX_SPLIT && nitems * split < cus) split *= 2;
-        const bool pays = 4L * nitems * split >= 3L * cus && nchunks / split >= (split >= 4 ? 16 : 8);
+        const bool pays = 4L * nitems * split >= 3L * cus && (long)pcount * nchunks / split >= (split >= 4 ? 16 : 8);
         if (!pays && call_variant(a) != 3) return BSMM_ERR_UNSUPPORTED;
         split = std::max(1, std::min(split, nchunks));
     }
-    float* scratch = nullptr;
+    float* scratch = images;
     const size_t nel = (size_t)a->blocks * 256;
-    if (split > 1) {      // one fp32 image of the sums per part
+    if (!f32 && split > 1) {      // one fp32 image of the sums per part
         if (!a->workspace || a->workspace_bytes < (size_t)split * nel * sizeof(float) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
         scratch = static_cast<float*>(a->workspace);
     }
@@ -901,15 +906,17 @@ int launch_updat16_rows(const PtrList8& xs, const PtrList8& es, void* DW, const 
     // (split 1 / 2 / 4 / 8: rounds of 8 workgroups = 8 / split items x split parts, see the kernel's workgroup map)
     const bool pow2 = split == 1 || split == 2 || split == 4 || split == 8;
     const unsigned grid = pow2 ? 8u * (unsigned)((nitems + 8 / split - 1) / (8 / split)) : (unsigned)nitems * split;
+    T* dw16 = f32 ? nullptr : static_cast<T*>(DW);
     if (wk == 32) {
         if (int rc = ensure_lds<&updat16_rows_kernel<DT, 32>>(U6Geom<32>::LDS)) return rc;
-        updat16_rows_kernel<DT, 32><<<grid, 64 * U6_WAVES, U6Geom<32>::LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, sec, a->N, a->C, a->K, a->pcount, a->alpha, a->beta, split, nel);
+        updat16_rows_kernel<DT, 32><<<grid, 64 * U6_WAVES, U6Geom<32>::LDS, st>>>(xs, es, dw16, scratch, sec, a->N, a->C, a->K, pcount, a->alpha, a->beta, split, nel);
     } else {
         if (int rc = ensure_lds<&updat16_rows_kernel<DT, 16>>(U6Geom<16>::LDS)) return rc;
-        updat16_rows_kernel<DT, 16><<<grid, 64 * U6_WAVES, U6Geom<16>::LDS, st>>>(xs, es, static_cast<T*>(DW), scratch, sec, a->N, a->C, a->K, a->pcount, a->alpha, a->beta, split, nel);
+        updat16_rows_kernel<DT, 16><<<grid, 64 * U6_WAVES, U6Geom<16>::LDS, st>>>(xs, es, dw16, scratch, sec, a->N, a->C, a->K, pcount, a->alpha, a->beta, split, nel);
     }
-    if (split > 1)
-        updat16_rows_finalize_kernel<DT><<<(unsigned)((nel / 4 + 255) / 256), 256, 0, st>>>(scratch, static_cast<T*>(DW), nel, split, a->alpha, a->beta);
+    const unsigned fgrid = (unsigned)((nel / 4 + 255) / 256);
+    if (f32)            updat16_rows_finalize_kernel<DTf32><<<fgrid, 256, 0, st>>>(scratch, static_cast<float*>(DW), nel, split, a->alpha, a->beta, gate, skip_if);
+    else if (split > 1) updat16_rows_finalize_kernel<DT><<<fgrid, 256, 0, st>>>(scratch, dw16, nel, split, a->alpha, a->beta);
     return (int)hipGetLastError();
 }
 
@@ -1240,6 +1247,46 @@ int updat16_f32_split(const void* const* X, const void* const* DY, void* DW, con
     return f32_split_repair<16, AXIS>(X, DY, DW, a, flag);
 }
 
+// ... and on feature axis 0 (round 5) the six pairs go through the row-owner kernel (bsmm_updat16_rows.h) where it pays -- its images take the
+// place of the sums: [U6_MAX_SPLIT images][pieces of X][pieces of DY][flag].  BSMM_ERR_UNSUPPORTED (short minibatches, few windows): the
+// caller takes the per-block fp32 kernel, as before.
+inline bool updat16_f32_rows_applies(const bsmm_args* a) {
+    return a->dtype == BSMM_F32 && a->bsize == 16 && a->axis == 0 && a->plan && a->plan_magic == UPLAN_MAGIC && (a->plan_width & 255) == UW16 && (a->plan_waves & 255) == UP_WAVES &&
+           a->plan_inner > 0 && a->pcount == 1 && !(a->flags & BSMM_FLAG_DW_SUMS) && a->N % 8 == 0 && (long)a->N * std::max(a->C, a->K) < (1L << 31) &&
+           call_variant(a) != 1 && call_variant(a) != 2;
+}
+inline size_t updat16_f32_rows_images_bytes(const bsmm_args* a) { return round16((size_t)U6_MAX_SPLIT * a->blocks * 256 * sizeof(float)); }
+int updat16_f32_rows(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const size_t img_b = updat16_f32_rows_images_bytes(a), nx = (size_t)a->N * a->C, ne = (size_t)a->N * a->K;
+    if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < img_b + 6 * (nx + ne) + F32_SPLIT_FLAG_BYTES) return BSMM_ERR_WORKSPACE;
+    if (!aligned16(X[0]) || !aligned16(DY[0]) || !aligned16(DW)) return BSMM_ERR_ARG;
+    // (will the row-owner kernel take it?  Ask before the pieces are made: a dry run of its rule)
+    {
+        const int nitems = a->plan_waves >> 8, nchunks = (a->N + 63) / 64, cus = device_cus();
+        int split = 1;
+        while (split < U6_MAX_SPLIT && nitems * split < cus) split *= 2;
+        const bool pays = a->split > 0 || (4L * nitems * split >= 3L * cus && 6L * nchunks / split >= (split >= 4 ? 16 : 8));
+        if (!pays && call_variant(a) != 3) return BSMM_ERR_UNSUPPORTED;
+    }
+    float* images = static_cast<float*>(a->workspace);
+    uint16_t* xp = reinterpret_cast<uint16_t*>(static_cast<char*>(a->workspace) + img_b);
+    uint16_t* ep = xp + 3 * nx;
+    int32_t* flag = reinterpret_cast<int32_t*>(ep + 3 * ne);
+    if (hipError_t e = hipMemsetAsync(flag, 0, F32_SPLIT_FLAG_BYTES, st); e != hipSuccess) return (int)e;
+    split3_x_kernel<<<(unsigned)((nx / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(X[0]), xp, nx, flag);
+    split3_x_kernel<<<(unsigned)((ne / 8 + 255) / 256), 256, 0, st>>>(static_cast<const float*>(DY[0]), ep, ne, flag);
+    static const int xi[6] = {2, 1, 0, 1, 0, 0}, ei[6] = {0, 1, 2, 0, 1, 0};      // the six products, smallest first (see updat32_f32_split)
+    PtrList8 xs, es;
+    for (int p = 0; p < 8; ++p) {
+        xs.p[p] = p < 6 ? xp + xi[p] * nx : nullptr;
+        es.p[p] = p < 6 ? ep + ei[p] * ne : nullptr;
+    }
+    const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;
+    if (int rc = launch_updat16_rows<DTbf16>(xs, es, DW, a, 6, images, ug, flag)) return rc;
+    return f32_split_repair<16, 0>(X, DY, DW, a, flag);
+}
+
 int updat64(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
     // the streaming bsize-32 kernel on the quadrants.  16-bit types with the streaming plan only (what the reference runs bsize 64 in: fp16
     // tensor cores).
@@ -1306,6 +1353,10 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
         if (updat_f32_split_applies(a) && (a->N >= 256 || call_variant(a) == 3 || (a->flags & BSMM_FLAG_DW_SUMS))) return updat32_f32_split(X, DY, DW, a);
         if (updat8_f32_split_applies(a) && (a->N >= 256 || call_variant(a) == 3)) return updat8_f32_split(X, DY, DW, a);
         if (updat16_f32_split_applies(a) && (a->N >= 256 || call_variant(a) == 3)) return updat16_f32_split<1>(X, DY, DW, a);
+        if (updat16_f32_rows_applies(a) && (a->N >= 256 || call_variant(a) == 3)) {
+            const int rc16 = updat16_f32_rows(X, DY, DW, a);
+            if (rc16 != BSMM_ERR_UNSUPPORTED) return rc16;
+        }
         if (a->flags & BSMM_FLAG_DW_SUMS) return BSMM_ERR_UNSUPPORTED;
         bsmm_args b = *a;
         b.plan = nullptr; b.plan_magic = b.plan_width = b.plan_waves = b.plan_items = b.plan_inner = 0;
@@ -1700,6 +1751,8 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
         }
         return op == BSMM_OP_UPDAT ? blk * sizeof(float) : std::max(round16(blk * elem_size(a->dtype)) + 16, lock);   // (+ the non-finite flag of the call)
     }
+    if (op == BSMM_OP_UPDAT && updat16_f32_rows_applies(a))     // fp32 / bsize 16 / feature axis 0 on the row-owner kernel: its images + the pieces of X and DY
+        return updat16_f32_rows_images_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K) + F32_SPLIT_FLAG_BYTES;
     if (op == BSMM_OP_UPDAT && updat16_f32_split_applies(a))    // fp32 / bsize 16 on the windowed kernel: the fp32 sums + the pieces of X and DY
         return updat16_f32_sums_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K) + F32_SPLIT_FLAG_BYTES;
     if (op == BSMM_OP_UPDAT && updat_f32_split_applies(a))      // fp32 through the bf16 streaming kernel: its workspace + the pieces of X and DY

@@ -288,18 +288,21 @@ updat16_rows_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, f
 #endif
 }
 
-// DW = alpha * (sum over the parts' images) + beta * DW, rounded once
+// DW = alpha * [gate *] (sum over the parts' images) + beta * DW, rounded once (fp32 DW: the fp32 call through six bf16 piece pairs,
+// bsmm_api.hip::updat16_f32_rows -- skip_if is its non-finite flag: the repair pass writes DW then)
 template <class DT>
 __global__ void __launch_bounds__(256)
-updat16_rows_finalize_kernel(const float* __restrict__ scratch, typename DT::T* __restrict__ DW, size_t nel, int split, float alpha, float beta) {
+updat16_rows_finalize_kernel(const float* __restrict__ scratch, typename DT::T* __restrict__ DW, size_t nel, int split, float alpha, float beta,
+                             const float* __restrict__ gate = nullptr, const int32_t* __restrict__ skip_if = nullptr) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= nel) return;
+    if (i >= nel || (skip_if && skip_if[0] != 0)) return;
     float4 s = *reinterpret_cast<const float4*>(scratch + i);
     for (int part = 1; part < split; ++part) {
         const float4 t = *reinterpret_cast<const float4*>(scratch + (size_t)part * nel + i);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
-    float v[4] = {alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w};
+    const float a = gate ? alpha * gate[i >> 8] : alpha;
+    float v[4] = {a * s.x, a * s.y, a * s.z, a * s.w};
     if (beta != 0.f) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += beta * DT::to_f32(DW[i + e]);

@@ -535,8 +535,9 @@ class BlocksparseMatMul(object):
             raise ValueError("updat(sums_only=True) returns the ungated sums: pass the gate to updat_finalize / DwReduce.start")
         flags = (_lib.FLAG_GATED_DW if (gate is not None and not sums_only) else 0) | (_lib.FLAG_DW_SUMS if sums_only else 0)
         # fp32: the library has a plan path for bsize 32 on feature axis 1 and for bsize 8 / 16 (the six significant bf16 piece products as six
-        # pairs of one launch of the 16-bit kernel, round 4); other fp32 configurations run the kernels without a plan
-        use_plan = xs[0].dtype != torch.float32 or (len(xs) == 1 and ((self.bsize in (16, 32) and self.axis == 1) or self.bsize == 8))
+        # pairs of one launch of the 16-bit kernel, round 4; bsize 16 on feature axis 0: round 5, where the row-owner kernel pays -- the library
+        # falls back to the kernels without a plan by itself); other fp32 configurations run the kernels without a plan
+        use_plan = xs[0].dtype != torch.float32 or (len(xs) == 1 and ((self.bsize == 32 and self.axis == 1) or self.bsize in (8, 16)))
         a, ws, _ = self._call_args(_lib.OP_UPDAT, tabs, tabs.updat, None, N, self.C, self.K, xs[0].dtype,
                                    tabs.updat_plan if use_plan else None, slot=slot, pcount=len(xs), flags=flags,
                                    gated=gate is not None and not sums_only)

@@ -132,3 +132,37 @@ def test_row_owner_updat_random_shapes(env):
         den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
         assert (num <= P.L2_BAR[dt] * np.maximum(den, 1e-30)).all(), (it, CB, KB, dens, N, split, dt, float((num / np.maximum(den, 1e-30)).max()))
     assert ran >= 10
+
+
+def test_fp32_updat_through_the_row_owner_kernel(env):
+    """fp32 weight gradient of bsize 16 on feature axis 0 (the reference's primary fp32 layout, src/blocksparse_matmul_op_gpu.cu:1395-1835):
+    X and DY split into three bf16 pieces each, the six significant piece products as six pairs of ONE launch of the row-owner kernel, fp32
+    finalize with alpha / beta / gate -- against the float64 oracle at the fp32 bar; an Inf / NaN input raises the split's flag and the
+    per-block fp32 kernel computes the call (same NaN / Inf sets as the oracle)."""
+    torch, BSMM, lib = env
+    lay = P.random_layout(256, 256, 0.10, seed=1234)
+    b = BSMM(lay, block_size=16, feature_axis=0)
+    N = 2048
+    t = orc.build_layout_luts(np.asarray(lay), 16)
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=3)
+    E = (E * 1e-3).astype(np.float32)
+    X[5, 7] = np.float32(3.4e38)                               # finite, beyond the bf16 range: the split stays exact
+    x, e = P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)
+    gate = torch.rand(b.blocks, device="cuda")
+    dw0 = (np.random.default_rng(5).standard_normal(b.w_shape) * 0.1).astype(np.float32)
+    got = P.to_host(b.updat(x, e, alpha=0.5, beta=2.0, dw=P.to_dev(dw0.copy(), "f32", torch), gate=gate))
+    assert lib.last_kernel() == lib.K_UPDAT16_ROWS
+    ref = orc.updat(t, X.astype(np.float64), E.astype(np.float64), 0, alpha=0.5, beta=2.0, dw_in=dw0, gate=gate.cpu().numpy())
+    assert np.isfinite(got).all()
+    num = np.sqrt(((got.astype(np.float64) - ref) ** 2).reshape(b.blocks, -1).sum(axis=1))
+    den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
+    assert (num <= P.L2_BAR["f32"] * den).all(), float((num / den).max())
+    X[9, 100] = np.inf
+    E[300, 11] = np.nan
+    got2 = P.to_host(b.updat(P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)))
+    with np.errstate(invalid="ignore", over="ignore"):
+        ref2 = orc.updat(t, X.astype(np.float64), E.astype(np.float64), 0)
+    assert np.isnan(ref2).any() and np.isinf(ref2).any()
+    assert np.array_equal(np.isnan(got2), np.isnan(ref2))
+    inf = np.isinf(ref2)
+    assert np.array_equal(np.isinf(got2), inf) and np.array_equal(np.sign(got2[inf]), np.sign(ref2[inf]))
