@@ -898,7 +898,7 @@ int launch_updat16_rows(const PtrList8& xs, const PtrList8& es, void* DW, const 
     }
     float* scratch = images;
     const size_t nel = (size_t)a->blocks * 256;
-    if (!f32 && split > 1) {      // one fp32 image of the sums per part
+    if (!f32 && (split > 1 || gate)) {      // one fp32 image of the sums per part (a gated call: always -- the finalize pass applies the gate)
         if (!a->workspace || a->workspace_bytes < (size_t)split * nel * sizeof(float) || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
         scratch = static_cast<float*>(a->workspace);
     }
@@ -915,8 +915,8 @@ int launch_updat16_rows(const PtrList8& xs, const PtrList8& es, void* DW, const 
         updat16_rows_kernel<DT, 16><<<grid, 64 * U6_WAVES, U6Geom<16>::LDS, st>>>(xs, es, dw16, scratch, sec, a->N, a->C, a->K, pcount, a->alpha, a->beta, split, nel);
     }
     const unsigned fgrid = (unsigned)((nel / 4 + 255) / 256);
-    if (f32)            updat16_rows_finalize_kernel<DTf32><<<fgrid, 256, 0, st>>>(scratch, static_cast<float*>(DW), nel, split, a->alpha, a->beta, gate, skip_if);
-    else if (split > 1) updat16_rows_finalize_kernel<DT><<<fgrid, 256, 0, st>>>(scratch, dw16, nel, split, a->alpha, a->beta);
+    if (f32)          updat16_rows_finalize_kernel<DTf32><<<fgrid, 256, 0, st>>>(scratch, static_cast<float*>(DW), nel, split, a->alpha, a->beta, gate, skip_if);
+    else if (scratch) updat16_rows_finalize_kernel<DT><<<fgrid, 256, 0, st>>>(scratch, dw16, nel, split, a->alpha, a->beta, gate);
     return (int)hipGetLastError();
 }
 
@@ -1027,6 +1027,14 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     if constexpr (BS == 16 && DT::is16) {
         bool al16 = aligned16(DW) && (AXIS == 1 || N % 8 == 0);
         for (int p = 0; p < a->pcount; ++p) al16 = al16 && aligned16(xs.p[p]) && aligned16(es.p[p]);
+        if constexpr (AXIS == 0) {
+            // a GATED call can take the row-owner kernel too (round 5: its finalize pass applies the gate); the windowed kernel has no gate
+            if (!use_valu && gated && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_magic == UPLAN_MAGIC && a->plan_inner > 0 &&
+                (long)N * std::max(a->C, a->K) < (1L << 31)) {
+                const int rc = launch_updat16_rows<DT>(xs, es, DW, a, 0, nullptr, ug);
+                if (rc != BSMM_ERR_UNSUPPORTED) return rc;
+            }
+        }
         if (!use_valu && !gated && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed, 16x16 blocks
             if (a->plan_magic != UPLAN_MAGIC || (a->plan_width & 255) != UW16 || (a->plan_waves & 255) != UP_WAVES) return BSMM_ERR_ARG;   // (bits 8..: the 'BSU6' section's window width / items)
             if constexpr (AXIS == 0) {

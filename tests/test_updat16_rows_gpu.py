@@ -102,6 +102,14 @@ def test_row_owner_updat_at_configs2(env):
     num = np.sqrt(((dw.astype(np.float64) - ref) ** 2).reshape(b.blocks, -1).sum(axis=1))
     den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
     assert (num <= P.L2_BAR["bf16"] * den).all(), float((num / den).max())
+    # a gated call stays on the kernel: its finalize pass scales the sums of block w by gate[w] before the one rounding
+    gate = torch.rand(b.blocks, device="cuda") * 2 - 0.5
+    dwg = P.to_host(b.updat(x, e, gate=gate))
+    assert lib.last_kernel() == lib.K_UPDAT16_ROWS
+    refg = orc.round_to(orc.updat_fast(t, P.to_host(x), P.to_host(e), 0, dtype=np.float64) * gate.cpu().numpy().astype(np.float64)[:, None, None], "bf16")
+    num = np.sqrt(((dwg.astype(np.float64) - refg) ** 2).reshape(b.blocks, -1).sum(axis=1))
+    den = np.sqrt((refg ** 2).reshape(b.blocks, -1).sum(axis=1))
+    assert (num <= P.L2_BAR["bf16"] * np.maximum(den, 1e-30)).all(), float((num / np.maximum(den, 1e-30)).max())
 
 
 def test_row_owner_updat_random_shapes(env):
