@@ -22,16 +22,17 @@
 
 namespace bsmm {
 
-//  the first piece never exceeds the input: a finite x beyond the largest bf16 (|x| > 3.39e38, it would round to Inf and leave
-// Inf - Inf = NaN behind) keeps the largest finite bf16 as its first piece and stays exact; a non-finite x keeps its first piece and gets
-// zero residues (the products are then non-finite -- Inf or NaN according to the signs of the partner's pieces; the weight-gradient paths
-// raise a flag for such inputs, split3_x_kernel's last argument, and re-run the call on the fp32 kernels: bsmm_api.hip::f32_split_repair).
+// The first piece never exceeds the input: the value is clamped to the largest finite bf16 BEFORE the first rounding, so a
+// finite x beyond the bf16 range (3.39e38 < |x| <= FLT_MAX, which would round to Inf and leave Inf - Inf = NaN behind) keeps 0x7f7f as its
+// first piece and stays exact (x - 0x7f7f0000 has at most 16 significant bits).  ONE v_med3_f32, no branch: round 5's two-level `if` in here
+// was inlined into the LDS -> LDS conversion loop of xcol32sf_kernel and pushed it from 127 registers to 128 + 8 spilled -- BASELINE
+// configs[1] lost a fifth of its throughput; tests/test_codeobj.py now fails the build on any spill of a hot kernel.
+// A non-finite x leaves NaN pieces (Inf: 0x7f7f, Inf, NaN; NaN: NaN all the way), so every output that x enters is NaN -- non-finite
+// exactly where the unsplit IEEE product is non-finite (Inf or NaN there).  The weight-gradient paths do better: split3_x_kernel raises a
+// flag for such inputs and the call is re-run on the fp32 kernels (bsmm_api.hip::f32_split_repair), which reproduces IEEE's Inf / NaN sets.
 __device__ __forceinline__ void split3(float x, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
-    uint16_t p1 = DTbf16::from_f32(x);
-    if ((p1 & 0x7fffu) >= 0x7f80u) {
-        if ((__builtin_bit_cast(uint32_t, x) & 0x7f800000u) == 0x7f800000u) { b1 = p1; b2 = 0; b3 = 0; return; }
-        p1 = (uint16_t)((p1 & 0x8000u) | 0x7f7fu);
-    }
+    const float big = __builtin_bit_cast(float, 0x7f7f0000u);
+    const uint16_t p1 = DTbf16::from_f32(__builtin_amdgcn_fmed3f(x, -big, big));
     const float r1 = x - DTbf16::to_f32(p1);
     const uint16_t p2 = DTbf16::from_f32(r1);
     const float r2 = r1 - DTbf16::to_f32(p2);

@@ -86,3 +86,82 @@ def run_case(torch, BlocksparseMatMul, layout, bs, axis, dtype, N, seed=0, segme
         ref = (orc.updat_fast(t, X, E, axis, np.float64) if fast_oracle else orc.updat(t, X, E, axis))
         out["DW"] = errors(to_host(bsmm.updat(x, e)), orc.round_to(ref, dtype))
     return out
+
+
+# ---- the ONE per-block criterion -------------------------------------------------------------------
+# A result is compared with the float64 oracle rounded ONCE to the storage type.  Three statements, all of which must hold:
+#   (1) every element: got and the rounded oracle value are the SAME or ADJACENT representable values of the storage type
+#       (the kernels accumulate in fp32 and round once, the oracle accumulates in float64 and rounds once: the two sums differ
+#       by fp32 noise, which can flip a rounding but cannot move it two steps) -- OR the two differ by less than
+#       ELEM_FLOOR x the block's rms (elements that cancelled to near zero, where fp32 noise spans many of their tiny ulps);
+#   (2) every block (256 .. 1024 elements, or whatever group the caller reshapes to): L2-relative error <= BLOCK_FACTOR x bar.
+#       A block of 256 bf16 values that all sit one fp32-noise away from a rounding boundary reaches 0.75 - 1.2e-3 through
+#       1-ulp flips alone (Monte-Carlo in VERDICT r5), so 1 x bar per block is a coin toss; 4 x is what the suite used for DW
+#       blocks since round 1;
+#   (3) the whole tensor: L2-relative error <= bar (the north-star statement).
+# fp32 storage has no statement (1): the bar there (2e-6) is already a few fp32 ulps of the L2 norm.
+ELEM_FLOOR = 1e-4
+BLOCK_FACTOR = 4.0
+
+
+def _ordinal(a, dtype):
+    """Monotonic integer index of the representable values of a 16-bit storage type (adjacent values differ by 1)."""
+    if dtype == "bf16":
+        bits = (np.ascontiguousarray(a, dtype=np.float32).view(np.uint32) >> 16).astype(np.int64)
+    elif dtype == "f16":
+        bits = np.ascontiguousarray(a).astype(np.float16).view(np.uint16).astype(np.int64)
+    else:
+        raise ValueError(dtype)
+    mag = bits & 0x7FFF
+    return np.where(bits & 0x8000, -mag, mag)
+
+
+def block_report(got, want64, dtype, groups):
+    """`got`: the device result (float32 array holding storage-type values); `want64`: the UNROUNDED float64 oracle; `groups`: the
+    leading dimension to reshape to (one row = one block).  Returns a dict of the three statements' worst cases."""
+    got = np.asarray(got)
+    want_r = round_to_storage(want64, dtype)
+    g = got.astype(np.float64).reshape(groups, -1)
+    r = want_r.astype(np.float64).reshape(groups, -1)
+    d = np.abs(g - r)
+    den = np.sqrt((r ** 2).sum(axis=1))
+    num = np.sqrt((d ** 2).sum(axis=1))
+    live = den > 0
+    rep = {"tensor_l2": float(np.sqrt((d ** 2).sum()) / max(np.sqrt((r ** 2).sum()), 1e-30)),
+           "block_l2": float((num[live] / den[live]).max()) if live.any() else 0.0,
+           "worst_block": int(np.argmax(np.where(live, num / np.maximum(den, 1e-30), 0.0))),
+           "dead_nonzero": int((np.abs(g[~live]).sum(axis=1) != 0).sum()),
+           "finite": bool(np.isfinite(got).all()), "elem_bad": 0, "elem_flips": 0}
+    if dtype in ("bf16", "f16"):
+        steps = np.abs(_ordinal(got.astype(np.float32), dtype) - _ordinal(want_r.astype(np.float32), dtype)).reshape(groups, -1)
+        rms = den / np.sqrt(r.shape[1])
+        bad = (steps > 1) & (d > ELEM_FLOOR * rms[:, None])
+        rep["elem_bad"] = int(bad.sum())
+        rep["elem_flips"] = int((steps == 1).sum())
+    return rep
+
+
+def assert_blocks(got, want64, dtype, groups, ctx=""):
+    rep = block_report(got, want64, dtype, groups)
+    bar = L2_BAR[dtype]
+    assert rep["finite"], (ctx, "non-finite values")
+    assert rep["dead_nonzero"] == 0, (ctx, "blocks whose oracle is all zero are not", rep)
+    assert rep["elem_bad"] == 0, (ctx, "elements more than one storage-type step from the rounded oracle", rep)
+    assert rep["block_l2"] <= BLOCK_FACTOR * bar, (ctx, "worst block", rep)
+    assert rep["tensor_l2"] <= bar, (ctx, "tensor", rep)
+    return rep
+
+
+def round_to_storage(a, dtype):
+    return orc.round_to(np.asarray(a), dtype)
+
+
+def act_blocks(a, axis, N, feat_blocks, bs):
+    """An activation-shaped array as (feature block, everything else): the grouping of the per-block-column statement."""
+    a = np.asarray(a)
+    return (a.reshape(N, feat_blocks, bs).transpose(1, 0, 2) if axis else a.reshape(feat_blocks, bs, N)).reshape(feat_blocks, -1)
+
+
+def gen(torch, seed, device="cuda"):
+    """A seeded generator: no test of this suite draws from the global RNG state."""
+    return torch.Generator(device=device).manual_seed(int(seed))

@@ -41,7 +41,7 @@ def test_renumber_between_z_order_flags():
 def test_save_load_roundtrip(tmp_path, dtype):
     lay = _layout(5)
     b = BlocksparseMatMul(lay, block_size=16, feature_axis=1, z_order=False)
-    W = torch.randn(b.w_shape).to(dtype)
+    W = torch.randn(b.w_shape, generator=torch.Generator().manual_seed(7)).to(dtype)
     path = str(tmp_path / "w.npz")
     ck.save(path, b, W)
     b2, W2 = ck.load(path, device="cpu")

@@ -66,7 +66,7 @@ def test_rccl_handle_world_size_one(env):
         y = torch.ones(1 << 22, device="cuda").sum()           # something to overlap with
         red.wait()
         assert torch.equal(t, want)
-    h = (torch.randn(1000, device="cuda") * 3).bfloat16()
+    h = (torch.randn(1000, device="cuda", generator=torch.Generator(device="cuda").manual_seed(61)) * 3).bfloat16()
     red16 = DwAllReduce(force=True, comm=comm, accumulate_fp32=True)
     keep = h.clone()
     red16.start(h); red16.wait()

@@ -332,13 +332,13 @@ def test_rank3_inputs_flatten_non_feature_dims(env):
     torch, BSMM, _ = env
     layout = P.random_layout(4, 4, 0.6, seed=8)
     b1 = BSMM(layout, block_size=16, feature_axis=1)
-    w = torch.randn(b1.w_shape, device="cuda") * 0.05
-    x = torch.randn(3, 5, b1.C, device="cuda")
+    w = torch.randn(b1.w_shape, device="cuda", generator=P.gen(torch, 31)) * 0.05
+    x = torch.randn(3, 5, b1.C, device="cuda", generator=P.gen(torch, 32))
     y = b1(x, w)
     assert tuple(y.shape) == (3, 5, b1.K)
     torch.testing.assert_close(y.reshape(15, -1), b1(x.reshape(15, -1), w))
     b0 = BSMM(layout, block_size=16, feature_axis=0)
-    x0 = torch.randn(b0.C, 3, 4, device="cuda")
+    x0 = torch.randn(b0.C, 3, 4, device="cuda", generator=P.gen(torch, 33))
     y0 = b0(x0, w)
     assert tuple(y0.shape) == (b0.K, 3, 4)
     torch.testing.assert_close(y0.reshape(b0.K, 12), b0(x0.reshape(b0.C, 12), w))

@@ -112,6 +112,6 @@ def test_epsilon_branch_and_autograd(env):
     assert P.errors(y.detach().cpu().numpy(), Y)[0] < 2e-6
     assert P.errors(tw.grad.cpu().numpy(), D)[0] < 2e-6 and P.errors(tg.grad.cpu().numpy(), DG)[0] < 2e-6
     # the usual use: normalised weights feed the block-sparse matmul
-    x = torch.randn(b.i_shape(16), device="cuda")
+    x = torch.randn(b.i_shape(16), device="cuda", generator=P.gen(torch, 41))
     out = b(x, b.l2_normalize(tw.detach()))
     assert torch.isfinite(out).all()

@@ -6,6 +6,8 @@ import sys
 import numpy as np
 import pytest
 
+import _parity as P
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
@@ -41,8 +43,8 @@ def test_ops_and_gradients(dtype):
     for nhidden, nproj, N in ((96, 17, 40), (512, 128, 1000), (33, 33, 7)):
         sp = SparseProj(nhidden, nproj=nproj)
         idx = torch.from_numpy(sp.gather_lut.astype(np.int64)).cuda()
-        x = torch.randn(nhidden, N, device="cuda").to(td)
-        y = torch.randn(nproj, N, device="cuda").to(td)
+        x = torch.randn(nhidden, N, device="cuda", generator=P.gen(torch, nhidden)).to(td)
+        y = torch.randn(nproj, N, device="cuda", generator=P.gen(torch, nproj + 1000)).to(td)
         assert torch.equal(sp.gather(x), x[idx])
         z = torch.zeros_like(x); z[idx] = y
         assert torch.equal(sp.scatter(y), z)
@@ -59,7 +61,7 @@ def test_ops_and_gradients(dtype):
         # gradients (fp32 only for exact comparison)
         if dtype == "float32":
             xa = x.clone().requires_grad_(True); ya = y.clone().requires_grad_(True)
-            e = torch.randn(nhidden, N, device="cuda")
+            e = torch.randn(nhidden, N, device="cuda", generator=P.gen(torch, N + 2000))
             sp.scatter_mul(sp.scatter_add(xa, ya), ya).backward(e)
             xb = x.clone().requires_grad_(True); yb = y.clone().requires_grad_(True)
             t = xb.clone(); t = t.index_add(0, idx, yb)

@@ -2,6 +2,8 @@
 the bsize-16 'BSUP' plan, round 5) against the float64 oracle (oracle/bsmm_oracle.py::updat, restating blocksparse/matmul.py:401-419 with the
 kernel semantics of alpha / beta / pairs, src/blocksparse_matmul_op_gpu.cu:2684-2814), every block of DW, with the kernel family asserted
 through bsmm_args.trace.  The windowed kernel (plan option PLAN_UPDAT16_WINDOWED) runs beside it: same inputs, same bar."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,10 @@ import _parity as P
 from oracle import bsmm_oracle as orc
 
 pytestmark = pytest.mark.gpu
+
+# Every random draw of this file is seeded; scripts/gpu_seed_sweep.py re-runs the three configs[2] / random-shape / fp32 tests under many values
+# of BSMM_TEST_SEED on one lease (the criterion must hold for every seed, not for the lucky one).
+SEED = int(os.environ.get("BSMM_TEST_SEED", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -57,13 +63,9 @@ def test_row_owner_updat_against_the_oracle(env, case):
     t = orc.build_layout_luts(np.asarray(lay), 16)
     Xh, Eh = P.to_host(x).astype(np.float64), P.to_host(e).astype(np.float64)
     ref = orc.updat(t, Xh, Eh, 0)
-    bar = P.L2_BAR[dt]
     for got, want, what in ((d1, ref, "dw"), (d2, 0.5 * ref + 2.0 * P.to_host(dw0).astype(np.float64), "alpha / beta"), (d3, 2.0 * ref, "two pairs"),
                             (dw_, ref, "windowed kernel")):
-        want_r = orc.round_to(want, dt)
-        num = np.sqrt(((got.astype(np.float64) - want_r) ** 2).reshape(b.blocks, -1).sum(axis=1))
-        den = np.sqrt((want_r ** 2).reshape(b.blocks, -1).sum(axis=1))
-        assert (num <= bar * np.maximum(den, 1e-30)).all(), (name, what, float((num / np.maximum(den, 1e-30)).max()))
+        P.assert_blocks(got, want, dt, b.blocks, (name, what))
     assert np.array_equal(d1, d1b)                       # no atomics: the parts are added in a fixed order
 
 
@@ -77,7 +79,7 @@ def test_row_owner_updat_falls_back_where_it_cannot_run(env):
     for N, dt, gated in ((1004, "bf16", False), (2048, "bf16", True), (2048, "f32", False), (128, "bf16", False)):
         W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dt, seed=5)
         x, e = P.to_dev(X, dt, torch), P.to_dev(E, dt, torch)
-        gate = torch.rand(b.blocks, device="cuda") if gated else None
+        gate = torch.rand(b.blocks, device="cuda", generator=torch.Generator(device="cuda").manual_seed(N)) if gated else None
         got = P.to_host(b.updat(x, e, gate=gate))
         assert lib.last_kernel() != lib.K_UPDAT16_ROWS, (N, dt, gated, lib.last_kernel())
         ref = orc.updat(t, P.to_host(x).astype(np.float64), P.to_host(e).astype(np.float64), 0, gate=None if gate is None else gate.cpu().numpy())
@@ -92,24 +94,20 @@ def test_row_owner_updat_at_configs2(env):
     lay = P.random_layout(256, 256, 0.10, seed=1234)
     b = BSMM(lay, block_size=16, feature_axis=0)
     N = 8192
-    g = torch.Generator(device="cuda").manual_seed(9)
+    g = torch.Generator(device="cuda").manual_seed(SEED + 9)
     x = (torch.randn(b.i_shape(N), device="cuda", generator=g) * 0.1).bfloat16()
     e = (torch.randn(b.o_shape(N), device="cuda", generator=g) * 0.1).bfloat16()
     dw = P.to_host(b.updat(x, e))
     assert lib.last_kernel() == lib.K_UPDAT16_ROWS
     t = orc.build_layout_luts(np.asarray(lay), 16)
-    ref = orc.round_to(orc.updat_fast(t, P.to_host(x), P.to_host(e), 0, dtype=np.float64), "bf16")
-    num = np.sqrt(((dw.astype(np.float64) - ref) ** 2).reshape(b.blocks, -1).sum(axis=1))
-    den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
-    assert (num <= P.L2_BAR["bf16"] * den).all(), float((num / den).max())
+    ref = orc.updat_fast(t, P.to_host(x), P.to_host(e), 0, dtype=np.float64)
+    P.assert_blocks(dw, ref, "bf16", b.blocks, "configs[2] dw")
     # a gated call stays on the kernel: its finalize pass scales the sums of block w by gate[w] before the one rounding
-    gate = torch.rand(b.blocks, device="cuda") * 2 - 0.5
+    gate = torch.rand(b.blocks, device="cuda", generator=torch.Generator(device="cuda").manual_seed(SEED + 10)) * 2 - 0.5
+    gate[::97] = 0.0                                     # gate == 0 blocks come out exactly zero
     dwg = P.to_host(b.updat(x, e, gate=gate))
     assert lib.last_kernel() == lib.K_UPDAT16_ROWS
-    refg = orc.round_to(orc.updat_fast(t, P.to_host(x), P.to_host(e), 0, dtype=np.float64) * gate.cpu().numpy().astype(np.float64)[:, None, None], "bf16")
-    num = np.sqrt(((dwg.astype(np.float64) - refg) ** 2).reshape(b.blocks, -1).sum(axis=1))
-    den = np.sqrt((refg ** 2).reshape(b.blocks, -1).sum(axis=1))
-    assert (num <= P.L2_BAR["bf16"] * np.maximum(den, 1e-30)).all(), float((num / np.maximum(den, 1e-30)).max())
+    P.assert_blocks(dwg, ref * gate.cpu().numpy().astype(np.float64)[:, None, None], "bf16", b.blocks, "configs[2] gated dw")
 
 
 def test_row_owner_updat_random_shapes(env):
@@ -117,7 +115,7 @@ def test_row_owner_updat_random_shapes(env):
     alpha / beta: whatever the section builder makes of them (32- or 16-column windows; none for the densest: those runs must take another
     kernel), every block against the float64 oracle."""
     torch, BSMM, lib = env
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SEED)
     ran = 0
     for it in range(16):
         CB, KB = int(rng.integers(20, 151)), int(rng.integers(20, 151))
@@ -128,18 +126,16 @@ def test_row_owner_updat_random_shapes(env):
         lay = P.random_layout(CB, KB, dens, seed=100 + it)
         b = BSMM(lay, block_size=16, feature_axis=0, updat_split=split)
         has = int(b._tables_on(torch.device("cuda")).updat_plan.host[8]) > 0
-        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dt, seed=it)
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dt, seed=it + 1000 * SEED)
         x, e = P.to_dev(X, dt, torch), P.to_dev(E, dt, torch)
         dw0 = P.to_dev(rng.standard_normal(b.w_shape).astype(np.float32) * 0.05, dt, torch)
         got = P.to_host(b.updat(x, e, alpha=1.5, beta=-0.5, dw=dw0.clone()))
         assert (lib.last_kernel() == lib.K_UPDAT16_ROWS) == has, (it, CB, KB, dens, N, split, lib.last_kernel())
         ran += has
         t = orc.build_layout_luts(np.asarray(lay), 16)
-        ref = orc.round_to(1.5 * orc.updat(t, P.to_host(x).astype(np.float64), P.to_host(e).astype(np.float64), 0) - 0.5 * P.to_host(dw0).astype(np.float64), dt)
-        num = np.sqrt(((got.astype(np.float64) - ref) ** 2).reshape(b.blocks, -1).sum(axis=1))
-        den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
-        assert (num <= P.L2_BAR[dt] * np.maximum(den, 1e-30)).all(), (it, CB, KB, dens, N, split, dt, float((num / np.maximum(den, 1e-30)).max()))
-    assert ran >= 10
+        ref = 1.5 * orc.updat(t, P.to_host(x).astype(np.float64), P.to_host(e).astype(np.float64), 0) - 0.5 * P.to_host(dw0).astype(np.float64)
+        P.assert_blocks(got, ref, dt, b.blocks, (it, CB, KB, dens, N, split, dt))
+    assert ran >= (10 if SEED == 0 else 4)
 
 
 def test_fp32_updat_through_the_row_owner_kernel(env):
@@ -152,19 +148,16 @@ def test_fp32_updat_through_the_row_owner_kernel(env):
     b = BSMM(lay, block_size=16, feature_axis=0)
     N = 2048
     t = orc.build_layout_luts(np.asarray(lay), 16)
-    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=3)
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "f32", seed=3 + SEED)
     E = (E * 1e-3).astype(np.float32)
     X[5, 7] = np.float32(3.4e38)                               # finite, beyond the bf16 range: the split stays exact
     x, e = P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)
-    gate = torch.rand(b.blocks, device="cuda")
+    gate = torch.rand(b.blocks, device="cuda", generator=torch.Generator(device="cuda").manual_seed(SEED + 5))
     dw0 = (np.random.default_rng(5).standard_normal(b.w_shape) * 0.1).astype(np.float32)
     got = P.to_host(b.updat(x, e, alpha=0.5, beta=2.0, dw=P.to_dev(dw0.copy(), "f32", torch), gate=gate))
     assert lib.last_kernel() == lib.K_UPDAT16_ROWS
     ref = orc.updat(t, X.astype(np.float64), E.astype(np.float64), 0, alpha=0.5, beta=2.0, dw_in=dw0, gate=gate.cpu().numpy())
-    assert np.isfinite(got).all()
-    num = np.sqrt(((got.astype(np.float64) - ref) ** 2).reshape(b.blocks, -1).sum(axis=1))
-    den = np.sqrt((ref ** 2).reshape(b.blocks, -1).sum(axis=1))
-    assert (num <= P.L2_BAR["f32"] * den).all(), float((num / den).max())
+    P.assert_blocks(got, ref, "f32", b.blocks, "fp32 through the row-owner kernel")
     X[9, 100] = np.inf
     E[300, 11] = np.nan
     got2 = P.to_host(b.updat(P.to_dev(X, "f32", torch), P.to_dev(E, "f32", torch)))
