@@ -19,7 +19,6 @@
 #include "bsmm_xcol.h"
 #include "bsmm_xcol_v2.h"
 #include "bsmm_xflow.h"
-#include "bsmm_xrows.h"
 #include "bsmm_updat16_rows.h"
 #include "bsmm_xsmall.h"
 #include "bsmm_xmid.h"
@@ -103,8 +102,7 @@ int check_plan(bool updat, const bsmm_args* a) {
     if (updat) return (((m == UPLAN_MAGIC && a->bsize == 16) || (m == U2PLAN_MAGIC && a->bsize == 32)) && a->plan_items > 0) ? BSMM_OK : BSMM_ERR_ARG;   // (bsize-32 'BSUP' plans: retired in round 4, refused as bsmm.h says)
     if (a->bsize == 16) return (m == X7PLAN_MAGIC && a->plan_width == X7_G && a->dtype != BSMM_F32) ? BSMM_OK : BSMM_ERR_ARG;
     if (a->dtype == BSMM_F32) return (m == XCPLAN_MAGIC && a->plan_width == XS_G) ? BSMM_OK : BSMM_ERR_ARG;
-    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G) || (m == X4PLAN_MAGIC && a->plan_width == X4_G && a->axis == 1) ||
-            (m == X5PLAN_MAGIC && a->plan_width == X5_G && a->axis == 1)) ? BSMM_OK : BSMM_ERR_ARG;
+    return (m == XCPLAN_MAGIC || (m == X2PLAN_MAGIC && a->plan_width == X2_G) || (m == X4PLAN_MAGIC && a->plan_width == X4_G && a->axis == 1)) ? BSMM_OK : BSMM_ERR_ARG;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -174,7 +172,7 @@ inline bool use_xcol() { return true; }
 // on feature axis 0 the list kernel wins at every density (50 %: 251 / 237 against 321 / 301).  Gated calls: the round-2 kernel.
 inline bool x7_use_list(const bsmm_args* a) {
 #ifdef X7_POSITIONAL
-    return false;
+    return a->axis == 0 && !a->gate;      // (measurement build: the pair kernel wherever it exists)
 #else
     if (a->gate) return false;
     const double dens = (double)a->blocks / std::max(1.0, (a->C / 16.0) * (a->K / 16.0));
@@ -198,9 +196,15 @@ int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* 
         xcol16_v2_kernel<DT, AXIS, true><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
                                                                          a->N, a->C, a->K, a->gate);
     } else if (!x7_use_list(a)) {
-        if (int rc = ensure_lds<&xcol16_v2_kernel<DT, AXIS, false>>(X7_LDS)) return rc;
-        xcol16_v2_kernel<DT, AXIS, false><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                                          a->N, a->C, a->K, nullptr);
+        // (feature axis 1, dense layouts only -- x7_use_list: on feature axis 0 the list kernel wins at every density, and that instantiation
+        //  of the pair kernel spilled 4 registers: not built)
+        if constexpr (AXIS == 1) {
+            if (int rc = ensure_lds<&xcol16_v2_kernel<DT, 1, false>>(X7_LDS)) return rc;
+            xcol16_v2_kernel<DT, 1, false><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
+                                                                           a->N, a->C, a->K, nullptr);
+        } else {
+            return BSMM_ERR_ARG;
+        }
     } else if (transw) {
         if (int rc = ensure_lds<&xcol16_list_kernel<DT, AXIS, true>>(X7_LDS)) return rc;
         xcol16_list_kernel<DT, AXIS, true><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
@@ -388,33 +392,8 @@ int launch_xflow(const void* X, const void* Wsel, void* Y, const bsmm_args* a, h
     return half ? launch_xflow_rt<DT, TRANSW, 2>(X, Wsel, Y, a, st) : launch_xflow_rt<DT, TRANSW, 4>(X, Wsel, Y, a, st);
 }
 
-// row-split persistent kernel ('BSX5' plans, bsmm_xrows.h): one workgroup of 4 waves (one per SIMD) per CU walks its (row tile of 128, group) units
-template <class DT, bool TRANSW>
-int launch_xrows(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st) {
-    typedef typename DT::T T;
-    const int n_out = a->K / 32;
-    XMap m;
-    m.ntiles = (a->N + X5_R - 1) / X5_R;
-    m.segments = (n_out + X5_G - 1) / X5_G;
-    m.P = m.ntiles >= 8 ? 1 : (8 + m.ntiles - 1) / m.ntiles;
-    if (m.P > m.segments) m.P = m.segments;
-    m.SP = (m.segments + m.P - 1) / m.P;
-    if (int rc = ensure_lds<&xrows32_kernel<DT, TRANSW>>(X5_LDS)) return rc;
-    trace(a, BSMM_K_XCOL32_ROWS);
-    const int cus = device_cus();
-    const int grid = std::min(m.grid(), std::max(8, cus / 8 * 8));
-    xrows32_kernel<DT, TRANSW><<<grid, 256, X5_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan,
-                                                          m, a->N, a->C, a->K);
-    return (int)hipGetLastError();
-}
-
 template <class DT, int AXIS>
 int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a, hipStream_t st, bool transw) {
-    if (a->plan_magic == X5PLAN_MAGIC) {
-        if (a->plan_width != X5_G || a->gate) return BSMM_ERR_ARG;
-        if constexpr (AXIS == 1) return transw ? launch_xrows<DT, true>(X, Wsel, Y, a, st) : launch_xrows<DT, false>(X, Wsel, Y, a, st);
-        else return BSMM_ERR_ARG;
-    }
     if (a->plan_magic == X4PLAN_MAGIC) {
         if (a->plan_width != X4_G || a->gate) return BSMM_ERR_ARG;
         if constexpr (AXIS == 1) return transw ? launch_xflow<DT, true>(X, Wsel, Y, a, st) : launch_xflow<DT, false>(X, Wsel, Y, a, st);
@@ -425,9 +404,11 @@ int launch_xgroup32(const void* X, const void* Wsel, void* Y, const bsmm_args* a
         if (a->gate) return transw ? launch_xcol_v2<DT, true, AXIS, true>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false, AXIS, true>(X, Wsel, Y, a, st);
         return transw ? launch_xcol_v2<DT, true, AXIS>(X, Wsel, Y, a, st) : launch_xcol_v2<DT, false, AXIS>(X, Wsel, Y, a, st);
     }
-    if (a->plan_magic != XCPLAN_MAGIC) return BSMM_ERR_ARG;
-    if constexpr (AXIS == 1) return transw ? launch_xcol<DT, true>(X, Wsel, Y, a, st) : launch_xcol<DT, false>(X, Wsel, Y, a, st);
-    else                     return transw ? launch_xcol0<DT, true>(X, Wsel, Y, a, st) : launch_xcol0<DT, false>(X, Wsel, Y, a, st);
+    // round-1 grouped kernels ('BSXC' plans: the bsize-8 super-block path): fprop always comes with the transposed copy of W (`transw` is
+    // only ever set for the staged / flow plans above), so the TRANSW = true instantiations -- the axis-0 one spilled 3 registers -- are not built
+    if (a->plan_magic != XCPLAN_MAGIC || transw) return BSMM_ERR_ARG;
+    if constexpr (AXIS == 1) return launch_xcol<DT, false>(X, Wsel, Y, a, st);
+    else                     return launch_xcol0<DT, false>(X, Wsel, Y, a, st);
 }
 
 template <class DT, int BS>
@@ -529,8 +510,8 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     if constexpr (BS == 32 && DT::is16) {
         if (AXIS == 0 && (a->N % 8 != 0)) return XP_SEGMENT;            // axis-0 xcol needs 16-byte aligned row pieces
         // staged kernel: 32-bit per-lane byte offsets inside a slab's source (128 rows of C elements / 64 rows of N elements)
-        if ((a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X4PLAN_MAGIC || a->plan_magic == X5PLAN_MAGIC) && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;
-        if ((a->plan_magic == X4PLAN_MAGIC || a->plan_magic == X5PLAN_MAGIC) && AXIS != 1) return XP_SEGMENT;
+        if ((a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X4PLAN_MAGIC) && (AXIS == 1 ? (long)a->C : (long)a->N) * 256 >= (1L << 32)) return XP_SEGMENT;
+        if (a->plan_magic == X4PLAN_MAGIC && AXIS != 1) return XP_SEGMENT;
         if (force) return XP_XCOL32;
         // Cost model fitted to the measurements in profiles/r01_sweeps.md (4096^2 / 20 % and 8192^2 / 5 %, N = 512 .. 8192):
         // the grouped kernel pays ~0.48 us per pair step of a group plus ~0.045 us per block, once per round of 256
@@ -544,7 +525,7 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         const double steps = std::ceil(CB / 2.0) * (1.0 - std::pow(1.0 - dens, 2.0 * G));
         double t_group = rounds * (0.48 * steps + 0.045 * a->blocks / ngroups) + 8.0;
         double t_segment = 17.0 + 1.04e-5 * (double)a->blocks * a->N;
-        if (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X4PLAN_MAGIC || a->plan_magic == X5PLAN_MAGIC) {
+        if (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X4PLAN_MAGIC) {
             // staged kernel, refit (scripts/gpu_xprop_sweep.py, 4096^2 20 % / 5 %, 8192^2 5 %, 2048^2 20 %, N = 128 .. 8192): a round
             // costs 0.28 us per pair step + 0.040 us per block of the group, up to 20 % more when the round fills all CUs
             const double fill = std::min(1.0, ntiles * ngroups / rounds / cus);
@@ -655,7 +636,7 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
     float* yacc = nullptr;
     size_t off = 0;
     const void* Wsel = W;
-    const bool staged = path == XP_XCOL32 && (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X4PLAN_MAGIC || a->plan_magic == X5PLAN_MAGIC);   // transposes the staged blocks itself
+    const bool staged = path == XP_XCOL32 && (a->plan_magic == X2PLAN_MAGIC || a->plan_magic == X4PLAN_MAGIC);   // transposes the staged blocks itself
     const bool staged16 = path == XP_XCOL16 && a->plan_magic == X7PLAN_MAGIC && x7_use_list(a);   // the list kernel reads them transposed
     if (fprop && path != XP_VALU && !staged && !staged16) {
         if constexpr (BS != 8) {
@@ -1528,9 +1509,6 @@ extern "C" int bsmm_debug_x4_timeline_copy(void* host) { return (int)hipMemcpyFr
 #ifdef U6_STAMPS
 extern "C" int bsmm_debug_u6_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_u6_trace), sizeof(bsmm::g_u6_trace)); }
 #endif
-#ifdef X5_STAMPS
-extern "C" int bsmm_debug_x5_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x5_trace), sizeof(bsmm::g_x5_trace)); }
-#endif
 #ifdef X4_STAMPS
 extern "C" int bsmm_debug_x4_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_trace), sizeof(bsmm::g_x4_trace)); }
 #endif
@@ -1571,7 +1549,7 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
         if (axis != 1 || !lut || segments <= 0 || blocks <= 0 || blocks >= (1 << 28)) return axis != 1 ? 0 : -1;
         std::vector<int32_t> lut32, nested;
         if (!b64_expand_xprop_lut(lut, segments, blocks, lut32)) return -1;
-        const int32_t nopt = options & ~BSMM_PLAN_XCOL_ROWS;       // (the composite call runs the flow / staged kernels: no 'BSX5' plans nested)
+        const int32_t nopt = options;
         const long nw = xprop_plan(lut32.data(), 2 * segments, 4 * blocks, 2 * n_out, 32, dtype, axis, nopt, nullptr);
         if (nw < 0) return -1;
         nested.resize((size_t)nw);
@@ -1586,10 +1564,6 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
     }
     if (bsize == 16)         // 'BSX7' (staged / list kernels); BSMM_PLAN_XCOL_UNSTAGED / _NARROW named the round-1 kernel, retired in round 4: ignored
         return build_xcol16s_plan(lut, segments, blocks, n_out, out);      // (0: the layout does not fit the table fields -> no plan, per-segment kernels)
-    if ((options & BSMM_PLAN_XCOL_ROWS) && axis == 1 && !(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW | BSMM_PLAN_XCOL_FLOW))) {   // row-split persistent kernel
-        const long n = build_xrows_plan(lut, segments, blocks, n_out, out);
-        if (n != 0) return n;
-    }
     if ((options & BSMM_PLAN_XCOL_FLOW) && axis == 1 && !(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // barrier-free persistent kernel
         const long n = build_xflow_plan(lut, segments, blocks, n_out, out, (options & BSMM_PLAN_FLOW_SCHEDULED) != 0);
         if (n != 0) return n;
@@ -1680,7 +1654,6 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
         case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR || p[11] < 2 || p[11] > 4) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
         case X4PLAN_MAGIC:   if (p[1] != X4PLAN_VERSION || words < X4_HDR || p[2] != X4_G) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
-        case X5PLAN_MAGIC:   if (p[1] != X5PLAN_VERSION || words < X5_HDR || p[2] != X5_G || p[7] != (X5_D | (X5_NW << 8) | (X5_CAP << 16) | (X5_P << 24))) return false;   d[1] = p[2]; d[2] = 4; d[3] = 0; break;
         case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR || p[8] < 0 || (p[8] > 0 && (p[8] + U6_HDR > words || p[p[8]] != U6PLAN_MAGIC ||
                                  p[8] + U6_HDR + (long)p[p[8] + 4] * U6_ITEM > words))) return false;

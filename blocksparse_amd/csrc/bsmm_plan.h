@@ -666,214 +666,6 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
 }  // namespace bsmm
 
 // =================================================================================================
-// rows xcol plan ('BSX5', round 5): schedule of the row-split xprop kernel (bsmm_xrows.h).  Groups of X5_G = 16 consecutive output blocks;
-// a workgroup of FOUR waves, wave q = row quarter q of the 128-row tile x all 16 output blocks: every wave walks every step and multiplies
-// every block of the group by its own 32 rows.  A group walks the union of its input-block PAIRS in ascending order; a pair with more than
-// X5_CAP blocks is cut into several steps that share its activation slab.  The plan is a list of RECORDS of X5_REC = 64 words per group:
-// X5_P duty-only records (the prologue: issued before the unit starts), then one record per step.
-//   record: [0] pair index of the step's slab   [1] byte offset of the step's slab slot inside the ring (slot * 16 KiB)
-//           [2] block mask: bit 2 col + half = the block (input block 2 p + half, output block first + col) exists.  The blocks of a step sit
-//               in CONSECUTIVE weight slots in ascending bit order.
-//           [3] first weight slot of the step
-//           [4] per wave (byte q): the vmcnt to wait with in front of the step's barrier = DMA instructions the wave issued after the last
-//               one the NEXT step reads (step 0: this and the next step; capped at 63; nothing to wait for: 63).  Everything a step reads
-//               has therefore landed one barrier EARLY: the waves request a step's first fragments while they finish the one before
-//           [5] duty: pair index of the activation slab to request during this record (-1: none)   [6] byte offset of its slab slot
-//           [8] byte offset of the NEXT step's slab slot   [9] the next step's block mask   [10] its first weight slot (the last step: 0, 0, 0)
-//           [16 + 8 q + 2 i], [.. + 1] duty: i-th weight block wave q fetches during this record: LDS byte offset of its slot (from the
-//               ring's base; -1: none, and none behind it), byte offset of the block inside W (id << 11); entry e of the record's fetch
-//               list (FIFO order) is (q, i) = (e & 3, e >> 2)
-// A wave issues, per record: its 4 instructions of the slab duty (if any), then 2 per fetch entry, in order.
-// Duties are placed as early as the ring allows: a slab / a weight slot may be requested during record t once the step that last read it is
-// < t (every wave has passed barrier t by then).  The builder checks that everything a step reads is requested at least two records earlier
-// (else 0: no plan for this layout).
-// Layout (int32): [0] magic 'BSX5' [1] version [2] X5_G [3] ngroups [4] nrecords_total [5] off_groups [6] off_records
-//                 [7] X5_D | X5_NW << 8 | X5_CAP << 16 | X5_P << 24  [8] n_out_blocks [9] max steps of a group [10] blocks [11] 0
-//   groups[ngroups][8] = (first record, nsteps, first_out_block, n_out_blocks_in_group, blocks_in_group, 0, 0, 0), longest group first
-// =================================================================================================
-namespace bsmm {
-
-constexpr int32_t X5PLAN_MAGIC = 0x42535835;
-constexpr int32_t X5PLAN_VERSION = 4;   // 4: four waves (row quarters) x 16 columns, one run of weight slots per step, waits per wave
-constexpr int X5_G = 16;
-constexpr int X5_HDR = 12;
-constexpr int X5_GROUP = 8;
-constexpr int X5_REC = 64;
-constexpr int X5_D = 5;            // activation slabs in the ring
-constexpr int X5_P = X5_D - 1;     // prologue records (= slabs requested before the first step)
-constexpr int X5_NW = 39;          // weight slots
-constexpr int X5_CAP = 9;          // blocks per step (THREE consecutive steps -- in use, landed, in flight -- plus the padding of a run that may not wrap fit the X5_NW slots)
-constexpr int X5_FMAX = 16;        // weight blocks fetched per record (4 per wave)
-
-inline long build_xrows_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
-    if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
-    if (blocks >= (1 << 21)) return 0;                               // 32-bit byte offsets of the weight blocks
-    const int G = X5_G, ngroups = (n_out_blocks + G - 1) / G;
-    struct E { int p, pos, w; };                                     // pos = 2 col + half: the order inside a step
-    std::vector<std::vector<E>> per_group(ngroups);
-    for (int s = 0; s < segments; ++s) {
-        const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
-        if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
-        for (int e = 0; e < cnt; ++e) {
-            const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
-            if (w < 0 || w >= blocks || c < 0) return -1;
-            if (c >= (1 << 24)) return 0;
-            per_group[ob / G].push_back({c >> 1, 2 * (ob % G) + (c & 1), w});
-        }
-    }
-    std::vector<int32_t> groups, recs;
-    int max_s = 0;
-    for (int g = 0; g < ngroups; ++g) {
-        auto& v = per_group[g];
-        std::sort(v.begin(), v.end(), [](const E& a, const E& b) { return a.p != b.p ? a.p < b.p : a.pos < b.pos; });
-        for (size_t i = 1; i < v.size(); ++i) if (v[i].p == v[i - 1].p && v[i].pos == v[i - 1].pos) return 0;   // (a block listed twice: not ours)
-        // ---- steps ----
-        struct Step { int pair, slab; uint32_t mask; int wstart; std::vector<int> fifo; };   // fifo: indices into `fb`
-        struct FB { int w, step, slot; };
-        std::vector<Step> steps;
-        std::vector<FB> fb;
-        std::vector<int> slab_last;                                  // last step of each slab
-        for (size_t i = 0; i < v.size();) {
-            size_t j = i;
-            while (j < v.size() && v[j].p == v[i].p) ++j;
-            const int n = (int)(j - i), nc = (n + X5_CAP - 1) / X5_CAP, per = (n + nc - 1) / nc;
-            const int slab = (int)slab_last.size();
-            slab_last.push_back(0);
-            for (int c = 0; c < nc; ++c) {
-                Step st; st.pair = v[i].p; st.slab = slab; st.mask = 0; st.wstart = 0;
-                for (int k = c * per; k < std::min(n, (c + 1) * per); ++k) {
-                    st.mask |= 1u << v[i + k].pos;
-                    st.fifo.push_back((int)fb.size());
-                    fb.push_back({v[i + k].w, (int)steps.size(), 0});
-                }
-                if (st.fifo.empty()) continue;
-                slab_last[slab] = (int)steps.size();
-                steps.push_back(st);
-            }
-            i = j;
-        }
-        const int nsteps = (int)steps.size(), nslabs = (int)slab_last.size();
-        // ---- weight slots: FIFO positions, a step's run never wraps ----
-        {
-            int pos = 0;
-            for (auto& st : steps) {
-                const int n = (int)st.fifo.size();
-                if (pos % X5_NW + n > X5_NW) pos += X5_NW - pos % X5_NW;
-                st.wstart = pos % X5_NW;
-                for (int k = 0; k < n; ++k) fb[st.fifo[k]].slot = (pos + k) % X5_NW;
-                pos += n;
-            }
-        }
-        // ---- duties, record by record (time t = record - X5_P: the step whose barrier the record follows) ----
-        const int nrec = X5_P + nsteps;
-        std::vector<int> xduty(nrec, -1);                            // slab requested in the record
-        std::vector<std::vector<int>> wduty(nrec);                   // fifo blocks fetched in the record
-        std::vector<int> slab_rec(nslabs, -1), fb_rec(fb.size(), -1);
-        {
-            int next_slab = 0; size_t next_fb = 0;
-            std::vector<int> slot_last(X5_NW, -1000000);             // step that last reads the slot's current occupant
-            for (int rr = 0; rr < nrec; ++rr) {
-                const int t = rr - X5_P;
-                if (next_slab < nslabs && (next_slab < X5_D ? (next_slab < X5_P || t >= 0) : slab_last[next_slab - X5_D] <= t - 1)) {
-                    xduty[rr] = next_slab; slab_rec[next_slab] = rr; ++next_slab;
-                }
-                while (next_fb < fb.size() && (int)wduty[rr].size() < X5_FMAX && slot_last[fb[next_fb].slot] <= t - 1) {
-                    slot_last[fb[next_fb].slot] = fb[next_fb].step;
-                    wduty[rr].push_back((int)next_fb); fb_rec[next_fb] = rr; ++next_fb;
-                }
-            }
-            for (int sl = 0; sl < nslabs; ++sl) {
-                int first = 0; while (steps[first].slab != sl) ++first;
-                if (slab_rec[sl] < 0 || slab_rec[sl] - X5_P >= std::max(first - 1, 0)) return 0;      // requested before the barrier it must have landed at
-            }
-            for (size_t f = 0; f < fb.size(); ++f) if (fb_rec[f] < 0 || fb_rec[f] - X5_P >= std::max(fb[f].step - 1, 0)) return 0;
-        }
-        // ---- per wave: issue order -> the vmcnt of every step ----
-        // a wave issues, per record: its 4 instructions of the slab (if any), then 2 per entry of its own, in order
-        std::vector<std::array<int, 4>> waitn(nsteps);
-        for (int q = 0; q < 4; ++q) {
-            std::vector<int> before(nrec + 1, 0);                    // instructions issued in records < rr
-            std::vector<int> slab_idx(nslabs, -1), fb_idx(fb.size(), -1);   // index of the LAST instruction of that request in the wave's order
-            int ops = 0;
-            for (int rr = 0; rr < nrec; ++rr) {
-                before[rr] = ops;
-                if (xduty[rr] >= 0) { ops += 4; slab_idx[xduty[rr]] = ops - 1; }
-                for (size_t e = 0; e < wduty[rr].size(); ++e)
-                    if ((int)(e & 3) == q) { ops += 2; fb_idx[wduty[rr][e]] = ops - 1; }
-            }
-            before[nrec] = ops;
-            auto last_of = [&](int s) {                              // the wave's last instruction among the requests step s reads (-1: none)
-                int last = slab_idx[steps[s].slab];
-                for (int f : steps[s].fifo) last = std::max(last, fb_idx[f]);
-                return last;
-            };
-            for (int s = 0; s < nsteps; ++s) {                       // in front of barrier s: what step s + 1 reads (step 0: and step 0) has landed
-                int last = s + 1 < nsteps ? last_of(s + 1) : -1;
-                if (s == 0) last = std::max(last, last_of(0));
-                const int issued = before[X5_P + s];
-                if (last >= issued) return 0;                        // (requested in this very record or later: the builder's placement rules exclude it)
-                waitn[s][q] = last < 0 ? 63 : std::min(63, std::max(0, issued - (last + 1)));
-            }
-        }
-        // ---- records ----
-        const int rec_off = (int)(recs.size() / X5_REC);
-        for (int rr = 0; rr < nrec; ++rr) {
-            int32_t rc[X5_REC];
-            std::fill(rc, rc + X5_REC, 0);
-            for (int k = 16; k < 48; k += 2) rc[k] = -1;
-            rc[5] = -1;
-            if (rr >= X5_P) {
-                const Step& st = steps[rr - X5_P];
-                rc[0] = st.pair; rc[1] = (st.slab % X5_D) * 16384;
-                rc[2] = (int32_t)st.mask;
-                rc[3] = st.wstart;
-                rc[4] = waitn[rr - X5_P][0] | (waitn[rr - X5_P][1] << 8) | (waitn[rr - X5_P][2] << 16) | (waitn[rr - X5_P][3] << 24);
-                if (rr + 1 < nrec) {
-                    const Step& nx = steps[rr + 1 - X5_P];
-                    rc[8] = (nx.slab % X5_D) * 16384;
-                    rc[9] = (int32_t)nx.mask;
-                    rc[10] = nx.wstart;
-                }
-            }
-            if (xduty[rr] >= 0) {
-                int first = 0; while (steps[first].slab != xduty[rr]) ++first;
-                rc[5] = steps[first].pair; rc[6] = (xduty[rr] % X5_D) * 16384;
-            }
-            for (size_t e = 0; e < wduty[rr].size(); ++e) {
-                const FB& b = fb[wduty[rr][e]];
-                rc[16 + 8 * (e & 3) + 2 * (e >> 2)] = X5_D * 16384 + b.slot * 2048;
-                rc[17 + 8 * (e & 3) + 2 * (e >> 2)] = (int32_t)((uint32_t)b.w << 11);
-            }
-            recs.insert(recs.end(), rc, rc + X5_REC);
-        }
-        max_s = std::max(max_s, nsteps);
-        groups.insert(groups.end(), {rec_off, nsteps, g * G, std::min(G, n_out_blocks - g * G), (int32_t)v.size(), 0, 0, 0});
-    }
-    {
-        std::vector<int> order(ngroups);
-        for (int g = 0; g < ngroups; ++g) order[g] = g;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[X5_GROUP * a + 4] > groups[X5_GROUP * b + 4]; });
-        std::vector<int32_t> sorted;
-        for (int g : order) sorted.insert(sorted.end(), groups.begin() + X5_GROUP * g, groups.begin() + X5_GROUP * (g + 1));
-        groups.swap(sorted);
-    }
-    recs.insert(recs.end(), (size_t)X5_REC, 0);                     // padding record: the kernel loads the record BEHIND a unit's last step (unused)
-    const int off_groups = X5_HDR, off_recs = (off_groups + (int)groups.size() + 3) & ~3;
-    const long total = off_recs + (long)recs.size();
-    if (out) {
-        const int32_t hdr[X5_HDR] = {X5PLAN_MAGIC, X5PLAN_VERSION, G, ngroups, (int32_t)(recs.size() / X5_REC - 1), off_groups, off_recs,
-                                     X5_D | (X5_NW << 8) | (X5_CAP << 16) | (X5_P << 24), n_out_blocks, max_s, blocks, 0};
-        std::fill(out, out + off_recs, 0);
-        std::copy(hdr, hdr + X5_HDR, out);
-        std::copy(groups.begin(), groups.end(), out + off_groups);
-        std::copy(recs.begin(), recs.end(), out + off_recs);
-    }
-    return total;
-}
-
-}  // namespace bsmm
-
-// =================================================================================================
 // staged xcol16 plan ('BSX7', bsize 16): the staged scheme of the 'BSX2' plan for 16x16 blocks (bsmm_xcol16_v2.h).  Groups of
 // X7_G = 32 consecutive output blocks, wave v of 16 owns blocks 2v and 2v+1; a step is a QUAD of input blocks (64 features);
 // a phase = up to two steps and up to X7_WCAP weight blocks = one half of the LDS ring (2 activation slabs of 16 KiB + X7_WCAP

@@ -22,17 +22,18 @@
 
 namespace bsmm {
 
-// The first piece never exceeds the input: the value is clamped to the largest finite bf16 BEFORE the first rounding, so a
-// finite x beyond the bf16 range (3.39e38 < |x| <= FLT_MAX, which would round to Inf and leave Inf - Inf = NaN behind) keeps 0x7f7f as its
-// first piece and stays exact (x - 0x7f7f0000 has at most 16 significant bits).  ONE v_med3_f32, no branch: round 5's two-level `if` in here
-// was inlined into the LDS -> LDS conversion loop of xcol32sf_kernel and pushed it from 127 registers to 128 + 8 spilled -- BASELINE
-// configs[1] lost a fifth of its throughput; tests/test_codeobj.py now fails the build on any spill of a hot kernel.
+// The first piece never exceeds the input: a first piece that ROUNDED UP to Inf (finite 3.39e38 < |x| <= FLT_MAX; it would leave
+// Inf - Inf = NaN behind) is stepped back to the largest finite bf16, 0x7f7f, and the split stays exact (x - 0x7f7f0000 has at most 16
+// significant bits).  Branch-free on the 16-bit piece (and / compare / subtract-with-carry, no constant in a vector register): round 5's
+// two-level `if` in here was inlined into the LDS -> LDS conversion loop of xcol32sf_kernel and pushed it from 127 registers to 128 + 8
+// spilled -- BASELINE configs[1] lost a fifth of its throughput; a v_med3_f32 clamp of x still spilled 4 (its two
+// constants live in vector registers across the loop).  tests/test_codeobj.py now fails on any spill of a hot kernel.
 // A non-finite x leaves NaN pieces (Inf: 0x7f7f, Inf, NaN; NaN: NaN all the way), so every output that x enters is NaN -- non-finite
 // exactly where the unsplit IEEE product is non-finite (Inf or NaN there).  The weight-gradient paths do better: split3_x_kernel raises a
 // flag for such inputs and the call is re-run on the fp32 kernels (bsmm_api.hip::f32_split_repair), which reproduces IEEE's Inf / NaN sets.
 __device__ __forceinline__ void split3(float x, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
-    const float big = __builtin_bit_cast(float, 0x7f7f0000u);
-    const uint16_t p1 = DTbf16::from_f32(__builtin_amdgcn_fmed3f(x, -big, big));
+    uint16_t p1 = DTbf16::from_f32(x);
+    p1 -= (uint16_t)((p1 & 0x7fffu) == 0x7f80u);      // rounded up to Inf (or was Inf): the largest finite bf16 instead
     const float r1 = x - DTbf16::to_f32(p1);
     const uint16_t p2 = DTbf16::from_f32(r1);
     const float r2 = r1 - DTbf16::to_f32(p2);
@@ -358,17 +359,25 @@ xcol32sf_kernel(const float* __restrict__ Xf, const uint16_t* __restrict__ Wp, f
     const int cR = 8 * wave + (lane >> 3), cj = lane & 7;
     const int c_rd = cR * 256 + cj * 32, c_wr = cR * 128 + ((cj ^ ((cR >> 1) & 7)) << 4);
     auto convert = [&](int pos) {
+        // two values at a time, packed as they are made: the live set is 2 floats + 3 packed words per pair, not 8 + 24
         const unsigned char* src = stage + pos * XSF_STAGE + c_rd;
-        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 16);
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        uint32_t pc[3][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) split3(v[j], pc[0][j], pc[1][j], pc[2][j]);
         unsigned char* dst = smem + pos * XS_SLOT + c_wr;
+        uint32_t pk[3][4];
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-            *reinterpret_cast<uint4*>(dst + q * XC_SLAB) = make_uint4(pc[q][0] | (pc[q][1] << 16), pc[q][2] | (pc[q][3] << 16),
-                                                                      pc[q][4] | (pc[q][5] << 16), pc[q][6] | (pc[q][7] << 16));
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const float4 a = *reinterpret_cast<const float4*>(src + 16 * hlf);
+            const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t lo[3], hi[3];
+                split3(v[2 * j], lo[0], lo[1], lo[2]);
+                split3(v[2 * j + 1], hi[0], hi[1], hi[2]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pk[q][2 * hlf + j] = lo[q] | (hi[q] << 16);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(dst + q * XC_SLAB) = make_uint4(pk[q][0], pk[q][1], pk[q][2], pk[q][3]);
     };
     const int xsw = (r >> 1) & 7;
     int xrd[2][2];

@@ -48,17 +48,6 @@ def _dtype_code(dt):
     raise TypeError("blocksparse_amd: unsupported dtype %s (float32, float16, bfloat16)" % dt)
 
 
-_CUS = {}
-
-
-def _device_cus(device):
-    """compute units of a device (cached)"""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _CUS:
-        _CUS[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
-    return _CUS[idx]
-
-
 def _host_plan(lut, segments, blocks, n_out_blocks, bsize, dtype_code, axis, options=0):
     """Grouped-kernel schedule for one xprop lut (host call into the library: bsmm_xprop_plan_build)."""
     lib = _lib.load()
@@ -131,15 +120,6 @@ class _DeviceTables(object):
         if bsize in (32, 64) and axis == 1 and not (plan_options & (_lib.PLAN_XCOL_UNSTAGED | _lib.PLAN_XCOL_NARROW | _lib.PLAN_XCOL_FLOW | (7 << _lib.PLAN_XPROP_PH_SHIFT))):
             self.fprop_flow = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_XCOL_FLOW))
             self.bprop_flow = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_XCOL_FLOW))
-        # round 5: the row-split persistent kernel ('BSX5' plans, csrc/bsmm_xrows.h) for ungated calls whose minibatch fills the chip with
-        # units of 128 rows (BlocksparseMatMul._xprop_plan picks per call; BlocksparseMatMul.rows = False keeps the flow kernel)
-        self.fprop_rows = self.bprop_rows = None
-        if bsize == 32 and axis == 1 and not (plan_options & (_lib.PLAN_XCOL_UNSTAGED | _lib.PLAN_XCOL_NARROW | _lib.PLAN_XCOL_FLOW | (7 << _lib.PLAN_XPROP_PH_SHIFT))):
-            def rows_plan(lut, segments, n_out):
-                w = _host_plan(lut, segments, B, n_out, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_XCOL_ROWS)
-                return plan(w) if (w is not None and int(w[0]) == 0x42535835) else None     # (0 words / another format: no 'BSX5' plan for this layout)
-            self.fprop_rows = rows_plan(f["lut"], f["segments"], KB)
-            self.bprop_rows = rows_plan(b["lut"], b["segments"], CB)
         # ... and fp32 has its own (xprop-only) plan kernels for bsize 32; the schedule format is the library's business
         self.fprop_plan_f32 = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.F32, axis, plan_options))
         self.bprop_plan_f32 = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.F32, axis, plan_options))
@@ -204,8 +184,6 @@ class BlocksparseMatMul(object):
         self._inner = None
         self._split64_hit = None
         self.native64 = True          # bsize 64: call the library with bsize = 64 (False: always the host-side quadrant view)
-        self.rows = False             # True: ... and the minibatch fills the chip with 128-row units -> the row-split kernel (round 5 experiment: bit-identical, but
-                                      # 105-125 us against the flow kernel's 77-90 at the bench shape -- profiles/r05_xrows_*; opt-in)
         self.flow = True              # bsize 32, feature axis 1, 16-bit, no gate: the barrier-free xprop kernel (False: the staged one)
         if block_size == 64:
             # same weights, cut into 32x32 blocks: inner block n is quadrant (i, j) of outer block b
@@ -405,17 +383,12 @@ class BlocksparseMatMul(object):
 
     # ---- the three passes ------------------------------------------------------------------------
     def _xprop_plan(self, tabs, which, N, n_out_features, dtype, gate):
-        """The schedule an fprop / bprop call runs with: fp32 -> its own plans; 16-bit, ungated, feature axis 1, bsize 32 -> the row-split
-        kernel when units of 128 rows x 16 output blocks fill the chip, else the flow kernel (which switches to 64-row units itself);
+        """The schedule an fprop / bprop call runs with: fp32 -> its own plans; 16-bit, ungated, feature axis 1, bsize 32 -> the flow
+        kernel (which switches to 64-row units itself when 128-row units do not fill the chip);
         gated calls and everything else -> the staged / per-bsize plans."""
         if dtype == torch.float32:
             return getattr(tabs, which + "_plan_f32")
         if gate is None:
-            rows = getattr(tabs, which + "_rows")
-            if self.rows and rows is not None:
-                units = ((N + 127) // 128) * ((n_out_features // 32 + 15) // 16)
-                if units >= _device_cus(tabs.fprop.device):
-                    return rows
             flow = getattr(tabs, which + "_flow")
             if self.flow and flow is not None:
                 return flow

@@ -49,8 +49,10 @@ extern "C" {
  *   'BSS8' / 'BS64' descriptors);  120 round 4 (see DESIGN.md "Round 4");  121 round 4: kernels retired -- 'BSX6' (bsize 16, round 1), 'BSXF' (fp32
  *   matrix-core instruction) and bsize-32 'BSUP' plans are no longer built or accepted, the options that named them are aliases;
  *   122 round 5: 'BSX5' plans (BSMM_PLAN_XCOL_ROWS), BSMM_K_XCOL32_ROWS;  123 round 5: 'BSUP' plans v6 (12 header words; bsize 16 on feature
- *   axis 0 carries a 'BSU6' section for the row-owner weight-gradient kernel), BSMM_K_UPDAT16_ROWS, BSMM_PLAN_UPDAT16_WINDOWED */
-#define BSMM_VERSION 123
+ *   axis 0 carries a 'BSU6' section for the row-owner weight-gradient kernel), BSMM_K_UPDAT16_ROWS, BSMM_PLAN_UPDAT16_WINDOWED;
+ *   124 round 6: the row-split xprop kernel of round 5 retired ('BSX5' plans are no longer built or accepted, BSMM_PLAN_XCOL_ROWS is ignored,
+ *   trace code 13 is not emitted; source and measurements: profiles/r05_xrows.patch) */
+#define BSMM_VERSION 124
 
 enum { BSMM_F32 = 0, BSMM_F16 = 1, BSMM_BF16 = 2 };
 enum {
@@ -74,7 +76,7 @@ enum {
     BSMM_K_NONE = 0,
     /* (4 BSMM_K_XCOL16, 6 BSMM_K_XCOL32_F32MFMA and 19 BSMM_K_UPDAT_WIN belonged to kernels retired in round 4: never reported any more) */
     BSMM_K_XPROP_VALU = 1, BSMM_K_XPROP_SEGMENT = 2, BSMM_K_XCOL32 = 3, BSMM_K_XCOL16 = 4, BSMM_K_XCOL32_F32SPLIT = 5,
-    BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7, BSMM_K_XCOL32_STAGED = 8, BSMM_K_XCOL16_STAGED = 9, BSMM_K_XCOL32_FLOW = 10, BSMM_K_XPROP_SMALL = 11, BSMM_K_XPROP_MID = 12, BSMM_K_XCOL32_ROWS = 13,
+    BSMM_K_XCOL32_F32MFMA = 6, BSMM_K_XPROP_SUPER8 = 7, BSMM_K_XCOL32_STAGED = 8, BSMM_K_XCOL16_STAGED = 9, BSMM_K_XCOL32_FLOW = 10, BSMM_K_XPROP_SMALL = 11, BSMM_K_XPROP_MID = 12, BSMM_K_XCOL32_ROWS = 13 /* retired, never emitted */,
     BSMM_K_UPDAT_VALU = 16, BSMM_K_UPDAT_BLOCK = 17, BSMM_K_UPDAT_BLOCK_TR = 18, BSMM_K_UPDAT_WIN = 19, BSMM_K_UPDAT16_WIN = 20,
     BSMM_K_UPDAT_SUPER8 = 21, BSMM_K_UPDAT_STREAM = 22, BSMM_K_UPDAT16_ROWS = 23
 };
@@ -98,9 +100,7 @@ enum {
     /* experiment knobs of the builders (0 = the builder's own choice); disjoint bit ranges, one meaning each: */
     BSMM_PLAN_XPROP_PH_SHIFT = 8,   /* bits  8..10  xprop staged plans ('BSX2'): steps per phase (2, 3, 4)                      */
     BSMM_PLAN_UPDAT_SETS_SHIFT = 12,/* bits 12..15  updat streaming plan ('BSU2'): item sets (1, 2, 4, 8)                       */
-    BSMM_PLAN_XCOL_ROWS = 0x20000,  /* xprop bsize 32, 16-bit, feature axis 1: the row-split persistent kernel (bsmm_xrows.h, 'BSX5' plans, round 5):
-                                       a SIMD owns a row quarter of the 128-row tile and multiplies every block of the group -- the matrix pipes are
-                                       balanced by construction.  Units of 128 rows: meant for minibatches that fill the chip with them               */
+    BSMM_PLAN_XCOL_ROWS = 0x20000,  /* retired in round 6 (named the row-split xprop kernel of round 5, slower than the flow kernel): ignored       */
     BSMM_PLAN_UPDAT16_WINDOWED = 0x40000, /* updat bsize 16, feature axis 0: do NOT append the 'BSU6' section (row-owner kernel, bsmm_updat16_rows.h,
                                        round 5: 512 x 512-feature windows, X rows straight into registers) -- the call then always runs the
                                        windowed kernel (256 x 256-feature windows through LDS); comparison / tests                        */

@@ -252,32 +252,6 @@ def test_timed_kernel_variants_full_output_at_n8192(env, density):
         assert l2 <= bar, (name, l2)
 
 
-def test_row_split_kernel_is_bit_identical_to_the_flow_kernel(env):
-    """The row-split kernel of round 5 ('BSX5' plans, csrc/bsmm_xrows.h; opt-in: BlocksparseMatMul.rows = True) sums a column's blocks in
-    the flow kernel's order with the same instructions: equal bits, on ragged tiles, partial groups, split steps and groups without blocks."""
-    torch, BSMM, lib = env
-    cases = [(P.random_layout(40, 24, 0.3, seed=2), 1000, "bf16"), (P.random_layout(33, 35, 0.25, seed=3), 520, "f16"),
-             (np.ones((64, 33), dtype=np.int32), 384, "bf16"), (np.eye(15, 33, dtype=np.int32), 520, "f16"),
-             (P.random_layout(128, 128, 0.2, seed=1234), 8192, "bf16")]
-    lib.set_kernel_variant(3)
-    try:
-        for layout, N, dt in cases:
-            b4 = BSMM(layout, block_size=32, feature_axis=1)
-            b5 = BSMM(layout, block_size=32, feature_axis=1)
-            tabs = b5._tables_on(torch.device("cuda", torch.cuda.current_device()))
-            assert tabs.fprop_rows is not None and tabs.bprop_rows is not None
-            b5._xprop_plan = lambda tabs_, which, N_, nf, dtype, gate: getattr(tabs_, which + "_rows")     # (whatever the minibatch)
-            w, x, e = _inputs(torch, b4, N, dt, seed=5)
-            y4, d4 = b4.fprop(x, w), b4.bprop(e, w)
-            assert lib.last_kernel() == lib.K_XCOL32_FLOW
-            y5 = b5.fprop(x, w); k5 = lib.last_kernel()
-            d5 = b5.bprop(e, w)
-            assert k5 == lib.K_XCOL32_ROWS
-            assert torch.equal(y4, y5) and torch.equal(d4, d5), (layout.shape, N, dt)
-    finally:
-        lib.set_kernel_variant(0)
-
-
 # ---- (b) BASELINE configs[3] -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("axis,N,force", [(1, 512, False), (1, 512, True), (1, 4096, False), (0, 512, True), (0, 4096, False)])
 def test_cfg3_8192_5pct(env, axis, N, force):
