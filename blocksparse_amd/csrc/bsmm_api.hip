@@ -778,25 +778,27 @@ inline int updat_split(const bsmm_args* a, int nitems, int nchunks) {
 // for `split` workgroups per item instead (1: one per item, direct).
 // partial-sum path of the streaming kernel: the workspace holds the fp32 sums [blocks][1024] (only written for
 // BSMM_FLAG_DW_SUMS) and behind them one region of 64 accumulator slots x 4 KiB per (round, workgroup)
-struct U2Launch { int grid; bool scratch; int flat; int rounds; };
+struct U2Launch { int grid; bool scratch; int flat; int rounds; int direct; };      // grid: the schedule's workgroups; direct: workgroups of the direct blocks behind them
+inline int u2_direct_blocks(const bsmm_args* a) { return (a->plan_inner >> 24) & 0x7f; }     // (descriptor of a 'BSU2' plan: describe_flat)
 // (+ 2 KiB: the fused data-parallel reduction reads / writes the sums in `world` 32-byte aligned shards, include/bsmm_dist.h)
 inline size_t u2_sums_bytes(const bsmm_args* a) { return round16((size_t)a->blocks * 1024 * sizeof(float)) + 2048; }
 inline size_t u2_region_bytes() { return (size_t)U2_WAVES * U2_SLOTS * 4096; }
 inline int u2_chunk(const bsmm_args* a) { return a->axis == 1 ? U2_CH : U2_CH0; }   // minibatch entries per chunk of the streaming kernel
 inline U2Launch updat2_shape(const bsmm_args* a, bool gated) {
     const int cus = device_cus();
-    const int nsets = a->plan_inner & 15, longest = a->plan_inner >> 8, common = (a->plan_inner & 16) ? longest : 0;
+    const int nsets = a->plan_inner & 15, longest = (a->plan_inner >> 8) & 0xffff, common = (a->plan_inner & 16) ? longest : 0;
     U2Launch L;
+    L.direct = u2_direct_blocks(a) * U2_DIRECT_PARTS;           // (their partial sums meet in the summing pass: such a plan always takes the scratch path)
     if (a->split >= 1) {
         const long nchunks = (long)a->pcount * ((a->N + u2_chunk(a) - 1) / u2_chunk(a));
         const long sp = std::max<long>(1, std::min<long>(a->split, nchunks));
-        L.grid = (int)(a->plan_items * sp); L.scratch = sp > 1 || gated; L.flat = 1;
+        L.grid = (int)(a->plan_items * sp); L.scratch = sp > 1 || gated || L.direct > 0; L.flat = 1;
         L.rounds = (a->plan_items + L.grid - 1) / L.grid;
         return L;
     }
     const int U = std::max(1, cus / 8);
     L.grid = 8 * U; L.flat = 0;
-    L.scratch = gated || !(nsets == 8 && common > 0 && common % U == 0);
+    L.scratch = gated || L.direct > 0 || !(nsets == 8 && common > 0 && common % U == 0);
     L.rounds = (longest + U - 1) / U;
     return L;
 }
@@ -807,13 +809,14 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     if (a->plan_magic != U2PLAN_MAGIC || a->plan_waves != U2_WAVES || a->plan_items <= 0 || (a->plan_width != 16 && a->plan_width != 8 && !(a->plan_width == 32 && AXIS == 1))) return BSMM_ERR_ARG;
     U2Launch L = updat2_shape(a, gate != nullptr);
+    if (L.direct > 0 && AXIS != 1) return BSMM_ERR_ARG;         // (the builder makes direct blocks for feature axis 1 only)
     const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;
     const bool q64 = (a->flags & FLAG_INTERNAL_Q64) != 0;       // (updat64: the summing pass writes the quadrants into their 64 x 64 blocks)
     if (sums_only || q64) L.scratch = true;
     float* scratch = nullptr;      // the partial-sum regions
     float* sums = nullptr;
     if (L.scratch) {
-        const size_t need = u2_sums_bytes(a) + (size_t)L.rounds * L.grid * u2_region_bytes();
+        const size_t need = u2_sums_bytes(a) + (size_t)L.rounds * (L.grid + L.direct) * u2_region_bytes();
         if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
         sums = static_cast<float*>(a->workspace);
         scratch = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + u2_sums_bytes(a));
@@ -823,25 +826,25 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     if (a->plan_width == 32) {
         if constexpr (AXIS == 1) {
             if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 32, 1>>(u2_lds_bytes(32))) return rc;
-            updat32_a1_v2_kernel<DT, 32, 1><<<L.grid, 64 * U2_WAVES, u2_lds_bytes(32), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                                            a->pcount, a->alpha, a->beta, L.flat);
+            updat32_a1_v2_kernel<DT, 32, 1><<<L.grid + L.direct, 64 * U2_WAVES, u2_lds_bytes(32), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
+                                                                                            a->pcount, a->alpha, a->beta, L.flat, L.grid);
         } else {
             return BSMM_ERR_ARG;
         }
     } else if (a->plan_width == 16) {
         if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 16, AXIS>>(LDS16)) return rc;
-        updat32_a1_v2_kernel<DT, 16, AXIS><<<L.grid, 64 * U2_WAVES, LDS16, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                                a->pcount, a->alpha, a->beta, L.flat);
+        updat32_a1_v2_kernel<DT, 16, AXIS><<<L.grid + L.direct, 64 * U2_WAVES, LDS16, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
+                                                                                a->pcount, a->alpha, a->beta, L.flat, L.grid);
     } else {
         if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 8, AXIS>>(LDS8)) return rc;
-        updat32_a1_v2_kernel<DT, 8, AXIS><<<L.grid, 64 * U2_WAVES, LDS8, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                              a->pcount, a->alpha, a->beta, L.flat);
+        updat32_a1_v2_kernel<DT, 8, AXIS><<<L.grid + L.direct, 64 * U2_WAVES, LDS8, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
+                                                                              a->pcount, a->alpha, a->beta, L.flat, L.grid);
     }
     if (scratch) {
         const int CPI = a->pcount * ((a->N + u2_chunk(a) - 1) / u2_chunk(a));
         const int32_t* bmap = a->plan + U2_HDR + (size_t)a->plan_items * U2_ITEM;     // behind the items (bsmm_plan.h)
-        if (sums_only) updat2_reduce_kernel<DT, true><<<a->blocks, 128, 0, st>>>(scratch, nullptr, sums, a->plan, bmap, nullptr, L.grid, L.flat, CPI, 1.f, 0.f);
-        else           updat2_reduce_kernel<DT, false><<<a->blocks, 128, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, bmap, gate, L.grid, L.flat, CPI, a->alpha, a->beta, q64 ? 1 : 0);
+        if (sums_only) updat2_reduce_kernel<DT, true><<<a->blocks, 128, 0, st>>>(scratch, nullptr, sums, a->plan, bmap, nullptr, L.grid + L.direct, L.grid, L.flat, CPI, 1.f, 0.f);
+        else           updat2_reduce_kernel<DT, false><<<a->blocks, 128, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, bmap, gate, L.grid + L.direct, L.grid, L.flat, CPI, a->alpha, a->beta, q64 ? 1 : 0);
     }
     return (int)hipGetLastError();
 }
@@ -959,7 +962,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                     const double chunks = (double)a->plan_items * a->pcount * ((N + 15) / 16);      // (the fit is per 16 minibatch entries)
                     double t_stream = 6.0 + chunks / L.grid * 0.40;
                     if (L.scratch && !L.flat) {
-                        const int nsets = a->plan_inner & 15, longest = a->plan_inner >> 8, U = std::max(1, L.grid / 8);
+                        const int nsets = a->plan_inner & 15, longest = (a->plan_inner >> 8) & 0xffff, U = std::max(1, L.grid / 8);
                         const int m_last = longest % U;
                         const double sliced = longest > 0 ? (double)m_last / longest : 0.0;
                         const double mult = (8.0 / std::max(1, nsets)) * ((1.0 - sliced) + sliced * (m_last > 0 ? std::min(U / m_last, U2_MAX_SLICES) : 1));
@@ -1506,6 +1509,9 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
 #ifdef X4_TIMELINE
 extern "C" int bsmm_debug_x4_timeline_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_tl), sizeof(bsmm::g_x4_tl)); }
 #endif
+#ifdef U2_STAMPS
+extern "C" int bsmm_debug_u2_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_u2_trace), sizeof(bsmm::g_u2_trace)); }
+#endif
 #ifdef U6_STAMPS
 extern "C" int bsmm_debug_u6_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_u6_trace), sizeof(bsmm::g_u6_trace)); }
 #endif
@@ -1598,10 +1604,11 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
                 lut32[(size_t)2 * (4 * w + q)] = 2 * lut[2 * w] + (q >> 1);
                 lut32[(size_t)2 * (4 * w + q) + 1] = 2 * lut[2 * w + 1] + (q & 1);
             }
-        const long nw = updat_plan(lut32.data(), 4 * blocks, 2 * CB, 2 * KB, 32, dtype, axis, options, nullptr);
+        const int32_t nopt = options | BSMM_PLAN_UPDAT_NO_DIRECT;      // (the composite call derives the nested plan's descriptor itself: no direct blocks there)
+        const long nw = updat_plan(lut32.data(), 4 * blocks, 2 * CB, 2 * KB, 32, dtype, axis, nopt, nullptr);
         if (nw < 0) return -1;
         nested.resize((size_t)nw);
-        if (nw > 0 && out) updat_plan(lut32.data(), 4 * blocks, 2 * CB, 2 * KB, 32, dtype, axis, options, nested.data());
+        if (nw > 0 && out) updat_plan(lut32.data(), 4 * blocks, 2 * CB, 2 * KB, 32, dtype, axis, nopt, nested.data());
         return b64_emit(1, blocks, 0, lut32, nested, out);
     }
     if (bsize == 8) return build_super8_updat_plan(lut, blocks, CB, KB, out);   // 'BSS8'
@@ -1630,7 +1637,9 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
         // 8192^2, N = 4096 (profiles/r03_updat_ws32.txt): 3 % 71 against 95 us; 5 % (BASELINE configs[3]) 102 against 96 -- so only below ~3.7 %
         const double windows32 = (double)((CB + 31) / 32) * ((KB + 31) / 32);
         if (force == BSMM_PLAN_STREAM_32 || (force == 0 && axis == 1 && windows32 >= 16 && blocks <= 38.0 * windows32)) ws = 32;
-        return build_updat2_plan(lut, blocks, CB, KB, ws, out, (options >> BSMM_PLAN_UPDAT_SETS_SHIFT) & 15);
+        // direct blocks (round 6): what a window's 16 waves cannot hold gets its own workgroups instead of a sliced last round (feature axis 1)
+        const int direct_max = (axis == 1 && !(options & BSMM_PLAN_UPDAT_NO_DIRECT)) ? U2_DIRECT_MAX : 0;
+        return build_updat2_plan(lut, blocks, CB, KB, ws, out, (options >> BSMM_PLAN_UPDAT_SETS_SHIFT) & 15, direct_max);
     }
 }
 
@@ -1664,7 +1673,9 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
                              }
                              break;
         case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR || p[26] != U2_HDR + p[4] * U2_ITEM || words < (long)p[26] + p[5]) return false;   // (the launcher addresses the block map behind the items)
-                               d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8] | (p[25] > 0 ? 16 : 0) | (p[27] << 8); break;   // item sets | all equally long | longest set
+                               if (p[27] < 0 || p[27] > 0xffff || p[28] < 0 || p[28] > U2_DIRECT_MAX) return false;
+                               if (p[28] > 0 && (p[30] != U2_DIRECT_PARTS || p[29] < p[26] + p[5] || words < (long)p[29] + 4L * p[28])) return false;      // direct blocks
+                               d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8] | (p[25] > 0 ? 16 : 0) | (p[27] << 8) | (p[28] << 24); break;   // item sets | all equally long | longest set | direct blocks
         default: return false;
     }
     d[0] = p[0];
@@ -1741,7 +1752,7 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32) {
         if (a->plan_magic == U2PLAN_MAGIC) {   // streaming kernel: the fp32 sums + one region of partial sums per (round, workgroup)
             const U2Launch L = updat2_shape(a, true);
-            return u2_sums_bytes(a) + (size_t)L.rounds * L.grid * u2_region_bytes();
+            return u2_sums_bytes(a) + (size_t)L.rounds * (L.grid + L.direct) * u2_region_bytes();
         }
         if (a->plan_magic != UPLAN_MAGIC || a->bsize != 16) return 0;     // (a plan check_plan refuses: nothing to size)
         // bsize 16 windowed kernel: one fp32 image of the sums (split-minibatch path); with the 'BSU6' section (feature axis 0) one image per part

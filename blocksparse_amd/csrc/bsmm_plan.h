@@ -939,7 +939,7 @@ inline long build_super8_xprop_plan(const int32_t* lut, int segments, int blocks
     return s8_emit(supers, nested, 0, out);
 }
 
-inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets);   // ('BSU2', below)
+inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets, int direct_max = 0);   // ('BSU2', below)
 
 // stream: nest the streaming kernel's 'BSU2' plan (round 3; the super layout of a 10 % bsize-8 layout is ~80 % dense: 8x8 windows) instead of the
 // round-1 windowed 'BSUP' plan; feature axis 1 and 0 alike (the streaming kernel serves both since round 3)
@@ -1050,7 +1050,15 @@ inline long b64_emit(int kind, int blocks64, int segments64, const std::vector<i
 // Layout (int32): [0] magic 'BSU2' [1] version [2] WS [3] U2_SLOTS [4] nitems [5] nblocks [6] off_items [7] U2_WAVES
 //                 [8] NSETS (1, 2, 4 or 8) [9 + 2 s], [10 + 2 s] first item / item count of set s
 //                 [25] the item count of every set if they are all equal, else 0  [26] off_bmap  [27] longest set
-//   bmap[nblocks] (behind the items): item << 8 | wave * U2_SLOTS + slot  of every block
+//                 [28] n_direct  [29] off_direct  [30] U2_DIRECT_PARTS  [31] 0
+//   bmap[nblocks] (behind the items): item << 8 | wave * U2_SLOTS + slot  of every block; -(2 + d) for DIRECT block d
+//   direct[n_direct][4] = (block, c, k, 0)  (round 6, version 3): the blocks a window cannot hold in its 16 waves -- a 65th block, or rows that do
+//         not pack -- used to form small OVERFLOW items that every set walked in a last, sliced round: at the bench layout (4096^2, 20 %: two
+//         windows of 65 blocks) 64 workgroups streamed the whole 32 KiB window per chunk again for THREE blocks, nothing shared in the L2, and
+//         the kernel ended 8.5 us later on those XCDs (profiles/r06_updat_loop.md).  With `direct_max` > 0 (feature axis 1, partial-sum schedules,
+//         at most that many blocks) such a block gets U2_DIRECT_PARTS extra workgroups BEHIND the schedule's: each multiplies one quarter of the
+//         minibatch from the block's own 64-byte row pieces (2 KiB per 16 rows instead of 32) and leaves one partial sum for the summing pass.
+//         They start as the first workgroups of the schedule retire and finish long before the last.
 //   item: U2_ITEM = 4 + U2_WAVES * 5 words = (c0_block, k0_block, nblocks_in_item, 0) then per wave
 //         word 0 = n0 | n1 << 4 | cidx0 << 8 | cidx1 << 12 | kidx[0] << 16 | kidx[1] << 20 | kidx[2] << 24 | kidx[3] << 28
 //                  slots [0, n0) are blocks (cidx0, kidx[j]), slots [n0, n0 + n1) blocks (cidx1, kidx[j]) of the window
@@ -1059,14 +1067,16 @@ inline long b64_emit(int kind, int blocks64, int segments64, const std::vector<i
 namespace bsmm {
 
 constexpr int32_t U2PLAN_MAGIC = 0x42535532;
-constexpr int32_t U2PLAN_VERSION = 2;   // 2: block map behind the items (header words 26, 27)
+constexpr int32_t U2PLAN_VERSION = 3;   // 2: block map behind the items (header words 26, 27); 3: direct blocks (header words 28 .. 31)
 constexpr int U2_WAVES = 16;
 constexpr int U2_SLOTS = 4;
 constexpr int U2_WWORDS = 5;
 constexpr int U2_ITEM = 4 + U2_WAVES * U2_WWORDS;
-constexpr int U2_HDR = 28;   // 9 + 2 * 8 set descriptors, padded to a multiple of 4 words
+constexpr int U2_HDR = 32;   // 9 + 2 * 8 set descriptors, block map, longest set, direct blocks
+constexpr int U2_DIRECT_PARTS = 4;       // workgroups (= quarters of the minibatch) per direct block
+constexpr int U2_DIRECT_MAX = 64;        // more overflow blocks than this: overflow items as before
 
-inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets) {
+inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets, int direct_max) {
     if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || (ws != 8 && ws != 16 && ws != 32) || blocks >= (1 << 29)) return -1;
     const int WS = ws;
     const int wc = (CB + WS - 1) / WS, wk = (KB + WS - 1) / WS;
@@ -1092,6 +1102,8 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
     std::vector<std::vector<std::vector<int32_t>>> row_items(wc), row_overflow(wc);
     std::vector<std::vector<int>> row_items_wj(wc), row_overflow_wj(wc);
     bool overflow_item = false;
+    const bool direct_ok = direct_max > 0 && nsets <= 2;      // (8 sets: every item may be one workgroup's and stored directly -- no summing pass to meet in)
+    std::vector<int32_t> direct;                              // (block, c, k, 0) per direct block
     auto emit = [&](int wi, int wj, const std::vector<Wave>& waves) {
         std::vector<int32_t> it(U2_ITEM, 0);
         int n = 0;
@@ -1167,17 +1179,28 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
                 const size_t cnt = std::min<size_t>(per_item, waves.size() - beg);
                 std::vector<Wave> dealt(U2_WAVES);
                 int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+                // (waves 0..7 are wave set A of the kernel, 8..15 set B: dealing in decreasing load puts the two heaviest waves of every SIMD into set
+                //  A.  Round 6 tried the balanced deal -- {heaviest, lightest} to A, the middle two to B: every item with more than 20 blocks in
+                //  set B got SLOWER, 50-block items 57.5 -> 63.8 us per range: the item's time follows set B's load, profiles/r06_updat_loop.md)
+                static const int kPos[4] = {0, 4, 8, 12};
                 for (size_t i = 0; i < cnt; ++i) {
                     int s = -1;
                     for (int q = 0; q < 4; ++q)
                         if (used[q] < 4 && (s < 0 || load[q] < load[s])) s = q;
-                    dealt[s + 4 * used[s]] = waves[beg + i];
+                    dealt[s + kPos[used[s]]] = waves[beg + i];
                     load[s] += waves[beg + i].n; ++used[s];
                 }
                 overflow_item = beg > 0;
+                if (overflow_item && direct_ok) {
+                    for (size_t i = 0; i < cnt; ++i)
+                        for (const Piece& pcs : waves[beg + i].p)
+                            for (const Ent& e : pcs.e) direct.insert(direct.end(), {e.w, e.c, e.k, 0});
+                    continue;
+                }
                 emit(wi, wj, dealt);
             }
         }
+    if ((long)direct.size() / 4 > direct_max) return build_updat2_plan(updat_lut, blocks, CB, KB, ws, out, force_sets, 0);   // too many: overflow items
     // window row -> row band of the set grid: equal thirds / halves of the grid, except for two sets: balanced item counts
     std::vector<int> band(wc);
     for (int wi = 0; wi < wc; ++wi) band[wi] = wi * pr / wc;
@@ -1216,7 +1239,9 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
     }
     const long nitems = (long)(items.size() / U2_ITEM);
     const long off_bmap = U2_HDR + (long)items.size();
-    const long total = off_bmap + blocks;
+    const long n_direct = (long)direct.size() / 4;
+    const long off_direct = (off_bmap + blocks + 3) & ~3L;
+    const long total = n_direct > 0 ? off_direct + 4 * n_direct : off_bmap + blocks;
     if (out) {
         int32_t hdr[U2_HDR] = {U2PLAN_MAGIC, U2PLAN_VERSION, WS, U2_SLOTS, (int32_t)nitems, blocks, U2_HDR, U2_WAVES, nsets};
         for (int st = 0; st < 8; ++st) { hdr[9 + 2 * st] = set_first[st]; hdr[10 + 2 * st] = set_count[st]; }
@@ -1226,6 +1251,7 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
         hdr[25] = equal ? set_count[0] : 0;
         hdr[26] = (int32_t)off_bmap;
         hdr[27] = longest;
+        hdr[28] = (int32_t)n_direct; hdr[29] = n_direct > 0 ? (int32_t)off_direct : 0; hdr[30] = U2_DIRECT_PARTS; hdr[31] = 0;
         std::copy(hdr, hdr + U2_HDR, out);
         std::copy(items.begin(), items.end(), out + U2_HDR);
         // block -> (item, accumulator slot wave * U2_SLOTS + j) for the summing pass over the per-workgroup partial sums
@@ -1243,7 +1269,16 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
                 }
             }
         }
+        for (long d = 0; d < n_direct; ++d) {
+            const int32_t wid = direct[4 * d];
+            if (wid < 0 || wid >= blocks || bmap[wid] != -1) return -1;
+            bmap[wid] = (int32_t)(-2 - d);
+        }
         for (int w = 0; w < blocks; ++w) if (bmap[w] == -1) return -1;
+        if (n_direct > 0) {
+            std::fill(out + off_bmap + blocks, out + off_direct, 0);
+            std::copy(direct.begin(), direct.end(), out + off_direct);
+        }
     }
     return total;
 }

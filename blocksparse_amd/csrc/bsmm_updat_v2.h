@@ -68,6 +68,16 @@ constexpr int U2_CH0 = 32;                 // minibatch columns per chunk
 #endif
 constexpr int u2_lds_bytes0(int ws) { return U2_RING5 ? 5 * ws * 32 * (U2_CH0 * 2) : 131072; }
 
+#ifdef U2_STAMPS
+// wall-clock stamps (s_memrealtime, 100 MHz, one clock for the chip) of wave 0 of every workgroup: [0] start, [1] chunk loop of its first range
+// done, [2] that range's sums stored, [3] end, [4] ranges walked, [5] chunks of the first range; bsmm_debug_u2_trace_copy(), scripts/gpu_updat_stamps.py.
+// Debug builds only (profiles/r06_updat_loop.md).
+__device__ unsigned long long g_u2_trace[1024 * 8];
+#define U2_STAMP(k, v) do { if (wave == 0 && lane == 0 && blockIdx.x < 1024) g_u2_trace[blockIdx.x * 8 + (k)] = (v); } while (0)
+#else
+#define U2_STAMP(k, v) do { } while (0)
+#endif
+
 // a wave-uniform pointer, provably so for the compiler (an "s" asm operand fed from a value it regards as divergent is
 // emitted as a VGPR and does not assemble)
 __device__ __forceinline__ const void* uniform_ptr(const void* p) {
@@ -116,13 +126,87 @@ __device__ __forceinline__ const unsigned char* pick_ptr(const PtrList8& l, int 
     return static_cast<const unsigned char*>(p);
 }
 
+// DIRECT blocks (bsmm_plan.h, 'BSU2' version 3; feature axis 1): workgroup `e` behind the schedule's multiplies quarter e % U2_DIRECT_PARTS of the
+// minibatch for direct block e / U2_DIRECT_PARTS -- the block's own 64-byte row pieces only (the per-block scheme of bsmm_updat_tr.h): wave v takes
+// 16-row chunks v, v + 16, ... of the quarter through a private ring of LDSB / 16 bytes (2 KiB per chunk: X rows | DY rows, the plain LDS-DMA image,
+// fragments by transposing reads), one MFMA per chunk; the 16 partial tiles meet in LDS and leave as ONE partial sum in accumulator slot 0 of this
+// workgroup's region, in the register order updat2_reduce_kernel expects.  ~3 us for a quarter of 2048 rows; nothing is shared, nothing is waited for.
+template <class DT, int LDSB>
+__device__ __forceinline__ void u2_direct_block(const PtrList8& Xs, const PtrList8& Es, float* __restrict__ scratch, const int32_t* __restrict__ plan,
+                                                int N, int Cf, int Kf, int pcount, int e, unsigned char* smem) {
+    typedef typename DT::T T;
+    constexpr int SLOT = 2048, D = LDSB / U2_WAVES / SLOT;       // ring slots per wave: 4 (128 KiB) or 2 (64 KiB)
+    static_assert(D >= 2 && LDSB >= U2_WAVES * 4096, "direct blocks: a ring of two chunks per wave and 64 KiB for the reduction");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int DP = plan[30];
+    const int d = e / DP, q = e - d * DP;
+    const int32_t* de = plan + plan[29] + 4 * d;
+    const int c = __builtin_amdgcn_readfirstlane(de[1]), k = __builtin_amdgcn_readfirstlane(de[2]);
+    unsigned char* ring = smem + wave * (D * SLOT);
+    const uint32_t ring_addr = lds_addr_of(ring);
+    const int drow = lane >> 2, dpiece = lane & 3;                // DMA: lane -> (row of the chunk, 16-byte piece of the 64-byte row piece)
+    const int g16 = lane >> 4, t16 = lane & 15, h = g16 >> 1;     // fragments: as updat32_a1_tr_kernel
+    const int rd_base = (8 * h + (t16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (t16 & 3)) * 2;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nch = (N + 15) >> 4;
+    const int lo = (int)((long)nch * q / DP), hi = (int)((long)nch * (q + 1) / DP);
+    const int first = lo + wave;
+    const int myq = hi > first ? (hi - first + U2_WAVES - 1) / U2_WAVES : 0;      // chunks of a pair this wave owns
+    for (int p = 0; p < pcount; ++p) {
+        const T* X = reinterpret_cast<const T*>(pick_ptr(Xs, p)) + c * 32 + dpiece * 8;
+        const T* E = reinterpret_cast<const T*>(pick_ptr(Es, p)) + k * 32 + dpiece * 8;
+        auto issue = [&](int j, int pos) {                       // (chunks past the end: clamped re-reads of row N - 1, never multiplied)
+            const int r = min((first + U2_WAVES * j) * 16 + drow, N - 1);
+            const uint32_t slot = __builtin_amdgcn_readfirstlane(ring_addr + pos * SLOT);
+            glds16_asm(X + (size_t)r * Cf, slot);
+            glds16_asm(E + (size_t)r * Kf, slot + 1024);
+        };
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) issue(j, j);
+        int rd_pos = 0, wr_pos = D - 1;
+        for (int j = 0; j < myq; ++j) {
+            issue(j + D - 1, wr_pos);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");     // chunk j has landed
+            const unsigned char* sp = ring + rd_pos * SLOT + rd_base;
+            rd_pos = (rd_pos + 1 == D) ? 0 : rd_pos + 1;
+            wr_pos = (wr_pos + 1 == D) ? 0 : wr_pos + 1;
+            const uint2 a0 = ds_tr16(sp), a1 = ds_tr16(sp + 4 * 64), b0 = ds_tr16(sp + 1024), b1 = ds_tr16(sp + 1024 + 4 * 64);
+            uint4 a = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            const uint4 b = make_uint4(b0.x, b0.y, b1.x, b1.y);
+            const int nb = (first + U2_WAVES * j) * 16 + 8 * h;      // K index i of this lane's fragment is row nb + i
+            if (nb + 8 > N) {                                        // ragged tail: rows >= N were clamped re-reads
+                uint32_t* u = reinterpret_cast<uint32_t*>(&a);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] &= ((nb + 2 * i < N) ? 0xffffu : 0u) | ((nb + 2 * i + 1 < N) ? 0xffff0000u : 0u);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the next request may overwrite this slot only after the reads returned)
+            acc = DT::mfma32(a, b, acc);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the clamped requests past the end, before the ring is reused
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[wave * 1024 + reg * 64 + lane] = acc[reg];
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < U2_WAVES; ++v) sum += red[v * 1024 + threadIdx.x];         // element (reg = tid >> 6, lane = tid & 63), waves in order
+    const int reg = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    float* region = scratch + (size_t)blockIdx.x * (U2_WAVES * U2_SLOTS) * 1024;    // (round 0 of this workgroup; accumulator slot 0)
+    region[((reg >> 2) * 64 + ln) * 4 + (reg & 3)] = sum;
+}
+
 // AXIS = 0: the same schedule, ring protocol, partial-sum regions and epilogue over slabs whose ROWS are the window's features
 // ([WS*32 rows][64 B] per operand and chunk; the 16-byte pieces of row r XOR-swizzled with (r >> 2) & 3, conflict-free for the plain
 // ds_read_b128 fragment reads: lane (row, k-half) takes 8 consecutive minibatch columns of its feature).  Needs N % 8 == 0.
 template <class DT, int WS, int AXIS = 1>
 __global__ void __launch_bounds__(64 * U2_WAVES, 4)
 updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
-                     const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta, int flat) {
+                     const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta, int flat, int main_grid) {
     typedef typename DT::T T;
     static_assert(DT::is16 && (WS == 8 || WS == 16 || (WS == 32 && AXIS == 1)), "updat v2: 16-bit storage types, 8x8 / 16x16 windows (32x32: feature axis 1)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -141,6 +225,12 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     constexpr int NI = 2 * IPO / U2_WAVES;        // DMA instructions per wave and chunk (consecutive pieces of ONE operand)
     static_assert((NI == 1 || NI == 2 || NI == 4) && NI * U2_WAVES == 2 * IPO && IPO % NI == 0, "the chunk must split evenly over the waves");
 
+    // workgroups behind the schedule's `main_grid`: direct blocks (feature axis 1; the launcher adds them only there and only with partial sums)
+    const int mg = main_grid > 0 ? main_grid : (int)gridDim.x;
+    if ((int)blockIdx.x >= mg) {
+        if constexpr (AXIS == 1) u2_direct_block<DT, u2_lds_bytes(WS)>(Xs, Es, scratch, plan, N, Cf, Kf, pcount, (int)blockIdx.x - mg, smem);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t* items = plan + plan[6];
@@ -151,10 +241,10 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     //      U = gridDim.x / 8 workgroups take the set's items in rounds of U, one item each over the whole part; a last
     //      incomplete round of m items is cut into floor(U / m) slices of the part per item so that every workgroup works.
     //      flat != 0: one set of all items, one part, the same rounds over all workgroups (grid = items x slices).
-    const bool xcd_mode = flat == 0 && (gridDim.x & 7) == 0;
+    const bool xcd_mode = flat == 0 && (mg & 7) == 0;
     const int nsets = xcd_mode ? plan[8] : 1;
     const int nparts = xcd_mode ? 8 / nsets : 1;
-    const int U = xcd_mode ? gridDim.x >> 3 : gridDim.x;
+    const int U = xcd_mode ? mg >> 3 : mg;
     const int xcd = xcd_mode ? (blockIdx.x & 7) : 0, uj = xcd_mode ? (blockIdx.x >> 3) : blockIdx.x;
     const int set = xcd / nparts, part = xcd - set * nparts;
     const int set_first = xcd_mode ? plan[9 + 2 * set] : 0, set_count = xcd_mode ? plan[10 + 2 * set] : plan[4];
@@ -189,6 +279,8 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     const bool setb = wave >= U2_WAVES / 2;
 #endif
 
+    U2_STAMP(0, __builtin_amdgcn_s_memrealtime());
+    U2_STAMP(4, (unsigned long long)total_rounds);
     for (int round = 0; round < total_rounds; ++round) {
         int item, r0, cnt;
         if (round < full_rounds) {
@@ -471,6 +563,7 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
             default:        RUN(4, 0); break;
         }
 #undef RUN
+        if (round == 0) { U2_STAMP(1, __builtin_amdgcn_s_memrealtime()); U2_STAMP(5, (unsigned long long)cnt); }
 
         // D[ci][ko]: col = ko = lane & 31, row ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         if (scratch != nullptr) {
@@ -517,7 +610,9 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
                 }
             }
         }
+        if (round == 0) U2_STAMP(2, __builtin_amdgcn_s_memrealtime());
     }
+    U2_STAMP(3, __builtin_amdgcn_s_memrealtime());
 }
 
 __device__ __forceinline__ float4 u2_ld(const float4* p) {
@@ -537,17 +632,20 @@ __device__ __forceinline__ float4 u2_ld(const float4* p) {
 template <class DT, bool SUMS>
 __global__ void __launch_bounds__(128)
 updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict__ DW, float* __restrict__ sums, const int32_t* __restrict__ plan,
-                     const int32_t* __restrict__ bmap, const float* __restrict__ gate, int grid, int flat, int CPI, float alpha, float beta, int q64 = 0) {
+                     const int32_t* __restrict__ bmap, const float* __restrict__ gate, int grid, int main_grid, int flat, int CPI, float alpha, float beta, int q64 = 0) {
     // 128 threads = (quad pair qq = tid >> 6, lane l): quads qq and qq + 2 -- all workgroups of the bench shape are resident at once,
     // and the block map is addressed from an argument so that its load does not wait for the plan header
     const int w = blockIdx.x;
     const int qq = threadIdx.x >> 6, l = threadIdx.x & 63;
+    // (`grid`: all workgroups of the streaming launch -- the region index of (round, workgroup) is round * grid + workgroup; `main_grid`: the
+    //  schedule's, the first of them; behind those the workgroups of the direct blocks)
     const int32_t bm = bmap[w];
-    const int item = bm >> 8, slot = bm & 255;
-    const bool xcd_mode = flat == 0 && (grid & 7) == 0;
+    const bool direct = bm <= -2;
+    const int item = direct ? 0 : bm >> 8, slot = direct ? 0 : bm & 255;
+    const bool xcd_mode = flat == 0 && (main_grid & 7) == 0;
     const int nsets = xcd_mode ? plan[8] : 1;
     const int nparts = xcd_mode ? 8 / nsets : 1;
-    const int U = xcd_mode ? grid >> 3 : grid;
+    const int U = xcd_mode ? main_grid >> 3 : main_grid;
     int set = 0;
     if (xcd_mode)
         for (int s = 1; s < nsets; ++s) if (item >= plan[9 + 2 * s]) set = s;
@@ -568,7 +666,19 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
         return (int)(part_hi - part_lo);
     };
     auto add = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
-    if (!sliced) {
+    if (direct) {
+        // a direct block: one partial sum per quarter of the minibatch, slot 0 of the regions of its U2_DIRECT_PARTS workgroups (always written)
+        const int dp = plan[30];
+        const float4* p0 = base + (size_t)(main_grid + (-2 - bm) * dp) * REGION;
+        float4 v0[8], v1[8];
+#pragma unroll
+        for (int part = 0; part < 8; ++part) {
+            v0[part] = v1[part] = zero4;
+            if (part < dp) { v0[part] = u2_ld(p0 + (size_t)part * REGION); v1[part] = u2_ld(p0 + (size_t)part * REGION + 128); }
+        }
+#pragma unroll
+        for (int part = 0; part < 8; ++part) { add(acc0, v0[part]); add(acc1, v1[part]); }
+    } else if (!sliced) {
         // one region per minibatch part (<= 8): all loads first
         const int round = pos / U, uj = pos - round * U;
         float4 v0[8], v1[8];

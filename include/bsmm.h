@@ -51,8 +51,9 @@ extern "C" {
  *   122 round 5: 'BSX5' plans (BSMM_PLAN_XCOL_ROWS), BSMM_K_XCOL32_ROWS;  123 round 5: 'BSUP' plans v6 (12 header words; bsize 16 on feature
  *   axis 0 carries a 'BSU6' section for the row-owner weight-gradient kernel), BSMM_K_UPDAT16_ROWS, BSMM_PLAN_UPDAT16_WINDOWED;
  *   124 round 6: the row-split xprop kernel of round 5 retired ('BSX5' plans are no longer built or accepted, BSMM_PLAN_XCOL_ROWS is ignored,
- *   trace code 13 is not emitted; source and measurements: profiles/r05_xrows.patch) */
-#define BSMM_VERSION 124
+ *   trace code 13 is not emitted; source and measurements: profiles/r05_xrows.patch);  125 round 6: 'BSU2' plans version 3 (32 header words; direct
+ *   blocks), BSMM_PLAN_UPDAT_NO_DIRECT */
+#define BSMM_VERSION 125
 
 enum { BSMM_F32 = 0, BSMM_F16 = 1, BSMM_BF16 = 2 };
 enum {
@@ -104,6 +105,8 @@ enum {
     BSMM_PLAN_UPDAT16_WINDOWED = 0x40000, /* updat bsize 16, feature axis 0: do NOT append the 'BSU6' section (row-owner kernel, bsmm_updat16_rows.h,
                                        round 5: 512 x 512-feature windows, X rows straight into registers) -- the call then always runs the
                                        windowed kernel (256 x 256-feature windows through LDS); comparison / tests                        */
+    BSMM_PLAN_UPDAT_NO_DIRECT = 0x80000, /* updat bsize 32, feature axis 1 ('BSU2' plans): no DIRECT blocks (round 6: the blocks a window's 16 waves cannot hold
+                                       get workgroups of their own behind the schedule's) -- overflow items in a sliced last round, as before; comparison / tests */
     BSMM_PLAN_FLOW_SCHEDULED = 0x10000 /* 'BSX4' plans, experiment: steps in the order the builder's list scheduling picks instead of ascending
                                        input blocks (the same sums in another fp32 summation order; measured no faster, see bsmm_plan.h) */
 };

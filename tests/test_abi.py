@@ -580,22 +580,25 @@ def test_fp32_updat_takes_the_streaming_plan_on_axis1_without_gpu(lib):
 def test_streaming_updat_plan(lib):
     """'BSU2' plans (bsize 32, either feature axis: the default): every block in exactly one (item, wave, slot); a wave holds <= 4 blocks from
     <= 2 rows of the window, group 0 first; a window side of 16 for layouts up to ~22 % density, 8 above; hub rows split over waves;
-    the two halves of the block rows alternate in the item list."""
+    the two halves of the block rows alternate in the item list.  Round 6 (version 3): on feature axis 1 the blocks a window's 16 waves cannot hold
+    are DIRECT blocks (own workgroups, no overflow items); feature axis 0 and PLAN_UPDAT_NO_DIRECT keep the overflow items."""
     import numpy as np
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_updat_plan
     rng = np.random.default_rng(7)
     cases = [(40, 52, 0.3), (128, 128, 0.2), (128, 128, 0.1), (128, 128, 0.5), (5, 3, 1.0), (1, 1, 1.0), (16, 16, 1.0), (33, 17, 0.05), (256, 256, 0.05)]
+    saw_direct = set()
     for CB, KB, dens in cases:
         lay = rng.random((CB, KB)) < dens
         lay[0, 0] = True
         if CB >= 40:
             lay[3, :] = True                                   # a hub row: more blocks than a wave has slots
         t = L.build_tables(lay)
-        for opt in (0, lib.PLAN_STREAM_16, lib.PLAN_STREAM_8):
-            plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, opt)
-            assert (plan == _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 0, opt)).all()    # the same items on feature axis 0
-            assert plan[0] == 0x42535532 and plan[1] == 2 and plan[3] == 4 and plan[5] == t["blocks"] and plan[7] == 16
+        for opt, axis in ((0, 1), (lib.PLAN_STREAM_16, 1), (lib.PLAN_STREAM_8, 1), (0, 0), (lib.PLAN_STREAM_16, 0)):
+            plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, axis, opt)
+            if axis == 0:       # the same items as feature axis 1 without direct blocks
+                assert (plan == _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, opt | lib.PLAN_UPDAT_NO_DIRECT)).all()
+            assert plan[0] == 0x42535532 and plan[1] == 3 and plan[3] == 4 and plan[5] == t["blocks"] and plan[7] == 16 and plan[6] == 32
             WS, nitems = int(plan[2]), int(plan[4])
             if opt == 0:
                 w32 = (-(-CB // 32)) * (-(-KB // 32))
@@ -606,9 +609,19 @@ def test_streaming_updat_plan(lib):
             else:
                 assert WS == (16 if opt == lib.PLAN_STREAM_16 else 8)
             items = plan[plan[6]:plan[6] + nitems * 84].reshape(nitems, 4 + 16 * 5)
-            assert int(plan[26]) == plan[6] + nitems * 84 and plan.size == int(plan[26]) + t["blocks"]
-            bmap = plan[int(plan[26]):]                       # block -> item << 8 | wave * 4 + slot (for the summing pass)
+            ndir, offd = int(plan[28]), int(plan[29])
+            assert int(plan[26]) == plan[6] + nitems * 84 and int(plan[30]) == 4 and int(plan[31]) == 0
+            assert (ndir == 0 and offd == 0 and plan.size == int(plan[26]) + t["blocks"]) or \
+                   (0 < ndir <= 64 and axis == 1 and offd % 4 == 0 and 0 <= offd - int(plan[26]) - t["blocks"] < 4 and plan.size == offd + 4 * ndir)
+            bmap = plan[int(plan[26]):int(plan[26]) + t["blocks"]]   # block -> item << 8 | wave * 4 + slot (for the summing pass); -(2 + d): direct block d
             seen = set()
+            for dd in range(ndir):                            # direct blocks: (block, c, k, 0), each once, none of them in an item
+                w, c, k, z = (int(v) for v in plan[offd + 4 * dd:offd + 4 * dd + 4])
+                assert z == 0 and tuple(t["updat_lut"][w]) == (c, k) and w not in seen and int(bmap[w]) == -2 - dd
+                seen.add(w)
+            if ndir:
+                assert int(plan[8]) <= 2                      # partial-sum schedules only
+                saw_direct.add((CB, KB, dens, opt))
             for ii, it in enumerate(items):
                 c0, k0, n = int(it[0]), int(it[1]), int(it[2])
                 assert c0 % WS == 0 and k0 % WS == 0 and 1 <= n <= 64
@@ -651,7 +664,10 @@ def test_streaming_updat_plan(lib):
                 assert abs(counts[0] - counts[1]) == best
         if (CB, KB, dens) == (128, 128, 0.2):
             p16 = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, 0)
-            assert 64 <= int(p16[4]) <= 72                      # ~one item per 16x16 window
+            assert int(p16[4]) == 64 and 0 < int(p16[28]) <= 64   # one item per 16x16 window, what does not fit: direct blocks
+            p16n = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, lib.PLAN_UPDAT_NO_DIRECT)
+            assert 64 < int(p16n[4]) <= 72 and int(p16n[28]) == 0
+    assert saw_direct
 
 
 def test_host_class_surface():
