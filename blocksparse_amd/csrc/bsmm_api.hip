@@ -1509,6 +1509,9 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
 #ifdef X4_TIMELINE
 extern "C" int bsmm_debug_x4_timeline_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_tl), sizeof(bsmm::g_x4_tl)); }
 #endif
+#ifdef X4_ENDSTAMPS
+extern "C" int bsmm_debug_x4_ends_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_ends), sizeof(bsmm::g_x4_ends)); }
+#endif
 #ifdef U2_STAMPS
 extern "C" int bsmm_debug_u2_trace_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_u2_trace), sizeof(bsmm::g_u2_trace)); }
 #endif

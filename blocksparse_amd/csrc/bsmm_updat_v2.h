@@ -47,6 +47,9 @@ namespace bsmm {
 #ifndef U2_CH_ROWS
 #define U2_CH_ROWS 16
 #endif
+#ifndef U2_SETB_FROM
+#define U2_SETB_FROM 0      // > 0: waves U2_SETB_FROM .. 15 form wave set B whatever the window (measurement builds); 0: the kernel's own choice
+#endif
 constexpr int U2_CH = U2_CH_ROWS;          // minibatch rows per chunk (one interval = one barrier): 16 or 32
 constexpr int U2_KS = U2_CH / 16;          // MFMA K-steps per chunk
 constexpr int U2_D = 64 / U2_CH;           // ring slots (128 KiB with 16x16 windows)
@@ -276,7 +279,10 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
 #ifdef U2_NO_PINGPONG
     const bool setb = false;
 #else
-    const bool setb = wave >= U2_WAVES / 2;
+    // waves SB .. 15 form wave set B.  8 x 8 windows (dense layouts, feature axis 1): FOUR waves in set A, twelve in set B -- measured at 4096^2 50 %
+    // (profiles/r06_updat_setb.txt): 170.8 against 176.9 us per call, every item 152 against 159 us; 16 x 16 windows: 4 / 8 / 10 / 12 within a microsecond
+    constexpr int SB = U2_SETB_FROM > 0 ? U2_SETB_FROM : ((WS == 8 && AXIS == 1) ? 4 : U2_WAVES / 2);
+    const bool setb = wave >= SB;
 #endif
 
     U2_STAMP(0, __builtin_amdgcn_s_memrealtime());

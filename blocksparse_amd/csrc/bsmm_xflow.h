@@ -140,6 +140,9 @@ __device__ __forceinline__ void x4_wait_ctl(uint32_t ctl) {
 
 // RT = 32-row tiles per unit: 4 (128 rows, slabs of 16 KiB, ring of X4_D) or 2 (64 rows, slabs of 8 KiB, ring of 2 X4_D: twice the units for
 // minibatches that do not fill the chip with 128-row units; same plans, same LDS layout).
+#ifdef X4_ENDSTAMPS
+__device__ unsigned long long g_x4_ends[512 * 16 * 8];
+#endif
 template <class DT, bool TRANSW, int RT = 4>
 __global__ void __launch_bounds__(64 * X4_G, 4)
 xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ Wsel, typename DT::T* __restrict__ Y,
@@ -193,6 +196,11 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
 #ifdef X4_STAMPS
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tstart = __builtin_readcyclecounter();
+#endif
+#ifdef X4_ENDSTAMPS
+    // wall clock (s_memrealtime, 100 MHz) of every wave of every workgroup: [0] start, [1 + u] its unit u stored (u < 6), [7] units; debug builds
+    int x4e_u = 0;
+    if (lane == 0 && blockIdx.x < 512) g_x4_ends[(blockIdx.x * 16 + wave) * 8] = __builtin_amdgcn_s_memrealtime();
 #endif
     uint32_t gs = 0;                 // global step number of the current unit's step 0 (ring slot = global step % X4_D)
     const int nunits = map.grid();
@@ -422,7 +430,14 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
                 asm volatile("" ::: "memory");
             }
         }
+#ifdef X4_ENDSTAMPS
+        if (lane == 0 && blockIdx.x < 512 && x4e_u < 6) g_x4_ends[(blockIdx.x * 16 + wave) * 8 + 1 + x4e_u] = __builtin_amdgcn_s_memrealtime();
+        ++x4e_u;
+#endif
     }
+#ifdef X4_ENDSTAMPS
+    if (lane == 0 && blockIdx.x < 512) g_x4_ends[(blockIdx.x * 16 + wave) * 8 + 7] = (unsigned long long)x4e_u;
+#endif
 #ifdef X4_STAMPS
     tacc[6] = __builtin_readcyclecounter() - tstart;
     if (blockIdx.x < 64 && lane == 0)
