@@ -191,8 +191,12 @@ def roofline_of(dom, d_ms, d_flops, d_bytes, dtype):
 def attention_extra(a):
     """BASELINE configs[4]: block-sparse attention, batch 4, 16 heads x 64, ctx 4096, bsize 32, local(4)+strided(8) causal
     layout (1466 blocks per head), fp32 activations / bf16 scores (the reference's fp32 pathway).  Reported per op:
-    ms, effective TFLOP/s (2 * blocks * 32 * 32 * 64 per head and batch entry), algorithmic GB/s, and the bound
-    max(flops / 157.3 TF, algorithmic bytes / 8 TB/s).  CPU baseline: the oracle (NumPy, fp32) on one batch entry and two heads."""
+    ms, effective TFLOP/s (2 * blocks * 32 * 32 * 64 per head and batch entry), algorithmic GB/s, and the bound of the arithmetic the kernel
+    actually runs: the fp32 products are computed as six bf16 piece products on the 16-bit matrix core, so the bound is
+    max(6 * flops / 2.5 PF, algorithmic bytes / 8 TB/s) -- HBM for every operator here (the fp32-MFMA peak these lines were
+    priced against in rounds 3-5 is not the instruction that runs).  `nt_softmax_fused` (round 6) is scores + softmax as one launch: the raw
+    scores never reach memory; `fwd_ms` / `fwd_bwd_ms` use it, `fwd_ms_two_launches` is the composed form.
+    CPU baseline: the oracle (NumPy, fp32) on one batch entry and two heads."""
     import torch
     from blocksparse_amd import BlocksparseTransformer
     B, H, HS, BS, CTX = 4, 16, 64, 32, 128
@@ -228,7 +232,9 @@ def attention_extra(a):
     flops = 2.0 * B * H * bst.blocks * BS * BS * HS
     sbytes = B * H * bst.blocks * BS * BS * 2
     abytes = q.numel() * 4
+    assert bst._nt_softmax(q, k, scale, mask, sd) is not None, "configs[4] is what the fused kernel is for"
     ops = [("nt", lambda: bst._nt(q, k, sd), flops, 2 * abytes + sbytes),
+           ("nt_softmax_fused", lambda: bst._nt_softmax(q, k, scale, mask, sd), flops, 2 * abytes + sbytes),
            ("masked_softmax", lambda: bst._softmax_fwd(w, scale, mask, sd), 0.0, 2 * sbytes),
            ("nn", lambda: bst._xn(p, v, False), flops, 2 * abytes + sbytes),
            ("tn", lambda: bst._xn(p, q, True), flops, 2 * abytes + sbytes),
@@ -236,23 +242,27 @@ def attention_extra(a):
     res = {}
     for name, fn, fl, by in ops:
         ms = timeit(fn)
-        bound = max(fl / (PEAK_MFMA["f32"] * 1e12), by / (PEAK_HBM * 1e9)) * 1e3
+        t_mfma, t_hbm = 6.0 * fl / (PEAK_MFMA["bf16"] * 1e12), by / (PEAK_HBM * 1e9)     # six bf16 piece products per fp32 product
+        bound = max(t_mfma, t_hbm) * 1e3
         res[name] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 2), "gbps": round(by / ms / 1e6, 1),
-                     "bound": "mfma" if fl / (PEAK_MFMA["f32"] * 1e12) > by / (PEAK_HBM * 1e9) else "hbm",
-                     "bound_ms": round(bound, 4), "frac": round(bound / ms, 4)}
-    # forward + backward of one attention layer = nt, softmax, nn | tn(dv), nt(dp), softmax_grad, nn(dq), tn(dk)
-    fb = res["nt"]["ms"] * 2 + res["masked_softmax"]["ms"] + res["softmax_grad"]["ms"] + res["nn"]["ms"] * 2 + res["tn"]["ms"] * 2
+                     "bound": "mfma" if t_mfma > t_hbm else "hbm", "bound_ms": round(bound, 4), "frac": round(bound / ms, 4)}
+    # forward + backward of one attention layer = [nt + softmax] (one launch), nn | tn(dv), nt(dp), softmax_grad, nn(dq), tn(dk)
+    fwd2 = res["nt"]["ms"] + res["masked_softmax"]["ms"] + res["nn"]["ms"]
+    fwd = res["nt_softmax_fused"]["ms"] + res["nn"]["ms"]
+    fb = fwd + res["nt"]["ms"] + res["softmax_grad"]["ms"] + res["nn"]["ms"] + res["tn"]["ms"] * 2
     # the same operators with bf16 activations (native 16-bit MFMA, HBM-bound): not the BASELINE configuration, for reference
     qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
     res16 = {}
-    for name, fn in (("nt", lambda: bst._nt(qb, kb, sd)), ("nn", lambda: bst._xn(p, vb, False)), ("tn", lambda: bst._xn(p, qb, True))):
+    for name, fn in (("nt", lambda: bst._nt(qb, kb, sd)), ("nt_softmax_fused", lambda: bst._nt_softmax(qb, kb, scale, mask, sd)),
+                     ("nn", lambda: bst._xn(p, vb, False)), ("tn", lambda: bst._xn(p, qb, True))):
         ms = timeit(fn)
         by = 2 * qb.numel() * 2 + sbytes
         res16[name] = {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2), "gbps": round(by / ms / 1e6, 1), "bound": "hbm",
                        "bound_ms": round(by / (PEAK_HBM * 1e9) * 1e3, 4), "frac": round(by / (PEAK_HBM * 1e9) * 1e3 / ms, 4)}
     out = {"workload": "BASELINE configs[4]: block-sparse attention batch %d heads %d x %d ctx %d bsize %d, %d blocks/head, fp32 activations, bf16 scores"
                        % (B, H, HS, CTX * BS, BS, bst.blocks),
-           "ops": res, "fwd_bwd_ms": round(fb, 4), "fwd_bwd_tflops": round(6 * flops / fb / 1e9, 2), "ops_bf16_activations": res16}
+           "ops": res, "fwd_ms": round(fwd, 4), "fwd_ms_two_launches": round(fwd2, 4), "fwd_bwd_ms": round(fb, 4),
+           "fwd_bwd_tflops": round(6 * flops / fb / 1e9, 2), "ops_bf16_activations": res16}
     if not a.no_cpu_baseline:
         from oracle import bst_oracle as O            # the oracle is only the timed CPU baseline here
         L = O.build_luts(lay)

@@ -182,6 +182,37 @@ int bst_masked_softmax(const void* x, void* y, const void* mask, int32_t mask_he
     });
 }
 
+// scores + softmax in one launch (round 6, bsize 32): see bst_nt_softmax_kernel.  args->lut = nn_lut; max_row_blocks = the longest query row of the layout
+int bst_nt_softmax(const void* q_, const void* k_, void* y_, const void* mask, int32_t mask_heads, float scale, int32_t max_row_blocks, const bst_args* a) {
+    if (int rc = check_mm(a)) return rc;
+    if (!q_ || !k_ || !y_ || max_row_blocks <= 0) return BSMM_ERR_ARG;
+    if (a->lut_dim != a->ctx_blks_q + a->blocks) return BSMM_ERR_ARG;
+    if (mask && mask_heads != 1 && mask_heads != a->heads) return BSMM_ERR_ARG;
+    // what the fused kernel serves; everything else: bst_nt, then bst_masked_softmax
+    if (a->bsize != 32 || max_row_blocks > 4 * NTS_MAXT || (a->head_state != 32 && a->head_state != 64 && a->head_state != 128) || (a->flags & BST_FLAG_FP32_MFMA))
+        return BSMM_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    return by_types(a->dtype, a->score_dtype, [&](auto ta, auto ts) {
+        typedef decltype(ta) TA;
+        typedef decltype(ts) TS;
+        const auto* Q = static_cast<const typename TA::T*>(q_);
+        const auto* K = static_cast<const typename TA::T*>(k_);
+        auto* Y = static_cast<typename TS::T*>(y_);
+        const int rq = a->ctx_blks_q * 32, rk = a->ctx_blks_k * 32;
+        const int mstride = (mask && mask_heads > 1) ? a->blocks * 32 : 0;
+        const int grid = xcd_head_grid(a->ctx_blks_q, a->heads, a->batch);
+        auto go = [&](auto ch_tag) {
+            constexpr int CH = decltype(ch_tag)::value;
+            bst_nt_softmax_kernel<TA, TS, CH, !TA::is16><<<grid, 256, 0, st>>>(Q, K, Y, a->lut, lut_stride(a), static_cast<const uint32_t*>(mask), mstride, a->blocks,
+                                                                              a->heads, a->batch, a->head_state, rq, rk, a->ctx_blks_q, scale);
+        };
+        if (a->head_state == 32) go(std::integral_constant<int, 1>{});
+        else if (a->head_state == 64) go(std::integral_constant<int, 2>{});
+        else go(std::integral_constant<int, 4>{});
+        return (int)hipGetLastError();
+    });
+}
+
 int bst_softmax_grad(const void* dy, const void* y, void* dx, float scale, int32_t dtype16, const bst_args* a) {
     if (int rc = check_common(a)) return rc;
     if (!dy || !y || !dx) return BSMM_ERR_ARG;

@@ -878,6 +878,262 @@ bst_softmax_grad_kernel(const typename T16::T* __restrict__ DY, const typename T
 }
 
 // mask [H][BS][blocks] -> same (src/bst_softmax_op_gpu.cu:461-503).  grid (ceil(blocks / 64), BS, H), 64 threads.
+// ------------------------------------------------------------------------------------------------------------------
+// Scores + softmax in ONE launch (round 6; bsize 32): Y[n][h][b] = softmax over the query row of (scale * bf16(Q . K^T) + mask).
+//
+// The two-launch form (bst_nt_mfma_kernel, then bst_softmax_kernel) writes 192 MB of raw scores at BASELINE configs[4], reads them back and
+// writes 192 MB of probabilities: 0.150 + 0.090 ms.  Here one workgroup owns a query block ROW (<= NTS_MAXT * 4 = 20 blocks; longer rows: the
+// caller takes the two launches): its four waves take every fourth block of the row's list (nn_lut: header (offset, count) per query block,
+// entries (block, key block)), multiply exactly as bst_nt_mfma_kernel does (same tile images, same fragment reads, same piece products in the
+// same order, the tile rounded to the score type -- the raw scores are what the two-launch form stores) and PARK the rounded tile in LDS instead
+// of memory (2 KiB per tile, the image bst_nt_mfma_kernel stages its stores through).  The softmax then runs over those images in the store
+// layout -- lane (row i, piece p) owns 8 consecutive keys of two rows per tile: max and sum meet across the four lanes of a row by two
+// shuffles and across the four waves through 1 KiB of LDS -- and the probabilities leave as contiguous 1 KiB stores.  The scores never reach
+// memory.  The Q tile is fetched once per workgroup (each wave a quarter of the DMA instructions).
+// Same arithmetic as bst_softmax_kernel: exp2((s - max) * 1) with s = score * scale * log2 e, masked keys = -FLT_MAX, 1 / sum.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int NTS_MAXT = 5;          // tiles per wave: rows of up to 20 blocks
+
+template <class TA, class TS, int NCH, bool SPLIT>
+__global__ void __launch_bounds__(256)
+bst_nt_softmax_kernel(const typename TA::T* __restrict__ A, const typename TA::T* __restrict__ B, typename TS::T* __restrict__ Y,
+                      const int32_t* __restrict__ lut, int lut_stride, const uint32_t* __restrict__ mask, int mask_stride, int blocks, int heads,
+                      int batch, int hs, int rows_q, int rows_k, int ctx_q, float scale) {
+    typedef typename TA::T T;
+    typedef NtTile<T> TL;
+    constexpr int BS = 32;
+    static_assert(!SPLIT || !TA::is16, "the three-piece split is for fp32 activations");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_k[4][NCH][TL::BYTES];      // per wave: the K tile of its current block
+    __shared__ __attribute__((aligned(16))) unsigned char lds_q[NCH][TL::BYTES];         // the row's Q tile (all waves)
+    __shared__ __attribute__((aligned(16))) unsigned char olds[4][NTS_MAXT][32 * 64];    // per wave: its finished tiles (score type)
+    // (row max / row sum of every wave: 256 B at the head of that wave's K buffer, idle by then -- 80 KiB in all: two workgroups per CU)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    int n, h, Q;
+    if (!xcd_head_map(ctx_q, heads, batch, n, h, Q)) return;
+    const int32_t* hl = lut + (size_t)h * lut_stride;
+    const int2 hdr = *reinterpret_cast<const int2*>(hl + 2 * Q);
+    const int cnt = __builtin_amdgcn_readfirstlane(hdr.y);
+    if (cnt == 0) return;                                                                // (the whole workgroup: no barrier is passed by a part of it)
+    const int32_t* ent = hl + 2 * __builtin_amdgcn_readfirstlane(hdr.x);
+    const size_t state = (size_t)heads * hs;
+    const int lrow = lane / TL::PPR, lp = lane % TL::PPR;
+    const T* abase = A + (size_t)n * rows_q * state + (size_t)h * hs + (size_t)Q * BS * state;
+    const T* bbase = B + (size_t)n * rows_k * state + (size_t)h * hs;
+    const uint32_t a_k = lds_addr_of(&lds_k[wave][0][0]), a_q = lds_addr_of(&lds_q[0][0]);
+    size_t soff[TL::NI];
+#pragma unroll
+    for (int i = 0; i < TL::NI; ++i) {
+        const int row = TL::RPI * i + lrow;
+        soff[i] = (size_t)row * state + (size_t)((lp ^ TL::sw(row)) * TL::EPP);
+    }
+    auto dma_tile = [&](const T* tile0, uint32_t dst) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < TL::NI; ++i)
+                glds16_asm(tile0 + soff[i] + 32 * c, __builtin_amdgcn_readfirstlane(dst + c * TL::BYTES + i * 1024));
+    };
+    auto frag = [&](const unsigned char* tile, float (&v)[16]) {
+        constexpr int NP = 16 / TL::EPP;
+#pragma unroll
+        for (int g = 0; g < NP; ++g) {
+            const uint4 x = *reinterpret_cast<const uint4*>(tile + r * TL::ROWB + (((NP * hh + g) ^ TL::sw(r)) << 4));
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * g + i] = __builtin_bit_cast(float, w[i]);
+        }
+    };
+    // the Q tile: instruction (c, i) by wave (c * NI + i) % 4; my first K tile behind it
+    {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int i = 0; i < TL::NI; ++i)
+                if (((c * TL::NI + i) & 3) == wave) glds16_asm(abase + soff[i] + 32 * c, __builtin_amdgcn_readfirstlane(a_q + c * TL::BYTES + i * 1024));
+    }
+    const int mine = wave < cnt ? (cnt - wave + 3) >> 2 : 0;                            // my tiles: entries wave, wave + 4, ...
+    if (mine > 0) dma_tile(bbase + (size_t)ent[2 * wave + 1] * BS * state, a_k);
+    // block ids and mask bytes of my tiles, for the softmax phase (requested here: their latency hides behind the tile loop; in the phase
+    // itself 30 dependent loads per wave cost more than the launch the fusion saves) -- lane (row i0 / i0 + 16, piece p): keys 8p .. 8p + 7
+    const int i0 = lane >> 2, p = lane & 3;
+    const uint32_t* mrow = mask ? mask + (size_t)h * mask_stride : nullptr;
+    int bt[NTS_MAXT];
+    uint32_t mk[NTS_MAXT][2];
+#pragma unroll
+    for (int t = 0; t < NTS_MAXT; ++t) {
+        bt[t] = 0; mk[t][0] = mk[t][1] = 0xffffffffu;
+        if (t < mine) {
+            bt[t] = __builtin_amdgcn_readfirstlane(ent[2 * (wave + 4 * t)]);
+            if (mrow) { mk[t][0] = mrow[(size_t)i0 * blocks + bt[t]]; mk[t][1] = mrow[(size_t)(i0 + 16) * blocks + bt[t]]; }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                                     // the Q tile is everyone's
+    // Q fragments / pieces once
+    float fq[TA::is16 ? 1 : NCH][16];
+    uint4 rq[TA::is16 ? NCH : 1][2];
+    uint4 qp[SPLIT ? NCH : 1][3][2];
+    auto split3 = [](const float (&v)[16], uint4 (&p)[3][2]) {                           // as bst_nt_mfma_kernel
+        auto pack2 = [](float lo, float hi) { return (uint32_t)DTbf16::from_f32(lo) | ((uint32_t)DTbf16::from_f32(hi) << 16); };
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint32_t a[4], b[4], c3[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v0 = v[8 * kk + 2 * i], v1 = v[8 * kk + 2 * i + 1];
+                a[i] = pack2(v0, v1);
+                const float r0 = v0 - __builtin_bit_cast(float, a[i] << 16), r1 = v1 - __builtin_bit_cast(float, a[i] & 0xffff0000u);
+                b[i] = pack2(r0, r1);
+                c3[i] = pack2(r0 - __builtin_bit_cast(float, b[i] << 16), r1 - __builtin_bit_cast(float, b[i] & 0xffff0000u));
+            }
+            p[0][kk] = make_uint4(a[0], a[1], a[2], a[3]);
+            p[1][kk] = make_uint4(b[0], b[1], b[2], b[3]);
+            p[2][kk] = make_uint4(c3[0], c3[1], c3[2], c3[3]);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if constexpr (TA::is16) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) rq[c][kk] = *reinterpret_cast<const uint4*>(&lds_q[c][0] + r * TL::ROWB + (((2 * kk + hh) ^ TL::sw(r)) << 4));
+        } else {
+            frag(&lds_q[c][0], fq[c]);
+            if constexpr (SPLIT) split3(fq[c], qp[c]);
+        }
+    }
+    for (int t = 0; t < mine; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                 // this tile's K has landed (the first time: the mask words too)
+        float fk[TA::is16 ? 1 : NCH][16];
+        uint4 rk[TA::is16 ? NCH : 1][2];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if constexpr (TA::is16) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) rk[c][kk] = *reinterpret_cast<const uint4*>(&lds_k[wave][c][0] + r * TL::ROWB + (((2 * kk + hh) ^ TL::sw(r)) << 4));
+            } else {
+                frag(&lds_k[wave][c][0], fk[c]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               // fragments in registers: the buffer is free
+        if (t + 1 < mine) dma_tile(bbase + (size_t)ent[2 * (wave + 4 * (t + 1)) + 1] * BS * state, a_k);
+        f32x16 acc, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc1[i] = 0.f; }
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                uint4 kp[3][2];
+                split3(fk[c], kp);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    acc1 = DTbf16::mfma32(kp[2][kk], qp[c][0][kk], acc1);
+                    acc1 = DTbf16::mfma32(kp[0][kk], qp[c][2][kk], acc1);
+                    acc1 = DTbf16::mfma32(kp[1][kk], qp[c][1][kk], acc1);
+                    acc = DTbf16::mfma32(kp[1][kk], qp[c][0][kk], acc);
+                    acc = DTbf16::mfma32(kp[0][kk], qp[c][1][kk], acc);
+                    acc = DTbf16::mfma32(kp[0][kk], qp[c][0][kk], acc);
+                }
+            }
+        } else if constexpr (TA::is16) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                acc = TA::mfma32(rk[c][0], rq[c][0], acc);
+                acc1 = TA::mfma32(rk[c][1], rq[c][1], acc1);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c & 1) mma32_f32(fk[c], fq[c], acc1);
+                else       mma32_f32(fk[c], fq[c], acc);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
+        unsigned char* img = &olds[wave][0][0] + t * 2048;                               // park (bst_nt_mfma_kernel's image of a stored tile)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t lo = (uint32_t)TS::from_f32(acc[4 * g + 0]) | ((uint32_t)TS::from_f32(acc[4 * g + 1]) << 16);
+            const uint32_t hi = (uint32_t)TS::from_f32(acc[4 * g + 2]) | ((uint32_t)TS::from_f32(acc[4 * g + 3]) << 16);
+            *reinterpret_cast<uint2*>(img + r * 64 + ((g ^ ((r >> 2) & 3)) << 4) + 8 * hh) = make_uint2(lo, hi);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---- softmax over the parked tiles: lane -> (row i0 = lane >> 2 and i0 + 16, piece p = lane & 3: keys 8p .. 8p + 7) ----
+    const float NEG = -3.402823466e+38f;
+    const float sc2 = scale * 1.4426950408889634f;
+    auto values = [&](int t, int k, uint32_t mbits, float (&v)[8]) {                    // scaled, masked scores of (tile t, row i0 + 16 k), my 8 keys
+        const int i = i0 + 16 * k;
+        const uint4 x = *reinterpret_cast<const uint4*>(&olds[wave][0][0] + t * 2048 + i * 64 + ((p ^ ((i >> 2) & 3)) << 4));
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+        const uint32_t m = mbits >> (8 * p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[2 * j] = ((m >> (2 * j)) & 1) ? TS::to_f32((uint16_t)(w[j] & 0xffffu)) * sc2 : NEG;
+            v[2 * j + 1] = ((m >> (2 * j + 1)) & 1) ? TS::to_f32((uint16_t)(w[j] >> 16)) * sc2 : NEG;
+        }
+    };
+#define XCH(w_, v_, i_) reinterpret_cast<float*>(&lds_k[v_][0][0])[32 * (w_) + (i_)]
+    float mx[2] = {NEG, NEG};
+#pragma unroll
+    for (int t = 0; t < NTS_MAXT; ++t)
+        if (t < mine) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float v[8];
+                values(t, k, mk[t][k], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx[k] = fmaxf(mx[k], v[j]);
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], 1)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], 2));
+        if (p == 0) XCH(0, wave, i0 + 16 * k) = mx[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) mx[k] = fmaxf(fmaxf(XCH(0, 0, i0 + 16 * k), XCH(0, 1, i0 + 16 * k)), fmaxf(XCH(0, 2, i0 + 16 * k), XCH(0, 3, i0 + 16 * k)));
+    float sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NTS_MAXT; ++t)
+        if (t < mine) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float v[8];
+                values(t, k, mk[t][k], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum[k] += __builtin_amdgcn_exp2f(v[j] - mx[k]);
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        sum[k] += __shfl_xor(sum[k], 1); sum[k] += __shfl_xor(sum[k], 2);
+        if (p == 0) XCH(1, wave, i0 + 16 * k) = sum[k];
+    }
+    __syncthreads();
+    float rcp[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) rcp[k] = 1.0f / (((XCH(1, 0, i0 + 16 * k) + XCH(1, 1, i0 + 16 * k)) + XCH(1, 2, i0 + 16 * k)) + XCH(1, 3, i0 + 16 * k));
+#undef XCH
+    typename TS::T* ybase = Y + ((size_t)n * heads + h) * blocks * (BS * BS);
+#pragma unroll
+    for (int t = 0; t < NTS_MAXT; ++t)
+        if (t < mine) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float v[8];
+                values(t, k, mk[t][k], v);
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[j] = (uint32_t)TS::from_f32(__builtin_amdgcn_exp2f(v[2 * j] - mx[k]) * rcp[k]) | ((uint32_t)TS::from_f32(__builtin_amdgcn_exp2f(v[2 * j + 1] - mx[k]) * rcp[k]) << 16);
+                *reinterpret_cast<uint4*>(ybase + (size_t)bt[t] * (BS * BS) + (size_t)(i0 + 16 * k) * BS + p * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+}
+
 template <int BS>
 __global__ void bst_partial_ar_mask_kernel(const typename MaskT<BS>::T* __restrict__ in, typename MaskT<BS>::T* __restrict__ out,
                                            const int32_t* __restrict__ nt_lut, int blocks, int key) {

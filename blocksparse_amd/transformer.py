@@ -202,6 +202,27 @@ class BlocksparseTransformer(object):
                                                   ctypes.byref(args)), "bst_masked_softmax")
         return y
 
+    def _nt_softmax(self, q, k, scale, mask_t, y_dtype):
+        """probabilities = softmax(scale * scores(q, k) + mask) as ONE launch (bst_nt_softmax, round 6); None where the fused kernel does not
+        serve the configuration (the caller composes the two ops then)."""
+        self._check_act(q, self.ctx_blks_q, "q")
+        self._check_act(k, self.ctx_blks_k, "k")
+        if q.dtype != k.dtype or q.shape[0] != k.shape[0] or q.shape[2] != k.shape[2]:
+            raise ValueError("Mismatched Shapes: q,k")
+        hs = q.shape[2] // self.heads
+        if self.blk_size != 32 or self.nn_max > 20 or hs not in (32, 64, 128):
+            return None
+        lut = self._table("nn_lut", q.device)
+        y = torch.empty((q.shape[0], self.heads, self.blocks, self.blk_size, self.blk_size), dtype=y_dtype, device=q.device)
+        args = self._args(lut, q.shape[0], hs, _code(q.dtype), _code(y_dtype))
+        mp = mask_t.data_ptr() if mask_t is not None else None
+        mh = mask_t.shape[0] if mask_t is not None else 1
+        rc = _lib.load().bst_nt_softmax(q.data_ptr(), k.data_ptr(), y.data_ptr(), mp, mh, float(scale), int(self.nn_max), ctypes.byref(args))
+        if rc == -2:                                                           # BSMM_ERR_UNSUPPORTED
+            return None
+        _lib.check(rc, "bst_nt_softmax")
+        return y
+
     def _softmax_bwd(self, dy, y, scale):
         self._check_scores(y, y.shape[0])
         dy = dy.contiguous().to(y.dtype)
@@ -237,6 +258,25 @@ class BlocksparseTransformer(object):
     def query_key_op(self, q, k, name=None, bench=0):
         self.softmax_dtype = self._score_dtype(q.dtype)
         return _NT.apply(self, q, k, torch.bfloat16)                             # blocksparse/transformer.py:364-374
+
+    def query_key_softmax(self, q, k, scale=1.0, autoregress_at_key=None, dtype=None):
+        """``masked_softmax(query_key_op(q, k), scale, autoregress_at_key, dtype)`` as one operator (round 6): where the fused kernel serves the
+        configuration (block size 32, head states of 32 / 64 / 128, query rows of up to 20 blocks) the raw scores never reach memory -- one
+        launch, a third of the bytes; elsewhere the two operators run as the reference composes them (blocksparse/transformer.py:364-409).  Same
+        values either way (the scores are rounded to the score type before the softmax in both), same gradients (blocksparse_softmax_grad, then
+        blocksparse_transformer_nt_grad)."""
+        self.softmax_dtype = self._score_dtype(q.dtype)
+        if self.softmax_mask is None:
+            if autoregress_at_key is not None:
+                raise ValueError("autoregress_at_key only applies to ops with mask_callback defined.")
+            mask_t = None
+        elif autoregress_at_key is not None:
+            mask_t = self.partial_autoregressive_mask(autoregress_at_key, q.device)
+        else:
+            mask_t = self._table("mask", q.device)
+        if dtype is None:
+            dtype = self.softmax_dtype
+        return _NTSoftmax.apply(self, q, k, float(scale), mask_t, dtype)
 
     def weight_value_op(self, w, v, name=None, bench=0):
         return _XN.apply(self, w, v, False)
@@ -352,6 +392,29 @@ if torch is not None:
             db = ctx.bst._xn(dw, a.contiguous(), True)
             da = ctx.bst._xn(dw, b.contiguous(), False)
             return None, da, db, None
+
+    class _NTSoftmax(torch.autograd.Function):
+        """probabilities = softmax(scale * (q . k^T) + mask): forward fused where the kernel serves it, else nt then softmax; backward =
+        blocksparse_softmax_grad followed by the nt gradients (blocksparse/transformer.py:411-438, 479-509)."""
+
+        @staticmethod
+        def forward(ctx, bst, q, k, scale, mask_t, y_dtype):
+            q, k = q.contiguous(), k.contiguous()
+            y = bst._nt_softmax(q, k, scale, mask_t, y_dtype)
+            if y is None:
+                y = bst._softmax_fwd(bst._nt(q, k, torch.bfloat16), scale, mask_t, y_dtype)
+            ctx.bst, ctx.scale = bst, scale
+            ctx.save_for_backward(q, k, y)
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            q, k, y = ctx.saved_tensors
+            bst = ctx.bst
+            dw = bst._softmax_bwd(dy, y, ctx.scale)
+            dk = bst._xn(dw, q, True)
+            dq = bst._xn(dw, k, False)
+            return None, dq, dk, None, None, None
 
     class _XN(torch.autograd.Function):
         """c = w . b (nn) or w^T . b (tn); nn gradients as blocksparse_transformer_nn_grad

@@ -66,6 +66,13 @@ int bst_tn(const void* scores, const void* b, void* c, const bst_args* args);
  * Only lut, lut_heads, lut_dim, blocks, bsize, batch, heads, ctx_blks_q, stream of args are read.                          */
 int bst_masked_softmax(const void* x, void* y, const void* mask, int32_t mask_heads, float scale, int32_t x_dtype,
                        int32_t y_dtype, const bst_args* args);
+/* y[n][h][b] = softmax over the query row of (scale * round_to_score_dtype(q . k^T) + mask): bst_nt followed by bst_masked_softmax as ONE launch
+ * (round 6) -- the raw scores never reach memory.  Replaces the pair bst_sgemm_nt / bst_hgemm_nt + BlocksparseMaskedSoftmax where a caller
+ * composes them (blocksparse/transformer.py:364-409: query_key_op, masked_softmax).  args->lut = nn_lut, args->score_dtype = type of y;
+ * max_row_blocks = the longest query row of the layout (the nn_max of the host tables).  Serves bsize 32, head_state 32 / 64 / 128, rows of
+ * up to 20 blocks; anything else returns BSMM_ERR_UNSUPPORTED and the caller runs the two entry points.                                      */
+int bst_nt_softmax(const void* q, const void* k, void* y, const void* mask, int32_t mask_heads, float scale, int32_t max_row_blocks,
+                   const bst_args* args);
 /* dx = (dy - sum_row(dy * y)) * y * scale; dy, y, dx share `dtype16` (bf16 / fp16).  args->lut = nn_lut.                   */
 int bst_softmax_grad(const void* dy, const void* y, void* dx, float scale, int32_t dtype16, const bst_args* args);
 /* mask_out = mask_in with keys >= autoregress_at_k made causal (see the kernel cited above).  nt_lut [lut_heads][blocks][2] */

@@ -222,3 +222,104 @@ def test_baseline_config_properties(env):
     exp.index_add_(1, ids, kb[:, torch.from_numpy(nn_lut[128:, 1].astype(np.int64)).to("cuda")])
     got = y.view(4, 128, 32, 16, 64)
     assert ((got - exp[:, :, None]).norm() / exp.norm() / np.sqrt(32)).item() < 1e-5
+
+
+# ---- scores + softmax in one launch (bst_nt_softmax, round 6) -----------------------------------------------------------
+def _fused_case(torch, BST, lay, heads, hs, batch, cb, seed, act, score, akey=None):
+    """query_key_softmax against the float64 oracle chain nt -> round to the score type -> masked softmax, and against the two-launch device path."""
+    import _parity as P
+    bst = BST(lay, block_size=32, heads=heads, mask_callback=cb)
+    L = O.build_luts(lay)
+    inp = G.gen_inputs(np.asarray(lay), heads, 32, hs, batch, bst.blocks, seed)
+    Q, K = R.round_to(inp["Q"], act), R.round_to(inp["K"], act)
+    scale = 1.0 / np.sqrt(hs)
+    tq, tk = _tt(torch, Q, act), _tt(torch, K, act)
+    sdt = getattr(torch, {"f16": "float16", "bf16": "bfloat16"}[score])
+    mask_t = None
+    if cb is not None:
+        mask_t = bst.partial_autoregressive_mask(akey, "cuda") if akey is not None else bst._table("mask", "cuda")
+    fused = bst._nt_softmax(tq, tk, scale, mask_t, sdt)
+    two = bst._softmax_fwd(bst._nt(tq, tk, sdt), scale, mask_t, sdt)
+    W = R.round_to(O.nt(L, Q, K, 32, heads), score)
+    mask_np = bst.softmax_mask_np
+    if akey is not None:
+        mask_np = np.ascontiguousarray(O.partial_autoregressive_mask(bst.softmax_mask, L["nt_lut"], 32, akey).transpose(0, 2, 1))
+    Y = O.masked_softmax(L, W, 32, scale, mask_np)
+    return bst, fused, two, Y
+
+
+@pytest.mark.parametrize("act,score", [("f32", "bf16"), ("bf16", "bf16"), ("f16", "f16")])
+@pytest.mark.parametrize("hs", [32, 64, 128])
+def test_fused_scores_softmax_against_oracle(env, act, score, hs):
+    """Local + strided causal layout (the pattern of BASELINE configs[4], 32 context blocks: rows of 1 .. 7 blocks), a rectangular layout
+    with empty rows, head-dependent masks, a partial autoregressive mask: every block against the oracle chain, and within one step of the
+    score type of the two-launch path element by element (the same rounded scores enter the same softmax arithmetic)."""
+    import _parity as P
+    torch, BST = env
+    cases = [(O.local_strided_layout(32), 2, 2, O.causal_mask_callback, None),
+             (O.local_strided_layout(32), 2, 1, O.causal_mask_callback, 7 * 32 + 5),
+             (G.layouts()["rect_3heads"], 3, 2, G.head_cb, None),
+             (np.ones((1, 3, 20), dtype=np.int32), 2, 1, None, None)]              # rows of exactly 20 blocks: five tiles per wave
+    for ci, (lay, heads, batch, cb, akey) in enumerate(cases):
+        bst, fused, two, Y = _fused_case(torch, BST, lay, heads, hs, batch, cb, 30 + ci, act, score, akey)
+        assert fused is not None, (ci, "the fused kernel serves this configuration")
+        got = _np(fused)
+        assert np.isfinite(got).all()
+        assert _err(got, R.round_to(Y, score)) < L2[score], (ci, act, score, hs, _err(got, R.round_to(Y, score)))
+        rep = P.block_report(got.reshape(-1, 32 * 32), _np(two).reshape(-1, 32 * 32), score, got.size // 1024)
+        assert rep["elem_bad"] == 0 and rep["tensor_l2"] < 2e-4, (ci, act, score, hs, rep)      # against the two launches: summation order only
+        # blocks of empty query rows do not exist; every stored block's rows sum to one over the row's blocks
+    lay = np.ones((1, 2, 21), dtype=np.int32)                                      # 21 blocks in a row: not served, the operator composes the two
+    bst = BST(lay, block_size=32, heads=1)
+    q = _tt(torch, np.zeros((1, 64, hs)), act)
+    k = _tt(torch, np.zeros((1, 21 * 32, hs)), act)
+    assert bst._nt_softmax(q, k, 1.0, None, getattr(torch, {"f16": "float16", "bf16": "bfloat16"}[score])) is None
+    y = bst.query_key_softmax(q, k, scale=1.0)
+    assert np.allclose(_np(y), 1.0 / (21 * 32), rtol=1e-2)
+
+
+def test_fused_operator_gradients_match_the_composed_operators(env):
+    """query_key_softmax(q, k) under autograd against masked_softmax(query_key_op(q, k)): the same forward values within a step of bf16 and
+    gradients that agree to the bar of test_autograd_chain_matches_reference_gradients."""
+    torch, BST = env
+    lay = O.local_strided_layout(16, local=3, stride=4)
+    heads, hs, batch = 2, 64, 2
+    bst = BST(lay, block_size=32, heads=heads, mask_callback=O.causal_mask_callback)
+    inp = G.gen_inputs(lay, heads, 32, hs, batch, bst.blocks, 41)
+    scale = 1.0 / np.sqrt(hs)
+    e = _tt(torch, inp["E"], "f32")
+    outs = []
+    for fused in (True, False):
+        q, k, v = (_tt(torch, inp[n], "f32").requires_grad_(True) for n in ("Q", "K", "V"))
+        a = bst.query_key_softmax(q, k, scale=scale) if fused else bst.masked_softmax(bst.query_key_op(q, k), scale=scale)
+        y = bst.weight_value_op(a, v)
+        y.backward(e)
+        outs.append((_np(a), _np(y), _np(q.grad), _np(k.grad), _np(v.grad)))
+    for name, f, c, bar in zip(("a", "y", "dq", "dk", "dv"), outs[0], outs[1], (2e-4, 1e-3, 1e-2, 1e-2, 1e-3)):
+        assert _err(f, c) < bar, (name, _err(f, c))
+
+
+def test_fused_at_baseline_config(env):
+    """BASELINE configs[4] at full size: the fused operator's rows sum to one, vanish above the diagonal, and equal the two launches within a bf16 step."""
+    import _parity as P
+    torch, BST = env
+    lay = O.local_strided_layout(128)
+    bst = BST(lay, block_size=32, heads=16, mask_callback=O.causal_mask_callback)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    shp = (4, 4096, 1024)
+    q = torch.rand(shp, device="cuda", generator=g) * 2 - 1
+    k = torch.rand(shp, device="cuda", generator=g) * 2 - 1
+    a = bst.query_key_softmax(q, k, scale=0.125)
+    b2 = bst.masked_softmax(bst.query_key_op(q, k), scale=0.125)
+    diff = (a.float() - b2.float()).abs()
+    assert (diff.norm() / b2.float().norm()).item() < 2e-4
+    step = torch.maximum(a.float().abs(), b2.float().abs()) * 2.0 ** -7 + 1e-6     # one bf16 step at the value's binade, generously
+    assert bool((diff <= step).all())
+    af = a.float()
+    nn_lut = bst.nn_lut[0]
+    rows = torch.zeros(4, 16, 128, 32, device="cuda")
+    ids = torch.from_numpy(np.repeat(np.arange(128), nn_lut[:128, 1])).to("cuda")
+    rows.index_add_(2, ids, af.sum(dim=-1)[:, :, torch.from_numpy(nn_lut[128:, 0].astype(np.int64)).to("cuda")])
+    assert (rows - 1).abs().max().item() < 2e-2
+    diag = torch.from_numpy(np.nonzero(bst.nt_lut[0][:, 0] == bst.nt_lut[0][:, 1])[0]).to("cuda")
+    assert af[:, :, diag].triu(1).abs().max().item() == 0.0
