@@ -248,6 +248,16 @@ __device__ __forceinline__ void atomic_accumulate(typename DT::T* p, float v) {
     }
 }
 
+// two floats -> two bf16 (round to nearest even) in one dword, lo in bits 0..15: ONE v_cvt_pk_bf16_f32.  (Written as two scalar conversions
+// and a shift / or, hipcc emits two single-operand conversions plus an SDWA or: the three-piece splits of the fp32 paths spent most of their
+// vector instructions there -- 488 per 32 x 32 x 64 tile in bst_nt_mfma_kernel, for 24 matrix instructions; round 6.)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pack2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 struct PtrList8 {
     const void* p[8];
 };

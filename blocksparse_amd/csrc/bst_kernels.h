@@ -234,7 +234,7 @@ bst_nt_mfma_kernel(const typename TA::T* __restrict__ A, const typename TA::T* _
         for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc1[i] = 0.f; }
         if constexpr (SPLIT && !TA::is16) {
             auto split3 = [](const float (&v)[16], uint4 (&p)[3][2]) {          // 16 floats -> 3 pieces x 2 MFMA operands
-                auto pack2 = [](float lo, float hi) { return (uint32_t)DTbf16::from_f32(lo) | ((uint32_t)DTbf16::from_f32(hi) << 16); };
+                auto pack2 = [](float lo, float hi) { return bf16_pack2(lo, hi); };
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     uint32_t a[4], b[4], c3[4];
@@ -487,7 +487,7 @@ bst_xn_split_kernel(const uint16_t* __restrict__ S, const float* __restrict__ Bm
 #pragma unroll
             for (int j = 0; j < 8; ++j) rb[8 * kk + j] = cvalid ? bp[(size_t)(16 * kk + j) * state] : 0.f;
     };
-    auto pack2 = [](float lo, float hi) { return (uint32_t)DTbf16::from_f32(lo) | ((uint32_t)DTbf16::from_f32(hi) << 16); };
+    auto pack2 = [](float lo, float hi) { return bf16_pack2(lo, hi); };
     if (wave < nsteps) request(wave);
     for (int q = wave; q < nsteps; q += 4) {
         uint4 fa[2];
@@ -976,7 +976,7 @@ bst_nt_softmax_kernel(const typename TA::T* __restrict__ A, const typename TA::T
     uint4 rq[TA::is16 ? NCH : 1][2];
     uint4 qp[SPLIT ? NCH : 1][3][2];
     auto split3 = [](const float (&v)[16], uint4 (&p)[3][2]) {                           // as bst_nt_mfma_kernel
-        auto pack2 = [](float lo, float hi) { return (uint32_t)DTbf16::from_f32(lo) | ((uint32_t)DTbf16::from_f32(hi) << 16); };
+        auto pack2 = [](float lo, float hi) { return bf16_pack2(lo, hi); };
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             uint32_t a[4], b[4], c3[4];
