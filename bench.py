@@ -195,7 +195,8 @@ def attention_extra(a):
     actually runs: the fp32 products are computed as six bf16 piece products on the 16-bit matrix core, so the bound is
     max(6 * flops / 2.5 PF, algorithmic bytes / 8 TB/s) -- HBM for every operator here (the fp32-MFMA peak these lines were
     priced against in rounds 3-5 is not the instruction that runs).  `nt_softmax_fused` (round 6) is scores + softmax as one launch: the raw
-    scores never reach memory; `fwd_ms` / `fwd_bwd_ms` use it, `fwd_ms_two_launches` is the composed form.
+    scores never reach memory; `nt_softmax_grad_fused` the backward pair (scores of (dy, v) + softmax gradient).  `fwd_ms` / `fwd_bwd_ms` use them
+    (BlocksparseTransformer.attention), `fwd_ms_two_launches` / `fwd_bwd_ms_composed_backward` are the composed forms.
     CPU baseline: the oracle (NumPy, fp32) on one batch entry and two heads."""
     import torch
     from blocksparse_amd import BlocksparseTransformer
@@ -238,7 +239,8 @@ def attention_extra(a):
            ("masked_softmax", lambda: bst._softmax_fwd(w, scale, mask, sd), 0.0, 2 * sbytes),
            ("nn", lambda: bst._xn(p, v, False), flops, 2 * abytes + sbytes),
            ("tn", lambda: bst._xn(p, q, True), flops, 2 * abytes + sbytes),
-           ("softmax_grad", lambda: bst._softmax_bwd(dp, p, scale), 0.0, 3 * sbytes)]
+           ("softmax_grad", lambda: bst._softmax_bwd(dp, p, scale), 0.0, 3 * sbytes),
+           ("nt_softmax_grad_fused", lambda: bst._nt_softmax_grad(q, v, p, scale), flops, 2 * abytes + 2 * sbytes)]
     res = {}
     for name, fn, fl, by in ops:
         ms = timeit(fn)
@@ -249,7 +251,8 @@ def attention_extra(a):
     # forward + backward of one attention layer = [nt + softmax] (one launch), nn | tn(dv), nt(dp), softmax_grad, nn(dq), tn(dk)
     fwd2 = res["nt"]["ms"] + res["masked_softmax"]["ms"] + res["nn"]["ms"]
     fwd = res["nt_softmax_fused"]["ms"] + res["nn"]["ms"]
-    fb = fwd + res["nt"]["ms"] + res["softmax_grad"]["ms"] + res["nn"]["ms"] + res["tn"]["ms"] * 2
+    fb2 = fwd + res["nt"]["ms"] + res["softmax_grad"]["ms"] + res["nn"]["ms"] + res["tn"]["ms"] * 2
+    fb = fwd + res["nt_softmax_grad_fused"]["ms"] + res["nn"]["ms"] + res["tn"]["ms"] * 2
     # the same operators with bf16 activations (native 16-bit MFMA, HBM-bound): not the BASELINE configuration, for reference
     qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
     res16 = {}
@@ -261,7 +264,7 @@ def attention_extra(a):
                        "bound_ms": round(by / (PEAK_HBM * 1e9) * 1e3, 4), "frac": round(by / (PEAK_HBM * 1e9) * 1e3 / ms, 4)}
     out = {"workload": "BASELINE configs[4]: block-sparse attention batch %d heads %d x %d ctx %d bsize %d, %d blocks/head, fp32 activations, bf16 scores"
                        % (B, H, HS, CTX * BS, BS, bst.blocks),
-           "ops": res, "fwd_ms": round(fwd, 4), "fwd_ms_two_launches": round(fwd2, 4), "fwd_bwd_ms": round(fb, 4),
+           "ops": res, "fwd_ms": round(fwd, 4), "fwd_ms_two_launches": round(fwd2, 4), "fwd_bwd_ms": round(fb, 4), "fwd_bwd_ms_composed_backward": round(fb2, 4),
            "fwd_bwd_tflops": round(6 * flops / fb / 1e9, 2), "ops_bf16_activations": res16}
     if not a.no_cpu_baseline:
         from oracle import bst_oracle as O            # the oracle is only the timed CPU baseline here

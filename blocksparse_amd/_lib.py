@@ -41,7 +41,7 @@ SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_updat_finalize", "bsm
 DIST_SYMBOLS = ("bsmm_dist_unique_id", "bsmm_dist_create", "bsmm_dist_allreduce_begin", "bsmm_dist_allreduce_end", "bsmm_dist_stream",
                 "bsmm_dist_world", "bsmm_dist_destroy", "bsmm_dist_dw_shard_elems", "bsmm_dist_dw_layout", "bsmm_dist_dw_begin", "bsmm_dist_dw_emulate",
                 "bsmm_dist_dw_end")
-BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask", "bst_nt_softmax")
+BST_SYMBOLS = ("bst_nt", "bst_nn", "bst_tn", "bst_masked_softmax", "bst_softmax_grad", "bst_partial_autoregressive_mask", "bst_nt_softmax", "bst_nt_softmax_grad")
 
 
 class BsmmArgs(ctypes.Structure):
@@ -191,6 +191,8 @@ def load():
     lib.bst_masked_softmax.restype = ctypes.c_int
     lib.bst_nt_softmax.argtypes = [vp, vp, vp, vp, i32, f32, i32, pbst]
     lib.bst_nt_softmax.restype = ctypes.c_int
+    lib.bst_nt_softmax_grad.argtypes = [vp, vp, vp, vp, f32, i32, pbst]
+    lib.bst_nt_softmax_grad.restype = ctypes.c_int
     lib.bst_softmax_grad.argtypes = [vp, vp, vp, f32, i32, pbst]
     lib.bst_softmax_grad.restype = ctypes.c_int
     lib.bst_partial_autoregressive_mask.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]

@@ -182,8 +182,10 @@ int bst_masked_softmax(const void* x, void* y, const void* mask, int32_t mask_he
     });
 }
 
-// scores + softmax in one launch (round 6, bsize 32): see bst_nt_softmax_kernel.  args->lut = nn_lut; max_row_blocks = the longest query row of the layout
-int bst_nt_softmax(const void* q_, const void* k_, void* y_, const void* mask, int32_t mask_heads, float scale, int32_t max_row_blocks, const bst_args* a) {
+// scores + softmax in one launch (round 6, bsize 32): see bst_nt_softmax_kernel.  args->lut = nn_lut; max_row_blocks = the longest query row of the layout.
+// probs != NULL: the backward pair -- dx = softmax_grad(round(e . v^T), probs) -- with q_ = e, k_ = v (bst_nt_softmax_grad below)
+static int nt_softmax(const void* q_, const void* k_, void* y_, const void* mask, int32_t mask_heads, float scale, int32_t max_row_blocks, const void* probs,
+                      const bst_args* a) {
     if (int rc = check_mm(a)) return rc;
     if (!q_ || !k_ || !y_ || max_row_blocks <= 0) return BSMM_ERR_ARG;
     if (a->lut_dim != a->ctx_blks_q + a->blocks) return BSMM_ERR_ARG;
@@ -203,14 +205,26 @@ int bst_nt_softmax(const void* q_, const void* k_, void* y_, const void* mask, i
         const int grid = xcd_head_grid(a->ctx_blks_q, a->heads, a->batch);
         auto go = [&](auto ch_tag) {
             constexpr int CH = decltype(ch_tag)::value;
-            bst_nt_softmax_kernel<TA, TS, CH, !TA::is16><<<grid, 256, 0, st>>>(Q, K, Y, a->lut, lut_stride(a), static_cast<const uint32_t*>(mask), mstride, a->blocks,
-                                                                              a->heads, a->batch, a->head_state, rq, rk, a->ctx_blks_q, scale);
+            if (probs)
+                bst_nt_softmax_kernel<TA, TS, CH, !TA::is16, true><<<grid, 256, 0, st>>>(Q, K, Y, a->lut, lut_stride(a), nullptr, 0, a->blocks, a->heads, a->batch,
+                                                                                        a->head_state, rq, rk, a->ctx_blks_q, scale, static_cast<const typename TS::T*>(probs));
+            else
+                bst_nt_softmax_kernel<TA, TS, CH, !TA::is16><<<grid, 256, 0, st>>>(Q, K, Y, a->lut, lut_stride(a), static_cast<const uint32_t*>(mask), mstride, a->blocks,
+                                                                                  a->heads, a->batch, a->head_state, rq, rk, a->ctx_blks_q, scale);
         };
         if (a->head_state == 32) go(std::integral_constant<int, 1>{});
         else if (a->head_state == 64) go(std::integral_constant<int, 2>{});
         else go(std::integral_constant<int, 4>{});
         return (int)hipGetLastError();
     });
+}
+
+int bst_nt_softmax(const void* q, const void* k, void* y, const void* mask, int32_t mask_heads, float scale, int32_t max_row_blocks, const bst_args* a) {
+    return nt_softmax(q, k, y, mask, mask_heads, scale, max_row_blocks, nullptr, a);
+}
+int bst_nt_softmax_grad(const void* e, const void* v, const void* probs, void* dx, float scale, int32_t max_row_blocks, const bst_args* a) {
+    if (!probs) return BSMM_ERR_ARG;
+    return nt_softmax(e, v, dx, nullptr, 1, scale, max_row_blocks, probs, a);
 }
 
 int bst_softmax_grad(const void* dy, const void* y, void* dx, float scale, int32_t dtype16, const bst_args* a) {

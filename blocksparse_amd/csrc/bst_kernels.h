@@ -894,11 +894,13 @@ bst_softmax_grad_kernel(const typename T16::T* __restrict__ DY, const typename T
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int NTS_MAXT = 5;          // tiles per wave: rows of up to 20 blocks
 
-template <class TA, class TS, int NCH, bool SPLIT>
+// GRAD: the same launch shape for the backward pair bst_nt (dP = E . V^T) + bst_softmax_grad: dX = (dP - sum_row(dP * P)) * P * scale with dP rounded
+// to the score type as the two launches would store it; P (the forward's probabilities) is read in the store layout, requested before the tile loop.
+template <class TA, class TS, int NCH, bool SPLIT, bool GRAD = false>
 __global__ void __launch_bounds__(256)
 bst_nt_softmax_kernel(const typename TA::T* __restrict__ A, const typename TA::T* __restrict__ B, typename TS::T* __restrict__ Y,
                       const int32_t* __restrict__ lut, int lut_stride, const uint32_t* __restrict__ mask, int mask_stride, int blocks, int heads,
-                      int batch, int hs, int rows_q, int rows_k, int ctx_q, float scale) {
+                      int batch, int hs, int rows_q, int rows_k, int ctx_q, float scale, const typename TS::T* __restrict__ Pin = nullptr) {
     typedef typename TA::T T;
     typedef NtTile<T> TL;
     constexpr int BS = 32;
@@ -960,13 +962,23 @@ bst_nt_softmax_kernel(const typename TA::T* __restrict__ A, const typename TA::T
     const int i0 = lane >> 2, p = lane & 3;
     const uint32_t* mrow = mask ? mask + (size_t)h * mask_stride : nullptr;
     int bt[NTS_MAXT];
-    uint32_t mk[NTS_MAXT][2];
+    uint32_t mk[GRAD ? 1 : NTS_MAXT][2];
+    uint4 pv[GRAD ? NTS_MAXT : 1][2];                                                    // GRAD: my 8 probabilities of (tile, row i0 / i0 + 16)
+    typename TS::T* ybase = Y + ((size_t)n * heads + h) * blocks * (BS * BS);
 #pragma unroll
     for (int t = 0; t < NTS_MAXT; ++t) {
-        bt[t] = 0; mk[t][0] = mk[t][1] = 0xffffffffu;
+        bt[t] = 0;
+        if constexpr (!GRAD) mk[t][0] = mk[t][1] = 0xffffffffu;
+        else pv[t][0] = pv[t][1] = make_uint4(0u, 0u, 0u, 0u);
         if (t < mine) {
             bt[t] = __builtin_amdgcn_readfirstlane(ent[2 * (wave + 4 * t)]);
-            if (mrow) { mk[t][0] = mrow[(size_t)i0 * blocks + bt[t]]; mk[t][1] = mrow[(size_t)(i0 + 16) * blocks + bt[t]]; }
+            if constexpr (!GRAD) {
+                if (mrow) { mk[t][0] = mrow[(size_t)i0 * blocks + bt[t]]; mk[t][1] = mrow[(size_t)(i0 + 16) * blocks + bt[t]]; }
+            } else {
+                const typename TS::T* pb = Pin + ((size_t)n * heads + h) * blocks * (BS * BS) + (size_t)bt[t] * (BS * BS) + p * 8;
+                pv[t][0] = *reinterpret_cast<const uint4*>(pb + (size_t)i0 * BS);
+                pv[t][1] = *reinterpret_cast<const uint4*>(pb + (size_t)(i0 + 16) * BS);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1060,6 +1072,54 @@ bst_nt_softmax_kernel(const typename TA::T* __restrict__ A, const typename TA::T
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define XCH(w_, v_, i_) reinterpret_cast<float*>(&lds_k[v_][0][0])[32 * (w_) + (i_)]
+    if constexpr (GRAD) {
+        // ---- softmax gradient over the parked tiles of dP, in the store layout ----
+        auto pair8 = [&](int t, int k, float (&d)[8], float (&y)[8]) {
+            const int i = i0 + 16 * k;
+            const uint4 x = *reinterpret_cast<const uint4*>(&olds[wave][0][0] + t * 2048 + i * 64 + ((p ^ ((i >> 2) & 3)) << 4));
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w}, q4[4] = {pv[t][k].x, pv[t][k].y, pv[t][k].z, pv[t][k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[2 * j] = TS::to_f32((uint16_t)(w[j] & 0xffffu)); d[2 * j + 1] = TS::to_f32((uint16_t)(w[j] >> 16));
+                y[2 * j] = TS::to_f32((uint16_t)(q4[j] & 0xffffu)); y[2 * j + 1] = TS::to_f32((uint16_t)(q4[j] >> 16));
+            }
+        };
+        float sum[2] = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NTS_MAXT; ++t)
+            if (t < mine) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float d[8], y[8];
+                    pair8(t, k, d, y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum[k] += d[j] * y[j];
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            sum[k] += __shfl_xor(sum[k], 1); sum[k] += __shfl_xor(sum[k], 2);
+            if (p == 0) XCH(1, wave, i0 + 16 * k) = sum[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) sum[k] = ((XCH(1, 0, i0 + 16 * k) + XCH(1, 1, i0 + 16 * k)) + XCH(1, 2, i0 + 16 * k)) + XCH(1, 3, i0 + 16 * k);
+#pragma unroll
+        for (int t = 0; t < NTS_MAXT; ++t)
+            if (t < mine) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float d[8], y[8];
+                    pair8(t, k, d, y);
+                    uint32_t o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = (uint32_t)TS::from_f32((d[2 * j] - sum[k]) * y[2 * j] * scale) | ((uint32_t)TS::from_f32((d[2 * j + 1] - sum[k]) * y[2 * j + 1] * scale) << 16);
+                    *reinterpret_cast<uint4*>(ybase + (size_t)bt[t] * (BS * BS) + (size_t)(i0 + 16 * k) * BS + p * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+    } else {
     // ---- softmax over the parked tiles: lane -> (row i0 = lane >> 2 and i0 + 16, piece p = lane & 3: keys 8p .. 8p + 7) ----
     const float NEG = -3.402823466e+38f;
     const float sc2 = scale * 1.4426950408889634f;
@@ -1074,7 +1134,6 @@ bst_nt_softmax_kernel(const typename TA::T* __restrict__ A, const typename TA::T
             v[2 * j + 1] = ((m >> (2 * j + 1)) & 1) ? TS::to_f32((uint16_t)(w[j] >> 16)) * sc2 : NEG;
         }
     };
-#define XCH(w_, v_, i_) reinterpret_cast<float*>(&lds_k[v_][0][0])[32 * (w_) + (i_)]
     float mx[2] = {NEG, NEG};
 #pragma unroll
     for (int t = 0; t < NTS_MAXT; ++t)
@@ -1116,8 +1175,6 @@ bst_nt_softmax_kernel(const typename TA::T* __restrict__ A, const typename TA::T
     float rcp[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) rcp[k] = 1.0f / (((XCH(1, 0, i0 + 16 * k) + XCH(1, 1, i0 + 16 * k)) + XCH(1, 2, i0 + 16 * k)) + XCH(1, 3, i0 + 16 * k));
-#undef XCH
-    typename TS::T* ybase = Y + ((size_t)n * heads + h) * blocks * (BS * BS);
 #pragma unroll
     for (int t = 0; t < NTS_MAXT; ++t)
         if (t < mine) {
@@ -1132,6 +1189,8 @@ bst_nt_softmax_kernel(const typename TA::T* __restrict__ A, const typename TA::T
                 *reinterpret_cast<uint4*>(ybase + (size_t)bt[t] * (BS * BS) + (size_t)(i0 + 16 * k) * BS + p * 8) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
+    }   // !GRAD
+#undef XCH
 }
 
 template <int BS>

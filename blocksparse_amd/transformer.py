@@ -223,6 +223,23 @@ class BlocksparseTransformer(object):
         _lib.check(rc, "bst_nt_softmax")
         return y
 
+    def _nt_softmax_grad(self, e, v, y, scale):
+        """dx = softmax_grad(scores(e, v) rounded to y's type, y) as ONE launch (bst_nt_softmax_grad); None where the fused kernel does not serve."""
+        self._check_act(e, self.ctx_blks_q, "e")
+        self._check_act(v, self.ctx_blks_k, "v")
+        self._check_scores(y, e.shape[0])
+        hs = e.shape[2] // self.heads
+        if self.blk_size != 32 or self.nn_max > 20 or hs not in (32, 64, 128) or e.dtype != v.dtype:
+            return None
+        lut = self._table("nn_lut", e.device)
+        dx = torch.empty_like(y)
+        args = self._args(lut, e.shape[0], hs, _code(e.dtype), _code(y.dtype))
+        rc = _lib.load().bst_nt_softmax_grad(e.data_ptr(), v.data_ptr(), y.data_ptr(), dx.data_ptr(), float(scale), int(self.nn_max), ctypes.byref(args))
+        if rc == -2:
+            return None
+        _lib.check(rc, "bst_nt_softmax_grad")
+        return dx
+
     def _softmax_bwd(self, dy, y, scale):
         self._check_scores(y, y.shape[0])
         dy = dy.contiguous().to(y.dtype)
@@ -280,6 +297,22 @@ class BlocksparseTransformer(object):
 
     def weight_value_op(self, w, v, name=None, bench=0):
         return _XN.apply(self, w, v, False)
+
+    def attention(self, q, k, v, scale=1.0, autoregress_at_key=None):
+        """``weight_value_op(masked_softmax(query_key_op(q, k), scale, autoregress_at_key), v)`` as one operator (round 6): two launches forward
+        (scores + softmax, weighted values) and four backward (dv; [scores of (dy, v) + softmax gradient] as one; dq; dk) where the fused kernels
+        serve the configuration, the reference's composition elsewhere.  The probabilities are kept for the backward pass, the raw scores and
+        the gradient of the probabilities never reach memory."""
+        self.softmax_dtype = self._score_dtype(q.dtype)
+        if self.softmax_mask is None:
+            if autoregress_at_key is not None:
+                raise ValueError("autoregress_at_key only applies to ops with mask_callback defined.")
+            mask_t = None
+        elif autoregress_at_key is not None:
+            mask_t = self.partial_autoregressive_mask(autoregress_at_key, q.device)
+        else:
+            mask_t = self._table("mask", q.device)
+        return _Attention.apply(self, q, k, v, float(scale), mask_t, self.softmax_dtype)
 
     def masked_softmax(self, x, scale=1.0, autoregress_at_key=None, dtype=None):
         if self.softmax_mask is None:
@@ -415,6 +448,33 @@ if torch is not None:
             dk = bst._xn(dw, q, True)
             dq = bst._xn(dw, k, False)
             return None, dq, dk, None, None, None
+
+    class _Attention(torch.autograd.Function):
+        """y = nn(softmax(scale * nt(q, k) + mask), v) with the gradients of the three registered ops composed
+        (blocksparse/transformer.py:411-509): dv = tn(a, dy); dx = softmax_grad(nt(dy, v), a); dq = nn(dx, k); dk = tn(dx, q)."""
+
+        @staticmethod
+        def forward(ctx, bst, q, k, v, scale, mask_t, a_dtype):
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+            a = bst._nt_softmax(q, k, scale, mask_t, a_dtype)
+            if a is None:
+                a = bst._softmax_fwd(bst._nt(q, k, torch.bfloat16), scale, mask_t, a_dtype)
+            ctx.bst, ctx.scale = bst, scale
+            ctx.save_for_backward(q, k, v, a)
+            return bst._xn(a, v, False)
+
+        @staticmethod
+        def backward(ctx, dy):
+            q, k, v, a = ctx.saved_tensors
+            bst = ctx.bst
+            dy = dy.contiguous()
+            dv = bst._xn(a, dy, True)
+            dx = bst._nt_softmax_grad(dy, v, a, ctx.scale)
+            if dx is None:
+                dx = bst._softmax_bwd(bst._nt(dy, v, a.dtype), a, ctx.scale)
+            dq = bst._xn(dx, k, False)
+            dk = bst._xn(dx, q, True)
+            return None, dq, dk, dv, None, None, None
 
     class _XN(torch.autograd.Function):
         """c = w . b (nn) or w^T . b (tn); nn gradients as blocksparse_transformer_nn_grad

@@ -73,6 +73,11 @@ int bst_masked_softmax(const void* x, void* y, const void* mask, int32_t mask_he
  * up to 20 blocks; anything else returns BSMM_ERR_UNSUPPORTED and the caller runs the two entry points.                                      */
 int bst_nt_softmax(const void* q, const void* k, void* y, const void* mask, int32_t mask_heads, float scale, int32_t max_row_blocks,
                    const bst_args* args);
+/* The backward pair of an attention layer as one launch: dx = (dp - sum_row(dp * probs)) * probs * scale with dp = round_to_score_dtype(e . v^T)
+ * -- bst_nt(e, v) followed by bst_softmax_grad(dp, probs) (blocksparse/transformer.py:446-509: the nn gradient w.r.t. the scores, then
+ * blocksparse_softmax_grad); dp never reaches memory.  e: gradient of the layer's output (query rows), v: values (key rows), probs and dx of
+ * args->score_dtype.  Same limits and the same BSMM_ERR_UNSUPPORTED contract as bst_nt_softmax.                                              */
+int bst_nt_softmax_grad(const void* e, const void* v, const void* probs, void* dx, float scale, int32_t max_row_blocks, const bst_args* args);
 /* dx = (dy - sum_row(dy * y)) * y * scale; dy, y, dx share `dtype16` (bf16 / fp16).  args->lut = nn_lut.                   */
 int bst_softmax_grad(const void* dy, const void* y, void* dx, float scale, int32_t dtype16, const bst_args* args);
 /* mask_out = mask_in with keys >= autoregress_at_k made causal (see the kernel cited above).  nt_lut [lut_heads][blocks][2] */

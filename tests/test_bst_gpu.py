@@ -323,3 +323,56 @@ def test_fused_at_baseline_config(env):
     assert (rows - 1).abs().max().item() < 2e-2
     diag = torch.from_numpy(np.nonzero(bst.nt_lut[0][:, 0] == bst.nt_lut[0][:, 1])[0]).to("cuda")
     assert af[:, :, diag].triu(1).abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("act,score", [("f32", "bf16"), ("bf16", "bf16"), ("f16", "f16")])
+def test_fused_backward_pair_against_oracle(env, act, score):
+    """bst_nt_softmax_grad: dx = softmax_grad(round(e . v^T), probs) as one launch, against the float64 oracle chain and within one step of the
+    score type of the two launches (bst_nt, bst_softmax_grad)."""
+    import _parity as P
+    torch, BST = env
+    for ci, (lay, heads, batch, hs) in enumerate(((O.local_strided_layout(32), 2, 2, 64), (G.layouts()["rect_3heads"], 3, 1, 32),
+                                                  (np.ones((1, 2, 20), dtype=np.int32), 2, 1, 128))):
+        bst = BST(lay, block_size=32, heads=heads, mask_callback=O.causal_mask_callback if ci == 0 else None)
+        L = O.build_luts(lay)
+        inp = G.gen_inputs(np.asarray(lay), heads, 32, hs, batch, bst.blocks, 50 + ci)
+        E, V = R.round_to(inp["E"], act), R.round_to(inp["V"], act)
+        X = R.round_to(inp["X"], score)
+        scale = 1.0 / np.sqrt(hs)
+        Yp = R.round_to(O.masked_softmax(L, X, 32, scale, bst.softmax_mask_np), score)          # some probabilities
+        te, tv, ty = _tt(torch, E, act), _tt(torch, V, act), _tt(torch, Yp, score)
+        fused = bst._nt_softmax_grad(te, tv, ty, scale)
+        assert fused is not None
+        two = bst._softmax_bwd(bst._nt(te, tv, ty.dtype), ty, scale)
+        DP = R.round_to(O.nt(L, E, V, 32, heads), score)
+        ref = O.masked_softmax_grad(L, DP, Yp, scale)
+        got = _np(fused)
+        assert np.isfinite(got).all()
+        assert _err(got, R.round_to(ref, score)) < L2[score], (ci, act, score, _err(got, R.round_to(ref, score)))
+        rep = P.block_report(got.reshape(-1, 1024), _np(two).reshape(-1, 1024), score, got.size // 1024)
+        assert rep["tensor_l2"] < 3e-4, (ci, act, score, rep)
+
+
+def test_attention_operator_matches_the_composed_operators(env):
+    """BlocksparseTransformer.attention(q, k, v): values and all three gradients against the three composed operators."""
+    torch, BST = env
+    lay = O.local_strided_layout(16, local=3, stride=4)
+    heads, hs, batch = 2, 64, 2
+    bst = BST(lay, block_size=32, heads=heads, mask_callback=O.causal_mask_callback)
+    inp = G.gen_inputs(lay, heads, 32, hs, batch, bst.blocks, 43)
+    scale = 1.0 / np.sqrt(hs)
+    e = _tt(torch, inp["E"], "f32")
+    outs = []
+    for fused in (True, False):
+        q, k, v = (_tt(torch, inp[n], "f32").requires_grad_(True) for n in ("Q", "K", "V"))
+        y = bst.attention(q, k, v, scale=scale) if fused else bst.weight_value_op(bst.masked_softmax(bst.query_key_op(q, k), scale=scale), v)
+        y.backward(e)
+        outs.append((_np(y), _np(q.grad), _np(k.grad), _np(v.grad)))
+    for name, f, c, bar in zip(("y", "dq", "dk", "dv"), outs[0], outs[1], (1e-3, 1e-2, 1e-2, 1e-3)):
+        assert _err(f, c) < bar, (name, _err(f, c))
+    # a layout the fused kernels do not serve (bsize 64): the operator composes the reference's three
+    bst64 = BST(np.tril(np.ones((4, 4), dtype=np.int32)), block_size=64, heads=2)
+    q, k, v = (torch.rand(1, 256, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3 + i)).requires_grad_(True) for i in range(3))
+    y = bst64.attention(q, k, v, scale=0.125)
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(q.grad).all() and torch.isfinite(k.grad).all() and torch.isfinite(v.grad).all()
