@@ -1175,6 +1175,9 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
             const size_t per_item = U2_WAVES;
             // spread the load over the four SIMDs: waves v, v+4, v+8, v+12 share a matrix pipe -> deal waves sorted by load
             std::sort(waves.begin(), waves.end(), [](const Wave& a, const Wave& b) { return a.n > b.n; });
+            // (Round 6 also tried to CAP an item at 60 / 56 / 52 blocks and give the rest to the direct list -- items of 57 - 64 blocks are compute-paced,
+            //  63 - 66 us against the 57.5 us of the stream-paced ones: 94.5 - 96.8 / 101.5 - 102.7 / 97.5 - 99.5 us per call against 92.5 - 93.1:
+            //  a few dozen direct blocks x 4 workgroups cost more than the dense items lose, profiles/r06_updat_item_cap.txt)
             for (size_t beg = 0; beg < waves.size(); beg += per_item) {
                 const size_t cnt = std::min<size_t>(per_item, waves.size() - beg);
                 std::vector<Wave> dealt(U2_WAVES);
