@@ -33,6 +33,7 @@ PLAN_UPDAT16_WINDOWED = 0x40000  # bsize 16, feature axis 0: no 'BSU6' section (
 PLAN_UPDAT_NO_DIRECT = 0x80000   # 'BSU2' plans without direct blocks (round 6): overflow items in a sliced last round instead
 PLAN_XCOL_ROWS = 0x20000       # retired in round 6 (the row-split kernel of round 5): ignored by the builders
 PLAN_FLOW_SCHEDULED = 0x10000  # BSX4 plans, experiment: list-scheduled step order instead of ascending input blocks
+PLAN_WINDOW_MASK = 0xf0         # the window / kernel-family field of the updat plan options
 PLAN_XCOL_NARROW, PLAN_F32_MFMA, PLAN_WINDOW_8, PLAN_WINDOW_16, PLAN_WINDOW_16W, PLAN_STREAM_16, PLAN_STREAM_8, PLAN_STREAM_32 = 1, 2, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60
 
 SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_updat_finalize", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_sparse_op", "bsmm_sparse_mul_grad", "bsmm_workspace_bytes",

@@ -1638,6 +1638,10 @@ static long updat_plan(const int32_t* lut, int32_t blocks, int32_t CB, int32_t K
         int ws = force == BSMM_PLAN_STREAM_16 ? 16 : (force == BSMM_PLAN_STREAM_8 ? 8 : (blocks <= 56.0 * windows ? 16 : 8));
         // very sparse layouts on feature axis 1: 32 x 32 windows (a 16 x 16 window then holds < 10 blocks for its 32 KiB per chunk).  Measured at
         // 8192^2, N = 4096 (profiles/r03_updat_ws32.txt): 3 % 71 against 95 us; 5 % (BASELINE configs[3]) 102 against 96 -- so only below ~3.7 %
+        // (Round 6: with DIRECT blocks the bigger window also wins at 4 - 5 % on a grid of >= 64 such windows -- 8192^2 N = 4096, BASELINE configs[3]:
+        //  81 / 85 / 91 us at 4 / 4.5 / 5 % against 99 / 98 / 100 -- but only for LONG minibatches: at N = 1024 / 2048 it loses, 42 / 57 against 29 / 50 us,
+        //  because 64 items need the partial sums and their summing pass where 256 items store directly.  A plan does not know the minibatch, so the
+        //  rule stays; the host class builds the BSMM_PLAN_STREAM_32 plan as well and picks per call: profiles/r06_updat_ws32.txt)
         const double windows32 = (double)((CB + 31) / 32) * ((KB + 31) / 32);
         if (force == BSMM_PLAN_STREAM_32 || (force == 0 && axis == 1 && windows32 >= 16 && blocks <= 38.0 * windows32)) ws = 32;
         // direct blocks (round 6): what a window's 16 waves cannot hold gets its own workgroups instead of a sliced last round (feature axis 1)

@@ -124,9 +124,16 @@ class _DeviceTables(object):
         self.fprop_plan_f32 = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.F32, axis, plan_options))
         self.bprop_plan_f32 = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.F32, axis, plan_options))
         self.updat_plan = plan(_host_updat_plan(tables["updat_lut"], B, CB, KB, bsize, _lib.BF16, axis, plan_options))
+        # round 6: 32 x 32-block windows for LONG minibatches on grids of >= 64 such windows at 3.7 .. 5 % density (BASELINE configs[3]: 91 against 100 us at
+        # N = 4096; at N <= 2048 the 16 x 16 windows' direct stores win) -- a plan does not know the minibatch, BlocksparseMatMul.updat picks per call
+        self.updat_plan_long = None
+        w32 = (-(-CB // 32)) * (-(-KB // 32))
+        if bsize == 32 and axis == 1 and not (plan_options & _lib.PLAN_WINDOW_MASK) and w32 >= 64 and 38 * w32 < B <= 52 * w32:
+            self.updat_plan_long = plan(_host_updat_plan(tables["updat_lut"], B, CB, KB, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_STREAM_32))
 
 
 class BlocksparseMatMul(object):
+    LONG_MINIBATCH = 3072     # rows x pairs from which the 32 x 32-window updat plan (where one was built) is used: between 2048 (loses) and 4096 (wins)
 
     def __getstate__(self):
         return (self.layout, self.bsize, self.axis, self.z_order, self.name, self.segmented, self.plan_options, self.updat_split)
@@ -511,8 +518,11 @@ class BlocksparseMatMul(object):
         # pairs of one launch of the 16-bit kernel, round 4; bsize 16 on feature axis 0: round 5, where the row-owner kernel pays -- the library
         # falls back to the kernels without a plan by itself); other fp32 configurations run the kernels without a plan
         use_plan = xs[0].dtype != torch.float32 or (len(xs) == 1 and ((self.bsize == 32 and self.axis == 1) or self.bsize in (8, 16)))
+        uplan = tabs.updat_plan
+        if tabs.updat_plan_long is not None and N * len(xs) >= self.LONG_MINIBATCH and xs[0].dtype != torch.float32:
+            uplan = tabs.updat_plan_long
         a, ws, _ = self._call_args(_lib.OP_UPDAT, tabs, tabs.updat, None, N, self.C, self.K, xs[0].dtype,
-                                   tabs.updat_plan if use_plan else None, slot=slot, pcount=len(xs), flags=flags,
+                                   uplan if use_plan else None, slot=slot, pcount=len(xs), flags=flags,
                                    gated=gate is not None and not sums_only)
         a.alpha, a.beta = alpha, beta
         if gate is not None and not sums_only:

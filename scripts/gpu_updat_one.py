@@ -25,7 +25,7 @@ out = []
 for c in cases:
     d, o = c.split(":")
     CBK, NN = int(os.environ.get("CB", "128")), int(os.environ.get("N", "8192"))
-    lay = P.random_layout(CBK, CBK, int(d[1:]) / 100.0, 1234)
+    lay = P.random_layout(CBK, CBK, float(d[1:]) / 100.0, 1234)
     b = BlocksparseMatMul(lay, block_size=32, feature_axis=int(os.environ.get("AXIS", "1")), plan_options=OPT[o])
     g = torch.Generator(device="cuda").manual_seed(1)
     x = (torch.randn(b.i_shape(NN), device="cuda", generator=g) * 0.1).bfloat16()

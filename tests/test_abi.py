@@ -596,13 +596,14 @@ def test_streaming_updat_plan(lib):
         t = L.build_tables(lay)
         for opt, axis in ((0, 1), (lib.PLAN_STREAM_16, 1), (lib.PLAN_STREAM_8, 1), (0, 0), (lib.PLAN_STREAM_16, 0)):
             plan = _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, axis, opt)
-            if axis == 0:       # the same items as feature axis 1 without direct blocks
-                assert (plan == _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, opt | lib.PLAN_UPDAT_NO_DIRECT)).all()
+            if axis == 0:       # the same items as feature axis 1 without direct blocks (and with the same window side: 32 x 32 windows are feature axis 1's)
+                force = opt or {16: lib.PLAN_STREAM_16, 8: lib.PLAN_STREAM_8}[int(plan[2])]
+                assert (plan == _host_updat_plan(t["updat_lut"], t["blocks"], CB, KB, 32, lib.BF16, 1, force | lib.PLAN_UPDAT_NO_DIRECT)).all()
             assert plan[0] == 0x42535532 and plan[1] == 3 and plan[3] == 4 and plan[5] == t["blocks"] and plan[7] == 16 and plan[6] == 32
             WS, nitems = int(plan[2]), int(plan[4])
             if opt == 0:
                 w32 = (-(-CB // 32)) * (-(-KB // 32))
-                if w32 >= 16 and t["blocks"] <= 38 * w32:
+                if axis == 1 and w32 >= 16 and t["blocks"] <= 38 * w32:
                     assert WS == 32                                    # very sparse layouts (round 3)
                     continue                                           # (the fifth index bits ride in the id words: decoded by the GPU tests)
                 assert WS == (16 if t["blocks"] <= 56 * (-(-CB // 16)) * (-(-KB // 16)) else 8)

@@ -38,6 +38,7 @@ CASES = [
     ("bench layout, ragged N 1000", P.random_layout(128, 128, 0.2, 1234), 1000, "f16"),
     ("bench layout, N 40: fewer chunks than parts x waves", P.random_layout(128, 128, 0.2, 1234), 40, "bf16"),
     ("bench layout, N 8: one chunk, three empty quarters", P.random_layout(128, 128, 0.2, 1234), 8, "bf16"),
+    ("8192^2 5 % (BASELINE configs[3]): 32 x 32-block windows with direct blocks, N 1024", P.random_layout(256, 256, 0.05, 1234), 1024, "bf16"),
     ("48 x 40, window (0, 0) crowded to ~80 blocks, N 520", _crowded(48, 40, 0.2, 5, 30), 520, "bf16"),
     ("33 x 17 (ragged windows), crowded, N 2048", _crowded(33, 17, 0.22, 9, 25), 2048, "f16"),
 ]
@@ -47,8 +48,9 @@ CASES = [
 def test_direct_blocks_against_the_oracle(env, case):
     torch, BSMM, lib = env
     name, lay, N, dt = case
-    b = BSMM(lay, block_size=32, feature_axis=1)
-    bn = BSMM(lay, block_size=32, feature_axis=1, plan_options=lib.PLAN_UPDAT_NO_DIRECT)
+    big = "32 x 32-block windows" in name                         # (the host class builds that plan for long minibatches only: force it here)
+    b = BSMM(lay, block_size=32, feature_axis=1, plan_options=lib.PLAN_STREAM_32 if big else 0)
+    bn = BSMM(lay, block_size=32, feature_axis=1, plan_options=lib.PLAN_UPDAT_NO_DIRECT | (lib.PLAN_STREAM_32 if big else 0))
     dev = torch.device("cuda")
     hp, hn = b._tables_on(dev).updat_plan.host, bn._tables_on(dev).updat_plan.host
     ndir = int(hp[28])
@@ -114,3 +116,30 @@ def test_direct_blocks_through_autograd_and_fp32(env):
     y.backward(P.to_dev(E, "bf16", torch))
     ref = orc.updat_fast(t, P.to_host(xb).astype(np.float64), P.to_host(P.to_dev(E, "bf16", torch)).astype(np.float64), 1, dtype=np.float64)
     P.assert_blocks(P.to_host(w.grad), ref, "bf16", b.blocks, "w.grad")
+
+
+def test_long_minibatches_take_the_big_window_plan(env):
+    """BASELINE configs[3]'s layout (8192^2, 5 %): the host class holds two weight-gradient plans and picks per call -- 16 x 16-block windows (direct
+    stores) below BlocksparseMatMul.LONG_MINIBATCH rows, 32 x 32-block windows (with direct blocks) from there on; both against the oracle."""
+    torch, BSMM, lib = env
+    lay = P.random_layout(256, 256, 0.05, 1234)
+    b = BSMM(lay, block_size=32, feature_axis=1)
+    tabs = b._tables_on(torch.device("cuda"))
+    assert tabs.updat_plan_long is not None and int(tabs.updat_plan.host[2]) == 16 and int(tabs.updat_plan_long.host[2]) == 32
+    t = orc.build_layout_luts(np.asarray(lay), 32)
+    for N in (2048, 4096):
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "bf16", seed=N)
+        x, e = P.to_dev(X, "bf16", torch), P.to_dev(E, "bf16", torch)
+        calls = []
+        real = b._call_args
+        b._call_args = lambda *a, **k: (calls.append(a[8]), real(*a, **k))[1]
+        try:
+            got = P.to_host(b.updat(x, e))
+        finally:
+            b._call_args = real
+        assert lib.last_kernel() == lib.K_UPDAT_STREAM
+        assert int(calls[-1].host[2]) == (32 if N >= b.LONG_MINIBATCH else 16), N        # window side of the plan the call ran with
+        ws = sorted(set(range(0, b.blocks, 37)) | {b.blocks - 1})
+        ref = orc.updat_blocks(t, P.to_host(x), P.to_host(e), 1, ws)
+        P.assert_blocks(np.stack([got[i] for i in ws]), np.stack([ref[i] for i in ws]), "bf16", len(ws), ("sampled blocks", N))
+    assert BSMM(P.random_layout(128, 128, 0.05, 1234), block_size=32, feature_axis=1)._tables_on(torch.device("cuda")).updat_plan_long is None     # 16 windows only
