@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                                            # GB/s (spec)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 CLOCK_GHZ = 2.4                                              # nominal shader clock the per-clock figures are quoted at
 L2_TO_LDS_CEILING = 52.0                                     # B/clk/CU: the L2-resident LDS-DMA streaming micro-benchmark (scripts/micro/l2_bw.hip)
 
