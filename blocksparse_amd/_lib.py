@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BSMM_LIB: load another build of the same library (kernel A/B experiments: scripts/build_variants.py); product = the default
 LIB_PATH = os.environ.get("BSMM_LIB") or os.path.join(_HERE, "libbsmm_hip.so")
 
-ABI_VERSION = 125        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
+ABI_VERSION = 126        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
 FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN, FLAG_DW_SUMS, FLAG_FORCE_MID = 1, 2, 4, 8, 16, 32
@@ -36,7 +36,7 @@ PLAN_FLOW_SCHEDULED = 0x10000  # BSX4 plans, experiment: list-scheduled step ord
 PLAN_WINDOW_MASK = 0xf0         # the window / kernel-family field of the updat plan options
 PLAN_XCOL_NARROW, PLAN_F32_MFMA, PLAN_WINDOW_8, PLAN_WINDOW_16, PLAN_WINDOW_16W, PLAN_STREAM_16, PLAN_STREAM_8, PLAN_STREAM_32 = 1, 2, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60
 
-SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_updat_finalize", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_sparse_op", "bsmm_sparse_mul_grad", "bsmm_workspace_bytes",
+SYMBOLS = ("bsmm_fprop", "bsmm_bprop", "bsmm_updat", "bsmm_updat_finalize", "bsmm_identity_init", "bsmm_gate_grad", "bsmm_gate_weights", "bsmm_l2_normalize", "bsmm_l2_normalize_grad", "bsmm_sparse_op", "bsmm_sparse_mul_grad", "bsmm_workspace_bytes",
            "bsmm_xprop_plan_words", "bsmm_xprop_plan_build", "bsmm_updat_plan_words", "bsmm_updat_plan_build",
            "bsmm_plan_attach", "bsmm_error_string", "bsmm_version", "bsmm_prepared_bytes", "bsmm_prepare_weights")
 DIST_SYMBOLS = ("bsmm_dist_unique_id", "bsmm_dist_create", "bsmm_dist_allreduce_begin", "bsmm_dist_allreduce_end", "bsmm_dist_stream",
@@ -155,6 +155,8 @@ def load():
     lib.bsmm_identity_init.restype = ctypes.c_int
     lib.bsmm_gate_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.bsmm_gate_grad.restype = ctypes.c_int
+    lib.bsmm_gate_weights.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.bsmm_gate_weights.restype = ctypes.c_int
     lib.bsmm_l2_normalize.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
     lib.bsmm_l2_normalize.restype = ctypes.c_int
     lib.bsmm_l2_normalize_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]

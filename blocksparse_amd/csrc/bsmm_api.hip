@@ -1506,6 +1506,25 @@ int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const
     return (int)hipGetLastError();
 }
 
+int bsmm_gate_weights(const void* W, const float* gate, void* out, int32_t blocks, int32_t bsize, int32_t dtype, int32_t pieces, void* stream) {
+    if (!W || !gate || !out || blocks <= 0) return BSMM_ERR_ARG;
+    if ((bsize != 8 && bsize != 16 && bsize != 32 && bsize != 64) || (dtype != BSMM_F16 && dtype != BSMM_BF16) || (pieces != 1 && pieces != 2)) return BSMM_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int per8 = bsize * bsize / 8;
+    const size_t total8 = (size_t)blocks * per8;
+    const unsigned grid = (unsigned)((total8 + 255) / 256);
+    const uint4* w = static_cast<const uint4*>(W);
+    uint4* o = static_cast<uint4*>(out);
+    if (dtype == BSMM_BF16) {
+        if (pieces == 1) gate_weights_kernel<DTbf16, 1><<<grid, 256, 0, st>>>(w, gate, o, per8, total8);
+        else             gate_weights_kernel<DTbf16, 2><<<grid, 256, 0, st>>>(w, gate, o, per8, total8);
+    } else {
+        if (pieces == 1) gate_weights_kernel<DTf16, 1><<<grid, 256, 0, st>>>(w, gate, o, per8, total8);
+        else             gate_weights_kernel<DTf16, 2><<<grid, 256, 0, st>>>(w, gate, o, per8, total8);
+    }
+    return (int)hipGetLastError();
+}
+
 #ifdef X4_TIMELINE
 extern "C" int bsmm_debug_x4_timeline_copy(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bsmm::g_x4_tl), sizeof(bsmm::g_x4_tl)); }
 #endif

@@ -255,4 +255,32 @@ gate_grad_kernel(typename DT::T* __restrict__ dw_out, float* __restrict__ dg, co
     if (threadIdx.x == 0) dg[w] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Gated weight images for the fast ungated xprop kernels (round 6): out[0][w] = round(gate[w] * W[w]) and, with PIECES == 2,
+// out[1][w] = round(gate[w] * W[w] - out[0][w]) -- hi + lo carry g * w to ~2^-17 (the same two pieces the staged GATED kernels form per
+// fragment, bsmm_xcol_v2.h, here once per call instead of once per row tile).  gate 0 = the block contributes nothing whatever it holds
+// (Inf / NaN included: the reference skips it, src/blocksparse_hgemm_cn_64_op_gpu.cu:96-100); gates 0 / 1 leave one exact image.
+// One thread per 8 elements (16 bytes); 16-bit storage types.
+template <class DT, int PIECES>
+__global__ void __launch_bounds__(256)
+gate_weights_kernel(const uint4* __restrict__ W, const float* __restrict__ gate, uint4* __restrict__ out, int per_block8, size_t total8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total8) return;
+    const float g = gate[i / (size_t)per_block8];
+    const uint4 v = W[i];
+    const uint32_t src[4] = {v.x, v.y, v.z, v.w};
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float p0 = g * DT::to_f32((uint16_t)(src[e] & 0xffffu)), p1 = g * DT::to_f32((uint16_t)(src[e] >> 16));
+        const uint16_t h0 = g == 0.f ? (uint16_t)0 : DT::from_f32(p0), h1 = g == 0.f ? (uint16_t)0 : DT::from_f32(p1);
+        hi[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        if constexpr (PIECES == 2) {
+            const uint16_t l0 = g == 0.f ? (uint16_t)0 : DT::from_f32(p0 - DT::to_f32(h0)), l1 = g == 0.f ? (uint16_t)0 : DT::from_f32(p1 - DT::to_f32(h1));
+            lo[e] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+    }
+    out[i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    if constexpr (PIECES == 2) out[total8 + i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
 }  // namespace bsmm

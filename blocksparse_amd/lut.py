@@ -169,3 +169,35 @@ def build_tables(layout, z_order=True, segmented=True):
     b = xprop_table(CB, ks[t], cs[t], wid[t], max_seg, min_seg)
     return dict(CB=CB, KB=KB, blocks=B, layout=layout, updat_lut=np.ascontiguousarray(updat, dtype=np.int32),
                 fprop=f, bprop=b)
+
+
+def double_tables(tables):
+    """The tables of a gated call that runs on the UNGATED kernels over two weight images (include/bsmm.h, bsmm_gate_weights): every
+    xprop entry (c, w) is followed by (c, w + blocks) -- image 0 holds round(g w), image 1 round(g w - image 0) -- so a column sums
+    hi and lo of each of its blocks back to back; ``blocks`` doubles, headers keep their order, segment lengths and offsets double.
+    The updat table is repeated only to keep the dict complete (a doubled table is never used for a weight gradient)."""
+    B = int(tables["blocks"])
+    out = dict(tables)
+    out["blocks"] = 2 * B
+    out["updat_lut"] = np.concatenate([tables["updat_lut"], tables["updat_lut"]], axis=0)
+    for side in ("fprop", "bprop"):
+        t = tables[side]
+        S = int(t["segments"])
+        lut = np.asarray(t["lut"], dtype=np.int32)
+        hdr = lut[:4 * S].reshape(S, 4)
+        ent = lut[4 * S:].reshape(B, 2)
+        new = np.empty(4 * S + 4 * B, dtype=np.int32)
+        nh = new[:4 * S].reshape(S, 4)
+        nh[:] = hdr
+        nh[:, 0] = 2 * S + 2 * (hdr[:, 0] - 2 * S)
+        nh[:, 1] = 2 * hdr[:, 1]
+        ne = new[4 * S:].reshape(B, 2, 2)
+        ne[:, 0, :] = ent
+        ne[:, 1, 0] = ent[:, 0]
+        ne[:, 1, 1] = ent[:, 1] + B
+        d = dict(t)
+        d["lut"] = new
+        d["shared"] = 2 * int(t["shared"])
+        d["cols"] = [(col, [e for (c, w) in lst for e in ((c, w), (c, w + B))]) for col, lst in t["cols"]]
+        out[side] = d
+    return out

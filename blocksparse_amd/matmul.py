@@ -98,7 +98,7 @@ class _DeviceTables(object):
     """int32 lookup tables resident on one device (the reference keeps them as TF variables, matmul.py:33-53),
     plus the derived schedules ("plans") of the grouped kernels."""
 
-    def __init__(self, tables, device, bsize, axis, plan_options=0):
+    def __init__(self, tables, device, bsize, axis, plan_options=0, xprop_only=False):
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
 
@@ -120,6 +120,9 @@ class _DeviceTables(object):
         if bsize in (32, 64) and axis == 1 and not (plan_options & (_lib.PLAN_XCOL_UNSTAGED | _lib.PLAN_XCOL_NARROW | _lib.PLAN_XCOL_FLOW | (7 << _lib.PLAN_XPROP_PH_SHIFT))):
             self.fprop_flow = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_XCOL_FLOW))
             self.bprop_flow = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.BF16, axis, plan_options | _lib.PLAN_XCOL_FLOW))
+        self.fprop_plan_f32 = self.bprop_plan_f32 = self.updat_plan = self.updat_plan_long = None
+        if xprop_only:        # the doubled tables of gated calls (lut.double_tables): 16-bit fprop / bprop only
+            return
         # ... and fp32 has its own (xprop-only) plan kernels for bsize 32; the schedule format is the library's business
         self.fprop_plan_f32 = plan(_host_plan(f["lut"], f["segments"], B, KB, bsize, _lib.F32, axis, plan_options))
         self.bprop_plan_f32 = plan(_host_plan(b["lut"], b["segments"], B, CB, bsize, _lib.F32, axis, plan_options))
@@ -192,6 +195,13 @@ class BlocksparseMatMul(object):
         self._split64_hit = None
         self.native64 = True          # bsize 64: call the library with bsize = 64 (False: always the host-side quadrant view)
         self.flow = True              # bsize 32, feature axis 1, 16-bit, no gate: the barrier-free xprop kernel (False: the staged one)
+        # round 6: gated 16-bit fprop / bprop calls on the fast UNGATED kernels over gated weight images (bsmm_gate_weights; _gated_xprop);
+        # False: the GATED instantiations of the staged kernels (gate applied per fragment inside the kernel)
+        self.gate_images = True
+        self.gate_kind = "auto"       # "auto": look at a gate once per (tensor object, version); "binary" / "general": the caller's promise
+        self._gate_kind_hit = None
+        self._dbl = None
+        self._xprop_only = False
         if block_size == 64:
             # same weights, cut into 32x32 blocks: inner block n is quadrant (i, j) of outer block b
             self._inner = BlocksparseMatMul(np.kron(self.layout, np.ones((2, 2), dtype=self.layout.dtype)), block_size=32, feature_axis=feature_axis,
@@ -265,7 +275,7 @@ class BlocksparseMatMul(object):
         key = (device.type, device.index)
         t = self._device_cache.get(key)
         if t is None:
-            t = _DeviceTables(self._dev_tables, device, self.bsize, self.axis, self.plan_options)
+            t = _DeviceTables(self._dev_tables, device, self.bsize, self.axis, self.plan_options, xprop_only=self._xprop_only)
             self._device_cache[key] = t
         return t
 
@@ -388,6 +398,63 @@ class BlocksparseMatMul(object):
             raise ValueError("gate lives on another device")
         return gate.contiguous()
 
+    # ---- gated calls on the ungated kernels (round 6) ----------------------------------------------
+    GATE_IMAGES_MIN_N = 1024      # below: the staged GATED kernels / the small-minibatch paths (a 3 us image pass is not free there)
+
+    def _gate_kind_of(self, gate):
+        """"binary" (every gate 0 or 1: a pruning mask -- ONE exact weight image) or "general" (two images, g w to ~2^-17).  Looked at once
+        per (tensor object, version): one host sync the first time a gate (or a changed gate) is seen, none afterwards; under stream capture
+        an unseen gate counts as "general" (always correct).  ``gate_kind = "binary" / "general"`` is the caller's promise instead."""
+        if self.gate_kind != "auto":
+            return self.gate_kind
+        key = (gate.data_ptr(), gate._version)
+        hit = self._gate_kind_hit
+        if hit is not None and hit[0]() is gate and hit[1] == key:
+            return hit[2]
+        if torch.cuda.is_current_stream_capturing():
+            return "general"
+        kind = "binary" if bool(((gate == 0) | (gate == 1)).all().item()) else "general"
+        self._gate_kind_hit = (weakref.ref(gate), key, kind)
+        return kind
+
+    def _doubled(self):
+        """This operator over lut.double_tables(): 2 x blocks weight images [hi ; lo], fprop / bprop only, never gated itself."""
+        d = self._dbl
+        if d is None:
+            d = object.__new__(BlocksparseMatMul)
+            d.axis, d.bsize, d.z_order, d.segmented = self.axis, self.bsize, self.z_order, self.segmented
+            d.plan_options, d.updat_split, d.name = self.plan_options, self.updat_split, self.name + "/gated2"
+            d._dev_tables = d._ref_tables = _lut.double_tables(self._dev_tables)
+            d.blocks = 2 * self.blocks
+            d.w_shape, d.g_shape = (d.blocks, self.bsize, self.bsize), (d.blocks,)
+            d.CB, d.KB, d.C, d.K = self.CB, self.KB, self.C, self.K
+            d._device_cache, d._workspaces, d._args_cache, d._prepared_w = {}, {}, {}, {}
+            d.cache_prepared, d._inner, d._split64_hit, d.native64 = True, None, None, True
+            d.gate_images, d.gate_kind, d._gate_kind_hit, d._dbl, d._xprop_only = False, "general", None, None, True
+            self._dbl = d
+        d.flow = self.flow
+        return d
+
+    def _gated_xprop(self, which, x, w, gate, N):
+        """A gated 16-bit fprop / bprop as [bsmm_gate_weights -> the UNGATED call]: the flow / list kernels carry no gate logic (their
+        registers are spoken for), and forming g w once per call (6.7 MB at the bench shape, ~3 us) replaces ~80 vector instructions per block
+        and row tile inside the staged GATED kernels.  0 / 1 gates: one image, the plain tables (exact); other gates: bf16 two images over the
+        doubled tables, fp16 one image (the reference's rounding).  None = not taken (fp32, bsize 8 / 64, locked tables, short minibatches): the caller runs the GATED kernels."""
+        if not (self.gate_images and gate is not None and x.dtype in (torch.float16, torch.bfloat16) and self.bsize in (16, 32)
+                and self._inner is None and N >= self.GATE_IMAGES_MIN_N
+                and self._dev_tables["fprop"]["locks"] == 0 and self._dev_tables["bprop"]["locks"] == 0):
+            return None
+        # fp16: ONE image for any gate -- round(g w) to fp16 is the reference's own arithmetic (mul.rn.f16x2 on the weight fragments,
+        # src/blocksparse_hgemm_cn_64_op_gpu.cu:104-110) and costs ~3e-4 against the float64 product; a bf16 rounding of g w would cost
+        # ~2e-3 (above the 1e-3 bar), hence the second image there unless the gate is a 0 / 1 mask
+        pieces = 1 if (w.dtype == torch.float16 or self._gate_kind_of(gate) == "binary") else 2
+        img = torch.empty((pieces * self.blocks, self.bsize, self.bsize), dtype=w.dtype, device=w.device)
+        stream = torch.cuda.current_stream(w.device).cuda_stream
+        _lib.check(_lib.load().bsmm_gate_weights(w.data_ptr(), gate.data_ptr(), img.data_ptr(), self.blocks, self.bsize, _dtype_code(w.dtype), pieces, stream),
+                   "bsmm_gate_weights")
+        op = self if pieces == 1 else self._doubled()
+        return op.fprop(x, img) if which == "fprop" else op.bprop(x, img)
+
     # ---- the three passes ------------------------------------------------------------------------
     def _xprop_plan(self, tabs, which, N, n_out_features, dtype, gate):
         """The schedule an fprop / bprop call runs with: fp32 -> its own plans; 16-bit, ungated, feature axis 1, bsize 32 -> the flow
@@ -412,6 +479,10 @@ class BlocksparseMatMul(object):
             return self._inner.fprop(x, self._split64_cached(w), gate=self._gate64(gate))
         x = x.contiguous(); w = w.contiguous()
         N = self._n_of(x, self.C)
+        if gate is not None:
+            y = self._gated_xprop("fprop", x, w, gate, N)
+            if y is not None:
+                return y
         lib = _lib.load()
         tabs = self._tables_on(x.device)
         y = torch.empty(self._out_shape(x, self.K), dtype=x.dtype, device=x.device)
@@ -435,6 +506,10 @@ class BlocksparseMatMul(object):
             return self._inner.bprop(dy, self._split64_cached(w), gate=self._gate64(gate))
         dy = dy.contiguous(); w = w.contiguous()
         N = self._n_of(dy, self.K)
+        if gate is not None:
+            dx = self._gated_xprop("bprop", dy, w, gate, N)
+            if dx is not None:
+                return dx
         lib = _lib.load()
         tabs = self._tables_on(dy.device)
         dx = torch.empty(self._out_shape(dy, self.C), dtype=dy.dtype, device=dy.device)

@@ -52,8 +52,8 @@ extern "C" {
  *   axis 0 carries a 'BSU6' section for the row-owner weight-gradient kernel), BSMM_K_UPDAT16_ROWS, BSMM_PLAN_UPDAT16_WINDOWED;
  *   124 round 6: the row-split xprop kernel of round 5 retired ('BSX5' plans are no longer built or accepted, BSMM_PLAN_XCOL_ROWS is ignored,
  *   trace code 13 is not emitted; source and measurements: profiles/r05_xrows.patch);  125 round 6: 'BSU2' plans version 3 (32 header words; direct
- *   blocks), BSMM_PLAN_UPDAT_NO_DIRECT */
-#define BSMM_VERSION 125
+ *   blocks), BSMM_PLAN_UPDAT_NO_DIRECT;  126 round 6: bsmm_gate_weights */
+#define BSMM_VERSION 126
 
 enum { BSMM_F32 = 0, BSMM_F16 = 1, BSMM_BF16 = 2 };
 enum {
@@ -208,6 +208,15 @@ int bsmm_identity_init(void* W, const int32_t* updat_lut, int32_t CB, int32_t KB
  * dw_out may alias dw.  dg is fp32 [blocks]. */
 int bsmm_gate_grad(void* dw_out, float* dg, const void* dw, const void* W, const float* gate, int32_t blocks,
                    int32_t bsize, int32_t dtype, void* stream);
+
+/* Gated weight images (round 6): how a gated fprop / bprop call reaches the fast UNGATED kernels.  The reference applies the gate to the weight
+ * fragments inside its tensor-core kernels (src/blocksparse_hgemm_cn_64_op_gpu.cu:54-66, 96-124: mul.rn.f16x2, one rounding); here
+ *   out[0][w] = round(gate[w] * W[w]),   pieces == 2:  out[1][w] = round(gate[w] * W[w] - out[0][w])      (gate 0: zeros)
+ * out: [pieces][blocks][bsize][bsize] of the storage type (16-bit types only).  A 0 / 1 gate (pruning mask) needs ONE piece and the
+ * ungated call over `out` is exact; any other gate takes both pieces and the ungated call over the DOUBLED lookup table (every entry (c, w)
+ * followed by (c, w + blocks); blocks' = 2 * blocks): the sum is g * w to ~2^-17.  blocksparse_amd/matmul.py composes the two. */
+int bsmm_gate_weights(const void* W, const float* gate, void* out, int32_t blocks, int32_t bsize, int32_t dtype, int32_t pieces,
+                      void* stream);
 
 /* Block-sparse L2 normalisation of W over each output feature (L2NormalizeCK / L2NormalizeGainCK and their gradients,
  * src/blocksparse_l2_norm_op_gpu.cu:396-426,911-934; Python: blocksparse/matmul.py:421-453):

@@ -15,9 +15,10 @@ def timeit(fn, reps=60, warm=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 
-lay = P.random_layout(128, 128, 0.2, 1234)
-for axis in (1, 0):
-    b = BlocksparseMatMul(lay, block_size=32, feature_axis=axis)
+import numpy as np
+for bs, axis in ((32, 1), (32, 0), (16, 0), (16, 1)):
+    lay = P.random_layout(128, 128, 0.2, 1234) if bs == 32 else P.random_layout(256, 256, 0.1, 1234)
+    b = BlocksparseMatMul(lay, block_size=bs, feature_axis=axis)
     g = torch.Generator(device="cuda").manual_seed(1)
     w = (torch.randn(b.w_shape, device="cuda", generator=g) * 0.05).bfloat16()
     x = (torch.randn(b.i_shape(8192), device="cuda", generator=g) * 0.1).bfloat16()
@@ -26,9 +27,11 @@ for axis in (1, 0):
     gate[::7] = 0
     out = []
     mask = (torch.rand(b.blocks, device="cuda", generator=g) < 0.8).float()
-    for name, gt, var in (("ungated", None, 0), ("gated plan", gate, 0), ("0/1 mask (80 % ones) plan", mask, 0), ("gated per-segment", gate, 2)):
+    for name, gt, var, img in (("ungated", None, 0, True), ("gated, in-kernel", gate, 0, False), ("gated, weight images", gate, 0, True),
+                               ("0/1 mask, in-kernel", mask, 0, False), ("0/1 mask, weight image", mask, 0, True)):
         _lib.set_kernel_variant(var)
+        b.gate_images = img
         b.fprop(x, w, gate=gt); k = _lib.last_kernel()
         out.append("%s f %.1f b %.1f (k%d)" % (name, timeit(lambda: b.fprop(x, w, gate=gt)), timeit(lambda: b.bprop(dy, w, gate=gt)), k))
     _lib.set_kernel_variant(0)
-    print("axis %d: %s" % (axis, " | ".join(out)), flush=True)
+    print("bsize %d axis %d: %s" % (bs, axis, " | ".join(out)), flush=True)

@@ -131,6 +131,7 @@ def test_gated_staged_plan_kernel_bsize16(env, axis, dtype):
         _lib.set_kernel_variant(0)
     lay = P.random_layout(256, 256, 0.1, seed=1234)
     b = BSMM(lay, block_size=16, feature_axis=axis)
+    b.gate_images = False            # (this test is about the GATED kernel; the default path: test_gated_calls_run_the_ungated_kernels)
     t = O.build_layout_luts(lay, 16)
     N = 4096
     W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=7)
@@ -175,6 +176,7 @@ def test_gated_staged_plan_kernel(env, axis, dtype):
     # the bench shape, library's own choice of kernel: sampled output block columns against the oracle
     lay = P.random_layout(128, 128, 0.2, seed=1234)
     b = BSMM(lay, block_size=32, feature_axis=axis)
+    b.gate_images = False
     t = O.build_layout_luts(lay, 32)
     N = 4096
     W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=7)
@@ -232,3 +234,75 @@ def test_gate_grad_and_autograd(env, dtype):
     assert l2 <= P.L2_BAR[dtype], l2
     with pytest.raises(ValueError):
         b.fprop(tx.detach(), tw.detach(), gate=tg.detach()[:-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("bs,axis", [(32, 1), (32, 0), (16, 0), (16, 1)])
+def test_gated_calls_run_the_ungated_kernels(env, bs, axis, dtype):
+    """Round 6: a gated 16-bit fprop / bprop with a long minibatch = bsmm_gate_weights + the UNGATED call (the reference gates inside its main
+    tensor-core kernels, src/blocksparse_hgemm_cn_64_op_gpu.cu:54-66,96-124; here the fast kernels carry no gate logic and run over gated weight
+    images instead): 0 / 1 gates -> one exact image over the plain tables, other gates -> hi / lo images over the doubled tables.  Every output
+    element against the oracle (which gates the float64 block product); the kernel family that ran is the ungated call's; a gate-0 block
+    holding Inf contributes nothing; the in-kernel GATED path (gate_images = False) agrees."""
+    torch, BSMM = env
+    from blocksparse_amd import _lib
+    lay = P.random_layout(40, 24, 0.3, seed=21) if bs == 32 else P.random_layout(72, 56, 0.15, seed=22)
+    b = BSMM(lay, block_size=bs, feature_axis=axis)
+    t = O.build_layout_luts(lay, bs)
+    rs = np.random.RandomState(5)
+    for N in (1024, 1160):
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=30 + N)
+        tw, tx, te = _t(torch, W, dtype), _t(torch, X, dtype), _t(torch, E, dtype)
+        y0 = b.fprop(tx, tw)
+        fam_f = _lib.last_kernel()
+        b.bprop(te, tw)
+        fam_b = _lib.last_kernel()
+        for kind in ("binary", "general"):
+            g = (rs.rand(b.blocks) < 0.8).astype(np.float32) if kind == "binary" else MG.gate_inputs(b.blocks, 40 + N)
+            tg = torch.from_numpy(g).cuda()
+            assert b._gate_kind_of(tg) == kind
+            general2 = kind == "general" and dtype == "bf16"      # (fp16: one image for any gate, the reference's own rounding of g w)
+            y = b.fprop(tx, tw, gate=tg)
+            assert general2 or _lib.last_kernel() == fam_f, (kind, _lib.last_kernel(), fam_f)    # (twice the blocks: the cost model
+            dx = b.bprop(te, tw, gate=tg)                                                          #  may choose another ungated kernel)
+            assert general2 or _lib.last_kernel() == fam_b, (kind, _lib.last_kernel(), fam_b)
+            for name, got, ref in (("Y", y, O.fprop(t, X, W, axis, gate=g)), ("DX", dx, O.bprop(t, E, W, axis, gate=g))):
+                l2, _ = P.errors(got.float().cpu().numpy(), O.round_to(ref, dtype))
+                assert l2 <= P.L2_BAR[dtype], (bs, axis, dtype, N, kind, name, l2)
+            # a block that is gated off may hold anything
+            off = np.nonzero(g == 0)[0]
+            W2 = np.array(W, dtype=np.float32, copy=True)
+            W2[off[0]] = np.inf
+            y2 = b.fprop(tx, _t(torch, W2, dtype), gate=tg)
+            assert torch.equal(y2, y)
+            # the GATED staged kernels compute the same thing (their own summation order)
+            b.gate_images = False
+            try:
+                ys = b.fprop(tx, tw, gate=tg)
+            finally:
+                b.gate_images = True
+            l2, _ = P.errors(ys.float().cpu().numpy(), y.float().cpu().numpy())
+            assert l2 <= 2 * P.L2_BAR[dtype], (kind, l2)
+        assert torch.equal(b.fprop(tx, tw, gate=torch.ones(b.blocks, device="cuda")), y0)     # all-ones gate: the ungated call on a copy of W
+
+
+@pytest.mark.gpu
+def test_gated_flow_kernel_at_the_bench_shape(env):
+    """a gated bsize-32 / feature-axis-1 call at the bench shape runs the flow kernel (BSMM_K_XCOL32_FLOW), for a pruning
+    mask and for arbitrary gates; sampled output block columns against the oracle."""
+    torch, BSMM = env
+    from blocksparse_amd import _lib
+    lay = P.random_layout(128, 128, 0.2, seed=1234)
+    b = BSMM(lay, block_size=32, feature_axis=1)
+    t = O.build_layout_luts(lay, 32)
+    N = 4096
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "bf16", seed=7)
+    rs = np.random.RandomState(3)
+    for g in ((rs.rand(b.blocks) < 0.8).astype(np.float32), MG.gate_inputs(b.blocks, 9)):
+        y = b.fprop(_t(torch, X, "bf16"), _t(torch, W, "bf16"), gate=torch.from_numpy(g).cuda())
+        assert _lib.last_kernel() == _lib.K_XCOL32_FLOW
+        yh = y.float().cpu().numpy()
+        for k, ref in O.fprop_cols(t, X * 1.0, np.asarray(W, dtype=np.float64) * g[:, None, None], 1, [0, 37, 127]).items():
+            l2, _ = P.errors(yh[:, k * 32:(k + 1) * 32], O.round_to(ref, "bf16"))
+            assert l2 <= P.L2_BAR["bf16"], (k, l2)
