@@ -169,7 +169,7 @@ inline bool use_xcol() { return true; }
 // bsize 16, 'BSX7' plan: which inner loop.  The list-driven kernel multiplies every block on its own with the K = 16 instruction; where most
 // blocks have their pair partner (dense layouts) the round-2 kernel's K = 32 instruction per PAIR wins on feature axis 1 -- measured at 4096^2,
 // N = 8192 (profiles/r03_x7_density.txt): 20 % 152 / 145 against 166 / 149 us, 30 % 201 / 193 against 210 / 184, 50 % 315 / 319 against 284 / 263;
-// on feature axis 0 the list kernel wins at every density (50 %: 251 / 237 against 321 / 301).  Gated calls: the round-2 kernel.
+// on feature axis 0 the list kernel wins at every density (50 %: 251 / 237 against 321 / 301).
 inline bool x7_use_list(const bsmm_args* a) {
 #ifdef X7_POSITIONAL
     return a->axis == 0 && !a->gate;      // (measurement build: the pair kernel wherever it exists)
@@ -192,9 +192,7 @@ int launch_xcol16_v2(const void* X, const void* Wsel, void* Y, const bsmm_args* 
     m.SP = (m.segments + m.P - 1) / m.P;
     trace(a, BSMM_K_XCOL16_STAGED);
     if (a->gate) {
-        if (int rc = ensure_lds<&xcol16_v2_kernel<DT, AXIS, true>>(X7_LDS)) return rc;
-        xcol16_v2_kernel<DT, AXIS, true><<<m.grid(), 1024, X7_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(Wsel), static_cast<T*>(Y), a->plan, m,
-                                                                         a->N, a->C, a->K, a->gate);
+        return BSMM_ERR_ARG;                     // (xprop_path never sends a gated call here)
     } else if (!x7_use_list(a)) {
         // (feature axis 1, dense layouts only -- x7_use_list: on feature axis 0 the list kernel wins at every density, and that instantiation
         //  of the pair kernel spilled 4 registers: not built)
@@ -449,9 +447,10 @@ template <class DT, int BS, int AXIS>
 XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a) {
     const int variant = call_variant(a);
     const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
-    // gated calls: the staged bsize-32 / bsize-16 kernels apply gates (exactly: bsmm_xcol_v2.h, bsmm_xcol16_v2.h); everything else runs
-    // the per-segment kernels
-    const bool gate_ok = a->gate == nullptr || (DT::is16 && ((BS == 32 && a->plan_magic == X2PLAN_MAGIC) || (BS == 16 && a->plan_magic == X7PLAN_MAGIC)));
+    // gated calls: the staged bsize-32 kernel applies gates (exactly: bsmm_xcol_v2.h); everything else runs the per-segment kernels.
+    // (Round 6: the GATED instantiation of the bsize-16 pair kernel is no longer built -- 22 spilled registers, 280-308 us at BASELINE
+    //  configs[2]'s shape against 85 us ungated; a gated call on the fast kernels is bsmm_gate_weights + the UNGATED call, include/bsmm.h.)
+    const bool gate_ok = a->gate == nullptr || (DT::is16 && BS == 32 && a->plan_magic == X2PLAN_MAGIC);
     const bool plan_ok = a->plan != nullptr && gate_ok && vec_ok && (variant == 0 || variant == 3);
     const bool force = variant == 3;
     if constexpr (BS == 8) {

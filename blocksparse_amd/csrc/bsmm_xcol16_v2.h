@@ -89,7 +89,9 @@ __device__ __forceinline__ void x7_epilogue(f32x4 (&acc)[2][8], unsigned char* s
     }
 }
 
-// GATED: per-block fp32 gates (the reference gates all three tensor-core block sizes, src/blocksparse_hgemm_cn_64_op_gpu.cu:256-717).
+// GATED (NOT INSTANTIATED since round 6: it spilled 22 registers and ran 3.3x slower than the ungated list kernel; gated bsize-16 calls are
+// bsmm_gate_weights + the ungated call, or the per-segment kernel): per-block fp32 gates (the reference gates all three tensor-core block sizes,
+// src/blocksparse_hgemm_cn_64_op_gpu.cu:256-717).
 // The wave that requests a pair of weight blocks also fetches their gates into the ring half's gate table (the two spare slots);
 // a block with gate 0 is treated as absent, gate 1 takes the plain path, otherwise g * w is formed per fragment element in fp32 and
 // split into TWO 16-bit pieces that are both multiplied (exact to ~2^-17; see bsmm_xcol_v2.h).

@@ -399,7 +399,9 @@ class BlocksparseMatMul(object):
         return gate.contiguous()
 
     # ---- gated calls on the ungated kernels (round 6) ----------------------------------------------
-    GATE_IMAGES_MIN_N = 1024      # below: the staged GATED kernels / the small-minibatch paths (a 3 us image pass is not free there)
+    # minibatch from which a gated call takes the weight images (scripts/gpu_gated_smalln.py: below, the per-segment kernel with its gate
+    # multiply wins -- the ungated call would run that kernel too, and the image pass is a second launch): bsize 32: 1024, bsize 16: 2048
+    GATE_IMAGES_MIN_N = {32: 1024, 16: 2048}
 
     def _gate_kind_of(self, gate):
         """"binary" (every gate 0 or 1: a pruning mask -- ONE exact weight image) or "general" (two images, g w to ~2^-17).  Looked at once
@@ -441,7 +443,7 @@ class BlocksparseMatMul(object):
         and row tile inside the staged GATED kernels.  0 / 1 gates: one image, the plain tables (exact); other gates: bf16 two images over the
         doubled tables, fp16 one image (the reference's rounding).  None = not taken (fp32, bsize 8 / 64, locked tables, short minibatches): the caller runs the GATED kernels."""
         if not (self.gate_images and gate is not None and x.dtype in (torch.float16, torch.bfloat16) and self.bsize in (16, 32)
-                and self._inner is None and N >= self.GATE_IMAGES_MIN_N
+                and self._inner is None and N >= self.GATE_IMAGES_MIN_N[self.bsize]
                 and self._dev_tables["fprop"]["locks"] == 0 and self._dev_tables["bprop"]["locks"] == 0):
             return None
         # fp16: ONE image for any gate -- round(g w) to fp16 is the reference's own arithmetic (mul.rn.f16x2 on the weight fragments,

@@ -20,9 +20,6 @@ HOT = ["xflow32_kernel", "updat32_a1_v2_kernel", "updat2_reduce_kernel", "updat1
        "bst_xn_mfma16_kernel", "bst_xn_split_kernel", "bst_softmax_grad_kernel"]
 # known spillers: (kernel name, substring of the mangled template arguments or None) -> (max vgpr spills, max sgpr spills).  They may shrink, not grow.
 KNOWN = {
-    # gated bsize-16 xprop (the two-piece gate split inside the round-2 pair kernel; ungated calls run xcol16_list_kernel): VERDICT r5 weak 6
-    ("xcol16_v2_kernel", "Li0ELb1E"): (22, 0),
-    ("xcol16_v2_kernel", "Li1ELb1E"): (8, 0),
     # sixteen scalar kernel arguments + the mask words: 6 SGPRs go to VGPR lanes (v_writelane, no memory)
     ("bst_softmax_kernel", None): (0, 6),
 }

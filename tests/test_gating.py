@@ -103,10 +103,11 @@ def test_gated_passes_match_oracle(env, bs, axis, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("axis", [1, 0])
-def test_gated_staged_plan_kernel_bsize16(env, axis, dtype):
-    """Gates on the bsize-16 plan kernel (bsmm_xcol16_v2.h, GATED; the reference gates all of its tensor-core block sizes,
-    src/blocksparse_hgemm_cn_64_op_gpu.cu:256-717): forced on small layouts -- gates 0 (block skipped: both of a K-concatenated pair,
-    one of them), 1, negative, > 1 -- and at BASELINE configs[2]'s shape, against the oracle, which gates the fp32 block product."""
+def test_gated_bsize16(env, axis, dtype):
+    """Gated bsize-16 calls (the reference gates all of its tensor-core block sizes, src/blocksparse_hgemm_cn_64_op_gpu.cu:256-717).  Round 6: the
+    GATED instantiation of the pair kernel is gone (22 spilled registers, 3.3x the ungated time); with a plan forced on small layouts -- gates 0, 1,
+    negative, > 1 -- a gated call runs the per-segment kernel, and at BASELINE configs[2]'s shape the list kernel over gated weight images (the
+    default) as well as the per-segment kernel (gate_images = False), all against the oracle, which gates the fp32 block product."""
     torch, BSMM = env
     from blocksparse_amd import _lib
     cases = [(P.random_layout(18, 14, 0.4, seed=8), (72, 200)), (np.ones((6, 40), dtype=bool), (128,)), (P.ba_layout(60, 3, seed=1), (264,))]
@@ -121,9 +122,9 @@ def test_gated_staged_plan_kernel_bsize16(env, axis, dtype):
                 tg = torch.from_numpy(g).cuda()
                 tw, tx, te = _t(torch, W, dtype), _t(torch, X, dtype), _t(torch, E, dtype)
                 y = b.fprop(tx, tw, gate=tg)
-                assert _lib.last_kernel() == _lib.K_XCOL16_STAGED
+                assert _lib.last_kernel() == _lib.K_XPROP_SEGMENT
                 dx = b.bprop(te, tw, gate=tg)
-                assert _lib.last_kernel() == _lib.K_XCOL16_STAGED
+                assert _lib.last_kernel() == _lib.K_XPROP_SEGMENT
                 for name, got, ref in (("Y", y, O.fprop(t, X, W, axis, gate=g)), ("DX", dx, O.bprop(t, E, W, axis, gate=g))):
                     l2, _ = P.errors(got.float().cpu().numpy(), O.round_to(ref, dtype))
                     assert l2 <= P.L2_BAR[dtype], (axis, dtype, li, N, name, l2)
@@ -131,18 +132,19 @@ def test_gated_staged_plan_kernel_bsize16(env, axis, dtype):
         _lib.set_kernel_variant(0)
     lay = P.random_layout(256, 256, 0.1, seed=1234)
     b = BSMM(lay, block_size=16, feature_axis=axis)
-    b.gate_images = False            # (this test is about the GATED kernel; the default path: test_gated_calls_run_the_ungated_kernels)
     t = O.build_layout_luts(lay, 16)
     N = 4096
     W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=7)
     g = MG.gate_inputs(b.blocks, 9)
-    y = b.fprop(_t(torch, X, dtype), _t(torch, W, dtype), gate=torch.from_numpy(g).cuda())
-    assert _lib.last_kernel() == _lib.K_XCOL16_STAGED
-    yh = y.float().cpu().numpy()
-    for k, ref in O.fprop_cols(t, X * 1.0, np.asarray(W, dtype=np.float64) * g[:, None, None], axis, [0, 77, 255]).items():
-        got = yh[:, k * 16:(k + 1) * 16] if axis else yh[k * 16:(k + 1) * 16, :]
-        l2, _ = P.errors(got, O.round_to(ref, dtype))
-        assert l2 <= P.L2_BAR[dtype], (axis, dtype, k, l2)
+    for images, family in ((True, _lib.K_XCOL16_STAGED), (False, _lib.K_XPROP_SEGMENT)):
+        b.gate_images = images
+        y = b.fprop(_t(torch, X, dtype), _t(torch, W, dtype), gate=torch.from_numpy(g).cuda())
+        assert _lib.last_kernel() == family
+        yh = y.float().cpu().numpy()
+        for k, ref in O.fprop_cols(t, X * 1.0, np.asarray(W, dtype=np.float64) * g[:, None, None], axis, [0, 77, 255]).items():
+            got = yh[:, k * 16:(k + 1) * 16] if axis else yh[k * 16:(k + 1) * 16, :]
+            l2, _ = P.errors(got, O.round_to(ref, dtype))
+            assert l2 <= P.L2_BAR[dtype], (axis, dtype, images, k, l2)
 
 
 @pytest.mark.gpu
@@ -249,6 +251,7 @@ def test_gated_calls_run_the_ungated_kernels(env, bs, axis, dtype):
     from blocksparse_amd import _lib
     lay = P.random_layout(40, 24, 0.3, seed=21) if bs == 32 else P.random_layout(72, 56, 0.15, seed=22)
     b = BSMM(lay, block_size=bs, feature_axis=axis)
+    b.GATE_IMAGES_MIN_N = {32: 1024, 16: 1024}      # (bsize 16 takes the images from 2048 rows by default: a measured rule, not a limit)
     t = O.build_layout_luts(lay, bs)
     rs = np.random.RandomState(5)
     for N in (1024, 1160):
