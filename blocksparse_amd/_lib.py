@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BSMM_LIB: load another build of the same library (kernel A/B experiments: scripts/build_variants.py); product = the default
 LIB_PATH = os.environ.get("BSMM_LIB") or os.path.join(_HERE, "libbsmm_hip.so")
 
-ABI_VERSION = 126        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
+ABI_VERSION = 127        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
 FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN, FLAG_DW_SUMS, FLAG_FORCE_MID = 1, 2, 4, 8, 16, 32
@@ -32,6 +32,7 @@ PLAN_XPROP_PH_SHIFT, PLAN_UPDAT_SETS_SHIFT = 8, 12
 PLAN_UPDAT16_WINDOWED = 0x40000  # bsize 16, feature axis 0: no 'BSU6' section (always the windowed weight-gradient kernel)
 PLAN_UPDAT_NO_DIRECT = 0x80000   # 'BSU2' plans without direct blocks (round 6): overflow items in a sliced last round instead
 PLAN_XCOL_ROWS = 0x20000       # retired in round 6 (the row-split kernel of round 5): ignored by the builders
+PLAN_FLOW_CONSECUTIVE = 0x100000  # BSX4 plans: never regroup the output blocks of an unbalanced layout (round 6)
 PLAN_FLOW_SCHEDULED = 0x10000  # BSX4 plans, experiment: list-scheduled step order instead of ascending input blocks
 PLAN_WINDOW_MASK = 0xf0         # the window / kernel-family field of the updat plan options
 PLAN_XCOL_NARROW, PLAN_F32_MFMA, PLAN_WINDOW_8, PLAN_WINDOW_16, PLAN_WINDOW_16W, PLAN_STREAM_16, PLAN_STREAM_8, PLAN_STREAM_32 = 1, 2, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60

@@ -1592,7 +1592,7 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
     if (bsize == 16)         // 'BSX7' (staged / list kernels); BSMM_PLAN_XCOL_UNSTAGED / _NARROW named the round-1 kernel, retired in round 4: ignored
         return build_xcol16s_plan(lut, segments, blocks, n_out, out);      // (0: the layout does not fit the table fields -> no plan, per-segment kernels)
     if ((options & BSMM_PLAN_XCOL_FLOW) && axis == 1 && !(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // barrier-free persistent kernel
-        const long n = build_xflow_plan(lut, segments, blocks, n_out, out, (options & BSMM_PLAN_FLOW_SCHEDULED) != 0);
+        const long n = build_xflow_plan(lut, segments, blocks, n_out, out, (options & BSMM_PLAN_FLOW_SCHEDULED) != 0, (options & BSMM_PLAN_FLOW_CONSECUTIVE) != 0);
         if (n != 0) return n;
     }
     if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel (either feature axis)

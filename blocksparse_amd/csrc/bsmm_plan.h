@@ -437,18 +437,23 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
 // exact `vmcnt` they wait with: the number of operations the wave issues between the fetch / request they need and themselves.
 // Layout (int32): [0] magic 'BSX4' [1] version [2] X4_G [3] ngroups [4] nsteps_total [5] off_groups [6] off_pairs
 //                 [7] off_lists [8] n_out_blocks [9] max list length [10] max steps of a group [11] X4_D | X4_DX << 8 | X4_PARTS << 16
-//   groups[ngroups][8] = (step_off, nsteps, first_out_block, n_out_blocks_in_group, list_off, lcap, blocks_in_group, 0)
+//   groups[ngroups][8] = (step_off, nsteps, output block of wave 0, n_out_blocks_in_group, list_off, lcap, blocks_in_group, 1 if regrouped)
 //   pairs [nsteps_total]            pair index p of each step (input blocks 2p, 2p + 1)
-//   lists at off_lists + list_off:  counts[16], then per wave lcap entries of 2 words:
+//   lists at off_lists + list_off:  counts[16], cols[16] (version 4: the output block each wave owns, -1 = none), then per wave lcap entries of 2 words:
 //        word 0: type (2 bits: 0 NOP, 1 BLOCK, 2 REQ, 3 ANN) | half or part << 2 | step << 4 (12 bits) | step of my next BLOCK << 16
 //                (12 bits, nsteps if none) | step % X4_D << 28
 //        word 1: weight block to fetch after the event (27 bits, all ones = none) | vmcnt to wait with << 27 (capped at 15)
 // Groups are sorted longest first (as in the 'BSX2' plan).
+// Version 4 (round 6): a group is ANY 16 output blocks.  Where 16 CONSECUTIVE ones would leave the groups unbalanced (the busiest holds > 1.15 x the
+// mean: hub layouts such as the reference's Barabasi-Albert bench layout, whose 16 oldest nodes are 16 neighbouring columns -- 64 of the 512 units
+// then took 2.5 x as long as the others and the pass ended when they did), adjacent PAIRS of output blocks (one 128-byte line of an output row) are
+// dealt to the groups heaviest first, each to the lightest group with room.  A column still sums its blocks in table order on one wave: the
+// results are bit-identical; uniform layouts keep consecutive groups (BSMM_PLAN_FLOW_CONSECUTIVE: always).
 // =================================================================================================
 namespace bsmm {
 
 constexpr int32_t X4PLAN_MAGIC = 0x42535834;
-constexpr int32_t X4PLAN_VERSION = 3;
+constexpr int32_t X4PLAN_VERSION = 4;
 constexpr uint32_t X4_NOFETCH = 0x7ffffffu;
 constexpr int X4_G = 16;
 constexpr int X4_HDR = 12;
@@ -467,12 +472,50 @@ constexpr int X4_DX = X4_DX_AHEAD;        // a slab is requested this many steps
 constexpr int X4_PARTS = X4_DUTY_PARTS;   // a slab is requested in this many parts (by different waves): 1, 2 or 4
 static_assert(X4_DX >= 1 && X4_DX < X4_D && X4_D <= 7 && (X4_PARTS == 1 || X4_PARTS == 2 || X4_PARTS == 4), "flow plan constants");
 
-inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, bool balance = false) {
+inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, bool balance = false, bool consecutive = false) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
     if (blocks >= (1 << 21)) return 0;          // the kernel addresses a weight block with a 32-bit byte offset (id << 11): no plan beyond 4 GiB of weights
     const int G = X4_G, ngroups = (n_out_blocks + G - 1) / G;
+    // ---- which (group, wave) owns an output block ----
+    std::vector<int> grp_of(n_out_blocks), wave_of(n_out_blocks);
+    for (int ob = 0; ob < n_out_blocks; ++ob) { grp_of[ob] = ob / G; wave_of[ob] = ob % G; }
+    bool regrouped = false;
+    if (!consecutive && ngroups > 1) {
+        std::vector<long> cnt_ob(n_out_blocks, 0), gl(ngroups, 0);
+        long total = 0;
+        for (int s = 0; s < segments; ++s) {
+            const int32_t cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
+            if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
+            cnt_ob[ob] += cnt; gl[ob / G] += cnt; total += cnt;
+        }
+        const long mx = *std::max_element(gl.begin(), gl.end());
+        if (total > 0 && (double)mx * ngroups > 1.15 * (double)total) {
+            const int npairs = (n_out_blocks + 1) / 2;
+            std::vector<int> order(npairs);
+            for (int i = 0; i < npairs; ++i) order[i] = i;
+            auto wt = [&](int i) { return cnt_ob[2 * i] + (2 * i + 1 < n_out_blocks ? cnt_ob[2 * i + 1] : 0); };
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wt(a) > wt(b); });
+            std::vector<long> load(ngroups, 0);
+            std::vector<int> used(ngroups, 0);                      // waves taken
+            for (int i : order) {
+                int best = -1;
+                for (int g = 0; g < ngroups; ++g)
+                    if (used[g] + 2 <= G && (best < 0 || load[g] < load[best])) best = g;
+                if (best < 0) return -1;                             // (cannot happen: ngroups * 8 >= npairs)
+                for (int k = 0; k < 2; ++k) {
+                    const int ob = 2 * i + k;
+                    if (ob < n_out_blocks) { grp_of[ob] = best; wave_of[ob] = used[best] + k; }
+                }
+                used[best] += 2; load[best] += wt(i);
+            }
+            regrouped = true;
+        }
+    }
     struct E { int p, wave, half, w; };
     std::vector<std::vector<E>> per_group(ngroups);
+    std::vector<std::array<int32_t, X4_G>> gcols(ngroups);
+    for (auto& c : gcols) c.fill(-1);
+    for (int ob = 0; ob < n_out_blocks; ++ob) gcols[grp_of[ob]][wave_of[ob]] = ob;
     for (int s = 0; s < segments; ++s) {
         const int32_t off = lut[4 * s], cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
         if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
@@ -480,7 +523,7 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
             const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
             if (w < 0 || w >= blocks || c < 0) return -1;
             if (c >= (1 << 24)) return 0;
-            per_group[ob / G].push_back({c >> 1, ob % G, c & 1, w});
+            per_group[grp_of[ob]].push_back({c >> 1, wave_of[ob], c & 1, w});
         }
     }
     // ORDER of the steps (a sum over input blocks: any order is the same product; fp32 rounding follows the order).  In ascending order a
@@ -552,8 +595,8 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
     int max_l = 0, max_s = 0;
     for (int g = 0; g < ngroups; ++g) {
         auto& v = per_group[g];
-        std::sort(v.begin(), v.end(), [&](const E& a, const E& b) {
-            const int ra = rank.empty() ? a.p : rank[a.p], rb = rank.empty() ? b.p : rank[b.p];
+        std::stable_sort(v.begin(), v.end(), [&](const E& a, const E& b) {     // (stable: entries that name the same input block twice -- the doubled
+            const int ra = rank.empty() ? a.p : rank[a.p], rb = rank.empty() ? b.p : rank[b.p];   //  tables of gated calls -- keep their table order)
             return ra != rb ? ra < rb : (a.wave != b.wave ? a.wave < b.wave : a.half < b.half);
         });
         const int step_off = (int)pairs.size();
@@ -636,11 +679,14 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
         max_l = std::max(max_l, lcap); max_s = std::max(max_s, nsteps);
         const int list_off = (int)lists.size();
         for (int wv = 0; wv < G; ++wv) lists.push_back((int32_t)wl[wv].size() / 2);
+        for (int wv = 0; wv < G; ++wv) lists.push_back(gcols[g][wv]);
         for (int wv = 0; wv < G; ++wv) {
             lists.insert(lists.end(), wl[wv].begin(), wl[wv].end());
             lists.insert(lists.end(), (size_t)2 * lcap - wl[wv].size(), 0);
         }
-        groups.insert(groups.end(), {step_off, nsteps, g * G, std::min(G, n_out_blocks - g * G), list_off, lcap, (int32_t)v.size(), 0});
+        int nob = 0;
+        for (int wv = 0; wv < G; ++wv) nob += gcols[g][wv] >= 0 ? 1 : 0;
+        groups.insert(groups.end(), {step_off, nsteps, gcols[g][0], nob, list_off, lcap, (int32_t)v.size(), regrouped ? 1 : 0});
     }
     {
         std::vector<int> order(ngroups);

@@ -209,12 +209,12 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
         if (!xmap_decode(map, unit, tile, grp)) continue;
         const int32_t* gh = plan + plan[5] + X4_GROUP * grp;
         const int step_off = __builtin_amdgcn_readfirstlane(gh[0]), nsteps = __builtin_amdgcn_readfirstlane(gh[1]);
-        const int ob0 = __builtin_amdgcn_readfirstlane(gh[2]), nob = __builtin_amdgcn_readfirstlane(gh[3]);
         const int list_off = __builtin_amdgcn_readfirstlane(gh[4]), lcap = __builtin_amdgcn_readfirstlane(gh[5]);
         const int32_t* pairs = plan + plan[6] + step_off;
         const int32_t* lists = plan + plan[7] + list_off;
         const int nev = __builtin_amdgcn_readfirstlane(lists[wave]);
-        const int32_t* mine = lists + X4_G + (size_t)2 * lcap * wave;
+        const int my_ob = __builtin_amdgcn_readfirstlane(lists[X4_G + wave]);      // the output block this wave owns in this group (-1: none)
+        const int32_t* mine = lists + 2 * X4_G + (size_t)2 * lcap * wave;
         const int n_tile = tile * R;
         // (a group without any block has no steps: its waves run their two NOPs and the epilogue writes the zeros the output must hold)
         const unsigned char* xtile = static_cast<const unsigned char*>(uniform_ptr(xt + (size_t)n_tile * Cin * 2));
@@ -403,9 +403,9 @@ xflow32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __res
         // Epilogue, per wave, through its own weight slots (idle now): D[o][n] with col n = r, rows o = (reg & 3) + 8 (reg >> 2) + 4h.
         // Two passes of two row tiles: [64 rows][64 B], the four 16-byte pieces of row n XOR-swizzled with (n >> 2) & 3; read back as
         // full 64-byte rows and stored (16 rows per instruction).
-        if (wave < nob) {
+        if (my_ob >= 0) {
             unsigned char* stage = smem + wslot0;
-            unsigned char* ybase = reinterpret_cast<unsigned char*>(Y + (size_t)(ob0 + wave) * 32);
+            unsigned char* ybase = reinterpret_cast<unsigned char*>(Y + (size_t)my_ob * 32);
 #pragma unroll
             for (int pass = 0; pass < RT / 2; ++pass) {
 #pragma unroll

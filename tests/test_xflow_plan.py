@@ -42,7 +42,7 @@ def _columns(side):
 
 @pytest.mark.parametrize("name,layout", [("random 40x24", P.random_layout(40, 24, 0.3, seed=2)), ("dense 12x20", np.ones((12, 20), dtype=np.int32)),
                                          ("BA 64", P.ba_layout(64, 5, seed=1)), ("sparse 300x16", P.random_layout(300, 16, 0.05, seed=6)),
-                                         ("single", np.ones((1, 1), dtype=np.int32)), ("groups without blocks", np.eye(15, 40, dtype=np.int32)), ("bench 20 %", P.random_layout(128, 128, 0.2, seed=1234))])
+                                         ("single", np.ones((1, 1), dtype=np.int32)), ("BA 128 + I", np.maximum(P.ba_layout(128, 14, seed=3), np.eye(128, dtype=np.int32))), ("groups without blocks", np.eye(15, 40, dtype=np.int32)), ("bench 20 %", P.random_layout(128, 128, 0.2, seed=1234))])
 @pytest.mark.parametrize("which", ["fprop", "bprop"])
 @pytest.mark.parametrize("order", ["natural", "scheduled"])
 def test_flow_plan_event_lists(name, layout, which, order):
@@ -53,23 +53,33 @@ def test_flow_plan_event_lists(name, layout, which, order):
     DI = 16 // PARTS
     cols = _columns(side)
     ngroups = p[3]
-    seen_groups = set()
+    assert p[1] == 4
+    owned = []                           # every output block belongs to exactly one (group, wave)
+    regrouped_any = False
     for g in range(ngroups):
-        step_off, nsteps, ob0, nob, list_off, lcap, nblk, _ = p[p[5] + 8 * g:p[5] + 8 * g + 8]
-        assert ob0 % 16 == 0 and ob0 not in seen_groups
-        seen_groups.add(ob0)
+        step_off, nsteps, ob0, nob, list_off, lcap, nblk, regrouped = p[p[5] + 8 * g:p[5] + 8 * g + 8]
+        gcols = [int(c) for c in p[p[7] + list_off + 16:p[7] + list_off + 32]]
+        assert gcols[0] == ob0 and sum(c >= 0 for c in gcols) == nob
+        if not regrouped:                # consecutive output blocks (uniform layouts, BSMM_PLAN_FLOW_CONSECUTIVE)
+            assert ob0 % 16 == 0 and gcols == [ob0 + v if v < nob else -1 for v in range(16)]
+        else:                            # adjacent pairs stay together (one 128-byte line of an output row)
+            regrouped_any = True
+            assert all(gcols[v] < 0 or gcols[v] % 2 == 0 for v in range(0, 16, 2))
+            assert all(gcols[v + 1] in (-1, gcols[v] + 1) for v in range(0, 16, 2))
+        owned += [c for c in gcols if c >= 0]
         pairs = p[p[6] + step_off:p[6] + step_off + nsteps]
         assert len(set(pairs)) == len(pairs)
         if order == "natural":              # ascending input blocks: the summation order of the staged kernel
             assert list(pairs) == sorted(pairs)
         base = p[7] + list_off
         counts = p[base:base + 16]
+        base += 16                           # (version 4: the group's output-block table sits between the counts and the lists)
         reqs, anns = {}, {}
         waves = []
         total_blocks = 0
         for wv in range(16):
             ev = np.asarray(p[base + 16 + 2 * lcap * wv:base + 16 + 2 * lcap * wv + 2 * counts[wv]], dtype=np.int64).reshape(-1, 2) & 0xffffffff
-            want = sorted(cols.get(ob0 + wv, [])) if wv < nob else []      # (c, w) ascending in c = step order, even half first
+            want = sorted(cols.get(gcols[wv], [])) if gcols[wv] >= 0 else []      # (c, w) ascending in c = step order, even half first
             blocks, ops, fetch_seq, req_seq, fetched = [], 0, [], {}, []
             events = []
             for i, (w0, w1) in enumerate(ev):
@@ -140,7 +150,12 @@ def test_flow_plan_event_lists(name, layout, which, order):
                     pc[wv] += 1
                     moved = True
         assert all(pc[wv] == len(waves[wv]) for wv in range(16)), "deadlock in the event lists of %s group %d" % (name, g)
-    assert len(seen_groups) == ngroups == (n_out + 15) // 16
+    assert sorted(owned) == list(range(n_out)) and ngroups == (n_out + 15) // 16
+    if name == "BA 128 + I":             # the reference's bench layout: hubs in 16 neighbouring columns -> regrouped, and balanced afterwards
+        loads = sorted(int(p[p[5] + 8 * g + 6]) for g in range(ngroups))
+        assert regrouped_any and loads[-1] <= 1.1 * (sum(loads) / len(loads)), loads
+    if name == "bench 20 %":
+        assert not regrouped_any
 
 
 def test_flow_plan_is_refused_where_the_kernel_does_not_exist():
