@@ -778,14 +778,18 @@ inline int updat_split(const bsmm_args* a, int nitems, int nchunks) {
 // partial-sum path of the streaming kernel: the workspace holds the fp32 sums [blocks][1024] (only written for
 // BSMM_FLAG_DW_SUMS) and behind them one region of 64 accumulator slots x 4 KiB per (round, workgroup)
 struct U2Launch { int grid; bool scratch; int flat; int rounds; int direct; };      // grid: the schedule's workgroups; direct: workgroups of the direct blocks behind them
-inline int u2_direct_blocks(const bsmm_args* a) { return (a->plan_inner >> 24) & 0x7f; }     // (descriptor of a 'BSU2' plan: describe_flat)
+// descriptor of a 'BSU2' plan (describe_flat): item sets (4 bits) | all sets equally long (bit 4) | longest set << 8 (13 bits) | direct blocks << 21 (10 bits)
+inline int u2_direct_blocks(const bsmm_args* a) { return (a->plan_inner >> 21) & 0x3ff; }
+inline int u2_longest_set(const bsmm_args* a) { return (a->plan_inner >> 8) & 0x1fff; }
 // (+ 2 KiB: the fused data-parallel reduction reads / writes the sums in `world` 32-byte aligned shards, include/bsmm_dist.h)
 inline size_t u2_sums_bytes(const bsmm_args* a) { return round16((size_t)a->blocks * 1024 * sizeof(float)) + 2048; }
 inline size_t u2_region_bytes() { return (size_t)U2_WAVES * U2_SLOTS * 4096; }
+// (a direct block's workgroup leaves ONE 4 KiB partial sum: packed behind the regions of the schedule's workgroups, 64 to a region's worth)
+inline size_t u2_direct_bytes(int direct_wgs) { return (size_t)((direct_wgs + 63) / 64) * u2_region_bytes(); }
 inline int u2_chunk(const bsmm_args* a) { return a->axis == 1 ? U2_CH : U2_CH0; }   // minibatch entries per chunk of the streaming kernel
 inline U2Launch updat2_shape(const bsmm_args* a, bool gated) {
     const int cus = device_cus();
-    const int nsets = a->plan_inner & 15, longest = (a->plan_inner >> 8) & 0xffff, common = (a->plan_inner & 16) ? longest : 0;
+    const int nsets = a->plan_inner & 15, longest = u2_longest_set(a), common = (a->plan_inner & 16) ? longest : 0;
     U2Launch L;
     L.direct = u2_direct_blocks(a) * U2_DIRECT_PARTS;           // (their partial sums meet in the summing pass: such a plan always takes the scratch path)
     if (a->split >= 1) {
@@ -815,7 +819,7 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
     float* scratch = nullptr;      // the partial-sum regions
     float* sums = nullptr;
     if (L.scratch) {
-        const size_t need = u2_sums_bytes(a) + (size_t)L.rounds * (L.grid + L.direct) * u2_region_bytes();
+        const size_t need = u2_sums_bytes(a) + (size_t)L.rounds * L.grid * u2_region_bytes() + u2_direct_bytes(L.direct);
         if (!a->workspace || a->workspace_bytes < need || !aligned16(a->workspace)) return BSMM_ERR_WORKSPACE;
         sums = static_cast<float*>(a->workspace);
         scratch = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + u2_sums_bytes(a));
@@ -826,24 +830,24 @@ int launch_updat2(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_a
         if constexpr (AXIS == 1) {
             if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 32, 1>>(u2_lds_bytes(32))) return rc;
             updat32_a1_v2_kernel<DT, 32, 1><<<L.grid + L.direct, 64 * U2_WAVES, u2_lds_bytes(32), st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                                            a->pcount, a->alpha, a->beta, L.flat, L.grid);
+                                                                                            a->pcount, a->alpha, a->beta, L.flat, L.grid, L.rounds);
         } else {
             return BSMM_ERR_ARG;
         }
     } else if (a->plan_width == 16) {
         if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 16, AXIS>>(LDS16)) return rc;
         updat32_a1_v2_kernel<DT, 16, AXIS><<<L.grid + L.direct, 64 * U2_WAVES, LDS16, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                                a->pcount, a->alpha, a->beta, L.flat, L.grid);
+                                                                                a->pcount, a->alpha, a->beta, L.flat, L.grid, L.rounds);
     } else {
         if (int rc = ensure_lds<&updat32_a1_v2_kernel<DT, 8, AXIS>>(LDS8)) return rc;
         updat32_a1_v2_kernel<DT, 8, AXIS><<<L.grid + L.direct, 64 * U2_WAVES, LDS8, st>>>(xs, es, static_cast<T*>(DW), scratch, a->plan, a->N, a->C, a->K,
-                                                                              a->pcount, a->alpha, a->beta, L.flat, L.grid);
+                                                                              a->pcount, a->alpha, a->beta, L.flat, L.grid, L.rounds);
     }
     if (scratch) {
         const int CPI = a->pcount * ((a->N + u2_chunk(a) - 1) / u2_chunk(a));
         const int32_t* bmap = a->plan + U2_HDR + (size_t)a->plan_items * U2_ITEM;     // behind the items (bsmm_plan.h)
-        if (sums_only) updat2_reduce_kernel<DT, true><<<a->blocks, 128, 0, st>>>(scratch, nullptr, sums, a->plan, bmap, nullptr, L.grid + L.direct, L.grid, L.flat, CPI, 1.f, 0.f);
-        else           updat2_reduce_kernel<DT, false><<<a->blocks, 128, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, bmap, gate, L.grid + L.direct, L.grid, L.flat, CPI, a->alpha, a->beta, q64 ? 1 : 0);
+        if (sums_only) updat2_reduce_kernel<DT, true><<<a->blocks, 128, 0, st>>>(scratch, nullptr, sums, a->plan, bmap, nullptr, L.rounds * L.grid, L.grid, L.flat, CPI, 1.f, 0.f);
+        else           updat2_reduce_kernel<DT, false><<<a->blocks, 128, 0, st>>>(scratch, static_cast<T*>(DW), nullptr, a->plan, bmap, gate, L.rounds * L.grid, L.grid, L.flat, CPI, a->alpha, a->beta, q64 ? 1 : 0);
     }
     return (int)hipGetLastError();
 }
@@ -961,7 +965,7 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                     const double chunks = (double)a->plan_items * a->pcount * ((N + 15) / 16);      // (the fit is per 16 minibatch entries)
                     double t_stream = 6.0 + chunks / L.grid * 0.40;
                     if (L.scratch && !L.flat) {
-                        const int nsets = a->plan_inner & 15, longest = (a->plan_inner >> 8) & 0xffff, U = std::max(1, L.grid / 8);
+                        const int nsets = a->plan_inner & 15, longest = u2_longest_set(a), U = std::max(1, L.grid / 8);
                         const int m_last = longest % U;
                         const double sliced = longest > 0 ? (double)m_last / longest : 0.0;
                         const double mult = (8.0 / std::max(1, nsets)) * ((1.0 - sliced) + sliced * (m_last > 0 ? std::min(U / m_last, U2_MAX_SLICES) : 1));
@@ -1698,9 +1702,9 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
                              }
                              break;
         case U2PLAN_MAGIC:   if (p[1] != U2PLAN_VERSION || words < U2_HDR || p[26] != U2_HDR + p[4] * U2_ITEM || words < (long)p[26] + p[5]) return false;   // (the launcher addresses the block map behind the items)
-                               if (p[27] < 0 || p[27] > 0xffff || p[28] < 0 || p[28] > U2_DIRECT_MAX) return false;
+                               if (p[27] < 0 || p[27] > 0x1fff || p[28] < 0 || p[28] > U2_DIRECT_MAX) return false;
                                if (p[28] > 0 && (p[30] != U2_DIRECT_PARTS || p[29] < p[26] + p[5] || words < (long)p[29] + 4L * p[28])) return false;      // direct blocks
-                               d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8] | (p[25] > 0 ? 16 : 0) | (p[27] << 8) | (p[28] << 24); break;   // item sets | all equally long | longest set | direct blocks
+                               d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8] | (p[25] > 0 ? 16 : 0) | (p[27] << 8) | (p[28] << 21); break;   // item sets | all equally long | longest set | direct blocks
         default: return false;
     }
     d[0] = p[0];
@@ -1777,7 +1781,7 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
     if (op == BSMM_OP_UPDAT && a->plan && (a->bsize == 32 || a->bsize == 16) && a->dtype != BSMM_F32) {
         if (a->plan_magic == U2PLAN_MAGIC) {   // streaming kernel: the fp32 sums + one region of partial sums per (round, workgroup)
             const U2Launch L = updat2_shape(a, true);
-            return u2_sums_bytes(a) + (size_t)L.rounds * (L.grid + L.direct) * u2_region_bytes();
+            return u2_sums_bytes(a) + (size_t)L.rounds * L.grid * u2_region_bytes() + u2_direct_bytes(L.direct);
         }
         if (a->plan_magic != UPLAN_MAGIC || a->bsize != 16) return 0;     // (a plan check_plan refuses: nothing to size)
         // bsize 16 windowed kernel: one fp32 image of the sums (split-minibatch path); with the 'BSU6' section (feature axis 0) one image per part

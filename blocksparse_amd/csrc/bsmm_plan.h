@@ -1120,7 +1120,7 @@ constexpr int U2_WWORDS = 5;
 constexpr int U2_ITEM = 4 + U2_WAVES * U2_WWORDS;
 constexpr int U2_HDR = 32;   // 9 + 2 * 8 set descriptors, block map, longest set, direct blocks
 constexpr int U2_DIRECT_PARTS = 4;       // workgroups (= quarters of the minibatch) per direct block
-constexpr int U2_DIRECT_MAX = 64;        // more overflow blocks than this: overflow items as before
+constexpr int U2_DIRECT_MAX = 64;        // more overflow blocks than this: overflow items as before (the call descriptor has 10 bits for the count)
 
 inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int KB, int ws, int32_t* out, int force_sets, int direct_max) {
     if (!updat_lut || blocks <= 0 || CB <= 0 || KB <= 0 || (ws != 8 && ws != 16 && ws != 32) || blocks >= (1 << 29)) return -1;
@@ -1150,6 +1150,9 @@ inline long build_updat2_plan(const int32_t* updat_lut, int blocks, int CB, int 
     bool overflow_item = false;
     const bool direct_ok = direct_max > 0 && nsets <= 2;      // (8 sets: every item may be one workgroup's and stored directly -- no summing pass to meet in)
     std::vector<int32_t> direct;                              // (block, c, k, 0) per direct block
+    // (Round 6 also tried LIGHT windows -- a window with <= 12 blocks, a quarter of the mean load, and the small overflow pieces of dense windows as
+    //  direct blocks, up to 768 of them -- for unbalanced layouts: the reference's Barabasi-Albert bench layout 130.3 -> 133.4 us, power-law columns
+    //  121.3 -> 144.6 us: a direct block costs four workgroups, more than a light item costs its window's stream.  profiles/r06_updat_light_windows.txt)
     auto emit = [&](int wi, int wj, const std::vector<Wave>& waves) {
         std::vector<int32_t> it(U2_ITEM, 0);
         int n = 0;

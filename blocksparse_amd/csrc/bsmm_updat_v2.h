@@ -136,7 +136,7 @@ __device__ __forceinline__ const unsigned char* pick_ptr(const PtrList8& l, int 
 // workgroup's region, in the register order updat2_reduce_kernel expects.  ~3 us for a quarter of 2048 rows; nothing is shared, nothing is waited for.
 template <class DT, int LDSB>
 __device__ __forceinline__ void u2_direct_block(const PtrList8& Xs, const PtrList8& Es, float* __restrict__ scratch, const int32_t* __restrict__ plan,
-                                                int N, int Cf, int Kf, int pcount, int e, unsigned char* smem) {
+                                                int N, int Cf, int Kf, int pcount, int e, long region0, unsigned char* smem) {
     typedef typename DT::T T;
     constexpr int SLOT = 2048, D = LDSB / U2_WAVES / SLOT;       // ring slots per wave: 4 (128 KiB) or 2 (64 KiB)
     static_assert(D >= 2 && LDSB >= U2_WAVES * 4096, "direct blocks: a ring of two chunks per wave and 64 KiB for the reduction");
@@ -199,7 +199,8 @@ __device__ __forceinline__ void u2_direct_block(const PtrList8& Xs, const PtrLis
 #pragma unroll
     for (int v = 0; v < U2_WAVES; ++v) sum += red[v * 1024 + threadIdx.x];         // element (reg = tid >> 6, lane = tid & 63), waves in order
     const int reg = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    float* region = scratch + (size_t)blockIdx.x * (U2_WAVES * U2_SLOTS) * 1024;    // (round 0 of this workgroup; accumulator slot 0)
+    // ONE partial sum of 4 KiB per direct workgroup, packed behind the regions of the schedule's workgroups of EVERY round (rounds * main grid regions)
+    float* region = scratch + ((size_t)region0 * (U2_WAVES * U2_SLOTS) + (size_t)e) * 1024;
     region[((reg >> 2) * 64 + ln) * 4 + (reg & 3)] = sum;
 }
 
@@ -209,7 +210,7 @@ __device__ __forceinline__ void u2_direct_block(const PtrList8& Xs, const PtrLis
 template <class DT, int WS, int AXIS = 1>
 __global__ void __launch_bounds__(64 * U2_WAVES, 4)
 updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, float* __restrict__ scratch,
-                     const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta, int flat, int main_grid) {
+                     const int32_t* __restrict__ plan, int N, int Cf, int Kf, int pcount, float alpha, float beta, int flat, int main_grid, int rounds) {
     typedef typename DT::T T;
     static_assert(DT::is16 && (WS == 8 || WS == 16 || (WS == 32 && AXIS == 1)), "updat v2: 16-bit storage types, 8x8 / 16x16 windows (32x32: feature axis 1)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -231,7 +232,7 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
     // workgroups behind the schedule's `main_grid`: direct blocks (feature axis 1; the launcher adds them only there and only with partial sums)
     const int mg = main_grid > 0 ? main_grid : (int)gridDim.x;
     if ((int)blockIdx.x >= mg) {
-        if constexpr (AXIS == 1) u2_direct_block<DT, u2_lds_bytes(WS)>(Xs, Es, scratch, plan, N, Cf, Kf, pcount, (int)blockIdx.x - mg, smem);
+        if constexpr (AXIS == 1) u2_direct_block<DT, u2_lds_bytes(WS)>(Xs, Es, scratch, plan, N, Cf, Kf, pcount, (int)blockIdx.x - mg, (long)rounds * mg, smem);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -577,7 +578,7 @@ updat32_a1_v2_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, 
             // this (round, workgroup) -- [slot = wave * 4 + j][quad q][lane] float4, 1 KiB per instruction; updat2_reduce_kernel
             // knows the schedule, sums the regions of a block and undoes the order.  (Round 2 first used fp32 atomics into
             // one zeroed image: 52 MiB of cross-XCD atomics per pass, ~30 us of the 112.)
-            float4* reg_base = reinterpret_cast<float4*>(scratch) + ((size_t)(round * gridDim.x + blockIdx.x) * (U2_WAVES * U2_SLOTS) + wave * U2_SLOTS) * 256 + lane;
+            float4* reg_base = reinterpret_cast<float4*>(scratch) + ((size_t)(round * mg + blockIdx.x) * (U2_WAVES * U2_SLOTS) + wave * U2_SLOTS) * 256 + lane;
 #pragma unroll
             for (int j = 0; j < U2_SLOTS; ++j) {
                 if (j >= n0 + n1) break;
@@ -638,13 +639,13 @@ __device__ __forceinline__ float4 u2_ld(const float4* p) {
 template <class DT, bool SUMS>
 __global__ void __launch_bounds__(128)
 updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict__ DW, float* __restrict__ sums, const int32_t* __restrict__ plan,
-                     const int32_t* __restrict__ bmap, const float* __restrict__ gate, int grid, int main_grid, int flat, int CPI, float alpha, float beta, int q64 = 0) {
+                     const int32_t* __restrict__ bmap, const float* __restrict__ gate, int direct_region0, int main_grid, int flat, int CPI, float alpha, float beta, int q64 = 0) {
     // 128 threads = (quad pair qq = tid >> 6, lane l): quads qq and qq + 2 -- all workgroups of the bench shape are resident at once,
     // and the block map is addressed from an argument so that its load does not wait for the plan header
     const int w = blockIdx.x;
     const int qq = threadIdx.x >> 6, l = threadIdx.x & 63;
-    // (`grid`: all workgroups of the streaming launch -- the region index of (round, workgroup) is round * grid + workgroup; `main_grid`: the
-    //  schedule's, the first of them; behind those the workgroups of the direct blocks)
+    // (`main_grid`: the schedule's workgroups -- the region index of (round, workgroup) is round * main_grid + workgroup; `direct_region0` = rounds *
+    //  main_grid: behind those regions the partial sums of the direct blocks' workgroups, 4 KiB each, packed)
     const int32_t bm = bmap[w];
     const bool direct = bm <= -2;
     const int item = direct ? 0 : bm >> 8, slot = direct ? 0 : bm & 255;
@@ -675,12 +676,12 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
     if (direct) {
         // a direct block: one partial sum per quarter of the minibatch, slot 0 of the regions of its U2_DIRECT_PARTS workgroups (always written)
         const int dp = plan[30];
-        const float4* p0 = base + (size_t)(main_grid + (-2 - bm) * dp) * REGION;
+        const float4* p0 = base + (size_t)direct_region0 * REGION + (size_t)((-2 - bm) * dp) * 256;
         float4 v0[8], v1[8];
 #pragma unroll
         for (int part = 0; part < 8; ++part) {
             v0[part] = v1[part] = zero4;
-            if (part < dp) { v0[part] = u2_ld(p0 + (size_t)part * REGION); v1[part] = u2_ld(p0 + (size_t)part * REGION + 128); }
+            if (part < dp) { v0[part] = u2_ld(p0 + (size_t)part * 256); v1[part] = u2_ld(p0 + (size_t)part * 256 + 128); }
         }
 #pragma unroll
         for (int part = 0; part < 8; ++part) { add(acc0, v0[part]); add(acc1, v1[part]); }
@@ -693,7 +694,7 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
             v0[part] = v1[part] = zero4;
             if (part < nparts && part_len(part) > 0) {
                 const int xcd = set * nparts + part;
-                const float4* p = base + ((size_t)round * grid + (xcd_mode ? uj * 8 + xcd : uj)) * REGION;
+                const float4* p = base + ((size_t)round * main_grid + (xcd_mode ? uj * 8 + xcd : uj)) * REGION;
                 v0[part] = u2_ld(p); v1[part] = u2_ld(p + 128);
             }
         }
@@ -704,7 +705,7 @@ updat2_reduce_kernel(const float* __restrict__ parts, typename DT::T* __restrict
             const int L = part_len(part);
             if (L <= 0) continue;
             const int xcd = set * nparts + part;
-            const float4* rb = base + (size_t)full_rounds * grid * REGION;
+            const float4* rb = base + (size_t)full_rounds * main_grid * REGION;
             auto where = [&](int slice) -> const float4* {
                 if (slice >= k_last) return nullptr;
                 if (L < k_last) {      // fewer chunks than slices: some slices are empty and wrote nothing
