@@ -793,6 +793,30 @@ def main():
             small["%d_n%d" % (hid_s, nn)] = r
             del bs_, ws_, xs_, dys_, dws_
         out["small_n"] = small
+        # gated fprop / bprop (per-block gates; round 6: gated weight images + the ungated kernels, blocksparse_amd/matmul.py::_gated_xprop)
+        try:
+            def ev_us(fn, reps=40, warm=10):
+                for _ in range(warm):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps * 1e3
+            gg = torch.Generator(device="cuda").manual_seed(17)
+            gen_gate = torch.rand(b.blocks, device="cuda", generator=gg) * 2 - 0.5
+            gen_gate[::7] = 0
+            mask_gate = (torch.rand(b.blocks, device="cuda", generator=gg) < 0.8).float()
+            grow = {}
+            for gname, gt in (("ungated", None), ("mask_0_1", mask_gate), ("general", gen_gate)):
+                grow[gname] = {"fprop_us": round(ev_us(lambda: b.fprop(x, w, gate=gt)), 1), "bprop_us": round(ev_us(lambda: b.bprop(dy, w, gate=gt)), 1)}
+            grow["workload"] = "headline shape, fprop / bprop with per-block gates: a 0/1 mask (80 % ones: one exact weight image) and arbitrary fp32 gates (bf16: hi + lo images over doubled tables)"
+            out["gated"] = grow
+        except Exception as e:          # an extra line must never cost the headline
+            out["gated"] = {"error": str(e)[:200]}
         side_row("bs8", random_layout(hidden0 // 8, hidden0 // 8, 0.10, seed=1234), 8, 0, n_local,
                  "4096x4096 block_size=8 density=10%% feature_axis=0 bf16, minibatch %d, fprop+bprop+updat (super-block path)" % n_local, steps_x=20)
     # BASELINE.json configs[1]: same layout, fp32, feature_axis=1, fprop only.  Priced against the fp32 matrix-core peak

@@ -1251,19 +1251,23 @@ inline bool updat16_f32_rows_applies(const bsmm_args* a) {
            call_variant(a) != 1 && call_variant(a) != 2;
 }
 inline size_t updat16_f32_rows_images_bytes(const bsmm_args* a) { return round16((size_t)U6_MAX_SPLIT * a->blocks * 256 * sizeof(float)); }
+// will the call run on the row-owner kernel?  ONE rule for the dispatch and for bsmm_workspace_bytes (the sizing used to reserve the
+// images and the pieces -- several hundred MB -- for shapes the dispatch then sent to the per-block kernel, which needs no workspace)
+inline bool updat16_f32_rows_taken(const bsmm_args* a) {
+    if (!updat16_f32_rows_applies(a)) return false;
+    if (call_variant(a) == 3) return true;
+    if (a->N < 256) return false;
+    const int nitems = a->plan_waves >> 8, nchunks = (a->N + 63) / 64, cus = device_cus();
+    int split = 1;
+    while (split < U6_MAX_SPLIT && nitems * split < cus) split *= 2;
+    return a->split > 0 || (4L * nitems * split >= 3L * cus && 6L * nchunks / split >= (split >= 4 ? 16 : 8));
+}
 int updat16_f32_rows(const void* const* X, const void* const* DY, void* DW, const bsmm_args* a) {
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     const size_t img_b = updat16_f32_rows_images_bytes(a), nx = (size_t)a->N * a->C, ne = (size_t)a->N * a->K;
     if (!a->workspace || !aligned16(a->workspace) || a->workspace_bytes < img_b + 6 * (nx + ne) + F32_SPLIT_FLAG_BYTES) return BSMM_ERR_WORKSPACE;
     if (!aligned16(X[0]) || !aligned16(DY[0]) || !aligned16(DW)) return BSMM_ERR_ARG;
-    // (will the row-owner kernel take it?  Ask before the pieces are made: a dry run of its rule)
-    {
-        const int nitems = a->plan_waves >> 8, nchunks = (a->N + 63) / 64, cus = device_cus();
-        int split = 1;
-        while (split < U6_MAX_SPLIT && nitems * split < cus) split *= 2;
-        const bool pays = a->split > 0 || (4L * nitems * split >= 3L * cus && 6L * nchunks / split >= (split >= 4 ? 16 : 8));
-        if (!pays && call_variant(a) != 3) return BSMM_ERR_UNSUPPORTED;
-    }
+    if (!updat16_f32_rows_taken(a)) return BSMM_ERR_UNSUPPORTED;      // (asked before the pieces are made)
     float* images = static_cast<float*>(a->workspace);
     uint16_t* xp = reinterpret_cast<uint16_t*>(static_cast<char*>(a->workspace) + img_b);
     uint16_t* ep = xp + 3 * nx;
@@ -1348,7 +1352,7 @@ int bsmm_updat(const void* const* X, const void* const* DY, void* DW, const bsmm
         if (updat_f32_split_applies(a) && (a->N >= 256 || call_variant(a) == 3 || (a->flags & BSMM_FLAG_DW_SUMS))) return updat32_f32_split(X, DY, DW, a);
         if (updat8_f32_split_applies(a) && (a->N >= 256 || call_variant(a) == 3)) return updat8_f32_split(X, DY, DW, a);
         if (updat16_f32_split_applies(a) && (a->N >= 256 || call_variant(a) == 3)) return updat16_f32_split<1>(X, DY, DW, a);
-        if (updat16_f32_rows_applies(a) && (a->N >= 256 || call_variant(a) == 3)) {
+        if (updat16_f32_rows_taken(a)) {
             const int rc16 = updat16_f32_rows(X, DY, DW, a);
             if (rc16 != BSMM_ERR_UNSUPPORTED) return rc16;
         }
@@ -1772,6 +1776,7 @@ size_t bsmm_workspace_bytes(int op, const bsmm_args* a) {
         }
         return op == BSMM_OP_UPDAT ? blk * sizeof(float) : std::max(round16(blk * elem_size(a->dtype)) + 16, lock);   // (+ the non-finite flag of the call)
     }
+    if (op == BSMM_OP_UPDAT && updat16_f32_rows_applies(a) && !updat16_f32_rows_taken(a)) return 0;      // (the per-block fp32 kernel: no workspace)
     if (op == BSMM_OP_UPDAT && updat16_f32_rows_applies(a))     // fp32 / bsize 16 / feature axis 0 on the row-owner kernel: its images + the pieces of X and DY
         return updat16_f32_rows_images_bytes(a) + 6 * ((size_t)a->N * a->C + (size_t)a->N * a->K) + F32_SPLIT_FLAG_BYTES;
     if (op == BSMM_OP_UPDAT && updat16_f32_split_applies(a))    // fp32 / bsize 16 on the windowed kernel: the fp32 sums + the pieces of X and DY

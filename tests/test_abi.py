@@ -199,6 +199,9 @@ def test_argument_validation_without_gpu(lib):
     a.axis, a.dtype = 1, lib.BF16
     assert L.bsmm_gate_grad(one, None, one, one, one, 4, 32, lib.F32, None) == -1
     assert L.bsmm_gate_grad(one, one, one, one, one, 4, 64, lib.F32, None) == -2
+    assert L.bsmm_gate_weights(one, None, one, 4, 32, lib.BF16, 1, None) == -1            # (round 6) gated weight images: arguments, then support
+    assert L.bsmm_gate_weights(one, one, one, 4, 32, lib.F32, 1, None) == -2
+    assert L.bsmm_gate_weights(one, one, one, 4, 32, lib.BF16, 3, None) == -2
 
 
 def _check_xcol_plan(plan, f, t, n_out):

@@ -75,3 +75,34 @@ def test_big_layout_builds_fast():
     t = L.build_tables(lay)
     assert time.time() - t0 < 5.0
     assert t["blocks"] == int(lay.sum())
+
+
+def test_double_tables_for_gated_calls():
+    """lut.double_tables (round 6: gated calls on the ungated kernels over hi / lo weight images): every entry (c, w) is followed by
+    (c, w + blocks), headers keep their order, lengths and offsets double, and the doubled table is a valid xprop table for every plan builder."""
+    import ctypes
+    from blocksparse_amd import _lib as lib
+    from blocksparse_amd.matmul import _host_plan
+    import _parity
+    lay = _parity.random_layout(24, 40, 0.3, seed=5)
+    for segmented in (False, True):
+        t = L.build_tables(lay, z_order=True, segmented=segmented)
+        d = L.double_tables(t)
+        B = t["blocks"]
+        assert d["blocks"] == 2 * B
+        for side, n_out in (("fprop", t["KB"]), ("bprop", t["CB"])):
+            a, b = t[side], d[side]
+            S = a["segments"]
+            assert b["segments"] == S and b["locks"] == a["locks"] and b["shared"] == 2 * a["shared"]
+            la, lb = np.asarray(a["lut"]), np.asarray(b["lut"])
+            assert lb.size == 4 * S + 4 * B
+            for s_ in range(S):
+                off, cnt, ob, lock = la[4 * s_:4 * s_ + 4]
+                off2, cnt2, ob2, lock2 = lb[4 * s_:4 * s_ + 4]
+                assert (cnt2, ob2, lock2) == (2 * cnt, ob, lock)
+                ea = la[2 * off:2 * (off + cnt)].reshape(-1, 2)
+                eb = lb[2 * off2:2 * (off2 + cnt2)].reshape(-1, 2, 2)
+                assert np.array_equal(eb[:, 0, :], ea) and np.array_equal(eb[:, 1, 0], ea[:, 0]) and np.array_equal(eb[:, 1, 1], ea[:, 1] + B)
+            if not segmented:
+                for bs, axis, opt in ((32, 1, lib.PLAN_XCOL_FLOW), (32, 0, 0), (16, 0, 0), (16, 1, 0)):
+                    assert _host_plan(b["lut"], S, 2 * B, n_out, bs, lib.BF16, axis, opt) is not None
