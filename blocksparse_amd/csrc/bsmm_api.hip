@@ -21,6 +21,7 @@
 #include "bsmm_xflow.h"
 #include "bsmm_updat16_rows.h"
 #include "bsmm_xsmall.h"
+#include "bsmm_xsmall0.h"
 #include "bsmm_xmid.h"
 #include "bsmm_xcol16_v2.h"
 #include "bsmm_b64.h"
@@ -431,6 +432,9 @@ enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_SUPER8, 
 #ifndef BSMM_SMALL_N_MAX
 #define BSMM_SMALL_N_MAX 4096     // the small-minibatch kernel (bsmm_xsmall.h) is considered up to this many minibatch rows (the cost model decides)
 #endif
+#ifndef XS0_NMAX
+#define XS0_NMAX 512              // feature axis 0: the small-minibatch kernel (bsmm_xsmall0.h) up to this many minibatch columns
+#endif
 #ifndef BSMM_MID_MODE
 #define BSMM_MID_MODE 0           // medium-minibatch kernel (bsmm_xmid.h): 0 = by the cost model, 1 = whenever it can run, -1 = never (measurement builds)
 #endif
@@ -483,6 +487,15 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         const double o = (double)a->segments * ((a->N + 63) / 64) / (8.0 * device_cus());
         t_mid = 4.5 + 0.9 * ((double)a->blocks / a->segments) * std::max(1.12 * o, 0.25 + 0.5 * o);   // (full rounds: 12 % more per round, measured)
         if ((BSMM_MID_MODE > 0 || (a->flags & BSMM_FLAG_FORCE_MID)) && mid_ok) return XP_MID;
+    }
+    // small minibatches on feature axis 0 (round 6, bsmm_xsmall0.h): the regime of the reference's own benchmark (N = 64).  Measured against the
+    // per-segment and the plan kernels in scripts/gpu_a0_xprop_sweep.py
+    if constexpr ((BS == 32 || BS == 16) && DT::is16 && AXIS == 0) {
+        // (hipGraph replays, fprop / bprop us, this kernel against what ran before: hidden 2560 dense N = 64 8.3 / 8.1 against 45.8 / 27.1, N = 512 22.7
+        //  against 64.6 / 54.3, N = 1024 38.5 against 95; 20480 at 1.7 % N = 64 10.5 against 63.8 / 44.3, N = 512 60 against 82 / 73, N = 1024 116
+        //  against 91 / 81: up to 512 columns always, up to 1024 where the columns are long -- >= 16 blocks on average)
+        const bool n_ok = a->N <= XS0_NMAX || (a->N <= 2 * XS0_NMAX && (long)a->blocks >= 16L * a->segments);
+        if (variant == 0 && !a->gate && a->locks == 0 && a->N % 8 == 0 && n_ok && a->C % BS == 0 && a->K % BS == 0 && a->segments > 0) return XP_SMALL;
     }
     if (!plan_ok) {
         if (mid_ok && t_mid < (small_ok ? t_small : 1e30) && t_mid < 6.0 + 1.2e-5 * (double)a->blocks * a->N + 8.0) return XP_MID;
@@ -585,6 +598,24 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         }
     }
     if (path == XP_SMALL) {
+        if constexpr (BS == 16 && DT::is16 && AXIS == 0) {
+            if (fprop) { if (int rc = ensure_lds<&xsmall16_a0_kernel<DT, true>>(XS16_LDS)) return rc; }
+            else       { if (int rc = ensure_lds<&xsmall16_a0_kernel<DT, false>>(XS16_LDS)) return rc; }
+            trace(a, BSMM_K_XPROP_SMALL);
+            dim3 grid(a->segments, (a->N + XS0_C - 1) / XS0_C);
+            if (fprop) xsmall16_a0_kernel<DT, true><<<grid, 64 * XS0_NW, XS16_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N);
+            else       xsmall16_a0_kernel<DT, false><<<grid, 64 * XS0_NW, XS16_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N);
+            return (int)hipGetLastError();
+        }
+        if constexpr (BS == 32 && DT::is16 && AXIS == 0) {
+            if (fprop) { if (int rc = ensure_lds<&xsmall32_a0_kernel<DT, true>>(XS0_LDS)) return rc; }
+            else       { if (int rc = ensure_lds<&xsmall32_a0_kernel<DT, false>>(XS0_LDS)) return rc; }
+            trace(a, BSMM_K_XPROP_SMALL);
+            dim3 grid(a->segments, (a->N + XS0_C - 1) / XS0_C);
+            if (fprop) xsmall32_a0_kernel<DT, true><<<grid, 64 * XS0_NW, XS0_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N);
+            else       xsmall32_a0_kernel<DT, false><<<grid, 64 * XS0_NW, XS0_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N);
+            return (int)hipGetLastError();
+        }
         if constexpr (BS == 32 && DT::is16 && AXIS == 1) {
             if (fprop) { if (int rc = ensure_lds<&xsmall32_kernel<DT, true>>(XSM_LDS)) return rc; }
             else       { if (int rc = ensure_lds<&xsmall32_kernel<DT, false>>(XSM_LDS)) return rc; }
@@ -955,7 +986,15 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             if (!use_valu && al && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_magic == U2PLAN_MAGIC &&
                 (long)N * std::max(a->C, a->K) < (1L << 30)) {
                 bool stream = true;
-                if (variant == 0 && AXIS == 1) {      // (axis 0 has no per-block kernel of that kind to fall back to)
+                if (variant == 0 && AXIS == 0 && a->split == 0 && !sums_only && !(a->flags & FLAG_INTERNAL_Q64)) {
+                    // feature axis 0 (round 6; scripts/gpu_a0_updat_sweep.py, hipGraph replays): the per-block kernel costs 7 + 1.37e-5 us per (block,
+                    // minibatch column) -- 12.8 against the streaming kernel's 33.9 us at the reference benchmark's hidden 2560 / N = 64, 12.8 against 46
+                    // at 20480 / 1.7 %.  It is taken while that stays under 45 us, and whenever the windows are nearly empty (< 8 blocks per item: the
+                    // streaming kernel then moves a 32 KiB window per chunk for a handful of blocks, 537 against 227 us at 20480 / 1.7 % / N = 2048)
+                    const double t_blk0 = 7.0 + 1.37e-5 * (double)a->blocks * N * a->pcount;
+                    if (a->blocks < 8L * a->plan_items || t_blk0 < 45.0) stream = false;
+                }
+                if (variant == 0 && AXIS == 1) {
                     // Fitted to scripts/gpu_updat_sweep.py (4096^2 20 % / 5 %, 8192^2 5 %, 2048^2 20 %, N = 128 .. 8192, us):
                     // streaming kernel: 6 + 0.40 per 16-row chunk of a workgroup's share + 0.45 per MiB of partial sums (written by the
                     // kernel, read back by the reduce pass; a block has nparts partial sums, times the slices of the last round);
@@ -1022,7 +1061,18 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                 if (rc != BSMM_ERR_UNSUPPORTED) return rc;
             }
         }
-        if (!use_valu && !gated && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed, 16x16 blocks
+        bool blk16 = false;
+        if constexpr (AXIS == 0) {
+            // (round 6, the same sweep: the per-block kernel costs 7 + 6.6e-6 us per (block, minibatch column); the windowed kernel about 5 + 0.03 per
+            //  window + 1.1e-4 per (window, column).  Nearly empty windows -- the reference benchmark's sparse shapes: 73 against 18.6 us at 20480 /
+            //  1.5 % / N = 64 -- always take the per-block kernel)
+            if (variant == 0 && a->split == 0 && a->plan != nullptr && a->plan_items > 0) {      // (a caller who names a split wants the plan kernels)
+                const double t_blk0 = 7.0 + 6.6e-6 * (double)a->blocks * N * a->pcount;
+                const double t_win0 = 5.0 + 0.03 * a->plan_items + 1.1e-4 * (double)a->plan_items * N * a->pcount;
+                blk16 = a->blocks < 8L * a->plan_items || t_blk0 < 0.6 * t_win0;
+            }
+        }
+        if (!use_valu && !gated && !blk16 && al16 && (variant == 0 || variant == 3) && a->plan != nullptr && a->plan_items > 0) {   // windowed, 16x16 blocks
             if (a->plan_magic != UPLAN_MAGIC || (a->plan_width & 255) != UW16 || (a->plan_waves & 255) != UP_WAVES) return BSMM_ERR_ARG;   // (bits 8..: the 'BSU6' section's window width / items)
             if constexpr (AXIS == 0) {
                 // row-owner kernel ('BSU6' section, bsmm_updat16_rows.h): half the bytes per block of the windowed kernel, 64 (or fewer) work items --

@@ -1,0 +1,76 @@
+"""Small minibatches on feature axis 0 (round 6: csrc/bsmm_xsmall0.h -- the regime of the reference's own benchmark, test/blocksparse_matmul_bench.py:37-78:
+feature axis 0, minibatch 64) and the weight-gradient dispatch there: fprop / bprop / updat of the product API against the float64 oracle, the kernel
+family asserted."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import _parity as P
+from oracle import bsmm_oracle as O
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import __graft_entry__ as g
+    g.build()
+    from blocksparse_amd import BlocksparseMatMul, _lib
+    return torch, BlocksparseMatMul, _lib
+
+
+LAYOUTS = [("dense 12x20", np.ones((12, 20), dtype=np.int32)), ("BA 64", P.ba_layout(64, 5, seed=1)), ("random 40x24", P.random_layout(40, 24, 0.3, seed=2)),
+           ("empty rows and columns", np.eye(15, 40, dtype=np.int32)), ("single", np.ones((1, 1), dtype=np.int32)), ("one long column", np.ones((70, 1), dtype=np.int32))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("bs", [32, 16])
+@pytest.mark.parametrize("name,layout", LAYOUTS)
+def test_small_minibatch_xprop_axis0(env, name, layout, bs, dtype):
+    torch, BSMM, lib = env
+    b = BSMM(layout, block_size=bs, feature_axis=0)
+    t = O.build_layout_luts(layout, bs)
+    for N in (8, 64, 72, 200, 512):
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=11 + N)
+        w, x, e = (P.to_dev(a, dtype, torch) for a in (W, X, E))
+        y = b.fprop(x, w)
+        assert lib.last_kernel() & 255 == lib.K_XPROP_SMALL, (name, N, lib.last_kernel())
+        dx = b.bprop(e, w)
+        assert lib.last_kernel() & 255 == lib.K_XPROP_SMALL
+        for what, got, ref in (("Y", y, O.fprop(t, X, W, 0)), ("DX", dx, O.bprop(t, E, W, 0))):
+            l2, _ = P.errors(P.to_host(got), O.round_to(ref, dtype))
+            assert l2 <= P.L2_BAR[dtype], (name, dtype, N, what, l2)
+        # the same sums as the per-segment kernel up to the fp32 summation order
+        lib.set_kernel_variant(2)
+        try:
+            y2 = b.fprop(x, w)
+        finally:
+            lib.set_kernel_variant(0)
+        l2, _ = P.errors(P.to_host(y), P.to_host(y2))
+        assert l2 <= P.L2_BAR[dtype], (name, N, l2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bs", [32, 16])
+def test_small_minibatch_updat_axis0_takes_the_per_block_kernel(env, bs):
+    """At the reference bench's shapes (hidden 2560 dense, Barabasi-Albert at 7680, minibatch 64) the weight gradient of feature axis 0 runs the
+    per-block kernel where the windows are nearly empty or the minibatch is short (measured: scripts/gpu_a0_updat_sweep.py), against the oracle."""
+    torch, BSMM, lib = env
+    n = 2560 // bs
+    for name, lay, N in (("dense", np.ones((n // 2, n // 2), dtype=np.int32), 64), ("BA", P.ba_layout(3 * n // 4, 6 if bs == 32 else 11, seed=1), 64)):
+        b = BSMM(lay, block_size=bs, feature_axis=0)
+        t = O.build_layout_luts(lay, bs)
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "bf16", seed=5)
+        x, e = (P.to_dev(a, "bf16", torch) for a in (X, E))
+        dw = b.updat(x, e)
+        k = lib.last_kernel() & 255
+        if bs == 32:
+            assert k == lib.K_UPDAT_BLOCK, (name, k)
+        l2, _ = P.errors(P.to_host(dw), O.round_to(O.updat_fast(t, X, E, 0, np.float64), "bf16"))
+        assert l2 <= P.L2_BAR["bf16"], (bs, name, l2)
