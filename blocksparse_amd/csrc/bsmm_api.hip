@@ -435,6 +435,9 @@ enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_SUPER8, 
 #ifndef XS0_NMAX
 #define XS0_NMAX 512              // feature axis 0: the small-minibatch kernel (bsmm_xsmall0.h) up to this many minibatch columns
 #endif
+#ifndef U8P_ON
+#define U8P_ON 1                  // bsize 8, feature axis 0, weight gradient: the pair kernel (bsmm_updat.h) where the cost model picks it (0: never; measurement builds)
+#endif
 #ifndef BSMM_MID_MODE
 #define BSMM_MID_MODE 0           // medium-minibatch kernel (bsmm_xmid.h): 0 = by the cost model, 1 = whenever it can run, -1 = never (measurement builds)
 #endif
@@ -458,6 +461,10 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     const bool plan_ok = a->plan != nullptr && gate_ok && vec_ok && (variant == 0 || variant == 3);
     const bool force = variant == 3;
     if constexpr (BS == 8) {
+        if constexpr (DT::is16 && AXIS == 0) {      // short minibatches on feature axis 0 (bsmm_xsmall0.h, round 6: the reference benchmark's (8, 0) shapes)
+            const bool n_ok8 = a->N <= XS0_NMAX || (a->N <= 2 * XS0_NMAX && (long)a->blocks >= 32L * a->segments);
+            if (variant == 0 && vec_ok && !a->gate && a->locks == 0 && a->N % 8 == 0 && n_ok8 && a->segments > 0) return XP_SMALL;
+        }
         if constexpr (DT::is16) {
             // bsize 8 on the matrix cores: expand W into the 32x32 super-blocks of the 'BSS8' plan and run the bsize-32 kernel
             const bool shape_ok = a->C % 32 == 0 && a->K % 32 == 0 && !(AXIS == 0 && (a->N % 8 != 0));
@@ -598,6 +605,15 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         }
     }
     if (path == XP_SMALL) {
+        if constexpr (BS == 8 && DT::is16 && AXIS == 0) {
+            if (fprop) { if (int rc = ensure_lds<&xsmall8_a0_kernel<DT, true>>(XS16_LDS)) return rc; }
+            else       { if (int rc = ensure_lds<&xsmall8_a0_kernel<DT, false>>(XS16_LDS)) return rc; }
+            trace(a, BSMM_K_XPROP_SMALL);
+            dim3 grid(a->segments, (a->N + XS0_C - 1) / XS0_C);
+            if (fprop) xsmall8_a0_kernel<DT, true><<<grid, 64 * XS0_NW, XS16_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N);
+            else       xsmall8_a0_kernel<DT, false><<<grid, 64 * XS0_NW, XS16_LDS, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N);
+            return (int)hipGetLastError();
+        }
         if constexpr (BS == 16 && DT::is16 && AXIS == 0) {
             if (fprop) { if (int rc = ensure_lds<&xsmall16_a0_kernel<DT, true>>(XS16_LDS)) return rc; }
             else       { if (int rc = ensure_lds<&xsmall16_a0_kernel<DT, false>>(XS16_LDS)) return rc; }
@@ -954,6 +970,23 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
     const bool sums_only = (a->flags & BSMM_FLAG_DW_SUMS) != 0;     // only the streaming kernel can leave raw sums
     const float* ug = (a->flags & BSMM_FLAG_GATED_DW) ? a->gate : nullptr;   // gated dw: per-block kernels only
     const bool gated = ug != nullptr;
+    if constexpr (BS == 8 && DT::is16 && AXIS == 0) {
+        // short minibatches (round 6, scripts/gpu_a0_updat8_sweep.py): one wave per pair of blocks, operand fragments straight from global memory
+        bool al8 = aligned16(DW) && N % 8 == 0;
+        for (int p = 0; p < a->pcount; ++p) al8 = al8 && aligned16(xs.p[p]) && aligned16(es.p[p]);
+        // (hipGraph replays, us: the pair kernel costs 6 + 3.4e-6 per (block, minibatch column); the super-block path about 30 + (0.0022 + 2e-6 N) per
+        //  super-block -- hidden 2560 dense N = 64: 29 against 41; 20480 at 1.4 %: 26.5 against 228 at N = 64, 333 against 724 at N = 1024; 4096 at 10 %:
+        //  9.4 against 45.5 at N = 64, 94 against 66 at N = 1024.  Without a plan the alternative is the V_FMA kernel: always the pair kernel)
+        const bool s8 = a->plan != nullptr && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0;
+        const double t_pair = 6.0 + 3.4e-6 * (double)a->blocks * N * a->pcount;
+        const double t_s8 = 30.0 + (double)a->plan_width * (0.0022 + 2e-6 * (double)N * a->pcount);
+        if (al8 && variant == 0 && a->split == 0 && !sums_only && (!s8 || t_pair < t_s8) && U8P_ON) {
+            trace(a, BSMM_K_UPDAT_BLOCK);
+            const int pairs = (a->blocks + 1) / 2;
+            updat8_a0_pairs_kernel<DT><<<(pairs + 3) / 4, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->pcount, a->alpha, a->beta, ug);
+            return (int)hipGetLastError();
+        }
+    }
     if constexpr (BS == 8 && DT::is16) {
         // bsize 8 on the matrix cores: fp32 sums of whole 32x32 super-blocks ('BSS8' plan) into the workspace, then the
         // present 8x8 parts get alpha / beta and are rounded once

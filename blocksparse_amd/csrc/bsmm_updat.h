@@ -283,4 +283,51 @@ gate_weights_kernel(const uint4* __restrict__ W, const float* __restrict__ gate,
     if constexpr (PIECES == 2) out[total8 + i] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
+// bsize 8, feature axis 0, 16-bit types, short minibatches (round 6: the reference benchmark's (8, 0) shapes at N = 64 -- 41 - 225 us through the
+// super-block path, 70 - 80 through the V_FMA kernel): one WAVE per PAIR of weight blocks on v_mfma_f32_16x16x16.  On this axis an operand fragment
+// is contiguous in memory: lane (row t16, K group g) loads 16 bytes = 8 minibatch columns 32 j + 8 g .. of its row -- rows 0 .. 7 of the A side are
+// the X rows of block 0, rows 8 .. 15 those of block 1, the B side the DY rows likewise -- and feeds the low / high 8 bytes to two MFMAs (A and B label
+// the contraction index alike, which is all the hardware asks).  The diagonal 8 x 8 quadrants of the 16 x 16 result are the two blocks; the
+// off-diagonal ones (block 0's X rows against block 1's DY rows) are discarded.  Needs N % 8 == 0.
+template <class DT>
+__global__ void __launch_bounds__(256)
+updat8_a0_pairs_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
+                       int blocks, int N, int pcount, float alpha, float beta, const float* __restrict__ gate = nullptr) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "bsize-8 pair kernel: 16-bit storage types");
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = lane >> 4, t16 = lane & 15;
+    const int w = 2 * pair + (t16 >> 3);                  // my block: rows 0 .. 7 -> block 0 of the pair, 8 .. 15 -> block 1
+    const bool have = w < blocks;
+    const int c = have ? lut[2 * w] : 0, k = have ? lut[2 * w + 1] : 0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t xrow = (size_t)(c * 8 + (t16 & 7)) * N, erow = (size_t)(k * 8 + (t16 & 7)) * N;
+    for (int p = 0; p < pcount; ++p) {
+        const T* X = static_cast<const T*>(Xs.p[p]) + xrow;
+        const T* E = static_cast<const T*>(Es.p[p]) + erow;
+        for (int nb = 0; nb < N; nb += 32) {                             // (uniform trip count: the matrix instruction wants every lane there)
+            const int n = nb + 8 * g;
+            const bool in = have && n < N;                               // a lane past the end of a ragged last chunk multiplies zeros
+            const uint4 a = in ? *reinterpret_cast<const uint4*>(X + n) : zero_u4();
+            const uint4 b = in ? *reinterpret_cast<const uint4*>(E + n) : zero_u4();
+            acc = DT::mfma16k16(make_uint2(a.x, a.y), make_uint2(b.x, b.y), acc);
+            acc = DT::mfma16k16(make_uint2(a.z, a.w), make_uint2(b.z, b.w), acc);
+        }
+    }
+    // D[m][col]: col = t16, rows m = 4 g + i.  Block 0 = (m < 8, col < 8), block 1 = (m >= 8, col >= 8): lane (g, t16) holds a diagonal quadrant iff
+    // (g >> 1) == (t16 >> 3); its block is the one it loaded for (w).
+    if (have && (g >> 1) == (t16 >> 3)) {
+        const float a = gate ? alpha * gate[w] : alpha;
+        T* out = DW + (size_t)w * 64 + (t16 & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = 4 * (g & 1) + i;
+            float v = a * acc[i];
+            if (beta != 0.f) v += beta * DT::to_f32(out[ci * 8]);
+            out[ci * 8] = DT::from_f32(v);
+        }
+    }
+}
+
 }  // namespace bsmm

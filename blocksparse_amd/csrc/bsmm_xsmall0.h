@@ -235,3 +235,100 @@ xsmall16_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* _
 }
 
 }  // namespace bsmm
+
+// ---- bsize 8 (the reference benchmark's third block size; before: the V_FMA kernel, 187 - 220 us per pass at its shapes) -----------------------------
+// The bsize-16 kernel over PAIRS of entries: two 8-row activation tiles stack to the [16 rows][64 columns] image, the two 8 x 8 weight blocks to the
+// K = 16 operand of v_mfma_f32_16x16x16 (fprop: [16 rows = (entry, ci)][8 outputs] through LDS, transposing read; bprop: lane (ci, K group g) takes
+// W_{g >> 1}[ci][4 (g & 1) ..] straight from global memory); rows 8 .. 15 of the 16 x 16 result belong to nobody.  A column with an odd number of
+// entries multiplies its last one against a zero block (and re-reads that entry's activations: finite values, times zero).
+namespace bsmm {
+
+template <class DT, bool TRANSW>
+__global__ void __launch_bounds__(64 * XS0_NW)
+xsmall8_a0_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ W, typename DT::T* __restrict__ Y,
+                  const int32_t* __restrict__ lut, int N) {
+    typedef typename DT::T T;
+    static_assert(DT::is16, "small-minibatch kernel: 16-bit storage types");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int4 hdr = *reinterpret_cast<const int4*>(lut + 4 * blockIdx.x);
+    const int cnt = __builtin_amdgcn_readfirstlane(hdr.y), ob = __builtin_amdgcn_readfirstlane(hdr.z);
+    const int2* ent = reinterpret_cast<const int2*>(lut) + __builtin_amdgcn_readfirstlane(hdr.x);
+    const int n0 = blockIdx.y * XS0_C;
+    const int npairs = (cnt + 1) >> 1;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned char* xst = smem + wave * XS16_PART;          // [16 rows = (entry of the pair, its 8 rows)][128 B]
+    unsigned char* wst = xst + 2048;                       // fprop: [16 rows = (entry, ci)][32 B], bytes 0 .. 15 of a row = the block's 8 outputs
+    const int pc = lane & 7, row0 = lane >> 3;
+    const int col = min(n0 + 8 * pc, N - 8);
+    const int xoff = row0 * N + col;
+    const int g = lane >> 4, t16 = lane & 15;
+    const int xfrag = (4 * g + (t16 >> 2)) * 128 + 4 * (t16 & 3) * 2;
+    const int wfrag = (4 * g + (t16 >> 2)) * 32 + 4 * (t16 & 3) * 2;
+
+    uint4 xl0 = zero_u4(), xl1 = zero_u4(), wl4 = zero_u4();
+    uint2 wl2 = make_uint2(0u, 0u);
+#define XS8_LOAD(q_)                                                                                                        \
+    do {                                                                                                                    \
+        const int2 e0_ = ent[2 * (q_)];                                                                                     \
+        const bool two_ = 2 * (q_) + 1 < cnt;                                                                               \
+        const int2 e1_ = ent[two_ ? 2 * (q_) + 1 : 2 * (q_)];                                                               \
+        const int c0_ = __builtin_amdgcn_readfirstlane(e0_.x), w0_ = __builtin_amdgcn_readfirstlane(e0_.y);                 \
+        const int c1_ = __builtin_amdgcn_readfirstlane(e1_.x), w1_ = __builtin_amdgcn_readfirstlane(e1_.y);                 \
+        xl0 = *reinterpret_cast<const uint4*>(X + (size_t)c0_ * 8 * N + xoff);                                              \
+        xl1 = *reinterpret_cast<const uint4*>(X + (size_t)c1_ * 8 * N + xoff);                                              \
+        if constexpr (TRANSW) {   /* lanes 0..7: row `lane` of block 0, lanes 8..15: row lane - 8 of block 1 (zeros if there is none) */ \
+            wl4 = zero_u4();                                                                                                \
+            if (lane < 8) wl4 = *reinterpret_cast<const uint4*>(W + (size_t)w0_ * 64 + lane * 8);                           \
+            else if (lane < 16 && two_) wl4 = *reinterpret_cast<const uint4*>(W + (size_t)w1_ * 64 + (lane - 8) * 8);       \
+        } else {                  /* A[m = ci][k = 8 (g >> 1) + 4 (g & 1) ..]: block g >> 1, row ci = t16, outputs 4 (g & 1) .. */       \
+            wl2 = make_uint2(0u, 0u);                                                                                       \
+            if (t16 < 8 && (g < 2 || two_))                                                                                 \
+                wl2 = *reinterpret_cast<const uint2*>(W + (size_t)(g < 2 ? w0_ : w1_) * 64 + t16 * 8 + 4 * (g & 1));        \
+        }                                                                                                                   \
+    } while (0)
+    if (wave < npairs) XS8_LOAD(wave);
+    for (int q = wave; q < npairs; q += XS0_NW) {
+        *reinterpret_cast<uint4*>(xst + lane * 16) = xl0;
+        *reinterpret_cast<uint4*>(xst + 1024 + lane * 16) = xl1;
+        uint2 wq;
+        if constexpr (TRANSW) { if (lane < 16) *reinterpret_cast<uint4*>(wst + lane * 32) = wl4; }
+        else wq = wl2;
+        if (q + XS0_NW < npairs) XS8_LOAD(q + XS0_NW);
+        uint2 xf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xf[t] = ds_tr16(xst + xfrag + t * 32);
+        if constexpr (TRANSW) wq = ds_tr16(wst + wfrag);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = DT::mfma16k16(wq, xf[t], acc[t]);
+    }
+#undef XS8_LOAD
+
+    const int nparts = min(npairs, XS0_NW);
+    if (wave < nparts) {
+        float* part = reinterpret_cast<float*>(smem + wave * XS16_PART);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[(t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    // D[o][n]: col n = lane & 15 (+ 16 t), rows o = 4 (lane >> 4) + i: the block's 8 outputs are the rows of lanes 0 .. 31
+    {
+        const int el = threadIdx.x;
+        const int ln = el & 63, ti = el >> 6, t = ti >> 2, i = ti & 3;
+        if (ln < 32) {
+            float s = 0.f;
+            for (int v = 0; v < nparts; ++v) s += reinterpret_cast<const float*>(smem + v * XS16_PART)[el];
+            const int o = 4 * (ln >> 4) + i, n = n0 + 16 * t + (ln & 15);
+            if (n < N) Y[(size_t)(ob * 8 + o) * N + n] = DT::from_f32(s);
+        }
+    }
+}
+
+}  // namespace bsmm
