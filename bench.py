@@ -817,6 +817,38 @@ def main():
             out["gated"] = grow
         except Exception as e:          # an extra line must never cost the headline
             out["gated"] = {"error": str(e)[:200]}
+        # the reference's OWN benchmark shapes (test/blocksparse_matmul_bench.py:37-78): hidden = k * 2560, Barabasi-Albert + I at the listed sparsity
+        # (k = 1: dense), block sizes 32 / 16 / 8 on feature axis 0, minibatch 64, bf16 -- one read of ~13 MB of weights per pass (round 6:
+        # csrc/bsmm_xsmall0.h, the per-block weight-gradient kernels; all 18 shapes before / after: profiles/r06_ref_bench_shapes.txt)
+        try:
+            refb = {}
+            for kmul, spars in ((1, 100.0), (3, 11.25), (8, 1.41)):
+                for bs_r in (32, 16, 8):
+                    n_r = kmul * 2560 // bs_r
+                    if spars == 100.0:
+                        lay_r = np.ones((n_r, n_r), dtype=np.int32)
+                    else:
+                        for m_r in range(1, n_r // 2):
+                            if 100.0 * (2 * m_r * (n_r - m_r) + m_r * m_r + n_r - m_r) / n_r ** 2 >= spars:
+                                break
+                        lay_r = ba_layout(n_r, m_r, seed=1)
+                    br = BlocksparseMatMul(lay_r, block_size=bs_r, feature_axis=0)
+                    gr = torch.Generator(device="cuda").manual_seed(19)
+                    wr = (torch.randn(br.w_shape, device="cuda", generator=gr) * 0.05).bfloat16()
+                    xr = (torch.randn(br.i_shape(64), device="cuda", generator=gr) * 0.1).bfloat16()
+                    er = (torch.randn(br.o_shape(64), device="cuda", generator=gr) * 0.1).bfloat16()
+                    dwr = torch.empty(br.w_shape, dtype=torch.bfloat16, device="cuda")
+                    fu, bu, uu = graph_us(lambda: br.fprop(xr, wr)), graph_us(lambda: br.bprop(er, wr)), graph_us(lambda: br.updat(xr, er, dw=dwr))
+                    wbytes = br.blocks * bs_r * bs_r * 2
+                    refb["hidden%d_bs%d" % (kmul * 2560, bs_r)] = {"blocks": int(br.blocks), "density_pct": round(100.0 * br.blocks / n_r ** 2, 2), "w_mb": round(wbytes / 1e6, 1),
+                                                                   "pass_us": {"fprop": round(fu, 1), "bprop": round(bu, 1), "updat": round(uu, 1)},
+                                                                   "tflops": round(3 * 2.0 * br.blocks * bs_r * bs_r * 64 / (fu + bu + uu) / 1e6, 1),
+                                                                   "w_stream_gbps": round(3 * wbytes / (fu + bu + uu) / 1e3, 0)}
+                    del br, wr, xr, er, dwr
+            refb["workload"] = "the reference benchmark's shapes: feature_axis=0, minibatch 64, bf16, hidden k * 2560 (Barabasi-Albert + I; k = 1 dense), hipGraph replays"
+            out["ref_bench_n64"] = refb
+        except Exception as e:
+            out["ref_bench_n64"] = {"error": str(e)[:200]}
         side_row("bs8", random_layout(hidden0 // 8, hidden0 // 8, 0.10, seed=1234), 8, 0, n_local,
                  "4096x4096 block_size=8 density=10%% feature_axis=0 bf16, minibatch %d, fprop+bprop+updat (super-block path)" % n_local, steps_x=20)
     # BASELINE.json configs[1]: same layout, fp32, feature_axis=1, fprop only.  Priced against the fp32 matrix-core peak
