@@ -1056,12 +1056,18 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
                         const double rounds_s = std::max(1.0, std::ceil(a->blocks / (20.0 * device_cus())));
                         t_blk = std::min(t_blk, 4.0 + rounds_s * (double)rows * (rows <= 384 ? 0.021 : 0.033));
                     }
-                    stream = t_stream <= t_blk || sums_only || (a->flags & FLAG_INTERNAL_Q64);
+                    stream = t_stream <= t_blk || sums_only;
+                    if (a->flags & FLAG_INTERNAL_Q64) {      // quadrants of 64 x 64 blocks: the streaming kernel, or (round 6) the one-wave-per-block kernel
+                        const double rounds_s = std::max(1.0, std::ceil(a->blocks / (20.0 * device_cus())));
+                        const double t_small = rows <= UTS_NMAX ? 4.0 + rounds_s * (double)rows * (rows <= 384 ? 0.021 : 0.033) : 1e30;
+                        stream = t_stream <= t_small;
+                    }
                 }
                 if (stream) return launch_updat2<DT, AXIS>(xs, es, DW, a, ug);
             }
         }
-        if (sums_only || (a->flags & FLAG_INTERNAL_Q64)) return BSMM_ERR_UNSUPPORTED;      // (only the streaming kernel's summing pass leaves raw sums / knows the quadrant layout)
+        // (only the streaming kernel's summing pass leaves raw sums; the quadrant layout: that pass or the small-minibatch kernel below)
+        if (sums_only || ((a->flags & FLAG_INTERNAL_Q64) && !(AXIS == 1 && variant == 0 && (long)N * a->pcount <= UTS_NMAX))) return BSMM_ERR_UNSUPPORTED;
     }
     if constexpr (BS == 32 && AXIS == 1 && DT::is16) {
         bool al = aligned16(DW);
@@ -1071,9 +1077,10 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             trace(a, BSMM_K_UPDAT_BLOCK_TR | (BSMM_KV_ONE_WAVE << 8));
             const int grid = 8 * (((a->blocks + 3) / 4 + 7) / 8);
             updat32_a1_small_kernel<DT><<<grid, 256, UTS_LDS, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K, a->pcount,
-                                                                   a->alpha, a->beta, ug);
+                                                                   a->alpha, a->beta, ug, (a->flags & FLAG_INTERNAL_Q64) ? 1 : 0);
             return (int)hipGetLastError();
         }
+        if (a->flags & FLAG_INTERNAL_Q64) return BSMM_ERR_UNSUPPORTED;
         if (!use_valu && !gated && al && variant != 1) {   // LDS-DMA + transposing-read kernel
             if (int rc = ensure_lds<&updat32_a1_tr_kernel<DT>>(UT_LDS)) return rc;
             trace(a, BSMM_K_UPDAT_BLOCK_TR);

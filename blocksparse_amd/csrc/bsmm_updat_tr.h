@@ -138,7 +138,10 @@ constexpr int UTS_LDS = 4 * UTS_D * UT_SLOT;      // 32 KiB
 template <class DT>
 __global__ void __launch_bounds__(256, 4)
 updat32_a1_small_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
-                        int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta, const float* __restrict__ gate) {
+                        int blocks, int N, int Cf, int Kf, int pcount, float alpha, float beta, const float* __restrict__ gate, int q64 = 0) {
+    // (q64, round 6: the blocks are the quadrants of 64 x 64 blocks, 4 w64 + 2 (row half) + (column half), bsmm_api.hip::updat64 -- every element goes
+    //  to its place in the 64 x 64 block and the gate is the 64-block's, as in updat2_reduce_kernel: short minibatches at bsize 64 ran the streaming
+    //  kernel before, 35 us at N = 64 where this one takes 6)
     typedef typename DT::T T;
     static_assert(DT::is16, "transposing-read kernel: 16-bit storage types");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -210,11 +213,12 @@ updat32_a1_small_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ D
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetch, before the next pair re-primes the ring
     }
     // D[ci][ko]: col = ko = lane & 31, row ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const float a_eff = gate ? alpha * gate[w] : alpha;
+    const float a_eff = gate ? alpha * gate[q64 ? w >> 2 : w] : alpha;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        const size_t idx = (size_t)w * 1024 + ci * 32 + (lane & 31);
+        const size_t idx = q64 ? (size_t)(w >> 2) * 4096 + (size_t)(32 * ((w >> 1) & 1) + ci) * 64 + 32 * (w & 1) + (lane & 31)
+                               : (size_t)w * 1024 + ci * 32 + (lane & 31);
         float out = a_eff * acc[reg];
         if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
         DW[idx] = DT::from_f32(out);

@@ -107,3 +107,27 @@ def test_small_minibatch_updat_bsize8_axis0(env, dtype):
         ref = (O.updat(t, X, E, 0) + O.updat(t, X2, E2, 0)) * g[:, None, None]
         l2, _ = P.errors(P.to_host(dw), O.round_to(ref, dtype))
         assert l2 <= P.L2_BAR[dtype], (name, dtype, "pairs + gate", l2)
+
+
+@pytest.mark.gpu
+def test_small_minibatch_updat_bsize64(env):
+    """bsize 64 (feature axis 1: the reference's other block size there) at short minibatches: the one-wave-per-block kernel writes every quadrant
+    into its 64 x 64 block (round 6; before: the streaming kernel, 35 us at N = 64 against 5) -- plain, gated with alpha, beta accumulate -- vs the oracle."""
+    torch, BSMM, lib = env
+    lay = P.random_layout(20, 12, 0.3, seed=6)
+    b = BSMM(lay, block_size=64, feature_axis=1)
+    t = O.build_layout_luts(lay, 64)
+    for N in (64, 200):
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "bf16", seed=5 + N)
+        x, e, w0 = (P.to_dev(a, "bf16", torch) for a in (X, E, W))
+        ref = O.updat(t, X, E, 1)
+        dw = b.updat(x, e)
+        assert lib.last_kernel() & 255 == lib.K_UPDAT_BLOCK_TR, lib.last_kernel()
+        l2, _ = P.errors(P.to_host(dw), O.round_to(ref, "bf16"))
+        assert l2 <= P.L2_BAR["bf16"], (N, l2)
+        g = np.random.RandomState(1).uniform(-1, 2, b.blocks).astype(np.float32)
+        dwg = b.updat(x, e, gate=torch.from_numpy(g).cuda(), alpha=0.5, beta=2.0, dw=w0.clone())
+        assert lib.last_kernel() & 255 == lib.K_UPDAT_BLOCK_TR
+        refg = 0.5 * ref * g[:, None, None] + 2.0 * np.asarray(P.to_host(w0), dtype=np.float64)
+        l2, _ = P.errors(P.to_host(dwg), O.round_to(refg, "bf16"))
+        assert l2 <= P.L2_BAR["bf16"], (N, "gated", l2)
