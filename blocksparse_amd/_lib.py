@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # BSMM_LIB: load another build of the same library (kernel A/B experiments: scripts/build_variants.py); product = the default
 LIB_PATH = os.environ.get("BSMM_LIB") or os.path.join(_HERE, "libbsmm_hip.so")
 
-ABI_VERSION = 127        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
+ABI_VERSION = 128        # include/bsmm.h BSMM_VERSION this binding was written against (struct layout, plan formats, option bits)
 F32, F16, BF16 = 0, 1, 2
 OP_FPROP, OP_BPROP, OP_UPDAT = 0, 1, 2
 FLAG_GATED_DW, FLAG_FORCE_VALU, FLAG_NO_PLAN, FLAG_FORCE_PLAN, FLAG_DW_SUMS, FLAG_FORCE_MID = 1, 2, 4, 8, 16, 32

@@ -1688,13 +1688,13 @@ static long xprop_plan(const int32_t* lut, int32_t segments, int32_t blocks, int
         return build_xcol_plan(lut, segments, blocks, n_out, out, XS_G);      // (BSMM_PLAN_F32_MFMA named the retired fp32 matrix-core kernel: ignored)
     }
     if (bsize == 16)         // 'BSX7' (staged / list kernels); BSMM_PLAN_XCOL_UNSTAGED / _NARROW named the round-1 kernel, retired in round 4: ignored
-        return build_xcol16s_plan(lut, segments, blocks, n_out, out);      // (0: the layout does not fit the table fields -> no plan, per-segment kernels)
+        return build_xcol16s_plan(lut, segments, blocks, n_out, out, !(options & BSMM_PLAN_FLOW_CONSECUTIVE));      // (0: the layout does not fit the table fields -> no plan, per-segment kernels)
     if ((options & BSMM_PLAN_XCOL_FLOW) && axis == 1 && !(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // barrier-free persistent kernel
         const long n = build_xflow_plan(lut, segments, blocks, n_out, out, (options & BSMM_PLAN_FLOW_SCHEDULED) != 0, (options & BSMM_PLAN_FLOW_CONSECUTIVE) != 0);
         if (n != 0) return n;
     }
     if (!(options & (BSMM_PLAN_XCOL_UNSTAGED | BSMM_PLAN_XCOL_NARROW))) {   // default: the staged kernel (either feature axis)
-        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out, (options >> BSMM_PLAN_XPROP_PH_SHIFT) & 7);
+        const long n = build_xcol2_plan(lut, segments, blocks, n_out, out, (options >> BSMM_PLAN_XPROP_PH_SHIFT) & 7, axis == 0 && !(options & BSMM_PLAN_FLOW_CONSECUTIVE));
         if (n != 0) return n;                                            // 0: the layout does not fit the table fields
     }
     return build_xcol_plan(lut, segments, blocks, n_out, out, opt_xc_group(options));
@@ -1784,9 +1784,9 @@ static bool describe_flat(const int32_t* p, long words, int32_t d[5]) {
     d[4] = 0;
     switch (p[0]) {
         case XCPLAN_MAGIC:   if (p[1] != XCPLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
-        case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR || p[11] < 2 || p[11] > 4) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
+        case X2PLAN_MAGIC:   if (p[1] != X2PLAN_VERSION || words < X2_HDR || p[11] < 2 || p[11] > 4 || p[12] < X2_HDR || words < (long)p[12] + (long)p[3] * X2_G) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; d[4] = p[11]; break;
         case X4PLAN_MAGIC:   if (p[1] != X4PLAN_VERSION || words < X4_HDR || p[2] != X4_G) return false;   d[1] = p[2]; d[2] = p[2]; d[3] = 0; break;
-        case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < XC_HDR) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
+        case X7PLAN_MAGIC:   if (p[1] != X7PLAN_VERSION || words < X7_HDR || p[12] < X7_HDR || words < (long)p[12] + (long)p[3] * X7_G) return false;   d[1] = p[2]; d[2] = 16; d[3] = 0; break;
         case UPLAN_MAGIC:    if (p[1] != UPLAN_VERSION || words < UP_HDR || p[8] < 0 || (p[8] > 0 && (p[8] + U6_HDR > words || p[p[8]] != U6PLAN_MAGIC ||
                                  p[8] + U6_HDR + (long)p[p[8] + 4] * U6_ITEM > words))) return false;
                              d[1] = p[2]; d[2] = p[7]; d[3] = p[4]; d[4] = p[8];               // (plan_inner: word offset of the 'BSU6' section, 0 = none;

@@ -287,6 +287,49 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
 
 }  // namespace bsmm
 
+
+// Which (group, position) owns an output block.  Default: G consecutive output blocks per group.  Where that leaves the groups unbalanced (the busiest
+// holds > 1.15 x the mean number of blocks: hub layouts such as the reference's Barabasi-Albert bench layouts, whose oldest nodes are neighbouring
+// columns -- the workgroups of that group then take 1.5 - 2.5 x as long as the others and the pass ends when they do), adjacent PAIRS of output
+// blocks are dealt to the groups heaviest first, each to the lightest group with room (round 6).  A column still sums its blocks in table order
+// on one wave: results are bit-identical.  Returns whether the layout was regrouped; false on a malformed table (grp_of left empty).
+namespace bsmm {
+inline bool regroup_output_blocks(const int32_t* lut, int segments, int n_out_blocks, int G, bool consecutive, std::vector<int>& grp_of, std::vector<int>& pos_of) {
+    const int ngroups = (n_out_blocks + G - 1) / G;
+    grp_of.assign(n_out_blocks, 0); pos_of.assign(n_out_blocks, 0);
+    for (int ob = 0; ob < n_out_blocks; ++ob) { grp_of[ob] = ob / G; pos_of[ob] = ob % G; }
+    if (consecutive || ngroups <= 1) return false;
+    std::vector<long> cnt_ob(n_out_blocks, 0), gl(ngroups, 0);
+    long total = 0;
+    for (int s = 0; s < segments; ++s) {
+        const int32_t cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
+        if (ob < 0 || ob >= n_out_blocks || cnt < 0) { grp_of.clear(); return false; }
+        cnt_ob[ob] += cnt; gl[ob / G] += cnt; total += cnt;
+    }
+    const long mx = *std::max_element(gl.begin(), gl.end());
+    if (total <= 0 || (double)mx * ngroups <= 1.15 * (double)total) return false;
+    const int npairs = (n_out_blocks + 1) / 2;
+    std::vector<int> order(npairs);
+    for (int i = 0; i < npairs; ++i) order[i] = i;
+    auto wt = [&](int i) { return cnt_ob[2 * i] + (2 * i + 1 < n_out_blocks ? cnt_ob[2 * i + 1] : 0); };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wt(a) > wt(b); });
+    std::vector<long> load(ngroups, 0);
+    std::vector<int> used(ngroups, 0);
+    for (int i : order) {
+        int best = -1;
+        for (int g = 0; g < ngroups; ++g)
+            if (used[g] + 2 <= G && (best < 0 || load[g] < load[best])) best = g;
+        if (best < 0) { grp_of.clear(); return false; }              // (cannot happen: ngroups * G / 2 >= npairs)
+        for (int k = 0; k < 2; ++k) {
+            const int ob = 2 * i + k;
+            if (ob < n_out_blocks) { grp_of[ob] = best; pos_of[ob] = used[best] + k; }
+        }
+        used[best] += 2; load[best] += wt(i);
+    }
+    return true;
+}
+}  // namespace bsmm
+
 // =================================================================================================
 // staged xcol plan ('BSX2'): schedule of the kernel that stages the weight blocks through LDS as well (bsmm_xcol_v2.h).
 // Groups of X2_G = 16 consecutive output blocks as in the xcol plan, wave v owns output block first + v.  The pair walk of a
@@ -299,6 +342,7 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
 // (<= 3 each).
 // Layout (int32): [0] magic 'BSX2' [1] version [2] X2_G [3] ngroups [4] nphases_total [5] off_groups [6] off_px
 //                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] WCAP [10] max phases of a group [11] PH
+//                 [12] off_cols: cols[ngroups][16] = the output block of every (group, wave), -1 = none (version 3)  [13] 1 if regrouped
 //   groups[ngroups][4] = (phase_off, nphases, first_out_block, n_out_blocks_in_group)
 //   px [nphases_total][2]        pairs of steps 0, 1 | 2, 3: 16 bits each, 0xffff = no such step
 //   tab[nphases_total][16][8]    per phase and wave:
@@ -308,16 +352,24 @@ inline long build_xcol_plan(const int32_t* lut, int segments, int blocks, int n_
 namespace bsmm {
 
 constexpr int32_t X2PLAN_MAGIC = 0x42535832;
-constexpr int32_t X2PLAN_VERSION = 2;
+constexpr int32_t X2PLAN_VERSION = 3;   // 3 (round 6): 16 header words, [12] off_cols: the output block of every (group, wave) -- regrouped layouts
 constexpr int X2_G = 16;
-constexpr int X2_HDR = 12;
+constexpr int X2_HDR = 16;
 constexpr int X2_ROW = 8;                                            // words per (phase, wave)
 constexpr int x2_wcap(int ph) { return (81920 - ph * 16384) / 2048 - 1; }   // 23, 15, 7 for PH = 2, 3, 4
 
-inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int force_ph = 0) {
+inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, int force_ph = 0, bool regroup = false) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
     if (blocks >= (1 << 25)) return 0;                                       // field widths of the tables
     const int G = X2_G, ngroups = (n_out_blocks + G - 1) / G;
+    // (round 6: an unbalanced layout is regrouped where the caller allows it -- feature axis 0, whose epilogue stores per output block; the axis-1
+    //  epilogue stores whole rows of 16 ADJACENT output blocks and keeps consecutive groups)
+    std::vector<int> grp_of, wave_of;
+    const bool regrouped = regroup_output_blocks(lut, segments, n_out_blocks, G, !regroup, grp_of, wave_of);
+    if (grp_of.empty()) return -1;
+    std::vector<std::array<int32_t, X2_G>> gcols(ngroups);
+    for (auto& c : gcols) c.fill(-1);
+    for (int ob = 0; ob < n_out_blocks; ++ob) gcols[grp_of[ob]][wave_of[ob]] = ob;
     struct E { int p, wave, half, w; };
     std::vector<std::vector<E>> per_group(ngroups);
     for (int s = 0; s < segments; ++s) {
@@ -327,7 +379,7 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
             const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
             if (w < 0 || w >= blocks || c < 0) return -1;
             if (c >= 2 * 0xffff) return 0;
-            per_group[ob / G].push_back({c >> 1, ob % G, c & 1, w});
+            per_group[grp_of[ob]].push_back({c >> 1, wave_of[ob], c & 1, w});
         }
     }
     // steps per phase from the mean number of blocks per (group, pair) step, with 30 % headroom for the spread
@@ -392,29 +444,38 @@ inline long build_xcol2_plan(const int32_t* lut, int segments, int blocks, int n
         }
         const int nph = (int)(px.size() / 2) - phase_off;
         max_ph = std::max(max_ph, nph);
-        groups.insert(groups.end(), {phase_off, nph, g * G, std::min(G, n_out_blocks - g * G)});
+        int nob = 0;
+        for (int wv = 0; wv < G; ++wv) nob += gcols[g][wv] >= 0 ? 1 : 0;
+        groups.insert(groups.end(), {phase_off, nph, gcols[g][0], nob});
     }
     // longest groups first: workgroup (tile, group index i) runs groups[i], and the CUs that finish a short group of one row tile
     // pick up the long groups of the next (skewed layouts: a Barabasi-Albert layout has 1.7x the blocks in its first group)
+    std::vector<int32_t> cols;
     {
         std::vector<int> order(ngroups);
         for (int g = 0; g < ngroups; ++g) order[g] = g;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[4 * a + 1] > groups[4 * b + 1]; });
         std::vector<int32_t> sorted;
-        for (int g : order) sorted.insert(sorted.end(), groups.begin() + 4 * g, groups.begin() + 4 * g + 4);
+        for (int g : order) {
+            sorted.insert(sorted.end(), groups.begin() + 4 * g, groups.begin() + 4 * g + 4);
+            cols.insert(cols.end(), gcols[g].begin(), gcols[g].end());
+        }
         groups.swap(sorted);
     }
     const int off_groups = X2_HDR, off_px = off_groups + (int)groups.size();
     const int off_tab = (off_px + (int)px.size() + 3) & ~3;
-    const long total = off_tab + (long)tab.size();
+    const long off_cols = off_tab + (long)tab.size();
+    const long total = off_cols + (long)cols.size();
+    if (total >= (1L << 31)) return 0;
     if (out) {
         std::fill(out, out + off_tab, 0);
         const int32_t hdr[X2_HDR] = {X2PLAN_MAGIC, X2PLAN_VERSION, G, ngroups, (int32_t)(px.size() / 2), off_groups, off_px, off_tab,
-                                     n_out_blocks, WCAP, max_ph, PH};
+                                     n_out_blocks, WCAP, max_ph, PH, (int32_t)off_cols, regrouped ? 1 : 0, 0, 0};
         std::copy(hdr, hdr + X2_HDR, out);
         std::copy(groups.begin(), groups.end(), out + off_groups);
         std::copy(px.begin(), px.end(), out + off_px);
         std::copy(tab.begin(), tab.end(), out + off_tab);
+        std::copy(cols.begin(), cols.end(), out + off_cols);
     }
     return total;
 }
@@ -477,40 +538,9 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
     if (blocks >= (1 << 21)) return 0;          // the kernel addresses a weight block with a 32-bit byte offset (id << 11): no plan beyond 4 GiB of weights
     const int G = X4_G, ngroups = (n_out_blocks + G - 1) / G;
     // ---- which (group, wave) owns an output block ----
-    std::vector<int> grp_of(n_out_blocks), wave_of(n_out_blocks);
-    for (int ob = 0; ob < n_out_blocks; ++ob) { grp_of[ob] = ob / G; wave_of[ob] = ob % G; }
-    bool regrouped = false;
-    if (!consecutive && ngroups > 1) {
-        std::vector<long> cnt_ob(n_out_blocks, 0), gl(ngroups, 0);
-        long total = 0;
-        for (int s = 0; s < segments; ++s) {
-            const int32_t cnt = lut[4 * s + 1], ob = lut[4 * s + 2];
-            if (ob < 0 || ob >= n_out_blocks || cnt < 0) return -1;
-            cnt_ob[ob] += cnt; gl[ob / G] += cnt; total += cnt;
-        }
-        const long mx = *std::max_element(gl.begin(), gl.end());
-        if (total > 0 && (double)mx * ngroups > 1.15 * (double)total) {
-            const int npairs = (n_out_blocks + 1) / 2;
-            std::vector<int> order(npairs);
-            for (int i = 0; i < npairs; ++i) order[i] = i;
-            auto wt = [&](int i) { return cnt_ob[2 * i] + (2 * i + 1 < n_out_blocks ? cnt_ob[2 * i + 1] : 0); };
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wt(a) > wt(b); });
-            std::vector<long> load(ngroups, 0);
-            std::vector<int> used(ngroups, 0);                      // waves taken
-            for (int i : order) {
-                int best = -1;
-                for (int g = 0; g < ngroups; ++g)
-                    if (used[g] + 2 <= G && (best < 0 || load[g] < load[best])) best = g;
-                if (best < 0) return -1;                             // (cannot happen: ngroups * 8 >= npairs)
-                for (int k = 0; k < 2; ++k) {
-                    const int ob = 2 * i + k;
-                    if (ob < n_out_blocks) { grp_of[ob] = best; wave_of[ob] = used[best] + k; }
-                }
-                used[best] += 2; load[best] += wt(i);
-            }
-            regrouped = true;
-        }
-    }
+    std::vector<int> grp_of, wave_of;
+    const bool regrouped = regroup_output_blocks(lut, segments, n_out_blocks, G, consecutive, grp_of, wave_of);
+    if (grp_of.empty()) return -1;
     struct E { int p, wave, half, w; };
     std::vector<std::vector<E>> per_group(ngroups);
     std::vector<std::array<int32_t, X4_G>> gcols(ngroups);
@@ -719,6 +749,7 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
 // dealt evenly over the 16 waves (<= 3 each).
 // Layout (int32): [0] magic 'BSX7' [1] version [2] X7_G [3] ngroups [4] nphases_total [5] off_groups [6] off_px
 //                 [7] off_tab (multiple of 4) [8] n_out_blocks [9] X7_WCAP [10] max phases of a group [11] off_lists
+//                 [12] off_cols: cols[ngroups][32] = the output block of every (group, column position), -1 = none (version 3)  [13] 1 if regrouped
 //   groups[ngroups][4] = (phase_off, nphases, first_out_block, n_out_blocks_in_group)
 //   px [nphases_total]           quad of step 0 | quad of step 1 << 16   (0xffff = no such step)
 //   tab[nphases_total][16][12]   per phase and wave:
@@ -737,17 +768,24 @@ inline long build_xflow_plan(const int32_t* lut, int segments, int blocks, int n
 namespace bsmm {
 
 constexpr int32_t X7PLAN_MAGIC = 0x42535837;
-constexpr int32_t X7PLAN_VERSION = 2;
+constexpr int32_t X7PLAN_VERSION = 3;   // 3 (round 6): 16 header words, [12] off_cols: the output block of every (group, column position) -- regrouped layouts
 constexpr int X7_G = 32;
+constexpr int X7_HDR = 16;
 constexpr int X7_WCAP = 94;            // even; slot X7_WCAP of each ring half stays zero (the fragment of an absent block)
 constexpr int X7_ROW = 12;             // words per (phase, wave)
 constexpr int X7_LIST = 40;            // words of a (phase, wave) block list: 16 entries of two words, words 0..31 entries, 38 = counts | role, 39 = the same of the next phase
 constexpr int X7_PHW = 16 * X7_LIST + 128;   // words of a phase in the list section: 16 block lists, then the request table
 
-inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out) {
+inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int n_out_blocks, int32_t* out, bool regroup = true) {
     if (!lut || segments <= 0 || blocks <= 0 || n_out_blocks <= 0) return -1;
     if (blocks >= (1 << 23)) return 0;                                       // 32-bit byte offsets into W
     const int G = X7_G, ngroups = (n_out_blocks + G - 1) / G;
+    std::vector<int> grp_of, pos_of;                      // (round 6: unbalanced layouts are regrouped, regroup_output_blocks)
+    const bool regrouped = regroup_output_blocks(lut, segments, n_out_blocks, G, !regroup, grp_of, pos_of);
+    if (grp_of.empty()) return -1;
+    std::vector<std::array<int32_t, X7_G>> gcols(ngroups);
+    for (auto& c : gcols) c.fill(-1);
+    for (int ob = 0; ob < n_out_blocks; ++ob) gcols[grp_of[ob]][pos_of[ob]] = ob;
     struct E { int p, col, sub, w; };
     std::vector<std::vector<E>> per_group(ngroups);
     for (int s = 0; s < segments; ++s) {
@@ -757,7 +795,7 @@ inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int
             const int32_t c = lut[2 * (off + e)], w = lut[2 * (off + e) + 1];
             if (w < 0 || w >= blocks || c < 0) return -1;
             if (c >= 4 * 0xffff) return 0;
-            per_group[ob / G].push_back({c >> 2, ob % G, c & 3, w});
+            per_group[grp_of[ob]].push_back({c >> 2, pos_of[ob], c & 3, w});
         }
     }
     std::vector<int32_t> groups, px, tab, lists;
@@ -845,22 +883,26 @@ inline long build_xcol16s_plan(const int32_t* lut, int segments, int blocks, int
         }
         const int nph = (int)px.size() - phase_off;
         max_ph = std::max(max_ph, nph);
-        groups.insert(groups.end(), {phase_off, nph, g * G, std::min(G, n_out_blocks - g * G)});
+        int nob = 0;
+        for (int c = 0; c < G; ++c) nob += gcols[g][c] >= 0 ? 1 : 0;
+        groups.insert(groups.end(), {phase_off, nph, gcols[g][0], nob});
     }
-    const int off_groups = XC_HDR, off_px = off_groups + (int)groups.size();
+    const int off_groups = X7_HDR, off_px = off_groups + (int)groups.size();
     const int off_tab = (off_px + (int)px.size() + 3) & ~3;
     const long off_lists = off_tab + (long)tab.size();
-    const long total = off_lists + (long)lists.size();
+    const long off_cols = off_lists + (long)lists.size();
+    const long total = off_cols + (long)ngroups * G;
     if (total >= (1L << 31)) return 0;
     if (out) {
         std::fill(out, out + off_tab, 0);
-        const int32_t hdr[XC_HDR] = {X7PLAN_MAGIC, X7PLAN_VERSION, G, ngroups, (int32_t)px.size(), off_groups, off_px, off_tab,
-                                     n_out_blocks, X7_WCAP, max_ph, (int32_t)off_lists};
-        std::copy(hdr, hdr + XC_HDR, out);
+        const int32_t hdr[X7_HDR] = {X7PLAN_MAGIC, X7PLAN_VERSION, G, ngroups, (int32_t)px.size(), off_groups, off_px, off_tab,
+                                     n_out_blocks, X7_WCAP, max_ph, (int32_t)off_lists, (int32_t)off_cols, regrouped ? 1 : 0, 0, 0};
+        std::copy(hdr, hdr + X7_HDR, out);
         std::copy(groups.begin(), groups.end(), out + off_groups);
         std::copy(px.begin(), px.end(), out + off_px);
         std::copy(tab.begin(), tab.end(), out + off_tab);
         std::copy(lists.begin(), lists.end(), out + off_lists);
+        for (int g = 0; g < ngroups; ++g) std::copy(gcols[g].begin(), gcols[g].end(), out + off_cols + (long)g * G);
     }
     return total;
 }

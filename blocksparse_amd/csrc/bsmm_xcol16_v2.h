@@ -43,10 +43,13 @@ static_assert(X7_LDS <= 163840 && XC_R * X7_G * 32 <= X7_LDS && X7_WCAP % 2 == 0
 // D[o][n] of a wave's 2 x 8 accumulator tiles: col = n = lane & 15 (row of tile tt), rows o = 4q + reg
 template <class DT, int AXIS>
 __device__ __forceinline__ void x7_epilogue(f32x4 (&acc)[2][8], unsigned char* smem, typename DT::T* __restrict__ Y, int lane, int wave, int n_tile,
-                                            int ob0, int nob, int N, int Kout) {
+                                            const int32_t* __restrict__ cols, int N, int Kout) {
+    // (`cols`: the group's 32 output blocks by column position, -1 = none -- 'BSX7' version 3, round 6: consecutive blocks, or the builder's pick for
+    //  an unbalanced layout; adjacent pairs stay together, so a wave's two columns are neighbours either way)
     typedef typename DT::T T;
     const int o16 = lane & 15, q = lane >> 4;
-    const bool own0 = 2 * wave < nob, own1 = 2 * wave + 1 < nob;
+    const int ob_0 = __builtin_amdgcn_readfirstlane(cols[2 * wave]), ob_1 = __builtin_amdgcn_readfirstlane(cols[2 * wave + 1]);
+    const bool own0 = ob_0 >= 0, own1 = ob_1 >= 0;
     if constexpr (AXIS == 1) {
         constexpr int ROWB = X7_G * 32;       // staged through LDS and stored as full rows (see xcol32_a1_kernel)
         __syncthreads();
@@ -63,14 +66,13 @@ __device__ __forceinline__ void x7_epilogue(f32x4 (&acc)[2][8], unsigned char* s
             }
         }
         __syncthreads();
-        const int rowbytes = nob * 32;
-        T* ybase = Y + (size_t)ob0 * 16;
         constexpr int PPR = ROWB / 16;
         for (int i = threadIdx.x; i < XC_R * PPR; i += 1024) {
             const int n = i / PPR, piece = i % PPR;
-            if (n_tile + n < N && piece * 16 < rowbytes) {
+            const int ob = cols[piece >> 1];                    // (a 16-wide output block is two 16-byte pieces of the row)
+            if (n_tile + n < N && ob >= 0) {
                 const uint4 v = *reinterpret_cast<const uint4*>(smem + n * ROWB + ((piece ^ (n & 31)) << 4));
-                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(ybase + (size_t)(n_tile + n) * Kout) + piece * 16) = v;
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(Y + (size_t)(n_tile + n) * Kout + (size_t)ob * 16) + (piece & 1) * 16) = v;
             }
         }
     } else {
@@ -83,7 +85,7 @@ __device__ __forceinline__ void x7_epilogue(f32x4 (&acc)[2][8], unsigned char* s
                 if (n >= N) continue;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg)
-                    Y[(size_t)((ob0 + 2 * wave + c) * 16 + 4 * q + reg) * N + n] = DT::from_f32(acc[c][tt][reg]);
+                    Y[(size_t)((c ? ob_1 : ob_0) * 16 + 4 * q + reg) * N + n] = DT::from_f32(acc[c][tt][reg]);
             }
         }
     }
@@ -107,7 +109,6 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
     const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
     const int ph_off = __builtin_amdgcn_readfirstlane(gh.x), nph = __builtin_amdgcn_readfirstlane(gh.y);
-    const int ob0 = __builtin_amdgcn_readfirstlane(gh.z), nob = __builtin_amdgcn_readfirstlane(gh.w);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t* pxt = plan + plan[6] + ph_off;
@@ -353,7 +354,7 @@ xcol16_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
             }
         }
     }
-    x7_epilogue<DT, AXIS>(acc, smem, Y, lane, wave, n_tile, ob0, nob, N, Kout);
+    x7_epilogue<DT, AXIS>(acc, smem, Y, lane, wave, n_tile, plan + plan[12] + X7_G * grp, N, Kout);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -406,7 +407,6 @@ xcol16_list_kernel(const typename DT::T* __restrict__ X, const typename DT::T* _
     if (!xmap_decode(map, blockIdx.x, tile, grp)) return;
     const int4 gh = *reinterpret_cast<const int4*>(plan + plan[5] + 4 * grp);
     const int ph_off = __builtin_amdgcn_readfirstlane(gh.x), nph = __builtin_amdgcn_readfirstlane(gh.y);
-    const int ob0 = __builtin_amdgcn_readfirstlane(gh.z), nob = __builtin_amdgcn_readfirstlane(gh.w);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // list section of my group: per phase X7_PHW words = [16 waves][X7_LIST] block lists, [64][2] request table
@@ -634,7 +634,7 @@ xcol16_list_kernel(const typename DT::T* __restrict__ X, const typename DT::T* _
 #undef X7L_REQUESTS
 #undef X7L_LOAD1
 #undef X7L_LOAD2
-    x7_epilogue<DT, AXIS>(acc, smem, Y, lane, wave, n_tile, ob0, nob, N, Kout);
+    x7_epilogue<DT, AXIS>(acc, smem, Y, lane, wave, n_tile, plan + plan[12] + X7_G * grp, N, Kout);
 }
 
 #undef X7L_DMA4

@@ -309,7 +309,9 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
     if constexpr (AXIS == 0) {
         // D[o][n]: col = n = r, rows o = (reg & 3) + 8 * (reg >> 2) + 4h  ->  Y[(ob * 32 + o) * N + n]: 64-byte row segments
         if (X2_NO_EPILOGUE) { if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.f) Y[0] = DT::from_f32(1.f); return; }
-        if (wave >= nob) return;
+        // (round 6, 'BSX2' version 3: the wave's output block comes from the plan's table -- an unbalanced layout is regrouped on this axis)
+        const int my_ob = __builtin_amdgcn_readfirstlane(plan[plan[12] + X2_G * grp + wave]);
+        if (my_ob < 0) return;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = n_tile + t * 32 + r;
@@ -317,7 +319,7 @@ xcol32_v2_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __r
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int o = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                Y[(size_t)((ob0 + wave) * 32 + o) * N + n] = DT::from_f32(acc[t][reg]);
+                Y[(size_t)(my_ob * 32 + o) * N + n] = DT::from_f32(acc[t][reg]);
             }
         }
         return;

@@ -53,8 +53,9 @@ extern "C" {
  *   124 round 6: the row-split xprop kernel of round 5 retired ('BSX5' plans are no longer built or accepted, BSMM_PLAN_XCOL_ROWS is ignored,
  *   trace code 13 is not emitted; source and measurements: profiles/r05_xrows.patch);  125 round 6: 'BSU2' plans version 3 (32 header words; direct
  *   blocks), BSMM_PLAN_UPDAT_NO_DIRECT;  126 round 6: bsmm_gate_weights;  127 round 6: 'BSX4' plans version 4 (per-group output-block table; unbalanced
- *   layouts regrouped), BSMM_PLAN_FLOW_CONSECUTIVE */
-#define BSMM_VERSION 127
+ *   layouts regrouped), BSMM_PLAN_FLOW_CONSECUTIVE;  128 round 6: 'BSX2' / 'BSX7' plans version 3 (16 header words, output-block table
+ *   per group; unbalanced layouts regrouped: 'BSX2' on feature axis 0, 'BSX7' on both) */
+#define BSMM_VERSION 128
 
 enum { BSMM_F32 = 0, BSMM_F16 = 1, BSMM_BF16 = 2 };
 enum {
@@ -108,7 +109,7 @@ enum {
                                        windowed kernel (256 x 256-feature windows through LDS); comparison / tests                        */
     BSMM_PLAN_UPDAT_NO_DIRECT = 0x80000, /* updat bsize 32, feature axis 1 ('BSU2' plans): no DIRECT blocks (round 6: the blocks a window's 16 waves cannot hold
                                        get workgroups of their own behind the schedule's) -- overflow items in a sliced last round, as before; comparison / tests */
-    BSMM_PLAN_FLOW_CONSECUTIVE = 0x100000, /* 'BSX4' plans: always groups of 16 CONSECUTIVE output blocks (round 6: an unbalanced layout -- hubs -- is
+    BSMM_PLAN_FLOW_CONSECUTIVE = 0x100000, /* 'BSX4' / 'BSX2' / 'BSX7' plans: always groups of CONSECUTIVE output blocks (round 6: an unbalanced layout -- hubs -- is
                                        regrouped by default: pairs of output blocks dealt to the groups heaviest first; same results) */
     BSMM_PLAN_FLOW_SCHEDULED = 0x10000 /* 'BSX4' plans, experiment: steps in the order the builder's list scheduling picks instead of ascending
                                        input blocks (the same sums in another fp32 summation order; measured no faster, see bsmm_plan.h) */

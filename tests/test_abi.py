@@ -274,16 +274,26 @@ def test_staged_xcol_plan(lib):
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_plan
     rng = np.random.default_rng(5)
+    import _parity as P
     for CB, KB, dens, ph in ((128, 128, 0.2, 2), (128, 128, 0.08, 3), (128, 128, 0.02, 4), (40, 52, 0.3, 2), (9, 35, 1.0, 2), (1, 1, 1.0, None),
-                             (64, 16, 0.6, 2), (64, 48, 0.5, (3 << 8)), (64, 48, 0.5, (4 << 8))):
-        lay = rng.random((CB, KB)) < dens
-        lay[0, :] = True
+                             (64, 16, 0.6, 2), (64, 48, 0.5, (3 << 8)), (64, 48, 0.5, (4 << 8)), (128, 128, "BA", None)):
+        if dens == "BA":            # the reference's bench layout: hubs in neighbouring columns -> regrouped on feature axis 0 (version 3)
+            lay = P.ba_layout(128, 14, seed=1) != 0
+        else:
+            lay = rng.random((CB, KB)) < dens
+            lay[0, :] = True
         t = L.build_tables(lay)
         opt = ph if (ph is not None and ph >= 256) else 0
-        for side, n_out in (("fprop", KB), ("bprop", CB)):
+        for axis, side, n_out in ((1, "fprop", KB), (1, "bprop", CB), (0, "fprop", KB), (0, "bprop", CB)):
             f = t[side]
-            plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, 1, opt)
-            assert plan[0] == 0x42535832 and int(plan[2]) == 16 and plan[8] == n_out and plan[7] % 4 == 0
+            plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 32, lib.BF16, axis, opt)
+            assert plan[0] == 0x42535832 and int(plan[1]) == 3 and int(plan[2]) == 16 and plan[8] == n_out and plan[7] % 4 == 0
+            cols = plan[plan[12]:plan[12] + 16 * int(plan[3])].reshape(-1, 16)
+            regrouped = int(plan[13])
+            assert int(plan[12]) + cols.size == plan.size and sorted(int(c) for c in cols.ravel() if c >= 0) == list(range(n_out))
+            assert not (regrouped and axis == 1)                  # (the axis-1 epilogue stores whole rows of 16 adjacent output blocks)
+            if dens == "BA":
+                assert regrouped == (1 if axis == 0 else 0)
             WCAP, PH = int(plan[9]), int(plan[11])
             assert (PH, WCAP) in ((2, 23), (3, 15), (4, 7))
             if opt:
@@ -295,10 +305,14 @@ def test_staged_xcol_plan(lib):
             px = plan[plan[6]:plan[6] + 2 * nph_total].reshape(-1, 2)
             tab = plan[plan[7]:plan[7] + nph_total * 128].reshape(-1, 16, 8)
             got = set()
-            assert sorted(int(x) for x in groups[:, 2]) == [16 * g for g in range(len(groups))]      # every group once ...
+            if not regrouped:
+                assert sorted(int(x) for x in groups[:, 2]) == [16 * g for g in range(len(groups))]      # every group once ...
             assert all(groups[i, 1] >= groups[i + 1, 1] for i in range(len(groups) - 1))              # ... longest first
             for g, (po, nph, ob0, nob) in enumerate(groups):
-                assert nob == min(16, n_out - ob0)
+                gc = [int(c) for c in cols[g]]
+                assert gc[0] == ob0 and sum(c >= 0 for c in gc) == nob
+                if not regrouped:
+                    assert nob == min(16, n_out - ob0) and gc == [ob0 + v if v < nob else -1 for v in range(16)]
                 for phs in range(po, po + nph):
                     pw = [int(px[phs, 0]) & 0xffffffff, int(px[phs, 1]) & 0xffffffff]
                     pairs = [(pw[u >> 1] >> (16 * (u & 1))) & 0xffff for u in range(4)]
@@ -320,9 +334,9 @@ def test_staged_xcol_plan(lib):
                             if sl == 0xff:
                                 continue
                             u, half = byte >> 1, byte & 1
-                            assert u < PH and wave < nob and pairs[u] != 0xffff and sl in slots and sl not in used
+                            assert u < PH and gc[wave] >= 0 and pairs[u] != 0xffff and sl in slots and sl not in used
                             used.add(sl)
-                            got.add((ob0 + wave, 2 * pairs[u] + half, slots[sl][0] >> 1))
+                            got.add((gc[wave], 2 * pairs[u] + half, slots[sl][0] >> 1))
                     assert used == set(slots) and len(used) <= WCAP
             want = {(ob, c, w) for ob, col in f["cols"] for c, w in col}
             assert got == want
@@ -338,17 +352,26 @@ def test_staged_xcol16_plan(lib):
     from blocksparse_amd import lut as L
     from blocksparse_amd.matmul import _host_plan
     rng = np.random.default_rng(6)
-    for CB, KB, dens in ((256, 256, 0.1), (40, 52, 0.3), (9, 70, 1.0), (1, 1, 1.0), (64, 16, 0.6), (7, 33, 0.5)):
-        lay = rng.random((CB, KB)) < dens
-        lay[0, :] = True
+    import _parity as P
+    for CB, KB, dens in ((256, 256, 0.1), (40, 52, 0.3), (9, 70, 1.0), (1, 1, 1.0), (64, 16, 0.6), (7, 33, 0.5), (256, 256, "BA")):
+        if dens == "BA":
+            lay = P.ba_layout(256, 14, seed=1) != 0
+        else:
+            lay = rng.random((CB, KB)) < dens
+            lay[0, :] = True
         t = L.build_tables(lay)
         for axis in (0, 1):
             for side, n_out in (("fprop", KB), ("bprop", CB)):
                 f = t[side]
                 plan = _host_plan(f["lut"], f["segments"], t["blocks"], n_out, 16, lib.BF16, axis)
-                assert plan[0] == 0x42535837 and int(plan[1]) == 2 and int(plan[2]) == 32 and plan[8] == n_out and plan[7] % 4 == 0
+                assert plan[0] == 0x42535837 and int(plan[1]) == 3 and int(plan[2]) == 32 and plan[8] == n_out and plan[7] % 4 == 0
                 sect = plan[plan[11]:plan[11] + int(plan[4]) * 768].reshape(-1, 768)
-                assert int(plan[11]) + sect.size == plan.size
+                cols = plan[plan[12]:plan[12] + 32 * int(plan[3])].reshape(-1, 32)
+                regrouped = int(plan[13])
+                assert int(plan[11]) + sect.size == int(plan[12]) and int(plan[12]) + cols.size == plan.size
+                assert sorted(int(c) for c in cols.ravel() if c >= 0) == list(range(n_out))
+                if dens == "BA":
+                    assert regrouped == 1
                 lists, reqs = sect[:, :640].reshape(-1, 16, 40), sect[:, 640:].reshape(-1, 64, 2)
                 WCAP = int(plan[9])
                 groups = plan[plan[5]:plan[5] + 4 * int(plan[3])].reshape(-1, 4)
@@ -356,7 +379,12 @@ def test_staged_xcol16_plan(lib):
                 tab = plan[plan[7]:plan[7] + int(plan[4]) * 16 * 12].reshape(-1, 16, 12)
                 got = set()
                 for g, (po, nph, ob0, nob) in enumerate(groups):
-                    assert ob0 == 32 * g and nob == min(32, n_out - ob0)
+                    gc = [int(c) for c in cols[g]]
+                    assert gc[0] == ob0 and sum(c >= 0 for c in gc) == nob
+                    if not regrouped:
+                        assert ob0 == 32 * g and nob == min(32, n_out - ob0)
+                    else:                # adjacent pairs stay together: a wave's two columns are neighbours
+                        assert all(gc[v + 1] in (-1, gc[v] + 1) and (gc[v] < 0 or gc[v] % 2 == 0) for v in range(0, 32, 2))
                     for ph in range(po, po + nph):
                         quads = (int(px[ph]) & 0xffff, (int(px[ph]) >> 16) & 0xffff)
                         assert quads[0] != 0xffff
@@ -380,9 +408,9 @@ def test_staged_xcol16_plan(lib):
                                     continue
                                 u, c, sub = byte >> 3, (byte >> 2) & 1, byte & 3
                                 col = 2 * wave + c
-                                assert col < nob and quads[u] != 0xffff and sl in slots and sl not in used
+                                assert gc[col] >= 0 and quads[u] != 0xffff and sl in slots and sl not in used
                                 used.add(sl)
-                                got.add((ob0 + col, 4 * quads[u] + sub, slots[sl]))
+                                got.add((gc[col], 4 * quads[u] + sub, slots[sl]))
                                 by_bytes[c].append((u, sub, sl))
                             n0, n1 = int(tab[ph, wave, 10]) & 0xff, (int(tab[ph, wave, 10]) >> 8) & 0xff
                             assert (n0, n1) == (len(by_bytes[0]), len(by_bytes[1])) and int(tab[ph, wave, 10]) >> 19 == 0
