@@ -435,6 +435,9 @@ enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_SUPER8, 
 #ifndef XS0_NMAX
 #define XS0_NMAX 512              // feature axis 0: the small-minibatch kernel (bsmm_xsmall0.h) up to this many minibatch columns
 #endif
+#ifndef UAW_NMAX
+#define UAW_NMAX 128              // bsize 32 / 16, feature axis 0, weight gradient: the one-wave-per-block kernel up to this many minibatch columns x pairs
+#endif
 #ifndef U8P_ON
 #define U8P_ON 1                  // bsize 8, feature axis 0, weight gradient: the pair kernel (bsmm_updat.h) where the cost model picks it (0: never; measurement builds)
 #endif
@@ -1151,6 +1154,18 @@ int updat_typed(const PtrList8& xs, const PtrList8& es, void* DW, const bsmm_arg
             const int grid = 8 * ((a->blocks + 7) / 8);
             updat16_a1_tr_kernel<DT><<<grid, 256, UT16_LDS, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->C, a->K, a->pcount,
                                                                 a->alpha, a->beta);
+            return (int)hipGetLastError();
+        }
+    }
+    if constexpr ((BS == 32 || BS == 16) && AXIS == 0 && DT::is16) {
+        // a few dozen minibatch columns (round 6): one wave per block, fragments straight from global memory (bsmm_updat.h::updat_a0_wave_kernel)
+        bool alw = aligned16(DW) && N % 8 == 0;
+        for (int p = 0; p < a->pcount; ++p) alw = alw && aligned16(xs.p[p]) && aligned16(es.p[p]);
+        // (hipGraph replays at the reference benchmark's shapes, N = 64: bsize 32 10.6 against 12.6 us, bsize 16 15 - 16 against 17 - 19; from 128 columns
+        //  on the four-wave kernels below are as fast or faster at bsize 32)
+        if (!use_valu && alw && variant == 0 && a->split == 0 && (long)N * a->pcount <= (BS == 32 ? UAW_NMAX / 2 : UAW_NMAX)) {
+            trace(a, BSMM_K_UPDAT_BLOCK);
+            updat_a0_wave_kernel<DT, BS><<<(a->blocks + 3) / 4, 256, 0, st>>>(xs, es, static_cast<T*>(DW), a->lut, a->blocks, N, a->pcount, a->alpha, a->beta, ug);
             return (int)hipGetLastError();
         }
     }

@@ -330,4 +330,67 @@ updat8_a0_pairs_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW
     }
 }
 
+// bsize 32 / 16, feature axis 0, 16-bit types, a few dozen minibatch columns (round 6: the reference benchmark's N = 64): ONE WAVE per weight block,
+// operand fragments straight from global memory (on this axis lane (row, K group) needs 8 consecutive minibatch columns of its row: 16 contiguous
+// bytes), no LDS, no reduction across waves -- the per-block kernels above cut the minibatch over four waves that meet in LDS, which at N = 64 is
+// most of their 12.5 / 17 us.  Needs N % 8 == 0.
+template <class DT, int BS>
+__global__ void __launch_bounds__(256)
+updat_a0_wave_kernel(PtrList8 Xs, PtrList8 Es, typename DT::T* __restrict__ DW, const int32_t* __restrict__ lut,
+                     int blocks, int N, int pcount, float alpha, float beta, const float* __restrict__ gate = nullptr) {
+    typedef typename DT::T T;
+    static_assert(DT::is16 && (BS == 32 || BS == 16), "one-wave weight-gradient kernel: 16-bit storage types, bsize 32 / 16");
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= blocks) return;
+    const int c = lut[2 * w], k = lut[2 * w + 1];
+    const float a_eff = gate ? alpha * gate[w] : alpha;
+    if constexpr (BS == 32) {
+        const int r = lane & 31, h = lane >> 5;                  // A[m = ci][k = n]: lane (ci = r, K half h) holds columns 16 s + 8 h ..
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int p = 0; p < pcount; ++p) {
+            const T* X = static_cast<const T*>(Xs.p[p]) + (size_t)(c * 32 + r) * N;
+            const T* E = static_cast<const T*>(Es.p[p]) + (size_t)(k * 32 + r) * N;
+            for (int nb = 0; nb < N; nb += 16) {                 // (uniform trip count; a lane past the end multiplies zeros)
+                const int n = nb + 8 * h;
+                const uint4 av = n < N ? *reinterpret_cast<const uint4*>(X + n) : zero_u4();
+                const uint4 bv = n < N ? *reinterpret_cast<const uint4*>(E + n) : zero_u4();
+                acc = DT::mfma32(av, bv, acc);
+            }
+        }
+        // D[ci][ko]: col = ko = lane & 31, row ci = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const size_t idx = (size_t)w * 1024 + ci * 32 + r;
+            float out = a_eff * acc[reg];
+            if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+            DW[idx] = DT::from_f32(out);
+        }
+    } else {
+        const int t16 = lane & 15, g = lane >> 4;                // v_mfma_f32_16x16x32: lane (row t16, K group g) holds columns 32 s + 8 g ..
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < pcount; ++p) {
+            const T* X = static_cast<const T*>(Xs.p[p]) + (size_t)(c * 16 + t16) * N;
+            const T* E = static_cast<const T*>(Es.p[p]) + (size_t)(k * 16 + t16) * N;
+            for (int nb = 0; nb < N; nb += 32) {
+                const int n = nb + 8 * g;
+                const uint4 av = n < N ? *reinterpret_cast<const uint4*>(X + n) : zero_u4();
+                const uint4 bv = n < N ? *reinterpret_cast<const uint4*>(E + n) : zero_u4();
+                acc = DT::mfma16(av, bv, acc);
+            }
+        }
+        // D[ci][ko]: col = ko = t16, rows ci = 4 g + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t idx = (size_t)w * 256 + (4 * g + i) * 16 + t16;
+            float out = a_eff * acc[i];
+            if (beta != 0.f) out += beta * DT::to_f32(DW[idx]);
+            DW[idx] = DT::from_f32(out);
+        }
+    }
+}
+
 }  // namespace bsmm
