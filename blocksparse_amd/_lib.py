@@ -223,3 +223,16 @@ def error_string(code):
 def check(code, where):
     if code != 0:
         raise BsmmError(code, where)
+
+
+def raw_stream(device):
+    """The current HIP stream of ``device`` as an integer handle.  ``torch.cuda.current_stream(dev).cuda_stream`` builds a Stream object on every
+    call (4 us of the ~12 us an eager small-minibatch call spends on the host, scripts/gpu_host_overhead.py); the C binding returns the handle."""
+    import torch
+    idx = device.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    try:
+        return torch._C._cuda_getCurrentRawStream(idx)
+    except AttributeError:          # (an older PyTorch)
+        return torch.cuda.current_stream(device).cuda_stream

@@ -310,7 +310,7 @@ class BlocksparseMatMul(object):
         a.C, a.K, a.N = Cin, Kout, N
         a.pcount, a.axis, a.dtype = pcount, self.axis, _dtype_code(dtype)
         a.alpha, a.beta = alpha, beta
-        a.stream = torch.cuda.current_stream(lut_t.device).cuda_stream
+        a.stream = _lib.raw_stream(lut_t.device)
         return a
 
     def _call_args(self, op, tabs, lut_t, side, N, Cin, Kout, dtype, plan, slot=0, pcount=1, flags=0, gated=False):
@@ -319,7 +319,7 @@ class BlocksparseMatMul(object):
         kernel takes on the device (profiles/r04_smalln.txt: 14-15 us per eager call before this cache).  Fields that change from call to
         call (gate, alpha / beta, prepared_w) are set by the caller -- on a COPY of the cached block (one mutable struct shared by
         every call of a key is not safe from two threads, and a gate-dependent workspace term needs the gate in the key: ``gated``)."""
-        stream = torch.cuda.current_stream(lut_t.device).cuda_stream
+        stream = _lib.raw_stream(lut_t.device)
         key = (op, N, dtype, lut_t.device.index, stream, id(plan), slot, pcount, _lib.call_flags() | flags, self.updat_split, bool(gated))
         hit = self._args_cache.get(key)
         if hit is None:
@@ -451,7 +451,7 @@ class BlocksparseMatMul(object):
         # ~2e-3 (above the 1e-3 bar), hence the second image there unless the gate is a 0 / 1 mask
         pieces = 1 if (w.dtype == torch.float16 or self._gate_kind_of(gate) == "binary") else 2
         img = torch.empty((pieces * self.blocks, self.bsize, self.bsize), dtype=w.dtype, device=w.device)
-        stream = torch.cuda.current_stream(w.device).cuda_stream
+        stream = _lib.raw_stream(w.device)
         _lib.check(_lib.load().bsmm_gate_weights(w.data_ptr(), gate.data_ptr(), img.data_ptr(), self.blocks, self.bsize, _dtype_code(w.dtype), pieces, stream),
                    "bsmm_gate_weights")
         op = self if pieces == 1 else self._doubled()
@@ -628,7 +628,7 @@ class BlocksparseMatMul(object):
                 raise ValueError("beta != 0 needs dw")
             dw = torch.empty(self.w_shape, dtype=dtype or torch.bfloat16, device=sums.device)
         gate = self._check_gate(gate, sums.device)
-        st = torch.cuda.current_stream(sums.device).cuda_stream
+        st = _lib.raw_stream(sums.device)
         blocks, bsize = self.blocks, self.bsize
         if bsize == 64:      # elementwise: a 64x64 block is four contiguous quarters of 1024 elements with the block's gate
             blocks, bsize = 4 * blocks, 32
@@ -675,7 +675,7 @@ class BlocksparseMatMul(object):
         dw = dw.contiguous(); w = w.contiguous()
         out = torch.empty_like(dw)
         dg = torch.empty(self.blocks, dtype=torch.float32, device=dw.device)
-        st = torch.cuda.current_stream(dw.device).cuda_stream
+        st = _lib.raw_stream(dw.device)
         _lib.check(_lib.load().bsmm_gate_grad(out.data_ptr(), dg.data_ptr(), dw.data_ptr(), w.data_ptr(), gate.data_ptr(), self.blocks,
                                               self.bsize, _dtype_code(dw.dtype), st), "bsmm_gate_grad")
         return out, dg
@@ -710,7 +710,7 @@ class BlocksparseMatMul(object):
         lut = self._l2_tables(W.device)
         y = torch.empty(self.w_shape, dtype=y_dtype, device=W.device)
         ss = torch.empty(self.K, dtype=torch.float32, device=W.device)
-        st = torch.cuda.current_stream(W.device).cuda_stream
+        st = _lib.raw_stream(W.device)
         _lib.check(_lib.load().bsmm_l2_normalize(y.data_ptr(), ss.data_ptr(), W.data_ptr(), gain.data_ptr() if gain is not None else None,
                                                  lut.data_ptr(), self.KB, self.bsize, _dtype_code(W.dtype), _dtype_code(y_dtype), epsilon, st),
                    "bsmm_l2_normalize")
@@ -721,7 +721,7 @@ class BlocksparseMatMul(object):
         lut = self._l2_tables(W.device)
         dx = torch.empty_like(W)
         dg = torch.empty(self.K, dtype=torch.float32, device=W.device) if gain is not None else None
-        st = torch.cuda.current_stream(W.device).cuda_stream
+        st = _lib.raw_stream(W.device)
         _lib.check(_lib.load().bsmm_l2_normalize_grad(dx.data_ptr(), dg.data_ptr() if dg is not None else None, dy.data_ptr(), W.data_ptr(),
                                                       gain.data_ptr() if gain is not None else None, ss.data_ptr(), lut.data_ptr(), self.KB,
                                                       self.bsize, _dtype_code(W.dtype), _dtype_code(dy.dtype), epsilon, st),
@@ -789,7 +789,7 @@ class BlocksparseMatMul(object):
             lib = _lib.load()
             tabs = self._tables_on(dev)
             W = torch.empty(self.w_shape, dtype=dtype, device=dev)
-            st = torch.cuda.current_stream(dev).cuda_stream
+            st = _lib.raw_stream(dev)
             _lib.check(lib.bsmm_identity_init(W.data_ptr(), tabs.updat.data_ptr(), self.CB, self.KB, self.blocks,
                                               self.bsize, float(scale), _dtype_code(dtype), st), "bsmm_identity_init")
             return W

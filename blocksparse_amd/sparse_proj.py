@@ -62,7 +62,7 @@ class SparseProj(object):
     def _op(self, op, x, y, lut, K, rows_z):
         N = x.numel() // x.shape[0]
         z = torch.empty((rows_z,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        st = torch.cuda.current_stream(x.device).cuda_stream
+        st = _lib.raw_stream(x.device)
         _lib.check(_lib.load().bsmm_sparse_op(z.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, lut.data_ptr(), op, K,
                                               rows_z, N, _code(x.dtype), st), "bsmm_sparse_op")
         return z
@@ -72,7 +72,7 @@ class SparseProj(object):
         N = x.numel() // x.shape[0]
         dx = torch.empty_like(x)
         dy = torch.empty_like(y)
-        st = torch.cuda.current_stream(x.device).cuda_stream
+        st = _lib.raw_stream(x.device)
         _lib.check(_lib.load().bsmm_sparse_mul_grad(dx.data_ptr(), dy.data_ptr(), dz.contiguous().data_ptr(), x.data_ptr(), y.data_ptr(),
                                                     g.data_ptr(), self.nproj, self.nhidden, N, _code(x.dtype), st), "bsmm_sparse_mul_grad")
         return dx, dy

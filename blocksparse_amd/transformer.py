@@ -146,7 +146,7 @@ class BlocksparseTransformer(object):
         a.blocks, a.bsize, a.batch, a.heads, a.head_state = self.blocks, self.blk_size, batch, self.heads, head_state
         a.ctx_blks_q, a.ctx_blks_k = self.ctx_blks_q, self.ctx_blks_k
         a.dtype, a.score_dtype = dtype, score_dtype
-        a.stream = torch.cuda.current_stream(lut_t.device).cuda_stream
+        a.stream = _lib.raw_stream(lut_t.device)
         return a
 
     def _check_act(self, t, ctx_blks, what):
@@ -257,7 +257,7 @@ class BlocksparseTransformer(object):
         m = self._table("mask", device)
         out = torch.empty_like(m)
         lut = self._table("nt_lut", device)
-        st = torch.cuda.current_stream(device).cuda_stream
+        st = _lib.raw_stream(device)
         _lib.check(_lib.load().bst_partial_autoregressive_mask(m.data_ptr(), out.data_ptr(), lut.data_ptr(), self.blk_size, self.blocks,
                                                                self.lut_heads, int(autoregress_at_key), st), "bst_partial_autoregressive_mask")
         return out
