@@ -465,7 +465,8 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
     const bool force = variant == 3;
     if constexpr (BS == 8) {
         if constexpr (DT::is16 && AXIS == 0) {      // short minibatches on feature axis 0 (bsmm_xsmall0.h, round 6: the reference benchmark's (8, 0) shapes)
-            const bool n_ok8 = a->N <= XS0_NMAX || (a->N <= 2 * XS0_NMAX && (long)a->blocks >= 32L * a->segments);
+            // (BS=8 in scripts/gpu_a0_xprop_sweep.py: at N = 1024 114 against 365, 51 against 108, 162 against 226, 249 against 451 us)
+            const bool n_ok8 = a->N <= 2 * XS0_NMAX;
             if (variant == 0 && vec_ok && !a->gate && a->locks == 0 && a->N % 8 == 0 && n_ok8 && a->segments > 0) return XP_SMALL;
         }
         if constexpr (DT::is16) {
@@ -504,7 +505,8 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         // (hipGraph replays, fprop / bprop us, this kernel against what ran before: hidden 2560 dense N = 64 8.3 / 8.1 against 45.8 / 27.1, N = 512 22.7
         //  against 64.6 / 54.3, N = 1024 38.5 against 95; 20480 at 1.7 % N = 64 10.5 against 63.8 / 44.3, N = 512 60 against 82 / 73, N = 1024 116
         //  against 91 / 81: up to 512 columns always, up to 1024 where the columns are long -- >= 16 blocks on average)
-        const bool n_ok = a->N <= XS0_NMAX || (a->N <= 2 * XS0_NMAX && (long)a->blocks >= 16L * a->segments);
+        // (bsize 16, the same sweep with BS=16: at N = 1024 the kernel still wins at every shape -- 51 against 118, 25 against 41, 72 against 83, 109 against 210 us)
+        const bool n_ok = a->N <= XS0_NMAX || (a->N <= 2 * XS0_NMAX && (BS == 16 || (long)a->blocks >= 16L * a->segments));
         if (variant == 0 && !a->gate && a->locks == 0 && a->N % 8 == 0 && n_ok && a->C % BS == 0 && a->K % BS == 0 && a->segments > 0) return XP_SMALL;
     }
     if (!plan_ok) {
