@@ -229,7 +229,7 @@ def raw_stream(device):
     """The current HIP stream of ``device`` as an integer handle.  ``torch.cuda.current_stream(dev).cuda_stream`` builds a Stream object on every
     call (4 us of the ~12 us an eager small-minibatch call spends on the host, scripts/gpu_host_overhead.py); the C binding returns the handle."""
     import torch
-    idx = device.index
+    idx = getattr(device, "index", None) if isinstance(device, torch.device) else torch.device(device).index     # (a device may arrive as "cuda" / "cuda:1")
     if idx is None:
         idx = torch.cuda.current_device()
     try:

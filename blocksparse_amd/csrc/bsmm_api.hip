@@ -476,6 +476,11 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
             // (locked reference-policy tables stay on the exact kernel: the repair pass of the super-block path writes Y directly)
             if (plan_ok && a->plan_magic == S8PLAN_MAGIC && a->plan_width > 0 && shape_ok && a->locks == 0 && (fill || force)) return XP_SUPER8;
         }
+        if constexpr (DT::is16 && AXIS == 0) {
+            // no super-block path for this call (no plan, or too few units for the chip -- hidden 2560 at N = 2048: 643 us on the V_FMA kernel): the
+            // pair kernel at any minibatch (its time grows with blocks x N like the V_FMA kernel's, at a third of it)
+            if (variant == 0 && vec_ok && !a->gate && a->locks == 0 && a->N % 8 == 0 && a->segments > 0) return XP_SMALL;
+        }
         return XP_VALU;
     }
     if (variant == 1 || !vec_ok) return XP_VALU;
