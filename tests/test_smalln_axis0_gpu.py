@@ -134,3 +134,61 @@ def test_small_minibatch_updat_bsize64(env):
         refg = 0.5 * ref * g[:, None, None] + 2.0 * np.asarray(P.to_host(w0), dtype=np.float64)
         l2, _ = P.errors(P.to_host(dwg), O.round_to(refg, "bf16"))
         assert l2 <= P.L2_BAR["bf16"], (N, "gated", l2)
+
+
+@pytest.mark.gpu
+def test_small_minibatch_axis0_fuzz(env):
+    """Eighteen seeded random cases over the small-minibatch kernels of feature axis 0: layouts of 1 .. 60 blocks a side at 3 .. 100 %, block sizes
+    8 / 16 / 32, minibatches that are multiples of 8 up to 1024, bf16 / fp16 -- all three passes against the float64 oracle (the kernel family of
+    fprop asserted where the rule of bsmm_api.hip must take the small kernel: N <= 512)."""
+    torch, BSMM, lib = env
+    rng = np.random.default_rng(20260930)
+    for it in range(18):
+        bs = (32, 16, 8)[it % 3]
+        CB, KB = int(rng.integers(1, 61)), int(rng.integers(1, 61))
+        dens = float(rng.choice([0.03, 0.1, 0.3, 0.6, 1.0]))
+        N = 8 * int(rng.integers(1, 129))
+        dt = ("bf16", "f16")[(it // 3) & 1]
+        lay = P.random_layout(CB, KB, dens, seed=500 + it)
+        if not lay.any():
+            lay[0, 0] = 1
+        b = BSMM(lay, block_size=bs, feature_axis=0)
+        t = O.build_layout_luts(lay, bs)
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dt, seed=900 + it)
+        w, x, e = (P.to_dev(a, dt, torch) for a in (W, X, E))
+        y = b.fprop(x, w)
+        if N <= 512:
+            assert lib.last_kernel() & 255 == lib.K_XPROP_SMALL, (it, bs, CB, KB, dens, N, lib.last_kernel())
+        for what, got, ref in (("Y", y, O.fprop(t, X, W, 0)), ("DX", b.bprop(e, w), O.bprop(t, E, W, 0)), ("DW", b.updat(x, e), O.updat(t, X, E, 0))):
+            l2, _ = P.errors(P.to_host(got), O.round_to(ref, dt))
+            assert l2 <= P.L2_BAR[dt], (it, bs, CB, KB, dens, N, dt, what, l2)
+
+
+@pytest.mark.gpu
+def test_gated_images_under_stream_capture(env):
+    """A gated call on the weight-image path inside a hipGraph capture: no host sync (an unseen gate counts as "general" there: two images), the
+    replayed result equals the eager one."""
+    torch, BSMM, lib = env
+    lay = P.random_layout(40, 24, 0.3, seed=21)
+    b = BSMM(lay, block_size=32, feature_axis=1)
+    N = 1024
+    W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), "bf16", seed=3)
+    w, x = P.to_dev(W, "bf16", torch), P.to_dev(X, "bf16", torch)
+    g = torch.from_numpy((np.random.RandomState(2).rand(b.blocks) < 0.7).astype(np.float32)).cuda()
+    b.gate_kind = "general"
+    want = b.fprop(x, w, gate=g)                       # (eager, two images: what the capture will take for a gate it has not looked at)
+    b.gate_kind = "auto"
+    b._gate_kind_hit = None
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        b.fprop(x, w)                                  # warm the ungated tables / plans outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    b._doubled()._tables_on(x.device)                  # (plans are host work: built before the capture)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        got = b.fprop(x, w, gate=g)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
