@@ -435,6 +435,9 @@ enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_SUPER8, 
 #ifndef XS0_NMAX
 #define XS0_NMAX 512              // feature axis 0: the small-minibatch kernel (bsmm_xsmall0.h) up to this many minibatch columns
 #endif
+#ifndef XSN_NMAX
+#define XSN_NMAX 512              // bsize 16 / 8, feature axis 1: the narrow small-minibatch kernel (bsmm_xsmall.h) up to this many minibatch rows
+#endif
 #ifndef UAW_NMAX
 #define UAW_NMAX 128              // bsize 32 / 16, feature axis 0, weight gradient: the one-wave-per-block kernel up to this many minibatch columns x pairs
 #endif
@@ -454,7 +457,7 @@ enum XPath { XP_VALU, XP_SEGMENT, XP_XCOL32, XP_XCOL16, XP_F32SPLIT, XP_SUPER8, 
 // ONE decision, used for the workspace layout, the zero-fill of locked outputs and the launch (the three used to be
 // derived separately and could disagree).
 template <class DT, int BS, int AXIS>
-XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a) {
+XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a, bool fprop = true) {
     const int variant = call_variant(a);
     const bool vec_ok = aligned16(X) && aligned16(W) && aligned16(Y);
     // gated calls: the staged bsize-32 kernel applies gates (exactly: bsmm_xcol_v2.h); everything else runs the per-segment kernels.
@@ -468,6 +471,11 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
             // (BS=8 in scripts/gpu_a0_xprop_sweep.py: at N = 1024 114 against 365, 51 against 108, 162 against 226, 249 against 451 us)
             const bool n_ok8 = a->N <= 2 * XS0_NMAX;
             if (variant == 0 && vec_ok && !a->gate && a->locks == 0 && a->N % 8 == 0 && n_ok8 && a->segments > 0) return XP_SMALL;
+        }
+        if constexpr (DT::is16 && AXIS == 1) {      // short minibatches on feature axis 1 (bsmm_xsmall.h::xsmall_narrow_kernel, round 6)
+            // (the same sweep: against the V_FMA kernel 11.6 against 32 us at 4096^2 10 % N = 64, 43 against 216 at 20480 / 1.5 %; up to 512 rows it also
+            //  beats the super-block path where that applies: 291 against 426 us at 20480 / 1.5 % N = 512)
+            if (variant == 0 && vec_ok && !a->gate && a->locks == 0 && a->N <= XSN_NMAX && a->C % 8 == 0 && a->K % 8 == 0 && a->segments > 0) return XP_SMALL;
         }
         if constexpr (DT::is16) {
             // bsize 8 on the matrix cores: expand W into the 32x32 super-blocks of the 'BSS8' plan and run the bsize-32 kernel
@@ -513,6 +521,11 @@ XPath xprop_path(const void* X, const void* W, const void* Y, const bsmm_args* a
         // (bsize 16, the same sweep with BS=16: at N = 1024 the kernel still wins at every shape -- 51 against 118, 25 against 41, 72 against 83, 109 against 210 us)
         const bool n_ok = a->N <= XS0_NMAX || (a->N <= 2 * XS0_NMAX && (BS == 16 || (long)a->blocks >= 16L * a->segments));
         if (variant == 0 && !a->gate && a->locks == 0 && a->N % 8 == 0 && n_ok && a->C % BS == 0 && a->K % BS == 0 && a->segments > 0) return XP_SMALL;
+    }
+    if constexpr (BS == 16 && DT::is16 && AXIS == 1) {
+        // (scripts/gpu_a1_narrow_sweep.py, hipGraph replays: against the per-segment kernel the narrow kernel wins fprop up to 256 rows -- 7.2 against
+        //  14.8 us at 4096^2 10 % N = 64, 58 against 73 at hidden 2560 dense N = 256: that kernel transposes W in a pre-pass -- and bprop up to 64)
+        if (variant == 0 && !a->gate && a->locks == 0 && a->N <= (fprop ? XSN_NMAX / 2 : XSN_NMAX / 8) && a->C % 16 == 0 && a->K % 16 == 0 && a->segments > 0) return XP_SMALL;
     }
     if (!plan_ok) {
         if (mid_ok && t_mid < (small_ok ? t_small : 1e30) && t_mid < 6.0 + 1.2e-5 * (double)a->blocks * a->N + 8.0) return XP_MID;
@@ -584,7 +597,7 @@ template <class DT, int BS, int AXIS>
 int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_args* a) {
     typedef typename DT::T T;
     hipStream_t st = static_cast<hipStream_t>(a->stream);
-    const XPath path = xprop_path<DT, BS, AXIS>(X, W, Y, a);
+    const XPath path = xprop_path<DT, BS, AXIS>(X, W, Y, a, fprop);
     if (path == XP_SUPER8) {
         if constexpr (BS == 8 && DT::is16) {
             // Exactness with non-finite activations: a super-block multiplies its zero-filled (absent) 8x8 parts with live
@@ -615,6 +628,16 @@ int xprop_typed(bool fprop, const void* X, const void* W, void* Y, const bsmm_ar
         }
     }
     if (path == XP_SMALL) {
+        if constexpr ((BS == 8 || BS == 16) && DT::is16 && AXIS == 1) {
+            constexpr int LDSN = XSM_NW * XSM_PART;
+            if (fprop) { if (int rc = ensure_lds<&xsmall_narrow_kernel<DT, BS, true>>(LDSN)) return rc; }
+            else       { if (int rc = ensure_lds<&xsmall_narrow_kernel<DT, BS, false>>(LDSN)) return rc; }
+            trace(a, BSMM_K_XPROP_SMALL);
+            dim3 grid(a->segments, (a->N + XSM_R - 1) / XSM_R);
+            if (fprop) xsmall_narrow_kernel<DT, BS, true><<<grid, 64 * XSM_NW, LDSN, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N, a->C, a->K);
+            else       xsmall_narrow_kernel<DT, BS, false><<<grid, 64 * XSM_NW, LDSN, st>>>(static_cast<const T*>(X), static_cast<const T*>(W), static_cast<T*>(Y), a->lut, a->N, a->C, a->K);
+            return (int)hipGetLastError();
+        }
         if constexpr (BS == 8 && DT::is16 && AXIS == 0) {
             if (fprop) { if (int rc = ensure_lds<&xsmall8_a0_kernel<DT, true>>(XS16_LDS)) return rc; }
             else       { if (int rc = ensure_lds<&xsmall8_a0_kernel<DT, false>>(XS16_LDS)) return rc; }

@@ -108,3 +108,100 @@ xsmall32_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __re
 }
 
 }  // namespace bsmm
+
+namespace bsmm {
+
+// ---- bsize 16 / 8 on feature axis 1 (round 6) --------------------------------------------------------------------------------------------------------
+// The reference runs 8 / 16-wide blocks on feature axis 0 only (blocksparse/matmul.py:84-89); here they run on both axes, and short minibatches on
+// axis 1 used to fall to the per-segment kernel (bsize 16) or V_FMA (bsize 8).  Same decomposition as above: workgroup = one output block x 64
+// minibatch rows, XSM_NW waves over the column's entries, partial tiles meet in LDS.  v_mfma_f32_16x16x16: A[m = row n][k] = 8 contiguous bytes of
+// an activation row straight from global memory (bsize 8: K = 16 = two entries, lane group g takes entry g >> 1); B[k][col = output]: bprop 8
+// contiguous bytes of a weight row from global memory, fprop the block(s) through 512 bytes of wave-private LDS and one transposing read.
+template <class DT, int BS, bool TRANSW>
+__global__ void __launch_bounds__(64 * XSM_NW)
+xsmall_narrow_kernel(const typename DT::T* __restrict__ X, const typename DT::T* __restrict__ W, typename DT::T* __restrict__ Y,
+                     const int32_t* __restrict__ lut, int N, int Cin, int Kout) {
+    typedef typename DT::T T;
+    static_assert(DT::is16 && (BS == 16 || BS == 8), "narrow small-minibatch kernel: 16-bit storage types, bsize 16 / 8");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, t16 = lane & 15;
+    const int4 hdr = *reinterpret_cast<const int4*>(lut + 4 * blockIdx.x);
+    const int cnt = __builtin_amdgcn_readfirstlane(hdr.y), ob = __builtin_amdgcn_readfirstlane(hdr.z);
+    const int2* ent = reinterpret_cast<const int2*>(lut) + __builtin_amdgcn_readfirstlane(hdr.x);
+    const int n0 = blockIdx.y * XSM_R;
+    constexpr int EPS = BS == 16 ? 1 : 2;                  // entries per step (K = 16)
+    const int nsteps = (cnt + EPS - 1) / EPS;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // my rows of the four 16-row tiles (rows past N are clamped re-reads, never stored) and my K offset inside an entry's features
+    const T* xrow[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xrow[t] = X + (size_t)min(n0 + 16 * t + t16, N - 1) * Cin + (BS == 16 ? 4 * g : 4 * (g & 1));
+    unsigned char* wst = smem + wave * XSM_PART;           // fprop: my weight staging [16 rows (k)][32 B], inside my partial tile
+    const int wfrag = (4 * g + (t16 >> 2)) * 32 + 4 * (t16 & 3) * 2;
+
+    for (int s = wave; s < nsteps; s += XSM_NW) {
+        int c, w, c1 = 0, w1 = 0;
+        bool two = false;
+        if constexpr (BS == 16) {
+            const int2 cw = ent[s];
+            c = __builtin_amdgcn_readfirstlane(cw.x); w = __builtin_amdgcn_readfirstlane(cw.y);
+        } else {
+            const int2 e0 = ent[2 * s];
+            two = 2 * s + 1 < cnt;
+            const int2 e1 = ent[two ? 2 * s + 1 : 2 * s];
+            c = __builtin_amdgcn_readfirstlane(e0.x); w = __builtin_amdgcn_readfirstlane(e0.y);
+            c1 = __builtin_amdgcn_readfirstlane(e1.x); w1 = __builtin_amdgcn_readfirstlane(e1.y);
+        }
+        const int cme = BS == 16 ? c : (g < 2 ? c : c1);    // the entry my K group belongs to (a missing second entry: the first one's features, times zero)
+        uint2 xa[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xa[t] = *reinterpret_cast<const uint2*>(xrow[t] + cme * BS);
+        uint2 wq = make_uint2(0u, 0u);
+        if constexpr (TRANSW) {
+            // B[k = ci][col = ko] = W[ci][ko]: the block(s) as they lie -> LDS [16 rows][32 B] -> transposing read
+            if constexpr (BS == 16) {
+                *reinterpret_cast<uint2*>(wst + lane * 8) = *reinterpret_cast<const uint2*>(W + (size_t)w * 256 + lane * 4);
+            } else {
+                if (lane < 16) {
+                    uint4 v = zero_u4();
+                    if (lane < 8) v = *reinterpret_cast<const uint4*>(W + (size_t)w * 64 + lane * 8);
+                    else if (two) v = *reinterpret_cast<const uint4*>(W + (size_t)w1 * 64 + (lane - 8) * 8);
+                    *reinterpret_cast<uint4*>(wst + lane * 32) = v;
+                }
+            }
+            wq = ds_tr16(wst + wfrag);
+        } else {
+            // B[k = ko][col = ci] = W[ci][ko]: lane (ci = t16, g) takes 4 consecutive outputs of row ci
+            if constexpr (BS == 16) wq = *reinterpret_cast<const uint2*>(W + (size_t)w * 256 + t16 * 16 + 4 * g);
+            else if (t16 < 8 && (g < 2 || two)) wq = *reinterpret_cast<const uint2*>(W + (size_t)(g < 2 ? w : w1) * 64 + t16 * 8 + 4 * (g & 1));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = DT::mfma16k16(xa[t], wq, acc[t]);
+    }
+
+    // D[m = row][col]: col = t16, rows 4 g + i of tile t -> part[wave][t][i][lane]
+    const int nparts = min(nsteps, XSM_NW);
+    if (wave < nparts) {
+        float* part = reinterpret_cast<float*>(smem + wave * XSM_PART);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[(t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    for (int el = threadIdx.x; el < 1024; el += 64 * XSM_NW) {
+        const int ln = el & 63, ti = el >> 6, t = ti >> 2, i = ti & 3;
+        const int col = ln & 15, n = n0 + 16 * t + 4 * (ln >> 4) + i;
+        if (col >= BS || n >= N) continue;
+        float sum = 0.f;
+        for (int v = 0; v < nparts; ++v) sum += reinterpret_cast<const float*>(smem + v * XSM_PART)[el];
+        Y[(size_t)n * Kout + ob * BS + col] = DT::from_f32(sum);
+    }
+}
+
+}  // namespace bsmm

@@ -192,3 +192,25 @@ def test_gated_images_under_stream_capture(env):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("bs", [16, 8])
+@pytest.mark.parametrize("name,layout", LAYOUTS)
+def test_small_minibatch_xprop_axis1_narrow_blocks(env, name, layout, bs, dtype):
+    """bsize 16 / 8 on feature axis 1 at short minibatches (csrc/bsmm_xsmall.h::xsmall_narrow_kernel, round 6): fprop / bprop against the float64
+    oracle, any minibatch (ragged row tiles, N = 1), odd entry counts (bsize 8 multiplies PAIRS of entries)."""
+    torch, BSMM, lib = env
+    b = BSMM(layout, block_size=bs, feature_axis=1)
+    t = O.build_layout_luts(layout, bs)
+    for N in (1, 50, 64, 200, 512):
+        W, X, E = P.make_inputs(b.w_shape, b.i_shape(N), b.o_shape(N), dtype, seed=17 + N)
+        w, x, e = (P.to_dev(a, dtype, torch) for a in (W, X, E))
+        y = b.fprop(x, w)
+        assert (lib.last_kernel() & 255 == lib.K_XPROP_SMALL) == (N <= (512 if bs == 8 else 256)), (name, N, lib.last_kernel())
+        dx = b.bprop(e, w)
+        assert (lib.last_kernel() & 255 == lib.K_XPROP_SMALL) == (N <= (512 if bs == 8 else 64)), (name, N, lib.last_kernel())
+        for what, got, ref in (("Y", y, O.fprop(t, X, W, 1)), ("DX", dx, O.bprop(t, E, W, 1))):
+            l2, _ = P.errors(P.to_host(got), O.round_to(ref, dtype))
+            assert l2 <= P.L2_BAR[dtype], (name, bs, dtype, N, what, l2)
